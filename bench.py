@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- Refign align-and-refine hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of b=2 synthetic (target, reference) image pairs per GPU at
+1080x1920 (BASELINE.json's metric configuration).  Image pairs are independent, so ranks shard pairs with no data-path
+collective ("scaling": "weak").  The timed region is bracketed by a barrier + torch.cuda.synchronize() on both sides, the
+MAX over ranks is taken, rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant kernel (patch-9 local correlation at level 1: C=128, 270x480 per image), algorithmic bytes
+                4*B*H*W*(2C+81) per launch / average launch duration measured live with HIP events on the launch stream.
+  cpu_baseline  the reference's CPU path for the same step on a bounded sample (1 pair), timed on this box's host
+                cores at N=1 on rank 0: kind "reference" = the reference's own correlation.cpp compiled into oracle/_ref
+                (+ torch-CPU ATen ops, which are what the reference's CPU path calls for warp/refine), else kind "port"
+                = oracle/ restatement.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="align_refine_kernels_1080x1920")
+    ap.add_argument("--pairs-per-gpu", type=int, default=2)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workload: the HIP-kernel part of align+refine at 1080x1920 (K4 shapes): three local correlation
+# layers with on-the-fly warp, the global correlation layer, the fused align tail (upsample + confidence + logits warp)
+# and refine.  Synthetic inputs: unit-norm random features, 5 px random flows, N(0,9) logits.
+# ------------------------------------------------------------------------------------------------------------------
+class AlignRefineKernels:
+    name = "align_refine_kernels_1080x1920"
+
+    def __init__(self, dev, b, seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        H, W = 1080, 1920
+        self.b, self.H, self.W = b, H, W
+
+        def feat(c, h, w):
+            return torch.nn.functional.normalize(torch.randn(b, c, h, w, generator=g), dim=1).to(dev)
+
+        def flow(h, w):
+            return (5.0 * torch.randn(b, 2, h, w, generator=g)).to(dev)
+
+        self.c11, self.c21 = feat(128, H // 4, W // 4), feat(128, H // 4, W // 4)
+        self.c12, self.c22 = feat(256, H // 8, W // 8), feat(256, H // 8, W // 8)
+        self.c13, self.c23 = feat(256, 32, 32), feat(256, 32, 32)
+        self.c14, self.c24 = feat(512, 16, 16), feat(512, 16, 16)
+        self.f1, self.f2, self.f3 = flow(H // 4, W // 4), flow(H // 8, W // 8), flow(32, 32)
+        self.logvar = (2.0 * torch.randn(b, 1, H // 4, W // 4, generator=g)).to(dev)
+        self.logits_trg = (3.0 * torch.randn(b, 19, H, W, generator=g)).to(dev)
+        self.logits_ref = (3.0 * torch.randn(b, 19, H, W, generator=g)).to(dev)
+
+    def step(self):
+        from refign_amd.correlation import local_correlation_layer
+        from refign_amd.matching import align_tail
+        from refign_amd.modules import GlobalFeatureCorrelationLayer
+        from refign_amd.refine import refine
+        corr4 = GlobalFeatureCorrelationLayer()(self.c24, self.c14)
+        corr3 = local_correlation_layer(self.c23, self.c13, flow=self.f3)
+        corr2 = local_correlation_layer(self.c22, self.c12, flow=self.f2)
+        corr1 = local_correlation_layer(self.c21, self.c11, flow=self.f1)
+        warped, mask, cert = align_tail(self.logits_ref, self.f1 * 4.0, self.logvar)
+        probs = refine(self.logits_trg, warped, mask, cert, gamma=0.25)
+        return corr4, corr3, corr2, corr1, probs
+
+    # ---- dominant kernel for the roofline: level-1 local correlation (fused relu+l2norm, on-the-fly warp) ----
+    def roofline_launch(self):
+        from refign_amd.correlation import local_correlation_layer
+        return local_correlation_layer(self.c21, self.c11, flow=self.f1)
+
+    def roofline_bytes(self):
+        b, c, h, w = self.c11.shape
+        # 4*B*H*W*(2C+81) (+ the flow, 2 floats/pixel, for the fused warp)
+        return 4 * b * h * w * (2 * c + 81 + 2)
+
+    # ---- CPU baseline: same step, 1 pair, reference code path on the host ----
+    def cpu_step(self, kind, corr_fn):
+        import torch.nn.functional as F
+        tc = lambda t: t[:1].cpu()  # noqa: E731
+
+        def warp_cpu(x, flo):
+            B, C, H, W = x.shape
+            xx = torch.arange(W, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
+            yy = torch.arange(H, dtype=torch.float32).view(1, 1, H, 1).expand(B, 1, H, W)
+            v = torch.cat((xx, yy), 1) + flo
+            vx = 2.0 * v[:, 0] / max(W - 1, 1) - 1.0
+            vy = 2.0 * v[:, 1] / max(H - 1, 1) - 1.0
+            grid = torch.stack((vx, vy), dim=3)
+            out = F.grid_sample(x, grid, align_corners=True, padding_mode="zeros")
+            return out, (vx > -1) & (vy > -1) & (vx < 1) & (vy < 1)
+
+        def local(src, trg, flo):
+            w, _ = warp_cpu(src, flo)
+            c = corr_fn(trg.contiguous(), w.contiguous())
+            return F.normalize(F.relu(c.reshape(c.shape[0], 81, *c.shape[-2:])), dim=1)
+
+        t0 = time.perf_counter()
+        fs, ft = tc(self.c24).flatten(2), tc(self.c14).flatten(2)
+        corr = torch.bmm(ft.transpose(1, 2), fs).transpose(1, 2)           # (b, S, T)
+        cb = corr / (corr.max(dim=1, keepdim=True)[0] + 1e-5)
+        ca = corr / (corr.max(dim=2, keepdim=True)[0] + 1e-5)
+        F.normalize(F.relu(corr * (ca * cb)), dim=1)
+        local(tc(self.c23), tc(self.c13), tc(self.f3))
+        local(tc(self.c22), tc(self.c12), tc(self.f2))
+        local(tc(self.c21), tc(self.c11), tc(self.f1))
+        fu = F.interpolate(tc(self.f1) * 4.0, size=(self.H, self.W), mode="bilinear", align_corners=False)
+        lu = F.interpolate(tc(self.logvar), size=(self.H, self.W), mode="bilinear", align_corners=False)
+        cert = 1.0 - torch.exp(-1.0 / (2 * torch.exp(lu)))
+        warped, mask = warp_cpu(tc(self.logits_ref), fu)
+        lt = tc(self.logits_trg)
+        pt, pr = F.softmax(lt, 1), F.softmax(warped, 1)
+        ent = -(pt * F.log_softmax(lt, 1)).sum(1) / torch.log(torch.tensor(19.0))
+        s = ent.mean(dim=(1, 2)) ** 0.25
+        at, ar = pt.argmax(1), pr.argmax(1)
+        static = torch.tensor([0, 1, 2, 3, 4, 8, 9, 10])
+        M = (torch.isin(at, static) & torch.isin(ar, static)).unsqueeze(1).expand_as(pt).clone()
+        M[:, 5:8] = 0
+        M[:, 11:] = 0
+        eps = s.view(-1, 1, 1, 1) * torch.maximum(cert.expand_as(pt), M.float())
+        eps = eps * mask.unsqueeze(1)
+        _ = (1 - eps) * pt + eps * pr
+        return time.perf_counter() - t0
+
+
+WORKLOADS = {AlignRefineKernels.name: AlignRefineKernels}
+
+
+def cpu_baseline(wl):
+    """Reference CPU path on the host cores, 1 pair.  Returns the cpu_baseline object."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    kind, corr_fn = "port", None
+    try:
+        import build_ref
+        ref = build_ref.load_prebuilt()
+        if ref is not None:
+            kind = "reference"
+            corr_fn = lambda a, b: ref.forward(a, b, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)  # noqa: E731
+    except Exception:
+        ref = None
+    if corr_fn is None:
+        import cpu_oracle
+        corr_fn = lambda a, b: torch.from_numpy(cpu_oracle.corr_forward(a.numpy(), b.numpy(), patch_size=9))  # noqa: E731
+    dt = wl.cpu_step(kind, corr_fn)
+    return {"value": round(1.0 / dt, 5), "unit": "image-pairs/s", "cores": cores, "kind": kind,
+            "sample": f"1 image pair through the same step ({wl.name}) on the host, {dt:.2f} s wall: "
+                      f"correlation = {'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'}"
+                      f" with OpenMP, warp/refine = torch-CPU ATen ops"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import refign_amd
+    refign_amd.load_library()
+    wl = WORKLOADS[args.workload](dev, args.pairs_per_gpu, seed=1234 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        reps = 20
+        for _ in range(3):
+            wl.roofline_launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            wl.roofline_launch()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        ach = wl.roofline_bytes() / (us * 1e-6) / 1e9
+        roof = {"kernel": "corr9_tile_kernel<fuse relu+l2norm, on-the-fly warp> level 1 (C=128, 270x480, b=%d)" % wl.b,
+                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(us, 2),
+                "algorithmic_bytes_per_launch": wl.roofline_bytes()}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(wl)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        pairs = args.pairs_per_gpu * world * args.steps
+        line = {
+            "metric": "image-pairs/s (align+refine HIP kernels, 1080x1920)",
+            "value": round(pairs / dt, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": "1080x1920",
+                       "parallelism": f"dp{world} (independent pairs, no data-path collective)"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

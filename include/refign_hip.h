@@ -1,0 +1,119 @@
+/*
+ * include/refign_hip.h -- C ABI of librefign_hip.so, the MI355X (gfx950) native implementation of the
+ * Refign align-and-refine hot path.
+ *
+ * This is the drop-in boundary: plain pointers (DEVICE memory unless stated otherwise), plain ints, and a
+ * hipStream_t passed as void*.  No torch / pybind types.  Every entry point
+ *   - is asynchronous on `stream` (pass NULL for the legacy default stream, which is what the reference's
+ *     CUDA path launches on: correlation_cuda_kernel.cu:271,311,321),
+ *   - borrows its inputs, writes only the caller-allocated outputs (the reference allocates with
+ *     torch::zeros / zeros_like and returns by value: correlation_cuda_kernel.cu:259,291-292 -- allocation is
+ *     the host shim's job, see refign_amd/correlation.py),
+ *   - never throws: returns RFN_OK (0) or a negative RFN_E* code; rfn_last_error() gives the message.  The
+ *     Python host turns a non-zero code into RuntimeError, which is what TORCH_CHECK produces in the reference
+ *     (correlation_sampler.cpp:13-16).
+ *
+ * Paths cited below are relative to the reference checkout (brdav/refign).
+ */
+#ifndef REFIGN_HIP_H
+#define REFIGN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFN_OK 0
+#define RFN_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported parameterisation) */
+#define RFN_ELAUNCH (-2)   /* hipLaunchKernel / runtime error, see rfn_last_error() */
+#define RFN_ENOTSUP (-3)   /* valid in the reference but not built here (documented per function) */
+
+#define RFN_ABI_VERSION 1
+
+typedef void* rfn_stream_t; /* hipStream_t */
+
+int rfn_abi_version(void);
+const char* rfn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Spatial correlation sampler -- replaces the pybind module `models.correlation_ops.correlation`
+ *   forward : correlation_sampler.cpp:62-90  -> correlation_cuda_forward  (correlation_cuda_kernel.cu:241-278)
+ *                                            == correlation_cpp_forward   (correlation.cpp:80-129)
+ *   backward: correlation_sampler.cpp:92-127 -> correlation_cuda_backward (correlation_cuda_kernel.cu:280-332)
+ *                                            == correlation_cpp_backward  (correlation.cpp:131-183)
+ * in1,in2: (B,C,iH,iW) NCHW contiguous.  out / grad_out: (B,patchH,patchW,oH,oW) contiguous with
+ *   oH = (iH + 2*padH - ((kH-1)*dilH+1)) / dH + 1   (correlation.cpp:98-99).
+ * The 12 ints are the same 12 ints, in the same order, as the reference's forward()/backward().
+ * The one parameterisation the hot path uses (kernel 1, patch 9, stride 1, pad 0, dilation 1, dilation_patch 1:
+ * modules.py:268-270) takes the LDS-tiled kernel; anything else takes a generic kernel.
+ * f32 and f64 are provided (the CPU reference dispatches float/double: correlation.cpp:107).  The CUDA
+ * reference additionally dispatches half (correlation_cuda_kernel.cu:267); the Python wrapper always casts to
+ * float32 (correlation_function.py:51), so half is RFN_ENOTSUP here.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_corr_fwd_f32(const float* in1, const float* in2, float* out, int B, int C, int iH, int iW,
+                     int kH, int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
+                     int dpH, int dpW, int dH, int dW, rfn_stream_t stream);
+int rfn_corr_fwd_f64(const double* in1, const double* in2, double* out, int B, int C, int iH, int iW,
+                     int kH, int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
+                     int dpH, int dpW, int dH, int dW, rfn_stream_t stream);
+int rfn_corr_bwd_f32(const float* in1, const float* in2, const float* grad_out, float* grad_in1,
+                     float* grad_in2, int B, int C, int iH, int iW, int kH, int kW, int patchH, int patchW,
+                     int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW,
+                     rfn_stream_t stream);
+int rfn_corr_bwd_f64(const double* in1, const double* in2, const double* grad_out, double* grad_in1,
+                     double* grad_in2, int B, int C, int iH, int iW, int kH, int kW, int patchH, int patchW,
+                     int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW,
+                     rfn_stream_t stream);
+
+/* LocalFeatureCorrelationLayer.forward (modules.py:266-274) in ONE kernel:
+ *   out[b, ph*9+pw, h, w] = L2-normalise_over_81( relu( sum_c trg[b,c,h,w] * src[b,c,h+ph-4,w+pw-4] ) ), eps 1e-12.
+ * feature_target is the sampler's input1 and feature_source its input2 (modules.py:268-269).
+ * If `flow` is non-NULL, `src` is the UN-warped source feature map and the bilinear warp of
+ * helpers/matching_utils.py:11-49 (align_corners=True, zero padding) is applied on the fly while the source
+ * tile is staged in LDS, i.e. warp() -> local_corr() of uawarpc.py:149-152,223-226,251-254 without ever
+ * materialising the warped features.  flow: (B,2,H,W), channel 0 = x displacement in pixels of THIS level. */
+int rfn_local_corr_layer_f32(const float* feature_target, const float* feature_source, const float* flow,
+                             float* out, int B, int C, int H, int W, rfn_stream_t stream);
+
+/* GlobalFeatureCorrelationLayer.forward (modules.py:294-308): '3D' H-first correlation (modules.py:361-375),
+ * mutual matching with eps 1e-5 (modules.py:310-333), ReLU, L2-normalise over the source axis.
+ * src: (B,C,Hs,Ws), trg: (B,C,Ht,Wt) -> out: (B,Hs*Ws,Ht,Wt).  Requires Hs*Ws <= 1024 and Ht*Wt <= 1024
+ * (the reference asserts 16x16: uawarpc.py:114). */
+int rfn_global_corr_layer_f32(const float* feature_source, const float* feature_target, float* out, int B,
+                              int C, int Hs, int Ws, int Ht, int Wt, int cyclic_consistency,
+                              rfn_stream_t stream);
+
+/* warp() (helpers/matching_utils.py:11-49): bilinear grid_sample, align_corners=True, zero padding.
+ * x: (B,C,H,W); flow: (B,2,H,W) pixels; out: (B,C,H,W); mask (nullable): (B,H,W) uint8, 1 where the
+ * normalised sampling position is strictly inside (-1,1)^2 (matching_utils.py:46-47).
+ * The reference's `if torch.all(flo == 0): return x` early-out (matching_utils.py:19-22) is a host-side
+ * decision; this kernel computes the general case, which returns x bit-exactly for zero flow except on the
+ * last row/column where the mask differs (handled by the host wrapper, refign_amd/matching.py). */
+int rfn_warp_f32(const float* x, const float* flow, float* out, unsigned char* mask, int B, int C, int H,
+                 int W, rfn_stream_t stream);
+
+/* F.normalize(x, p=2, dim=1) on NCHW (uawarpc.py:101-108), eps 1e-12. */
+int rfn_l2norm_channels_f32(const float* x, float* out, int B, int C, int HW, rfn_stream_t stream);
+
+/* refine() + eta() (segmentation_model.py:438-491), gamma = trust-score exponent.
+ * logits_trg, logits_ref: (B,19,H,W); warp_mask (nullable): (B,H,W) uint8; certs (nullable): (B,1,H,W);
+ * out: (B,19,H,W) refined probabilities (NOT a simplex);
+ * workspace: at least rfn_refine_workspace_bytes(B) bytes of device memory (entropy partial sums);
+ * flags: bit0 = disable_M, bit1 = disable_P. */
+unsigned long rfn_refine_workspace_bytes(int B);
+int rfn_refine_f32(const float* logits_trg, const float* logits_ref, const unsigned char* warp_mask,
+                   const float* certs, float* out, void* workspace, int B, int C, int H, int W, float gamma,
+                   int flags, rfn_stream_t stream);
+
+/* Tail of align() (segmentation_model.py:514-522) fused: bilinear (align_corners=False) upsampling of the
+ * quarter-resolution flow (B,2,h,w) and log-variance (B,1,h,w) to (H,W), confidence
+ * P_R = 1 - exp(-1/(2 exp(logvar))) (matching_utils.py:52-57), and warp of logits_ref (B,C,H,W) with the
+ * upsampled flow.  Outputs: warped (B,C,H,W), mask (B,H,W) uint8, cert (B,1,H,W), and (nullable) flow_up
+ * (B,2,H,W). */
+int rfn_align_tail_f32(const float* logits_ref, const float* flow_q, const float* logvar_q, float* warped,
+                       unsigned char* mask, float* cert, float* flow_up, int B, int C, int H, int W, int h,
+                       int w, rfn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REFIGN_HIP_H */

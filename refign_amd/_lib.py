@@ -1,0 +1,75 @@
+"""ctypes binding of librefign_hip.so (C ABI: include/refign_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C refign_amd/csrc` into refign_amd/lib/.
+Loading is lazy and LOUD: if the .so is missing or does not export a declared symbol we raise -- the product path
+never falls back to a CPU or PyTorch implementation.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "librefign_hip.so")
+_lock = threading.Lock()
+_lib = None
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+
+_CORR12 = [c_int] * 12
+# name -> (restype, argtypes); must list every entry point declared in include/refign_hip.h
+SIGNATURES = {
+    "rfn_abi_version": (c_int, []),
+    "rfn_last_error": (ctypes.c_char_p, []),
+    "rfn_corr_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + _CORR12 + [c_void_p]),
+    "rfn_corr_fwd_f64": (c_int, [c_void_p] * 3 + [c_int] * 4 + _CORR12 + [c_void_p]),
+    "rfn_corr_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
+    "rfn_corr_bwd_f64": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
+    "rfn_local_corr_layer_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "rfn_global_corr_layer_f32": (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
+    "rfn_warp_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "rfn_l2norm_channels_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
+    "rfn_refine_workspace_bytes": (ctypes.c_ulong, [c_int]),
+    "rfn_refine_f32": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_int, c_void_p]),
+    "rfn_align_tail_f32": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
+}
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load librefign_hip.so and bind every declared entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"refign_amd: HIP library not built: {_LIB_PATH} is missing. Run `python -c 'import "
+                f"__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise RuntimeError(f"refign_amd: {_LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def abi_version():
+    return load_library().rfn_abi_version()
+
+
+def check(rc, what):
+    """Turn a non-zero ABI return code into RuntimeError (what TORCH_CHECK raises in the reference)."""
+    if rc != 0:
+        msg = load_library().rfn_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

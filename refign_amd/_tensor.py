@@ -1,0 +1,33 @@
+"""Tensor plumbing between torch (device memory + streams) and the C ABI.  torch is plumbing only."""
+import torch
+
+
+def require_device_tensor(t, name, dtype=None):
+    """Mirror of the reference's CHECK_CUDA / CHECK_CONTIGUOUS (correlation_sampler.cpp:13-16): RuntimeError."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a HIP (cuda:N) tensor: refign_amd has no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def same_device(*ts):
+    dev = ts[0].device
+    for t in ts[1:]:
+        if t is not None and t.device != dev:
+            raise RuntimeError("all tensors must be on the same device")  # CHECK_SAME_DEVICE
+    return dev
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device):
+    """Raw hipStream_t of torch's current stream on `device` (the reference launches on the legacy default
+    stream, correlation_cuda_kernel.cu:271; we honour torch's stream semantics instead so graphs/streams work)."""
+    return torch.cuda.current_stream(device).cuda_stream

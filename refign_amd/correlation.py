@@ -1,0 +1,137 @@
+"""Spatial correlation sampler -- host side of the drop-in boundary.
+
+Mirrors, name for name, what the reference exposes for this op:
+  * `forward(input1, input2, kH, kW, patchH, patchW, padH, padW, dilationH, dilationW, dilation_patchH,
+    dilation_patchW, dH, dW)` and `backward(input1, input2, grad_output, <same 12 ints>)` -- the two functions of the
+    pybind module `models.correlation_ops.correlation` (correlation_sampler.cpp:62-70,92-101,129-132);
+  * `spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stride=1, padding=0, dilation=1,
+    dilation_patch=1)` and `SpatialCorrelationSamplerFunction` (correlation_function.py:14-94): fp32 under autocast,
+    once-differentiable, saves both inputs.
+Inputs are borrowed and must be contiguous NCHW on one HIP device; outputs are freshly allocated and returned by
+value (the reference: torch::zeros / zeros_like, correlation_cuda_kernel.cu:259,291-292).  Errors are RuntimeError.
+"""
+import torch
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+from ._tensor import current_stream, ptr, require_device_tensor, same_device
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _suffix(t):
+    try:
+        return _SUFFIX[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"correlation: unsupported dtype {t.dtype} (float32/float64; the Python wrapper of the "
+                           f"reference always casts to float32, correlation_function.py:51)") from None
+
+
+def output_size(iH, iW, kH, kW, padH, padW, dilationH, dilationW, dH, dW):
+    """correlation.cpp:94-99."""
+    oH = (iH + 2 * padH - ((kH - 1) * dilationH + 1)) // dH + 1
+    oW = (iW + 2 * padW - ((kW - 1) * dilationW + 1)) // dW + 1
+    return oH, oW
+
+
+def forward(input1, input2, kH, kW, patchH, patchW, padH, padW, dilationH, dilationW, dilation_patchH,
+            dilation_patchW, dH, dW):
+    require_device_tensor(input1, "input1")
+    require_device_tensor(input2, "input2", input1.dtype)
+    dev = same_device(input1, input2)
+    if input1.dim() != 4 or input1.shape != input2.shape:
+        raise RuntimeError("correlation.forward: input1/input2 must both be (B,C,H,W) of the same shape")
+    B, C, iH, iW = input1.shape
+    oH, oW = output_size(iH, iW, kH, kW, padH, padW, dilationH, dilationW, dH, dW)
+    if oH <= 0 or oW <= 0:
+        raise RuntimeError(f"correlation.forward: empty output {oH}x{oW}")
+    out = torch.empty((B, patchH, patchW, oH, oW), dtype=input1.dtype, device=dev)
+    lib = _lib.load_library()
+    fn = getattr(lib, "rfn_corr_fwd_" + _suffix(input1))
+    with torch.cuda.device(dev):
+        rc = fn(ptr(input1), ptr(input2), ptr(out), B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilationH,
+                dilationW, dilation_patchH, dilation_patchW, dH, dW, current_stream(dev))
+    _lib.check(rc, "correlation.forward")
+    return out
+
+
+def backward(input1, input2, grad_output, kH, kW, patchH, patchW, padH, padW, dilationH, dilationW,
+             dilation_patchH, dilation_patchW, dH, dW):
+    require_device_tensor(input1, "input1")
+    require_device_tensor(input2, "input2", input1.dtype)
+    grad_output = grad_output.contiguous()
+    require_device_tensor(grad_output, "grad_output", input1.dtype)
+    dev = same_device(input1, input2, grad_output)
+    B, C, iH, iW = input1.shape
+    oH, oW = output_size(iH, iW, kH, kW, padH, padW, dilationH, dilationW, dH, dW)
+    if tuple(grad_output.shape) != (B, patchH, patchW, oH, oW):
+        raise RuntimeError(f"correlation.backward: grad_output shape {tuple(grad_output.shape)} != "
+                           f"{(B, patchH, patchW, oH, oW)}")
+    g1 = torch.empty_like(input1)
+    g2 = torch.empty_like(input2)
+    lib = _lib.load_library()
+    fn = getattr(lib, "rfn_corr_bwd_" + _suffix(input1))
+    with torch.cuda.device(dev):
+        rc = fn(ptr(input1), ptr(input2), ptr(grad_output), ptr(g1), ptr(g2), B, C, iH, iW, kH, kW, patchH, patchW,
+                padH, padW, dilationH, dilationW, dilation_patchH, dilation_patchW, dH, dW, current_stream(dev))
+    _lib.check(rc, "correlation.backward")
+    return [g1, g2]
+
+
+class SpatialCorrelationSamplerFunction(torch.autograd.Function):
+    """correlation_function.py:46-94."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, input1, input2, kernel_size=1, patch_size=1, stride=1, padding=0, dilation=1,
+                dilation_patch=1):
+        input1 = input1.contiguous()
+        input2 = input2.contiguous()
+        ctx.save_for_backward(input1, input2)
+        ctx.geometry = (*_pair(kernel_size), *_pair(patch_size), *_pair(padding), *_pair(dilation),
+                        *_pair(dilation_patch), *_pair(stride))
+        return forward(input1, input2, *ctx.geometry)
+
+    @staticmethod
+    @once_differentiable
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        g1, g2 = backward(input1, input2, grad_output, *ctx.geometry)
+        return g1, g2, None, None, None, None, None, None
+
+
+def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stride=1, padding=0, dilation=1,
+                               dilation_patch=1):
+    """Same signature and semantics as correlation_function.py:14-43.  Every parameter except the inputs may be an
+    int or a pair.  Returns (B, patchH, patchW, oH, oW)."""
+    return SpatialCorrelationSamplerFunction.apply(input1, input2, kernel_size, patch_size, stride, padding,
+                                                   dilation, dilation_patch)
+
+
+def local_correlation_layer(feature_source, feature_target, flow=None):
+    """LocalFeatureCorrelationLayer.forward (modules.py:266-274) as ONE kernel: patch-9 correlation (input1 = target,
+    input2 = source) + ReLU + L2-normalisation over the 81 shifts -> (B,81,H,W).
+
+    With `flow` (B,2,H,W; pixels of this level) the source features are bilinearly warped on the fly while the tile is
+    staged in LDS, i.e. warp(feature_source, flow) of uawarpc.py:149-152 is fused in and never materialised.
+    Inference-only (the UDA step runs align under no_grad, segmentation_model.py:194).
+    """
+    require_device_tensor(feature_target, "feature_target", torch.float32)
+    require_device_tensor(feature_source, "feature_source", torch.float32)
+    if flow is not None:
+        require_device_tensor(flow, "flow", torch.float32)
+    dev = same_device(feature_target, feature_source, flow)
+    if feature_target.shape != feature_source.shape or feature_target.dim() != 4:
+        raise RuntimeError("local_correlation_layer: features must both be (B,C,H,W) of the same shape")
+    B, C, H, W = feature_target.shape
+    if flow is not None and tuple(flow.shape) != (B, 2, H, W):
+        raise RuntimeError("local_correlation_layer: flow must be (B,2,H,W)")
+    out = torch.empty((B, 81, H, W), dtype=torch.float32, device=dev)
+    lib = _lib.load_library()
+    with torch.cuda.device(dev):
+        rc = lib.rfn_local_corr_layer_f32(ptr(feature_target), ptr(feature_source), ptr(flow), ptr(out), B, C, H, W,
+                                          current_stream(dev))
+    _lib.check(rc, "local_correlation_layer")
+    return out

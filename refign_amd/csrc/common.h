@@ -1,0 +1,42 @@
+// refign_amd/csrc/common.h -- shared helpers for the gfx950 kernels (error reporting, launch checks, math).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/refign_hip.h"
+
+namespace rfn {
+
+// Thread-local last-error message (rfn_last_error()).
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RFN_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return RFN_OK;
+}
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace rfn
+
+#define RFN_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return rfn::fail(RFN_EINVAL, __VA_ARGS__); \
+  } while (0)

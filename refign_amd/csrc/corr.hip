@@ -1,0 +1,487 @@
+// refign_amd/csrc/corr.hip -- spatial correlation sampler for gfx950 (MI355X), written from scratch.
+//
+// What it computes (reference: models/correlation_ops/correlation.cpp:13-42,80-129; the CUDA twin
+// correlation_cuda_kernel.cu:26-88 computes the same numbers on NHWC copies):
+//   out[n,ph,pw,h,w] = sum_c sum_{i<kH} sum_{j<kW} in1[n,c,u+i*dil,v+j*dil] * in2[n,c,u+i*dil+sU,v+j*dil+sV]
+//   u = -pad + h*stride, v = -pad + w*stride, sU = (ph - (patchH-1)/2)*dil_patch, zero outside the image.
+//
+// Two forward kernels:
+//   * corr9_tile_kernel -- the ONE parameterisation the hot path uses (kernel 1, patch 9, stride 1, pad 0;
+//     models/modules.py:268-270).  HBM-bound by design: algorithmic traffic 4*(2C+81) bytes per pixel against
+//     162*C flops per pixel (15 flop/B at C=128), so the only way to approach the HBM roofline on fp32 VALU is
+//     register tiling.  Layout:
+//       - a workgroup owns a TH x 64 pixel tile and walks the channels in chunks of CC; per chunk the
+//         target tile (TH x 64) and the source tile with its 4-pixel halo ((TH+8) x 72) are staged in LDS with
+//         16-byte coalesced global loads (NCHW rows are contiguous along w);
+//       - a thread owns a strip of 4 consecutive pixels x 9 horizontal shifts x 3 vertical shifts
+//         = 108 fp32 accumulators; per channel it issues 1 + 9 ds_read_b128 (40 dwords) for 108 FMAs;
+//         the three vertical-shift groups of a tile are three sets of waves (wave-uniform, no divergence);
+//       - lanes 16-31 / 48-63 of a wave take their strips rotated by 14 so that, with the 72-dword row pitch,
+//         every ds_read_b128 lane group {0-3,12-15,20-27}/{4-11,16-19,28-31} hits 64 distinct banks
+//         (MI355X LDS: b128 reads are serviced in those non-contiguous 16-lane groups);
+//       - the 81 output planes are written once, 16 bytes per lane, contiguous along w.
+//     Optional fusions selected by template flags:
+//       FUSE  : ReLU + L2-normalisation over the 81 shifts (LocalFeatureCorrelationLayer, modules.py:272-273)
+//               in the epilogue -- saves three full passes over the 81xHxW volume;
+//       WARP  : the source tile is produced by bilinear-warping the un-warped source features with the flow
+//               while staging (helpers/matching_utils.py:11-49) -- the warped feature map never exists in HBM.
+//   * corr_generic_fwd_kernel -- any parameterisation, one thread per output element, float or double.
+//
+// Backward (reference: correlation.cpp:44-78,131-183; CUDA gather form correlation_cuda_kernel.cu:91-238):
+//   * corr_k1_bwd_kernel     -- gather form for kernel 1 / stride 1 / pad 0 (deterministic, no atomics);
+//   * corr_generic_bwd_kernel -- scatter with hardware float/double atomics for everything else.
+#include "common.h"
+
+namespace rfn {
+
+// --------------------------------------------------------------------------------------------------------
+// Tiled patch-9 forward
+// --------------------------------------------------------------------------------------------------------
+constexpr int kTW = 64;            // tile width in pixels
+constexpr int kStrips = 16;        // 4-pixel strips per tile row
+constexpr int kHalo = 4;           // (9-1)/2
+constexpr int kPitch = kTW + 2 * kHalo;  // 72 dwords: LDS row pitch of BOTH tiles (same bank geometry)
+
+// bilinear tap of the warp (matching_utils.py:35-43): returns the 4 clamped offsets and weights (0 for taps
+// outside the image => zero padding).
+struct WarpTap {
+  int o00, o01, o10, o11;
+  float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ WarpTap make_tap(float gx, float gy, float fx, float fy, int H, int W) {
+#pragma clang fp contract(off)
+  // normalise exactly as the reference does (2*v/max(W-1,1) - 1), then ATen's align_corners=True unnormalise
+  const float wm = (float)max(W - 1, 1), hm = (float)max(H - 1, 1);
+  float vx = 2.0f * (gx + fx) / wm - 1.0f;
+  float vy = 2.0f * (gy + fy) / hm - 1.0f;
+  float ix = ((vx + 1.0f) / 2.0f) * (float)(W - 1);
+  float iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
+  float x0f = floorf(ix), y0f = floorf(iy);
+  float tx = ix - x0f, ty = iy - y0f;
+  // guard int conversion against huge / NaN flows
+  x0f = fminf(fmaxf(x0f, -2.0f), (float)W);
+  y0f = fminf(fmaxf(y0f, -2.0f), (float)H);
+  if (!(ix == ix) || !(iy == iy)) { x0f = -2.0f; y0f = -2.0f; }
+  int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+  bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+  int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+  int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+  WarpTap t;
+  t.o00 = cy0 * W + cx0; t.o01 = cy0 * W + cx1; t.o10 = cy1 * W + cx0; t.o11 = cy1 * W + cx1;
+  float ax = 1.0f - tx, ay = 1.0f - ty;
+  t.w00 = (vx0 && vy0) ? ax * ay : 0.0f;
+  t.w01 = (vx1 && vy0) ? tx * ay : 0.0f;
+  t.w10 = (vx0 && vy1) ? ax * ty : 0.0f;
+  t.w11 = (vx1 && vy1) ? tx * ty : 0.0f;
+  return t;
+}
+
+template <int TH, int CC, bool FUSE, bool WARP>
+__global__ __launch_bounds__(TH * kStrips * 3) void corr9_tile_kernel(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ flow,
+    float* __restrict__ out, int C, int H, int W, int tilesX, int tilesY) {
+  constexpr int NT = TH * kStrips * 3;
+  constexpr int R2 = TH + 2 * kHalo;
+  __shared__ __attribute__((aligned(16))) float smem[CC * (R2 + TH) * kPitch];
+  float* s2 = smem;                      // [CC][R2][kPitch]  source tile + halo
+  float* s1 = smem + CC * R2 * kPitch;   // [CC][TH][kPitch]  target tile
+
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY;
+  const int n = bid / tilesY;
+  const int h0 = ty * TH, w0 = tx * kTW;
+
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int WPG = TH / 4;            // waves per vertical-shift group
+  const int dyg = wave / WPG;            // 0..2 : vertical shifts dyg*3 .. dyg*3+2   (wave-uniform)
+  const int q = lane >> 4, j = lane & 15;
+  const int row = (wave % WPG) * 4 + q;
+  const int strip = (q & 1) ? ((j + 14) & 15) : j;   // bank-conflict-free b128 lane groups, see header
+
+  const size_t plane = (size_t)H * W;
+  const float* p1 = in1 + (size_t)n * C * plane;
+  const float* p2 = in2 + (size_t)n * C * plane;
+  const bool vec_ok = (W & 3) == 0;
+
+  float acc[3][9][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 9; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[a][b][i] = 0.0f;
+
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    __syncthreads();  // previous chunk fully consumed
+    // ---- stage the target tile: CC x TH rows x 16 float4 ----
+    for (int idx = tid; idx < CC * TH * kStrips; idx += NT) {
+      const int v = idx % kStrips, r = (idx / kStrips) % TH, c = idx / (kStrips * TH);
+      const int gy = h0 + r, gx = w0 + 4 * v, gc = c0 + c;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gc < C && gy < H) {
+        const float* src = p1 + (size_t)gc * plane + (size_t)gy * W + gx;
+        if (vec_ok && gx + 3 < W) {
+          val = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (gx + 0 < W) val.x = src[0];
+          if (gx + 1 < W) val.y = src[1];
+          if (gx + 2 < W) val.z = src[2];
+          if (gx + 3 < W) val.w = src[3];
+        }
+      }
+      *reinterpret_cast<float4*>(&s1[(c * TH + r) * kPitch + 4 * v]) = val;
+    }
+    // ---- stage the source tile with halo ----
+    if constexpr (!WARP) {
+      constexpr int V2 = kPitch / 4;  // 18 float4 per row
+      for (int idx = tid; idx < CC * R2 * V2; idx += NT) {
+        const int v = idx % V2, r = (idx / V2) % R2, c = idx / (V2 * R2);
+        const int gy = h0 - kHalo + r, gx = w0 - kHalo + 4 * v, gc = c0 + c;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gc < C && gy >= 0 && gy < H) {
+          const float* src = p2 + (size_t)gc * plane + (size_t)gy * W + gx;
+          if (vec_ok && gx >= 0 && gx + 3 < W) {
+            val = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (gx + 0 >= 0 && gx + 0 < W) val.x = src[0];
+            if (gx + 1 >= 0 && gx + 1 < W) val.y = src[1];
+            if (gx + 2 >= 0 && gx + 2 < W) val.z = src[2];
+            if (gx + 3 >= 0 && gx + 3 < W) val.w = src[3];
+          }
+        }
+        *reinterpret_cast<float4*>(&s2[(c * R2 + r) * kPitch + 4 * v]) = val;
+      }
+    } else {
+      // one (row, col) position per iteration, all CC channels: the bilinear taps are channel-independent
+      const float* fl = flow + (size_t)n * 2 * plane;
+      for (int pos = tid; pos < R2 * kPitch; pos += NT) {
+        const int x = pos % kPitch, r = pos / kPitch;
+        const int gy = h0 - kHalo + r, gx = w0 - kHalo + x;
+        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        WarpTap t;
+        if (inside) {
+          const float fx = fl[(size_t)gy * W + gx], fy = fl[plane + (size_t)gy * W + gx];
+          t = make_tap((float)gx, (float)gy, fx, fy, H, W);
+        }
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+          float val = 0.0f;
+          if (inside && c0 + c < C) {
+            const float* src = p2 + (size_t)(c0 + c) * plane;
+            // same accumulation order as ATen's grid_sampler_2d (nw, ne, sw, se)
+            val = src[t.o00] * t.w00 + src[t.o01] * t.w01 + src[t.o10] * t.w10 + src[t.o11] * t.w11;
+          }
+          s2[(c * R2 + r) * kPitch + x] = val;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 108 FMAs per channel per thread ----
+#pragma unroll 2
+    for (int c = 0; c < CC; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(&s1[(c * TH + row) * kPitch + 4 * strip]);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        const float* rp = &s2[(c * R2 + row + dyg * 3 + dyi) * kPitch + 4 * strip];
+        const float4 b0 = *reinterpret_cast<const float4*>(rp);
+        const float4 b1 = *reinterpret_cast<const float4*>(rp + 4);
+        const float4 b2 = *reinterpret_cast<const float4*>(rp + 8);
+        const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[dyi][dx][i] = fmaf(av[i], bv[i + dx], acc[dyi][dx][i]);
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  const int h = h0 + row, wx = w0 + 4 * strip;
+  float scale[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (FUSE) {
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 9; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = fmaxf(acc[a][b][i], 0.0f);
+          acc[a][b][i] = v;
+          ss[i] = fmaf(v, v, ss[i]);
+        }
+    __syncthreads();  // tiles no longer needed: reuse LDS for the 3-way reduction
+    float* red = smem;  // [3][TH][64]
+    *reinterpret_cast<float4*>(&red[(dyg * TH + row) * kTW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float tot = red[(0 * TH + row) * kTW + 4 * strip + i] + red[(1 * TH + row) * kTW + 4 * strip + i] +
+                        red[(2 * TH + row) * kTW + 4 * strip + i];
+      scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);   // F.normalize: v / max(||v||, eps)
+    }
+  }
+  if (h < H && wx < W) {
+    float* obase = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
+    const bool full = vec_ok && wx + 3 < W;
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi)
+#pragma unroll
+      for (int dx = 0; dx < 9; ++dx) {
+        float* o = obase + (size_t)(dyi * 9 + dx) * plane;
+        float r0 = acc[dyi][dx][0], r1 = acc[dyi][dx][1], r2 = acc[dyi][dx][2], r3 = acc[dyi][dx][3];
+        if constexpr (FUSE) { r0 *= scale[0]; r1 *= scale[1]; r2 *= scale[2]; r3 *= scale[3]; }
+        if (full) {
+          *reinterpret_cast<float4*>(o) = make_float4(r0, r1, r2, r3);
+        } else {
+          o[0] = r0;
+          if (wx + 1 < W) o[1] = r1;
+          if (wx + 2 < W) o[2] = r2;
+          if (wx + 3 < W) o[3] = r3;
+        }
+      }
+  }
+}
+
+template <bool FUSE, bool WARP>
+static int launch_corr9(const float* in1, const float* in2, const float* flow, float* out, int B, int C, int H,
+                        int W, hipStream_t st) {
+  constexpr int TH = 8, CC = 8;
+  const int tilesX = cdiv(W, kTW), tilesY = cdiv(H, TH);
+  const long blocks = (long)B * tilesX * tilesY;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");
+  hipLaunchKernelGGL((corr9_tile_kernel<TH, CC, FUSE, WARP>), dim3((unsigned)blocks), dim3(TH * kStrips * 3), 0,
+                     st, in1, in2, flow, out, C, H, W, tilesX, tilesY);
+  return check_launch("corr9_tile_kernel");
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Generic forward: any kernel/patch/stride/pad/dilation, one thread per output element (coalesced along w).
+// --------------------------------------------------------------------------------------------------------
+struct CorrParams {
+  int B, C, iH, iW, oH, oW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void corr_generic_fwd_kernel(const T* __restrict__ in1,
+                                                               const T* __restrict__ in2, T* __restrict__ out,
+                                                               CorrParams p, long total) {
+  const int radH = (p.patchH - 1) / 2, radW = (p.patchW - 1) / 2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int w = t % p.oW; t /= p.oW;
+    const int h = t % p.oH; t /= p.oH;
+    const int pw = t % p.patchW; t /= p.patchW;
+    const int ph = t % p.patchH;
+    const int n = t / p.patchH;
+    const int u = -p.padH + h * p.dH, v = -p.padW + w * p.dW;
+    const int sU = (ph - radH) * p.dpH, sV = (pw - radW) * p.dpW;
+    const size_t plane = (size_t)p.iH * p.iW;
+    const T* a = in1 + (size_t)n * p.C * plane;
+    const T* b = in2 + (size_t)n * p.C * plane;
+    T acc = 0;
+    for (int c = 0; c < p.C; ++c) {
+      for (int i = 0; i < p.kH; ++i) {
+        const int i1 = u + i * p.dilH, i2 = i1 + sU;
+        if (i1 < 0 || i1 >= p.iH || i2 < 0 || i2 >= p.iH) continue;
+        for (int jj = 0; jj < p.kW; ++jj) {
+          const int j1 = v + jj * p.dilW, j2 = j1 + sV;
+          if (j1 < 0 || j1 >= p.iW || j2 < 0 || j2 >= p.iW) continue;
+          acc += a[c * plane + (size_t)i1 * p.iW + j1] * b[c * plane + (size_t)i2 * p.iW + j2];
+        }
+      }
+    }
+    out[idx] = acc;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Backward, gather form for kernel 1 / stride 1 / pad 0 (deterministic): one thread per (n,c,h,w).
+//   g1[n,c,h,w] = sum_{ph,pw} gout[n,ph,pw,h,w]       * in2[n,c,h+sU,w+sV]
+//   g2[n,c,y,x] = sum_{ph,pw} gout[n,ph,pw,y-sU,x-sV] * in1[n,c,y-sU,x-sV]
+// --------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void corr_k1_bwd_kernel(const T* __restrict__ in1, const T* __restrict__ in2,
+                                                          const T* __restrict__ gout, T* __restrict__ g1,
+                                                          T* __restrict__ g2, CorrParams p, long total) {
+  const int radH = (p.patchH - 1) / 2, radW = (p.patchW - 1) / 2;
+  const size_t plane = (size_t)p.iH * p.iW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int w = t % p.iW; t /= p.iW;
+    const int h = t % p.iH; t /= p.iH;
+    const int c = t % p.C;
+    const int n = t / p.C;
+    const T* a = in1 + ((size_t)n * p.C + c) * plane;
+    const T* b = in2 + ((size_t)n * p.C + c) * plane;
+    const T* go = gout + (size_t)n * p.patchH * p.patchW * plane;
+    T s1 = 0, s2 = 0;
+    for (int ph = 0; ph < p.patchH; ++ph) {
+      const int sU = (ph - radH) * p.dpH;
+      for (int pw = 0; pw < p.patchW; ++pw) {
+        const int sV = (pw - radW) * p.dpW;
+        const T* gp = go + (size_t)(ph * p.patchW + pw) * plane;
+        const int y2 = h + sU, x2 = w + sV;
+        if (y2 >= 0 && y2 < p.iH && x2 >= 0 && x2 < p.iW) s1 += gp[(size_t)h * p.iW + w] * b[(size_t)y2 * p.iW + x2];
+        const int y1 = h - sU, x1 = w - sV;
+        if (y1 >= 0 && y1 < p.iH && x1 >= 0 && x1 < p.iW)
+          s2 += gp[(size_t)y1 * p.iW + x1] * a[(size_t)y1 * p.iW + x1];
+      }
+    }
+    g1[idx] = s1;
+    g2[idx] = s2;
+  }
+}
+
+// Generic backward: scatter with hardware atomics, one thread per gout element (grads pre-zeroed by the caller).
+template <typename T>
+__global__ __launch_bounds__(256) void corr_generic_bwd_kernel(const T* __restrict__ in1,
+                                                               const T* __restrict__ in2,
+                                                               const T* __restrict__ gout, T* __restrict__ g1,
+                                                               T* __restrict__ g2, CorrParams p, long total) {
+  const int radH = (p.patchH - 1) / 2, radW = (p.patchW - 1) / 2;
+  const size_t plane = (size_t)p.iH * p.iW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int w = t % p.oW; t /= p.oW;
+    const int h = t % p.oH; t /= p.oH;
+    const int pw = t % p.patchW; t /= p.patchW;
+    const int ph = t % p.patchH;
+    const int n = t / p.patchH;
+    const T g = gout[idx];
+    const int u = -p.padH + h * p.dH, v = -p.padW + w * p.dW;
+    const int sU = (ph - radH) * p.dpH, sV = (pw - radW) * p.dpW;
+    const T* a = in1 + (size_t)n * p.C * plane;
+    const T* b = in2 + (size_t)n * p.C * plane;
+    T* ga = g1 + (size_t)n * p.C * plane;
+    T* gb = g2 + (size_t)n * p.C * plane;
+    for (int i = 0; i < p.kH; ++i) {
+      const int i1 = u + i * p.dilH, i2 = i1 + sU;
+      if (i1 < 0 || i1 >= p.iH || i2 < 0 || i2 >= p.iH) continue;
+      for (int jj = 0; jj < p.kW; ++jj) {
+        const int j1 = v + jj * p.dilW, j2 = j1 + sV;
+        if (j1 < 0 || j1 >= p.iW || j2 < 0 || j2 >= p.iW) continue;
+        const size_t o1 = (size_t)i1 * p.iW + j1, o2 = (size_t)i2 * p.iW + j2;
+        for (int c = 0; c < p.C; ++c) {
+          atomicAdd(&gb[c * plane + o2], g * a[c * plane + o1]);
+          atomicAdd(&ga[c * plane + o1], g * b[c * plane + o2]);
+        }
+      }
+    }
+  }
+}
+
+static int fill_params(CorrParams& p, int B, int C, int iH, int iW, int kH, int kW, int patchH, int patchW,
+                       int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW) {
+  if (B <= 0 || C <= 0 || iH <= 0 || iW <= 0) return fail(RFN_EINVAL, "corr: non-positive tensor size");
+  if (kH <= 0 || kW <= 0 || patchH <= 0 || patchW <= 0 || dH <= 0 || dW <= 0 || dilH <= 0 || dilW <= 0 ||
+      dpH <= 0 || dpW <= 0 || padH < 0 || padW < 0)
+    return fail(RFN_EINVAL, "corr: invalid kernel/patch/stride/dilation/padding");
+  p = {B, C, iH, iW, 0, 0, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW};
+  p.oH = (iH + 2 * padH - ((kH - 1) * dilH + 1)) / dH + 1;
+  p.oW = (iW + 2 * padW - ((kW - 1) * dilW + 1)) / dW + 1;
+  if (p.oH <= 0 || p.oW <= 0) return fail(RFN_EINVAL, "corr: empty output (%d x %d)", p.oH, p.oW);
+  return RFN_OK;
+}
+
+static inline bool is_hot_param(const CorrParams& p) {
+  return p.kH == 1 && p.kW == 1 && p.patchH == 9 && p.patchW == 9 && p.padH == 0 && p.padW == 0 && p.dH == 1 &&
+         p.dW == 1 && p.dpH == 1 && p.dpW == 1;
+}
+static inline bool is_k1(const CorrParams& p) {
+  return p.kH == 1 && p.kW == 1 && p.padH == 0 && p.padW == 0 && p.dH == 1 && p.dW == 1;
+}
+
+template <typename T>
+static int corr_fwd_any(const T* in1, const T* in2, T* out, const CorrParams& p, hipStream_t st) {
+  const long total = (long)p.B * p.patchH * p.patchW * p.oH * p.oW;
+  const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 32);
+  hipLaunchKernelGGL((corr_generic_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, in1, in2, out, p, total);
+  return check_launch("corr_generic_fwd_kernel");
+}
+
+template <typename T>
+static int corr_bwd_any(const T* in1, const T* in2, const T* gout, T* g1, T* g2, const CorrParams& p,
+                        hipStream_t st) {
+  if (is_k1(p)) {
+    const long total = (long)p.B * p.C * p.iH * p.iW;
+    const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 32);
+    hipLaunchKernelGGL((corr_k1_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, in1, in2, gout, g1, g2, p, total);
+    return check_launch("corr_k1_bwd_kernel");
+  }
+  const size_t bytes = sizeof(T) * (size_t)p.B * p.C * p.iH * p.iW;
+  if (hipMemsetAsync(g1, 0, bytes, st) != hipSuccess || hipMemsetAsync(g2, 0, bytes, st) != hipSuccess)
+    return fail(RFN_ELAUNCH, "corr bwd: hipMemsetAsync failed");
+  const long total = (long)p.B * p.patchH * p.patchW * p.oH * p.oW;
+  const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 32);
+  hipLaunchKernelGGL((corr_generic_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, in1, in2, gout, g1, g2, p,
+                     total);
+  return check_launch("corr_generic_bwd_kernel");
+}
+
+}  // namespace rfn
+
+using namespace rfn;
+
+extern "C" {
+
+int rfn_corr_fwd_f32(const float* in1, const float* in2, float* out, int B, int C, int iH, int iW, int kH,
+                     int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW, int dpH, int dpW,
+                     int dH, int dW, rfn_stream_t stream) {
+  RFN_REQUIRE(in1 && in2 && out, "rfn_corr_fwd_f32: null pointer");
+  CorrParams p;
+  if (int rc = fill_params(p, B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW))
+    return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (is_hot_param(p)) return launch_corr9<false, false>(in1, in2, nullptr, out, B, C, iH, iW, st);
+  return corr_fwd_any<float>(in1, in2, out, p, st);
+}
+
+int rfn_corr_fwd_f64(const double* in1, const double* in2, double* out, int B, int C, int iH, int iW, int kH,
+                     int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW, int dpH, int dpW,
+                     int dH, int dW, rfn_stream_t stream) {
+  RFN_REQUIRE(in1 && in2 && out, "rfn_corr_fwd_f64: null pointer");
+  CorrParams p;
+  if (int rc = fill_params(p, B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW))
+    return rc;
+  return corr_fwd_any<double>(in1, in2, out, p, (hipStream_t)stream);
+}
+
+int rfn_corr_bwd_f32(const float* in1, const float* in2, const float* grad_out, float* grad_in1,
+                     float* grad_in2, int B, int C, int iH, int iW, int kH, int kW, int patchH, int patchW,
+                     int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW,
+                     rfn_stream_t stream) {
+  RFN_REQUIRE(in1 && in2 && grad_out && grad_in1 && grad_in2, "rfn_corr_bwd_f32: null pointer");
+  CorrParams p;
+  if (int rc = fill_params(p, B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW))
+    return rc;
+  return corr_bwd_any<float>(in1, in2, grad_out, grad_in1, grad_in2, p, (hipStream_t)stream);
+}
+
+int rfn_corr_bwd_f64(const double* in1, const double* in2, const double* grad_out, double* grad_in1,
+                     double* grad_in2, int B, int C, int iH, int iW, int kH, int kW, int patchH, int patchW,
+                     int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW,
+                     rfn_stream_t stream) {
+  RFN_REQUIRE(in1 && in2 && grad_out && grad_in1 && grad_in2, "rfn_corr_bwd_f64: null pointer");
+  CorrParams p;
+  if (int rc = fill_params(p, B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW))
+    return rc;
+  return corr_bwd_any<double>(in1, in2, grad_out, grad_in1, grad_in2, p, (hipStream_t)stream);
+}
+
+int rfn_local_corr_layer_f32(const float* feature_target, const float* feature_source, const float* flow,
+                             float* out, int B, int C, int H, int W, rfn_stream_t stream) {
+  RFN_REQUIRE(feature_target && feature_source && out, "rfn_local_corr_layer_f32: null pointer");
+  RFN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "rfn_local_corr_layer_f32: non-positive size");
+  hipStream_t st = (hipStream_t)stream;
+  if (flow) return launch_corr9<true, true>(feature_target, feature_source, flow, out, B, C, H, W, st);
+  return launch_corr9<true, false>(feature_target, feature_source, nullptr, out, B, C, H, W, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// refign_amd/csrc/warp.hip -- bilinear warp kernels (gfx950).
+//
+// Reference behaviour restated from scratch:
+//   warp()            helpers/matching_utils.py:11-49  (grid = base + flow, normalise with max(W-1,1),
+//                      grid_sample bilinear / align_corners=True / zeros; mask = strictly inside (-1,1)^2)
+//   tail of align()   models/segmentation_model.py:514-522 (bilinear align_corners=False upsampling of the
+//                      quarter-res flow and log-variance, confidence, warp of the reference logits)
+//
+// HBM-bound gathers: one thread per output pixel computes the four taps once and streams the channels, so every
+// global access of a wave is contiguous along w for the store and near-contiguous (smooth flow) for the loads.
+#include "common.h"
+
+namespace rfn {
+
+struct Tap {
+  int o00, o01, o10, o11;
+  float w00, w01, w10, w11;
+  bool inside;  // strict-inequality validity of the NORMALISED coordinate (matching_utils.py:46-47)
+};
+
+__device__ __forceinline__ Tap bilinear_tap(float gx, float gy, float fx, float fy, int H, int W) {
+#pragma clang fp contract(off)
+  const float wm = (float)max(W - 1, 1), hm = (float)max(H - 1, 1);
+  const float vx = 2.0f * (gx + fx) / wm - 1.0f;               // matching_utils.py:35
+  const float vy = 2.0f * (gy + fy) / hm - 1.0f;               // matching_utils.py:36
+  const float ix = ((vx + 1.0f) / 2.0f) * (float)(W - 1);      // ATen grid_sampler_unnormalize(align_corners)
+  const float iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
+  float x0f = floorf(ix), y0f = floorf(iy);
+  const float tx = ix - x0f, ty = iy - y0f;
+  x0f = fminf(fmaxf(x0f, -2.0f), (float)W);
+  y0f = fminf(fmaxf(y0f, -2.0f), (float)H);
+  if (!(ix == ix) || !(iy == iy)) { x0f = -2.0f; y0f = -2.0f; }
+  const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+  const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+  const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+  Tap t;
+  t.o00 = cy0 * W + cx0; t.o01 = cy0 * W + cx1; t.o10 = cy1 * W + cx0; t.o11 = cy1 * W + cx1;
+  const float ax = 1.0f - tx, ay = 1.0f - ty;
+  t.w00 = (vx0 && vy0) ? ax * ay : 0.0f;
+  t.w01 = (vx1 && vy0) ? tx * ay : 0.0f;
+  t.w10 = (vx0 && vy1) ? ax * ty : 0.0f;
+  t.w11 = (vx1 && vy1) ? tx * ty : 0.0f;
+  t.inside = (vx > -1.0f) && (vy > -1.0f) && (vx < 1.0f) && (vy < 1.0f);
+  return t;
+}
+
+__device__ __forceinline__ float tap_sample(const float* __restrict__ src, const Tap& t) {
+#pragma clang fp contract(off)
+  // ATen grid_sampler_2d accumulation order: nw, ne, sw, se
+  return src[t.o00] * t.w00 + src[t.o01] * t.w01 + src[t.o10] * t.w10 + src[t.o11] * t.w11;
+}
+
+// grid: (ceil(HW/256), channel groups, B)
+template <int CG>
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                   float* __restrict__ out, unsigned char* __restrict__ mask,
+                                                   int C, int H, int W) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (pix >= HW) return;
+  const int n = blockIdx.z, c0 = blockIdx.y * CG;
+  const int gy = pix / W, gx = pix - gy * W;
+  const float* fl = flow + (size_t)n * 2 * HW;
+  const Tap t = bilinear_tap((float)gx, (float)gy, fl[pix], fl[HW + pix], H, W);
+  if (mask != nullptr && blockIdx.y == 0) mask[(size_t)n * HW + pix] = t.inside ? 1 : 0;
+  const float* src = x + ((size_t)n * C + c0) * HW;
+  float* dst = out + ((size_t)n * C + c0) * HW + pix;
+  const int cend = min(CG, C - c0);
+  for (int c = 0; c < cend; ++c) dst[(size_t)c * HW] = tap_sample(src + (size_t)c * HW, t);
+}
+
+// ATen upsample_bilinear2d source index, align_corners=False: max(scale*(dst+0.5)-0.5, 0)
+__device__ __forceinline__ void up_index(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+#pragma clang fp contract(off)
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.0f ? 0.0f : s;
+  i0 = min((int)s, in_size - 1);
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+__device__ __forceinline__ float up_sample(const float* __restrict__ p, int w, int y0, int y1, int x0, int x1,
+                                           float ly0, float ly1, float lx0, float lx1) {
+#pragma clang fp contract(off)
+  return ly0 * (lx0 * p[y0 * w + x0] + lx1 * p[y0 * w + x1]) + ly1 * (lx0 * p[y1 * w + x0] + lx1 * p[y1 * w + x1]);
+}
+
+// grid: (ceil(HW/256), 1, B)
+__global__ __launch_bounds__(256) void align_tail_kernel(const float* __restrict__ logits,
+                                                         const float* __restrict__ flow_q,
+                                                         const float* __restrict__ logvar_q,
+                                                         float* __restrict__ warped, unsigned char* __restrict__ mask,
+                                                         float* __restrict__ cert, float* __restrict__ flow_up, int C,
+                                                         int H, int W, int h, int w, float sy, float sx) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W, hw = h * w;
+  if (pix >= HW) return;
+  const int n = blockIdx.z;
+  const int gy = pix / W, gx = pix - gy * W;
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+  up_index(gy, sy, h, y0, y1, ly0, ly1);
+  up_index(gx, sx, w, x0, x1, lx0, lx1);
+  const float* fq = flow_q + (size_t)n * 2 * hw;
+  const float fx = up_sample(fq, w, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+  const float fy = up_sample(fq + hw, w, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+  const float lv = up_sample(logvar_q + (size_t)n * hw, w, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+  // matching_utils.py:55-56 with R = 1
+  cert[(size_t)n * HW + pix] = 1.0f - expf(-1.0f / (2.0f * expf(lv)));
+  if (flow_up != nullptr) {
+    flow_up[(size_t)n * 2 * HW + pix] = fx;
+    flow_up[(size_t)n * 2 * HW + HW + pix] = fy;
+  }
+  const Tap t = bilinear_tap((float)gx, (float)gy, fx, fy, H, W);
+  mask[(size_t)n * HW + pix] = t.inside ? 1 : 0;
+  const float* src = logits + (size_t)n * C * HW;
+  float* dst = warped + (size_t)n * C * HW + pix;
+  for (int c = 0; c < C; ++c) dst[(size_t)c * HW] = tap_sample(src + (size_t)c * HW, t);
+}
+
+// F.normalize(p=2, dim=1) for NCHW: one thread per pixel, channels strided by HW (coalesced across the wave).
+__global__ __launch_bounds__(256) void l2norm_channels_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                              int C, int HW) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW) return;
+  const float* p = x + (size_t)blockIdx.y * C * HW + pix;
+  float* o = out + (size_t)blockIdx.y * C * HW + pix;
+  float ss = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    const float v = p[(size_t)c * HW];
+    ss = fmaf(v, v, ss);
+  }
+  const float d = fmaxf(sqrtf(ss), 1e-12f);
+  for (int c = 0; c < C; ++c) o[(size_t)c * HW] = p[(size_t)c * HW] / d;
+}
+
+}  // namespace rfn
+
+using namespace rfn;
+
+extern "C" {
+
+int rfn_warp_f32(const float* x, const float* flow, float* out, unsigned char* mask, int B, int C, int H, int W,
+                 rfn_stream_t stream) {
+  RFN_REQUIRE(x && flow && out, "rfn_warp_f32: null pointer");
+  RFN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "rfn_warp_f32: non-positive size");
+  RFN_REQUIRE((long)H * W < 0x7fffffffL && B <= 65535, "rfn_warp_f32: tensor too large");
+  constexpr int CG = 32;
+  dim3 grid(cdiv((long)H * W, 256), cdiv(C, CG), B);
+  hipLaunchKernelGGL((warp_kernel<CG>), grid, dim3(256), 0, (hipStream_t)stream, x, flow, out, mask, C, H, W);
+  return check_launch("warp_kernel");
+}
+
+int rfn_align_tail_f32(const float* logits_ref, const float* flow_q, const float* logvar_q, float* warped,
+                       unsigned char* mask, float* cert, float* flow_up, int B, int C, int H, int W, int h, int w,
+                       rfn_stream_t stream) {
+  RFN_REQUIRE(logits_ref && flow_q && logvar_q && warped && mask && cert, "rfn_align_tail_f32: null pointer");
+  RFN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && h > 0 && w > 0, "rfn_align_tail_f32: non-positive size");
+  RFN_REQUIRE((long)H * W < 0x7fffffffL && B <= 65535, "rfn_align_tail_f32: tensor too large");
+  dim3 grid(cdiv((long)H * W, 256), 1, B);
+  // ATen area_pixel_compute_scale(align_corners=False, no explicit scale): input_size / output_size in float
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  hipLaunchKernelGGL(align_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, logits_ref, flow_q, logvar_q,
+                     warped, mask, cert, flow_up, C, H, W, h, w, sy, sx);
+  return check_launch("align_tail_kernel");
+}
+
+int rfn_l2norm_channels_f32(const float* x, float* out, int B, int C, int HW, rfn_stream_t stream) {
+  RFN_REQUIRE(x && out, "rfn_l2norm_channels_f32: null pointer");
+  RFN_REQUIRE(B > 0 && C > 0 && HW > 0 && B <= 65535, "rfn_l2norm_channels_f32: bad size");
+  dim3 grid(cdiv(HW, 256), B);
+  hipLaunchKernelGGL(l2norm_channels_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, C, HW);
+  return check_launch("l2norm_channels_kernel");
+}
+
+}  // extern "C"

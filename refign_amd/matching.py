@@ -1,0 +1,106 @@
+"""Host mirror of helpers/matching_utils.py for the functions on the hot path (warp, mapping->flow, confidence),
+backed by the HIP kernels in csrc/warp.hip.  Same names, argument meaning and return conventions."""
+import torch
+
+from . import _lib
+from ._tensor import current_stream, ptr, require_device_tensor, same_device
+
+
+def warp(x, flo, padding_mode='zeros', return_mask=False):
+    """warp an image/tensor back according to the flow (matching_utils.py:11-49).
+
+    x: [B,C,H,W], flo: [B,2,H,W] in pixels.  Bilinear, align_corners=True, zero padding; the mask is True where the
+    normalised sampling position is strictly inside (-1,1)^2.  Like the reference, an identically-zero flow returns
+    `x` itself (and an all-True mask) -- that costs one host sync, as it does there (matching_utils.py:19).
+    """
+    if padding_mode != 'zeros':
+        raise RuntimeError("warp: only padding_mode='zeros' is used by the reference hot path")
+    x = require_device_tensor(x.float().contiguous(), "x", torch.float32)
+    flo = require_device_tensor(flo.float().contiguous(), "flo", torch.float32)
+    dev = same_device(x, flo)
+    B, C, H, W = x.shape
+    if tuple(flo.shape) != (B, 2, H, W):
+        raise RuntimeError("warp: flo must be (B,2,H,W)")
+    if bool(torch.all(flo == 0)):
+        if return_mask:
+            return x, torch.ones((B, H, W), dtype=torch.bool, device=dev)
+        return x
+    return warp_nocheck(x, flo, return_mask)
+
+
+def warp_nocheck(x, flo, return_mask=False):
+    """warp() without the `flo == 0` host synchronisation (graph-capturable)."""
+    dev = x.device
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev) if return_mask else None
+    lib = _lib.load_library()
+    with torch.cuda.device(dev):
+        rc = lib.rfn_warp_f32(ptr(x), ptr(flo), ptr(out), ptr(mask), B, C, H, W, current_stream(dev))
+    _lib.check(rc, "warp")
+    if return_mask:
+        return out, mask.view(torch.bool)
+    return out
+
+
+def l2_normalize_channels(x):
+    """F.normalize(x, p=2, dim=1) for NCHW features (uawarpc.py:101-108)."""
+    x = require_device_tensor(x.contiguous(), "x", torch.float32)
+    B, C = x.shape[:2]
+    hw = x[0, 0].numel()
+    out = torch.empty_like(x)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.rfn_l2norm_channels_f32(ptr(x), ptr(out), B, C, hw, current_stream(x.device))
+    _lib.check(rc, "l2_normalize_channels")
+    return out
+
+
+def unnormalise_and_convert_mapping_to_flow(map, output_channel_first=True):
+    """matching_utils.py:77-103 (4-D case): mapping normalised to [-1,1] -> flow in pixels.  16x16 only on the hot
+    path, so this stays a handful of tensor ops."""
+    if map.dim() != 4:
+        raise RuntimeError("unnormalise_and_convert_mapping_to_flow: expects (B,2,H,W)")
+    if map.shape[1] != 2:
+        map = map.permute(0, 3, 1, 2)
+    B, C, H, W = map.shape
+    xx = torch.arange(0, W, dtype=map.dtype, device=map.device).view(1, 1, W)
+    yy = torch.arange(0, H, dtype=map.dtype, device=map.device).view(1, H, 1)
+    fx = (map[:, 0] + 1) * (W - 1) / 2.0 - xx
+    fy = (map[:, 1] + 1) * (H - 1) / 2.0 - yy
+    flow = torch.stack((fx, fy), dim=1)
+    if not output_channel_first:
+        flow = flow.permute(0, 2, 3, 1)
+    return flow
+
+
+def estimate_probability_of_confidence_interval_of_mixture_density(uncert_output, R=1.0):
+    """matching_utils.py:52-57 (Gaussian only)."""
+    assert uncert_output.shape[1] == 1
+    var = torch.exp(uncert_output)
+    return 1.0 - torch.exp(-R ** 2 / (2 * var))
+
+
+def align_tail(logits_ref, flow_q, logvar_q, return_flow=False):
+    """Fused tail of align() (segmentation_model.py:514-522): bilinear-upsample the quarter-res flow / log-variance
+    to the logits' size, confidence P_R, warp the reference logits.  Returns (warped, mask, cert[, flow_up])."""
+    logits_ref = require_device_tensor(logits_ref.contiguous(), "logits_ref", torch.float32)
+    flow_q = require_device_tensor(flow_q.contiguous(), "flow_q", torch.float32)
+    logvar_q = require_device_tensor(logvar_q.contiguous(), "logvar_q", torch.float32)
+    dev = same_device(logits_ref, flow_q, logvar_q)
+    B, C, H, W = logits_ref.shape
+    h, w = flow_q.shape[-2:]
+    if tuple(flow_q.shape) != (B, 2, h, w) or tuple(logvar_q.shape) != (B, 1, h, w):
+        raise RuntimeError("align_tail: flow_q must be (B,2,h,w) and logvar_q (B,1,h,w)")
+    warped = torch.empty_like(logits_ref)
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    cert = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+    flow_up = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev) if return_flow else None
+    lib = _lib.load_library()
+    with torch.cuda.device(dev):
+        rc = lib.rfn_align_tail_f32(ptr(logits_ref), ptr(flow_q), ptr(logvar_q), ptr(warped), ptr(mask), ptr(cert),
+                                    ptr(flow_up), B, C, H, W, h, w, current_stream(dev))
+    _lib.check(rc, "align_tail")
+    if return_flow:
+        return warped, mask.view(torch.bool), cert, flow_up
+    return warped, mask.view(torch.bool), cert

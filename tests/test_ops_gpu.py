@@ -1,0 +1,197 @@
+"""GPU parity: the HIP kernels (through the C ABI) against the golden vectors captured from the reference and against
+the CPU oracle on fresh seeded inputs, plus size-independent properties at the benchmark's full sizes."""
+import numpy as np
+import pytest
+import torch
+from conftest import golden, golden_names
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ------------------------------------------------------------------ correlation sampler (a1-a5) -> G1
+@pytest.mark.parametrize("name", golden_names("corr_"))
+def test_corr_fwd_bwd_golden(dev, name):
+    from refign_amd import correlation
+    g = golden(name)
+    a = [int(v) for v in g["args"]]
+    in1, in2, go = T(g["in1"], dev), T(g["in2"], dev), T(g["grad_out"], dev)
+    out = correlation.forward(in1, in2, *a)
+    tol = dict(rtol=1e-4, atol=1e-4) if g["in1"].dtype == np.float32 else dict(rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], **tol)
+    g1, g2 = correlation.backward(in1, in2, go, *a)
+    np.testing.assert_allclose(g1.cpu().numpy(), g["grad_in1"], **tol)
+    np.testing.assert_allclose(g2.cpu().numpy(), g["grad_in2"], **tol)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 3, 2, 130), (2, 9, 17, 63), (1, 130, 9, 65), (3, 8, 8, 64)])
+def test_corr_hot_vs_oracle_ragged(dev, oracle, shape):
+    """ragged / tiny / tile-boundary sizes of the hot parameterisation, autograd API"""
+    from refign_amd.correlation import spatial_correlation_sample
+    rng = np.random.default_rng(sum(shape))
+    a = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape).astype(np.float32)
+    ta, tb = T(a, dev).requires_grad_(), T(b, dev).requires_grad_()
+    out = spatial_correlation_sample(ta, tb, patch_size=9)
+    want = oracle.corr_forward(a, b, patch_size=9)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    go = rng.standard_normal(want.shape).astype(np.float32)
+    out.backward(T(go, dev))
+    w1, w2 = oracle.corr_backward(a, b, go, patch_size=9)
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), w1, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(tb.grad.cpu().numpy(), w2, rtol=1e-4, atol=1e-4)
+
+
+def test_corr_errors(dev):
+    from refign_amd import correlation
+    a = torch.zeros(1, 2, 4, 4, device=dev)
+    with pytest.raises(RuntimeError):
+        correlation.forward(a, torch.zeros(1, 2, 4, 5, device=dev), 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        correlation.forward(a, a, 9, 9, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1)      # kernel larger than the image
+    with pytest.raises(RuntimeError):
+        correlation.forward(a.half(), a.half(), 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        correlation.forward(a.transpose(2, 3), a, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)   # non-contiguous
+
+
+def test_corr_full_size_properties(dev):
+    """K4 level-1 size (C=128, 270x480): linearity in input1, shift structure, and agreement with torch on a sampled
+    set of shifts (size-independent properties; the oracle would take seconds per call here)."""
+    from refign_amd.correlation import spatial_correlation_sample
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn(1, 128, 270, 480, generator=g).to(dev)
+    b = torch.randn(1, 128, 270, 480, generator=g).to(dev)
+    a2 = torch.randn(1, 128, 270, 480, generator=g).to(dev)
+    o1 = spatial_correlation_sample(a, b, patch_size=9)
+    o2 = spatial_correlation_sample(a2, b, patch_size=9)
+    o12 = spatial_correlation_sample(a + 2 * a2, b, patch_size=9)
+    assert torch.allclose(o12, o1 + 2 * o2, rtol=1e-3, atol=2e-3)
+    for (ph, pw) in [(0, 0), (4, 4), (8, 8), (2, 7), (6, 1)]:
+        dy, dx = ph - 4, pw - 4
+        bs = torch.zeros_like(b)
+        ys, ye = max(0, -dy), min(270, 270 - dy)
+        xs, xe = max(0, -dx), min(480, 480 - dx)
+        bs[:, :, ys:ye, xs:xe] = b[:, :, ys + dy:ye + dy, xs + dx:xe + dx]
+        want = (a.double() * bs.double()).sum(1)
+        assert torch.allclose(o1[:, ph, pw].double(), want, rtol=1e-4, atol=1e-3), (ph, pw)
+
+
+# ------------------------------------------------------------------ LocalFeatureCorrelationLayer (a6) -> G2
+@pytest.mark.parametrize("name", golden_names("localcorr_"))
+def test_local_layer_golden(dev, name):
+    from refign_amd.correlation import local_correlation_layer
+    g = golden(name)
+    out = local_correlation_layer(T(g["source"], dev), T(g["target"], dev))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+
+
+def test_local_layer_fused_warp_vs_oracle(dev, oracle):
+    """warp -> correlate -> relu -> l2norm in one kernel == oracle.warp followed by the oracle layer"""
+    from refign_amd.correlation import local_correlation_layer
+    rng = np.random.default_rng(11)
+    B, C, H, W = 2, 24, 21, 70
+    src = oracle.l2_normalize(rng.standard_normal((B, C, H, W)).astype(np.float32))
+    trg = oracle.l2_normalize(rng.standard_normal((B, C, H, W)).astype(np.float32))
+    flo = (2.5 * rng.standard_normal((B, 2, H, W))).astype(np.float32)
+    flo[0, :, :3, :3] = 40.0   # out of range region
+    want = oracle.local_correlation_layer(oracle.warp(src, flo), trg)
+    out = local_correlation_layer(T(src, dev), T(trg, dev), flow=T(flo, dev))
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-3, atol=2e-5)
+
+
+# ------------------------------------------------------------------ GlobalFeatureCorrelationLayer (a7) -> G3
+@pytest.mark.parametrize("name", ["globalcorr_c64_16x16", "globalcorr_c24_5x7_6x4"])
+def test_global_layer_golden(dev, name):
+    from refign_amd.modules import GlobalFeatureCorrelationLayer
+    g = golden(name)
+    out = GlobalFeatureCorrelationLayer(cyclic_consistency=True)(T(g["source"], dev), T(g["target"], dev))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=2e-4, atol=2e-6)
+
+
+def test_global_layer_level4(dev):
+    from fill import hashed_uniform
+    from refign_amd.matching import l2_normalize_channels
+    from refign_amd.modules import GlobalFeatureCorrelationLayer
+    g = golden("globalcorr_c512_level4")
+    src = l2_normalize_channels(T(hashed_uniform((2, 512, 16, 16), "g3/src") - 0.5, dev))
+    trg = l2_normalize_channels(T(hashed_uniform((2, 512, 16, 16), "g3/trg") - 0.5, dev))
+    out = GlobalFeatureCorrelationLayer()(src, trg).cpu().numpy()
+    np.testing.assert_allclose(out[:, ::7, ::3, ::5], g["out_sample"], rtol=5e-4, atol=5e-6)
+    assert abs(out.astype(np.float64).sum() - g["checksum"]) < 1e-3 * g["abs_checksum"]
+
+
+# ------------------------------------------------------------------ warp (a12) -> G6
+@pytest.mark.parametrize("name", golden_names("warp_"))
+def test_warp_golden(dev, name):
+    from refign_amd.matching import warp
+    g = golden(name)
+    out, mask = warp(T(g["x"], dev), T(g["flow"], dev), return_mask=True)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])
+
+
+def test_matching_misc_golden(dev):
+    from refign_amd import matching
+    g = golden("matching_misc")
+    f = matching.unnormalise_and_convert_mapping_to_flow(T(g["mapping"], dev))
+    np.testing.assert_allclose(f.cpu().numpy(), g["flow"], atol=1e-5)
+    c = matching.estimate_probability_of_confidence_interval_of_mixture_density(T(g["logvar"], dev))
+    np.testing.assert_allclose(c.cpu().numpy(), g["conf"], rtol=1e-5, atol=1e-6)
+
+
+def test_align_tail_vs_unfused(dev, oracle):
+    """fused upsample+confidence+warp == torch bilinear upsample -> oracle confidence -> oracle warp"""
+    from refign_amd.matching import align_tail
+    rng = np.random.default_rng(3)
+    B, H, W, h, w = 2, 52, 76, 13, 19
+    logits = rng.standard_normal((B, 19, H, W)).astype(np.float32)
+    fq = (4 * rng.standard_normal((B, 2, h, w))).astype(np.float32)
+    lq = rng.uniform(-4, 4, (B, 1, h, w)).astype(np.float32)
+    fu = torch.nn.functional.interpolate(torch.from_numpy(fq), size=(H, W), mode="bilinear", align_corners=False).numpy()
+    lu = torch.nn.functional.interpolate(torch.from_numpy(lq), size=(H, W), mode="bilinear", align_corners=False).numpy()
+    want_w, want_m = oracle.warp(logits, fu, return_mask=True)
+    warped, mask, cert, flow_up = align_tail(T(logits, dev), T(fq, dev), T(lq, dev), return_flow=True)
+    np.testing.assert_allclose(flow_up.cpu().numpy(), fu, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cert.cpu().numpy(), oracle.confidence_from_logvar(lu), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(warped.cpu().numpy(), want_w, rtol=1e-4, atol=2e-4)
+    assert (mask.cpu().numpy() != want_m).mean() < 1e-3    # only pixels within 1 ulp of the border may differ
+
+
+# ------------------------------------------------------------------ refine (a17, a24) -> G8
+@pytest.mark.parametrize("name", golden_names("refine_"))
+def test_refine_golden(dev, name):
+    from refign_amd.refine import refine
+    g = golden(name)
+    if bool(g["no_mask"]):
+        out = refine(T(g["logits_trg"], dev), T(g["logits_ref"], dev), None, None, gamma=float(g["gamma"]))
+    else:
+        out = refine(T(g["logits_trg"], dev), T(g["logits_ref"], dev), T(g["mask"], dev), T(g["cert"], dev),
+                     gamma=float(g["gamma"]), disable_M=bool(g["disable_M"]), disable_P=bool(g["disable_P"]))
+    out = out.cpu().numpy()
+    np.testing.assert_allclose(out, g["out"], rtol=1e-4, atol=1e-5)     # north star: 1e-3
+    # pixel-exact argmax mask wherever the reference's top-2 margin is above float noise
+    srt = np.sort(g["out"], axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > 1e-5
+    assert np.array_equal(out.argmax(1)[decided], g["pseudo_label"][decided])
+    assert decided.mean() > 0.99
+
+
+def test_refine_full_size_properties(dev):
+    """1080x1920: identical trg/ref logits => output == softmax (blend of equal things); invalid mask => softmax"""
+    from refign_amd.refine import refine
+    g = torch.Generator(device="cpu").manual_seed(9)
+    lt = (2 * torch.randn(2, 19, 1080, 1920, generator=g)).to(dev)
+    cert = torch.rand(2, 1, 1080, 1920, generator=g).to(dev)
+    mask = torch.ones(2, 1080, 1920, dtype=torch.bool, device=dev)
+    sm = torch.softmax(lt, dim=1)
+    out = refine(lt, lt.clone(), mask, cert)
+    assert torch.allclose(out, sm, rtol=1e-4, atol=1e-6)
+    lr = lt.flip(1).contiguous()
+    out = refine(lt, lr, torch.zeros_like(mask), cert)
+    assert torch.allclose(out, sm, rtol=1e-4, atol=1e-6)
+    out = refine(lt, lr, mask, cert)
+    assert torch.isfinite(out).all() and (out >= 0).all() and (out <= 1.0001).all()
