@@ -27,7 +27,7 @@ SIGNATURES = {
     "rfn_corr_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
     "rfn_corr_bwd_f64": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
     "rfn_local_corr_layer_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
-    "rfn_global_corr_layer_f32": (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
+    "rfn_global_corr_layer_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     "rfn_warp_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "rfn_l2norm_channels_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "rfn_refine_workspace_bytes": (ctypes.c_ulong, [c_int]),
@@ -52,6 +52,10 @@ def load_library():
             raise RuntimeError(
                 f"refign_amd: HIP library not built: {_LIB_PATH} is missing. Run `python -c 'import "
                 f"__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch owns device memory and streams; import it FIRST so that its bundled libamdhip64.so.7 is the one HIP
+        # runtime in the process (our .so NEEDs the same SONAME and binds to the already-loaded copy).  Loading ours
+        # first would pull /opt/rocm's runtime in beside torch's: two runtimes, "no ROCm-capable device" at launch.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:
