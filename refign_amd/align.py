@@ -1,0 +1,452 @@
+"""UAWarpC align path: VGG-16 pyramid -> coarse-to-fine flow + log-variance -> warp of the reference logits.
+
+Host mirror of (brdav/refign):
+  models/backbones/vgg.py            VGG(model_type, out_indices, pretrained).forward(x, extract_only_indices)
+  models/modules.py:16-56,395-561    ConvBNReLU, OpticalFlowEstimatorResidualConnection, RefinementModule,
+                                     UncertaintyModule
+  models/heads/uawarpc.py            UAWarpCHead(in_index, input_transform, ..., estimate_uncertainty).forward(
+                                     trg, src, trg_256, src_256, out_size)
+  models/segmentation_model.py:493-523   align()      models/alignment_model.py:55-79   AlignmentModel.forward
+
+The module tree and therefore the state_dict keys are identical to the reference's
+(`decoder4.conv_0.conv.weight`, `estimate_uncertainty_components1.pred_conv_0.bn.running_var`,
+`refinement_module_finest.dc_convs.3.conv.weight`, `features.17.bias`, ...) so reference checkpoints load with
+strict=True.  The execution is not a transcription:
+  * correlation volumes, warps, ReLU/L2-norm and the logits tail run in the HIP kernels of csrc/ -- the warped feature
+    maps of levels 3/2/1 are never materialised (warp fused into the correlation staging),
+  * the alignment nets are frozen and always in eval() on the UDA step (segmentation_model.py:73-75,693-694), so
+    BatchNorm is folded into the convolution weights once and LeakyReLU rides on the conv output,
+  * per-channel flow rescalings between pixel-unit systems are folded into scalar multipliers.
+Dense convolutions currently go through the ROCm library conv (torch.nn.functional.conv2d -> MIOpen); they are the
+next kernels to be replaced by hand-written MFMA implicit-GEMM ("What is library code today").
+"""
+import math
+import os
+from typing import List, Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import matching
+from .modules import GlobalFeatureCorrelationLayer, LocalFeatureCorrelationLayer
+
+LEAKY_SLOPE = 0.1   # activation_layer = partial(nn.LeakyReLU, negative_slope=0.1)  (modules.py:407,459,498)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# building block: conv [+ BN] [+ activation]  (state_dict: conv.weight[, conv.bias], bn.*)
+# ---------------------------------------------------------------------------------------------------------------------
+class ConvBNReLU(nn.Module):
+    """Same constructor semantics and parameter names as models/modules.py:16-56 (non depthwise-separable case)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, groups=1, padding=None,
+                 norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, bias='auto', depthwise_separable=False,
+                 inplace=True, affine=True):
+        super().__init__()
+        if depthwise_separable:
+            raise NotImplementedError("depthwise_separable ConvBNReLU is not on the align path")
+        self.padding = dilation * (kernel_size - 1) // 2 if padding is None else padding
+        self.stride, self.dilation, self.groups = stride, dilation, groups
+        self.use_norm = norm_layer is not None
+        if bias == 'auto':
+            bias = not self.use_norm
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, self.padding, dilation=dilation,
+                              groups=groups, bias=bias)
+        if self.use_norm:
+            self.bn = norm_layer(out_channels, affine=affine)
+        # activation: None, 'relu' or 'leaky' (negative slope 0.1)
+        if activation_layer is None:
+            self.act = None
+        else:
+            probe = activation_layer()
+            self.act = 'leaky' if isinstance(probe, nn.LeakyReLU) else 'relu'
+            self.act_slope = getattr(probe, 'negative_slope', 0.0)
+        self._folded = None
+
+    def folded(self):
+        """(weight, bias) with eval-mode BatchNorm folded in; cached until the module is put back in train()."""
+        if self._folded is None:
+            w, b = self.conv.weight, self.conv.bias
+            if self.use_norm:
+                bn = self.bn
+                inv = torch.rsqrt(bn.running_var + bn.eps)
+                g = inv if bn.weight is None else bn.weight * inv
+                w = w * g.view(-1, 1, 1, 1)
+                shift = -bn.running_mean * g
+                if bn.bias is not None:
+                    shift = shift + bn.bias
+                b = shift if b is None else b * g + shift
+            self._folded = (w.detach().contiguous(), None if b is None else b.detach().contiguous())
+        return self._folded
+
+    def train(self, mode=True):
+        self._folded = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._folded = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def forward(self, x, act=True):
+        if self.training or torch.is_grad_enabled():
+            x = self.conv(x)
+            if self.use_norm:
+                x = self.bn(x)
+        else:
+            w, b = self.folded()
+            x = F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
+        if act and self.act is not None:
+            x = F.leaky_relu(x, self.act_slope, inplace=True) if self.act == 'leaky' else F.relu(x, inplace=True)
+        return x
+
+
+def _leaky():
+    return nn.LeakyReLU(LEAKY_SLOPE)
+
+
+class OpticalFlowEstimatorResidualConnection(nn.Module):
+    """Flow decoder (models/modules.py:395-443): 3x3 stack in->128->128->96->64->32 with two 1x1 skip projections,
+    then a 3x3 head to `out_channels`; returns (mapping, 32-channel feature) when output_x."""
+
+    def __init__(self, in_channels, out_channels=2, batch_norm=True, output_x=False, extra_bias='auto'):
+        super().__init__()
+        self.output_x = output_x
+        nl = nn.BatchNorm2d if batch_norm else None
+        kw = dict(norm_layer=nl, bias=extra_bias)
+        self.conv_0 = ConvBNReLU(in_channels, 128, 3, activation_layer=None, **kw)
+        self.conv0_skip = ConvBNReLU(128, 96, 1, norm_layer=nl, activation_layer=None)
+        self.conv_1 = ConvBNReLU(128, 128, 3, activation_layer=_leaky, **kw)
+        self.conv_2 = ConvBNReLU(128, 96, 3, activation_layer=None, **kw)
+        self.conv2_skip = ConvBNReLU(96, 32, 1, norm_layer=nl, activation_layer=None)
+        self.conv_3 = ConvBNReLU(96, 64, 3, activation_layer=_leaky, **kw)
+        self.conv_4 = ConvBNReLU(64, 32, 3, activation_layer=None, **kw)
+        self.predict_mapping = nn.Conv2d(32, out_channels, kernel_size=3, padding=1, bias=True)
+
+    def forward(self, x):
+        x0 = self.conv_0(x)                                             # pre-activation kept for the skip
+        t = self.conv_2(self.conv_1(F.leaky_relu(x0, LEAKY_SLOPE)))
+        x2 = t + self.conv0_skip(x0)
+        t = self.conv_4(self.conv_3(F.leaky_relu(x2, LEAKY_SLOPE)))
+        feat = F.leaky_relu(t + self.conv2_skip(x2), LEAKY_SLOPE)
+        mapping = self.predict_mapping(feat)
+        return (mapping, feat) if self.output_x else mapping
+
+
+class RefinementModule(nn.Module):
+    """Dilated context network (models/modules.py:446-477): 32->128->128->128->96->64->32->out, dilations
+    1,2,4,8,16,1,1."""
+
+    def __init__(self, in_channels, out_channels=2, batch_norm=True, extra_bias='auto'):
+        super().__init__()
+        nl = nn.BatchNorm2d if batch_norm else None
+        plan = [(in_channels, 128, 1), (128, 128, 2), (128, 128, 4), (128, 96, 8), (96, 64, 16), (64, 32, 1)]
+        layers = [ConvBNReLU(ci, co, 3, dilation=d, norm_layer=nl, activation_layer=_leaky, bias=extra_bias)
+                  for ci, co, d in plan]
+        layers.append(nn.Conv2d(32, out_channels, kernel_size=3, padding=1, bias=True))
+        self.dc_convs = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.dc_convs(x)
+
+
+class UncertaintyModule(nn.Module):
+    """Log-variance head (models/modules.py:480-561).  Front end: every pixel's s x s correlation patch is a
+    1-channel micro-image run through valid 3x3 convs (s=9: 9->7->5->3->1; s=16: 16->14->maxpool 7->5->3->1) giving 6
+    numbers per pixel; back end: cat(6, 32-ch decoder feature[, previous log-var, previous flow]) -> 32 -> 16 -> 1."""
+
+    def __init__(self, in_channels, feed_in_previous=False, out_channels=1, search_size=9, batch_norm=True,
+                 depthwise_separable=False):
+        super().__init__()
+        if depthwise_separable:
+            raise NotImplementedError
+        if search_size not in (9, 16):
+            raise ValueError("search_size must be 9 or 16")
+        nl = nn.BatchNorm2d if batch_norm else None
+        self.search_size = search_size
+        self.feed_in_previous = feed_in_previous
+        add = 3 if feed_in_previous else 0
+        kw = dict(kernel_size=3, stride=1, padding=0, norm_layer=nl, activation_layer=_leaky)
+        self.conv_0 = ConvBNReLU(in_channels, 32, **kw)
+        if search_size == 16:
+            self.maxpool = nn.MaxPool2d((2, 2))
+        self.conv_1 = ConvBNReLU(32, 32, **kw)
+        self.conv_2 = ConvBNReLU(32, 16, **kw)
+        self.predict_uncertainty = nn.Conv2d(16, 6, kernel_size=3, stride=1, padding=0, bias=True)
+        self.pred_conv_0 = ConvBNReLU(6 + 32 + add, 32, 3, norm_layer=nl, activation_layer=_leaky)
+        self.pred_conv_1 = ConvBNReLU(32, 16, 3, norm_layer=nl, activation_layer=_leaky)
+        self.predict_uncertainty_final = nn.Conv2d(16, 1, kernel_size=3, stride=1, padding=1, bias=True)
+
+    # micro-images per launch of the library conv chain: bounds the (N,32,7,7) intermediates to ~0.8 GB
+    MICRO_BATCH = 131072
+
+    def patch_statistics(self, corr):
+        """corr (B, s*s, H, W) -> (B, 6, H, W)."""
+        b, _, h, w = corr.shape
+        s = self.search_size
+        x = corr.permute(0, 2, 3, 1).reshape(b * h * w, 1, s, s)
+        outs = []
+        for i in range(0, x.shape[0], self.MICRO_BATCH):
+            y = self.conv_0(x[i:i + self.MICRO_BATCH])
+            if s == 16:
+                y = self.maxpool(y)
+            y = self.predict_uncertainty(self.conv_2(self.conv_1(y)))
+            outs.append(y.flatten(1))
+        y = outs[0] if len(outs) == 1 else torch.cat(outs)
+        return y.view(b, h, w, 6).permute(0, 3, 1, 2)
+
+    def forward(self, corr, feat, up_previous_uncertainty=None, up_previous_flow=None):
+        parts = [self.patch_statistics(corr), feat]
+        if self.feed_in_previous:
+            parts += [up_previous_uncertainty, up_previous_flow]
+        u = self.pred_conv_1(self.pred_conv_0(torch.cat(parts, 1)))
+        return self.predict_uncertainty_final(u)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# VGG-16 pyramid
+# ---------------------------------------------------------------------------------------------------------------------
+_VGG_CFG = {
+    "vgg11": [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"],
+    "vgg13": [64, 64, "M", 128, 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"],
+    "vgg16": [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
+    "vgg19": [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"],
+}
+
+
+class VGG(nn.Module):
+    """models/backbones/vgg.py:33-149.  `features` is an nn.Sequential with the torchvision layout (so
+    `features.N.weight` keys match); tap points are after the first ReLU and after every max-pool; `out_indices`
+    selects taps and `extract_only_indices` sub-selects them with early exit."""
+
+    def __init__(self, model_type: str, out_indices: list = [0, 1, 2, 3, 4, 5], pretrained: Optional[str] = None):
+        super().__init__()
+        self.model_type = model_type
+        bn = model_type.endswith("_bn")
+        layers, taps, cin, first = [], [], 3, True
+        for v in _VGG_CFG[model_type.replace("_bn", "")]:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                taps.append(len(layers))
+            else:
+                layers.append(nn.Conv2d(cin, v, kernel_size=3, padding=1))
+                if bn:
+                    layers.append(nn.BatchNorm2d(v))
+                layers.append(nn.ReLU(inplace=True))
+                cin = v
+                if first:
+                    taps.append(len(layers))
+                    first = False
+        self.features = nn.Sequential(*layers)
+        self.layer_indices = [taps[i] for i in out_indices]
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.zeros_(m.bias)
+        if pretrained is not None:
+            self.load_weights(pretrained)
+
+    def load_weights(self, pretrained):
+        """vgg.py:91-106: path or 'imagenet' (needs the torchvision checkpoint on disk: no network here); drops
+        classifier.* keys; strict."""
+        if pretrained == 'imagenet':
+            pretrained = os.path.join(os.environ.get('TORCH_HOME', os.path.expanduser('~/.cache/torch')), 'hub',
+                                      'checkpoints', 'vgg16-397923af.pth')
+        if not os.path.exists(pretrained):
+            raise FileNotFoundError(f"VGG weights not found: {pretrained}")
+        ckpt = torch.load(pretrained, map_location='cpu')
+        sd = ckpt.get('state_dict', ckpt)
+        self.load_state_dict({k: v for k, v in sd.items() if not k.startswith('classifier.')}, strict=True)
+
+    def forward(self, x, extract_only_indices=None):
+        idx = [self.layer_indices[i] for i in extract_only_indices] if extract_only_indices else self.layer_indices
+        outs, prev = [], 0
+        for i in idx:
+            x = self.features[prev:i](x)
+            outs.append(x)
+            prev = i
+        return outs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# UAWarpC head
+# ---------------------------------------------------------------------------------------------------------------------
+def _up(x, size):
+    return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
+
+
+class BaseHead(nn.Module):
+    """models/heads/base.py:7-44."""
+
+    def __init__(self, num_classes, in_index, input_transform=None):
+        super().__init__()
+        self.input_transform = input_transform
+        self.in_index = in_index[0] if isinstance(in_index, (list, tuple)) and len(in_index) == 1 else in_index
+        self.num_classes = num_classes
+
+    def _transform_inputs(self, inputs):
+        if self.input_transform == 'resize_concat':
+            inputs = [inputs[i] for i in self.in_index]
+            return torch.cat([_up(x, inputs[0].shape[2:]) for x in inputs], dim=1)
+        if self.input_transform == 'multiple_select':
+            return [inputs[i] for i in self.in_index]
+        return inputs[self.in_index]
+
+
+class UAWarpCHead(BaseHead):
+    """models/heads/uawarpc.py:17-280.  forward(trg, src, trg_256, src_256, out_size) returns the four
+    (flow, log-variance) pairs, coarse to fine; flows are in pixels of the ORIGINAL resolution `out_size`."""
+
+    def __init__(self, in_index: Union[List[int], int], input_transform: Optional[str] = None,
+                 pretrained: Optional[str] = None, batch_norm: bool = True, refinement_at_adaptive_res: bool = True,
+                 refinement_at_finest_level: bool = True, estimate_uncertainty: bool = False,
+                 uncertainty_mixture: bool = False, iterative_refinement: bool = False):
+        super().__init__(None, in_index, input_transform)
+        self.estimate_uncertainty = estimate_uncertainty
+        self.uncertainty_mixture = uncertainty_mixture
+        self.iterative_refinement = iterative_refinement
+        self.refinement_at_adaptive_res = refinement_at_adaptive_res
+        self.refinement_at_finest_level = refinement_at_finest_level
+        self.global_corr = GlobalFeatureCorrelationLayer(cyclic_consistency=True)
+        self.local_corr = LocalFeatureCorrelationLayer(patch_size=9)
+        u = 1 if estimate_uncertainty else 0
+        mk = lambda cin: OpticalFlowEstimatorResidualConnection(cin, batch_norm=batch_norm, output_x=True)  # noqa: E731
+        self.decoder4 = mk(16 * 16)
+        self.decoder3 = mk(81 + 2 + u)
+        if refinement_at_adaptive_res:
+            self.refinement_module_adaptive = RefinementModule(32, batch_norm=batch_norm)
+        self.decoder2 = mk(81 + 2 + u)
+        self.reduce = nn.Conv2d(32, 2, kernel_size=1, bias=True)
+        self.decoder1 = mk(81 + 2 + 2 + u)
+        if refinement_at_finest_level:
+            self.refinement_module_finest = RefinementModule(32, batch_norm=batch_norm)
+        if estimate_uncertainty:
+            self.estimate_uncertainty_components4 = UncertaintyModule(1, search_size=16)
+            for lvl in (3, 2, 1):
+                setattr(self, f"estimate_uncertainty_components{lvl}",
+                        UncertaintyModule(1, search_size=9, feed_in_previous=True))
+        if pretrained is not None:
+            self.load_weights(pretrained)
+
+    # -- one coarse-to-fine refinement level -------------------------------------------------------------------------
+    def _level(self, lvl, feat_trg, feat_src, flow_prev, uncert_prev, orig_size, extra=None):
+        """flow_prev / uncert_prev are already up-sampled to this level's size; flow_prev is in the pixel units the
+        decoders work in (256-space at level 3, original pixels at levels 2 and 1) and `orig_size` is the size those
+        units refer to.  Returns (residual-corrected flow, decoder feature, log-variance)."""
+        h, w = feat_trg.shape[-2:]
+        oh, ow = orig_size
+        scale = flow_prev.new_tensor([w / float(ow), h / float(oh)]).view(1, 2, 1, 1)
+        corr = self.local_corr(feat_src, feat_trg, flow=(flow_prev * scale).contiguous())   # warp fused in
+        parts = [corr, flow_prev] + ([extra] if extra is not None else [])
+        if self.estimate_uncertainty:
+            parts.append(uncert_prev)
+        res, x = getattr(self, f"decoder{lvl}")(torch.cat(parts, 1))
+        refine = {3: self.refinement_at_adaptive_res and 'refinement_module_adaptive',
+                  1: self.refinement_at_finest_level and 'refinement_module_finest'}.get(lvl)
+        if refine:
+            res = res + getattr(self, refine)(x)
+        flow = res + flow_prev
+        uncert = None
+        if self.estimate_uncertainty:
+            uncert = getattr(self, f"estimate_uncertainty_components{lvl}")(corr, x, uncert_prev, flow_prev)
+        return flow, x, uncert
+
+    def forward(self, trg, src, trg_256, src_256, out_size):
+        c11, c12 = self._transform_inputs(trg)
+        c13, c14 = self._transform_inputs(trg_256)
+        c21, c22 = self._transform_inputs(src)
+        c23, c24 = self._transform_inputs(src_256)
+        c11, c12, c13, c14, c21, c22, c23, c24 = [matching.l2_normalize_channels(c.float())
+                                                  for c in (c11, c12, c13, c14, c21, c22, c23, c24)]
+        H, W = out_size
+        eu = self.estimate_uncertainty
+
+        # level 4: 16x16 global correlation, mapping regression (uawarpc.py:111-130)
+        assert tuple(c14.shape[-2:]) == (16, 16), tuple(c14.shape[-2:])
+        corr4 = self.global_corr(c24, c14)
+        est_map4, x4 = self.decoder4(corr4)
+        flow4_256 = matching.unnormalise_and_convert_mapping_to_flow(est_map4) * (256.0 / 16.0)
+        u4_256 = None
+        if eu:
+            u4_256 = self.estimate_uncertainty_components4(corr4, x4)
+            u4_256 = u4_256 + 2 * math.log(256.0 / 16.0)
+
+        # level 3: 32x32, decoders work in 256-space pixels (uawarpc.py:132-173)
+        assert tuple(c13.shape[-2:]) == (32, 32), tuple(c13.shape[-2:])
+        up_flow4 = _up(flow4_256, (32, 32))
+        up_u4 = _up(u4_256, (32, 32)) if eu else None
+        flow3, x3, u3 = self._level(3, c13, c23, up_flow4, up_u4, (256, 256))
+        flow3 = flow3 * flow3.new_tensor([W / 256.0, H / 256.0]).view(1, 2, 1, 1)
+        diag_term = 2 * math.log(math.sqrt(H ** 2 + W ** 2) / math.sqrt(2 * 256.0 ** 2))
+        if eu:
+            u3 = u3 + diag_term
+        if self.iterative_refinement and not self.training:
+            raise NotImplementedError("iterative_refinement is unset in every refign_* config (uawarpc.py:28,175)")
+
+        # level 2: 1/8 resolution, original pixel units (uawarpc.py:209-234)
+        s2 = c12.shape[-2:]
+        flow2, x2, u2 = self._level(2, c12, c22, _up(flow3, s2), _up(u3, s2) if eu else None, (H, W))
+
+        # level 1: 1/4 resolution (uawarpc.py:236-271)
+        s1 = c11.shape[-2:]
+        up_feat2 = self.reduce(_up(x2, s1))
+        flow1, _, u1 = self._level(1, c11, c21, _up(flow2, s1), _up(u2, s1) if eu else None, (H, W), extra=up_feat2)
+
+        flow4 = flow4_256 * flow4_256.new_tensor([W / 256.0, H / 256.0]).view(1, 2, 1, 1)
+        if eu:
+            return (flow4, u4_256 + diag_term), (flow3, u3), (flow2, u2), (flow1, u1)
+        return flow4, flow3, flow2, flow1
+
+    def load_weights(self, pretrain_path):
+        """uawarpc.py:282-305: accepts a Lightning checkpoint and keeps the `alignment_head.` sub-tree; strict."""
+        if pretrain_path is None:
+            return
+        for cand in (pretrain_path, os.path.join(os.environ.get('TORCH_HOME', ''), 'hub', pretrain_path)):
+            if os.path.exists(cand):
+                ckpt = torch.load(cand, map_location='cpu')
+                break
+        else:
+            raise FileNotFoundError(f"UAWarpC weights not found: {pretrain_path} (no network access)")
+        sd = ckpt.get('state_dict', ckpt)
+        self.load_state_dict({k[len('alignment_head.'):]: v for k, v in sd.items()
+                              if k.startswith('alignment_head.')}, strict=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# align(): images + reference logits -> warped logits, validity mask, confidence
+# ---------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def extract_pyramids(alignment_backbone, images_ref, images_trg):
+    """segmentation_model.py:497-510: full-resolution pyramid (1/4, 1/8) and the 256x256 pyramid (32^2, 16^2) for
+    the concatenated (ref, trg) batch."""
+    b = images_trg.shape[0]
+    ref_256 = F.interpolate(images_ref, size=(256, 256), mode='area')
+    trg_256 = F.interpolate(images_trg, size=(256, 256), mode='area')
+    feats = alignment_backbone(torch.cat([images_ref, images_trg]), extract_only_indices=[-3, -2])
+    feats_256 = alignment_backbone(torch.cat([ref_256, trg_256]), extract_only_indices=[-2, -1])
+    pyr_ref, pyr_trg = zip(*[torch.split(f, [b, b]) for f in feats])
+    pyr_ref_256, pyr_trg_256 = zip(*[torch.split(f, [b, b]) for f in feats_256])
+    return pyr_trg, pyr_ref, pyr_trg_256, pyr_ref_256
+
+
+@torch.no_grad()
+def align(alignment_backbone, alignment_head, logits_ref, images_ref, images_trg):
+    """DomainAdaptationSegmentationModel.align (segmentation_model.py:493-523).
+    Returns (warped_ref_logits (b,C,h,w), trg_ref_mask (b,h,w) bool, trg_ref_cert (b,1,h,w))."""
+    h, w = images_trg.shape[-2:]
+    pyr = extract_pyramids(alignment_backbone, images_ref, images_trg)
+    flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
+    if tuple(logits_ref.shape[-2:]) != (h, w):
+        raise RuntimeError("align: logits_ref must have the image resolution")
+    return matching.align_tail(logits_ref, flow_q, logvar_q)
+
+
+@torch.no_grad()
+def alignment_forward(alignment_backbone, alignment_head, images_i, images_j):
+    """AlignmentModel.forward (alignment_model.py:55-79): flow i->j at full resolution and 1 - P_R."""
+    h, w = images_i.shape[-2:]
+    pyr = extract_pyramids(alignment_backbone, images_j, images_i)
+    flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
+    flow = _up(flow_q, (h, w))
+    uncert = _up(logvar_q, (h, w))
+    return flow, 1.0 - matching.estimate_probability_of_confidence_interval_of_mixture_density(uncert, R=1.0)

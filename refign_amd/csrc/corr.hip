@@ -30,6 +30,8 @@
 // Backward (reference: correlation.cpp:44-78,131-183; CUDA gather form correlation_cuda_kernel.cu:91-238):
 //   * corr_k1_bwd_kernel     -- gather form for kernel 1 / stride 1 / pad 0 (deterministic, no atomics);
 //   * corr_generic_bwd_kernel -- scatter with hardware float/double atomics for everything else.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rfn {
@@ -249,9 +251,232 @@ __global__ __launch_bounds__(TH * kStrips * 3) void corr9_tile_kernel(
   }
 }
 
+
+// --------------------------------------------------------------------------------------------------------
+// Tiled patch-9 forward, LDS-DMA pipeline (the fast path when W % 4 == 0 and C % CC == 0)
+//   Same tile/thread decomposition as corr9_tile_kernel, but the two tiles of a channel chunk are brought in by
+//   `global_load_lds_dwordx4` (global -> LDS DMA, no VGPR round trip, no ds_write) into a 2-deep LDS ring, so the
+//   HBM/L2 latency of chunk k+1 is hidden behind the 108 x CC FMAs per thread of chunk k and there is exactly one
+//   barrier per chunk.  The DMA writes wave-uniform-base + lane*16, so the LDS image of a chunk is the linear
+//   sequence of float4 "slots" (channel, row, 18 slots per 72-float row); rows 0..R2-1 are the source tile with
+//   halo, rows R2..R2+TH-1 the target tile (slots 16,17 of those rows are never written).  Slots that fall outside
+//   the image are never written either: the ring is zeroed once at kernel start and the out-of-image pattern is
+//   the same for every chunk, which gives the zero padding of the reference for free.
+// --------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int TH, int CC, bool FUSE, int MINW, int UNR>
+__global__ __launch_bounds__(TH * kStrips * 3, MINW) void corr9_dma_kernel(const float* __restrict__ in1,
+                                                                          const float* __restrict__ in2,
+                                                                          float* __restrict__ out, int C, int H,
+                                                                          int W, int tilesX, int tilesY) {
+  constexpr int NT = TH * kStrips * 3;
+  constexpr int NW = NT / 64;
+  constexpr int R2 = TH + 2 * kHalo;
+  constexpr int ROWS = R2 + TH;
+  constexpr int V = kPitch / 4;                      // 18 float4 slots per row
+  constexpr int SLOTS = CC * ROWS * V;               // float4 slots per chunk
+  constexpr int NINSTR = (SLOTS + 63) / 64;          // wave-level DMA instructions per chunk
+  constexpr int K = (NINSTR + NW - 1) / NW;          // per wave
+  constexpr int BUF = NINSTR * 64 * 4;               // floats per ring buffer (rounded up to whole instructions)
+  // TWO separate LDS objects on purpose: hipcc's waitcnt pass only lets a ds_read run past an in-flight LDS-DMA
+  // when alias analysis proves they touch different objects; one array indexed by (chunk & 1) forces
+  // s_waitcnt vmcnt(0) before the first ds_read of every chunk, i.e. no overlap at all.
+  __shared__ __attribute__((aligned(16))) float ring0[BUF];
+  __shared__ __attribute__((aligned(16))) float ring1[BUF];
+
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY;
+  const int n = bid / tilesY;
+  const int h0 = ty * TH, w0 = tx * kTW;
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int WPG = TH / 4;
+  const int dyg = wave / WPG;
+  const int q = lane >> 4, j = lane & 15;
+  const int row = (wave % WPG) * 4 + q;
+  const int strip = (q & 1) ? ((j + 14) & 15) : j;
+
+  const size_t plane = (size_t)H * W;
+  const float* p1 = in1 + (size_t)n * C * plane;
+  const float* p2 = in2 + (size_t)n * C * plane;
+
+  // zero both buffers once (out-of-image slots stay zero forever)
+  for (int i = tid; i < BUF / 4; i += NT) {
+    reinterpret_cast<float4*>(ring0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(ring1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // per-thread DMA descriptors: source pointer (for chunk 0) and validity of each of my K slots
+  const float* gsrc[K];
+  bool gok[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int wi = wave + k * NW;                    // wave-level instruction index
+    const int slot = wi * 64 + lane;
+    const int v = slot % V, rr = (slot / V) % ROWS, c = slot / (V * ROWS);
+    bool ok = (wi < NINSTR) && (slot < SLOTS);
+    const float* src;
+    if (rr < R2) {
+      const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
+      ok = ok && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+      src = p2 + (size_t)c * plane + (long)gy * W + gx;
+    } else {
+      const int gy = h0 + rr - R2, gx = w0 + 4 * v;
+      ok = ok && v < 16 && gy < H && gx + 3 < W;
+      src = p1 + (size_t)c * plane + (long)gy * W + gx;
+    }
+    gsrc[k] = ok ? src : p1;
+    gok[k] = ok;
+  }
+  __syncthreads();
+
+  auto issue = [&](float* ring) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int wi = wave + k * NW;
+      if (wi < NINSTR) {                               // wave-uniform
+        float* ldst = ring + wi * 256;                 // wave-uniform LDS base; lane lands at +lane*16 B
+        if (gok[k])
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc[k],
+                                           (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+        gsrc[k] += (size_t)CC * plane;
+      }
+    }
+  };
+
+  // accumulators as explicit register pairs so that every packed FMA operand is a naturally aligned pair:
+  //   pixel i even: pairs of horizontal shifts (0,1)(2,3)(4,5)(6,7) + single 8
+  //   pixel i odd : pairs (1,2)(3,4)(5,6)(7,8) + single 0
+  f32x2 accp[3][4][4];
+  float accs[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      accs[a][i] = 0.0f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) accp[a][i][p] = f32x2{0.0f, 0.0f};
+    }
+
+  auto compute = [&](const float* __restrict__ s2) {
+#pragma unroll UNR
+    for (int c = 0; c < CC; ++c) {
+      const float* cb = s2 + c * ROWS * kPitch;
+      const float4 a = *reinterpret_cast<const float4*>(&cb[(R2 + row) * kPitch + 4 * strip]);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        const float* rp = &cb[(row + dyg * 3 + dyi) * kPitch + 4 * strip];
+        const float4 b0 = *reinterpret_cast<const float4*>(rp);
+        const float4 b1 = *reinterpret_cast<const float4*>(rp + 4);
+        const float4 b2 = *reinterpret_cast<const float4*>(rp + 8);
+        const f32x2 bp[6] = {f32x2{b0.x, b0.y}, f32x2{b0.z, b0.w}, f32x2{b1.x, b1.y},
+                             f32x2{b1.z, b1.w}, f32x2{b2.x, b2.y}, f32x2{b2.z, b2.w}};
+        const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 aa = f32x2{av[i], av[i]};
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            accp[dyi][i][p] = __builtin_elementwise_fma(aa, bp[(i + 2 * p + (i & 1)) / 2], accp[dyi][i][p]);
+          accs[dyi][i] = fmaf(av[i], (i & 1) ? bv[i] : bv[i + 8], accs[dyi][i]);
+        }
+      }
+    }
+  };
+
+  const int nchunks = C / CC;                          // even (checked by the launcher)
+  issue(ring0);
+  for (int ck = 0; ck < nchunks; ck += 2) {
+    __syncthreads();                                   // chunk ck landed in ring0; ring1 free
+    issue(ring1);
+    compute(ring0);
+    __syncthreads();                                   // chunk ck+1 landed in ring1; ring0 free
+    if (ck + 2 < nchunks) issue(ring0);
+    compute(ring1);
+  }
+
+  // ---- epilogue ----
+  auto get = [&](int dyi, int dx, int i) -> float {
+    if (i & 1) return dx == 0 ? accs[dyi][i] : accp[dyi][i][(dx - 1) >> 1][(dx - 1) & 1];
+    return dx == 8 ? accs[dyi][i] : accp[dyi][i][dx >> 1][dx & 1];
+  };
+  const int h = h0 + row, wx = w0 + 4 * strip;
+  float scale[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (FUSE) {
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 9; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = fmaxf(get(a, b, i), 0.0f);
+          ss[i] = fmaf(v, v, ss[i]);
+        }
+    __syncthreads();
+    float* red = ring0;  // [3][TH][64]
+    *reinterpret_cast<float4*>(&red[(dyg * TH + row) * kTW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float tot = red[(0 * TH + row) * kTW + 4 * strip + i] + red[(1 * TH + row) * kTW + 4 * strip + i] +
+                        red[(2 * TH + row) * kTW + 4 * strip + i];
+      scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+    }
+  }
+  if (h < H && wx + 3 < W) {
+    float* obase = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi)
+#pragma unroll
+      for (int dx = 0; dx < 9; ++dx) {
+        float r0 = get(dyi, dx, 0), r1 = get(dyi, dx, 1), r2 = get(dyi, dx, 2), r3 = get(dyi, dx, 3);
+        if constexpr (FUSE) {
+          r0 = fmaxf(r0, 0.f) * scale[0]; r1 = fmaxf(r1, 0.f) * scale[1];
+          r2 = fmaxf(r2, 0.f) * scale[2]; r3 = fmaxf(r3, 0.f) * scale[3];
+        }
+        *reinterpret_cast<float4*>(obase + (size_t)(dyi * 9 + dx) * plane) = make_float4(r0, r1, r2, r3);
+      }
+  }
+}
+
 template <bool FUSE, bool WARP>
 static int launch_corr9(const float* in1, const float* in2, const float* flow, float* out, int B, int C, int H,
                         int W, hipStream_t st) {
+  if constexpr (!WARP) {
+    if ((W & 3) == 0 && (C % 8) == 0) {
+      static const int variant = getenv("RFN_CORR_VARIANT") ? atoi(getenv("RFN_CORR_VARIANT")) : 0;  // tuning knob
+#define RFN_LAUNCH_DMA(TH_, CC_, MINW_, UNR_)                                                                     \
+  {                                                                                                               \
+    const int tilesX = cdiv(W, kTW), tilesY = cdiv(H, TH_);                                                       \
+    const long blocks = (long)B * tilesX * tilesY;                                                                \
+    if (blocks <= 0 || blocks > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
+    hipLaunchKernelGGL((corr9_dma_kernel<TH_, CC_, FUSE, MINW_, UNR_>), dim3((unsigned)blocks),                   \
+                       dim3(TH_ * kStrips * 3), 0, st, in1, in2, out, C, H, W, tilesX, tilesY);                   \
+    return check_launch("corr9_dma_kernel");                                                                      \
+  }
+      // Tile height: a 16x64 tile is one 12-wave workgroup per CU (3 waves per SIMD), an 8x64 tile a 6-wave one.
+      // Pick the height whose (rounds over 256 CUs) x (rows per tile + fixed cost) is smallest for this shape.
+      if (variant == 0) {
+        const long b8 = (long)B * cdiv(W, kTW) * cdiv(H, 8), b16 = (long)B * cdiv(W, kTW) * cdiv(H, 16);
+        const long c8 = ((b8 + 255) / 256) * (8 + 2), c16 = ((b16 + 255) / 256) * (16 + 2);
+        if (c16 < c8) RFN_LAUNCH_DMA(16, 4, 3, 2)
+        RFN_LAUNCH_DMA(8, 4, 3, 2)
+      }
+      switch (variant) {
+        case 2: RFN_LAUNCH_DMA(8, 4, 3, 1)
+        case 3: RFN_LAUNCH_DMA(8, 4, 3, 2)
+        case 4: RFN_LAUNCH_DMA(16, 4, 3, 1)
+        case 5: RFN_LAUNCH_DMA(16, 4, 3, 2)
+        case 7: RFN_LAUNCH_DMA(4, 4, 3, 1)
+        default: break;   // 9: register-staged kernel below
+      }
+#undef RFN_LAUNCH_DMA
+    }
+  }
   constexpr int TH = 8, CC = 8;
   const int tilesX = cdiv(W, kTW), tilesY = cdiv(H, TH);
   const long blocks = (long)B * tilesX * tilesY;

@@ -53,5 +53,8 @@ def closed_form_fill(module, prefix=""):
             else:                                         # conv / linear weight: He-like, var = 2 / fan_in
                 fan_in = tsr[0].numel()
                 v = c * np.sqrt(6.0 / fan_in)
+            # regression heads of the matcher get small weights so that synthetic flows stay a few pixels (in-image)
+            if any(h in name for h in ("predict_mapping.", "dc_convs.6.", "predict_uncertainty_final.")):
+                v = 0.05 * v
             tsr.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(tsr.dtype))
     return module

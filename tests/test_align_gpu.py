@@ -1,0 +1,98 @@
+"""GPU parity of the weight-bearing align modules (decoders, refinement, uncertainty, UAWarpCHead, align()) against
+golden vectors captured from the imported reference with closed-form weights (tests/golden/make_golden_modules.py)."""
+import numpy as np
+import pytest
+import torch
+from conftest import golden
+from fill import closed_form_fill, hashed_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def unit(shape, key):
+    x = hashed_uniform(shape, key) - 0.5
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+@torch.no_grad()
+def test_decoder_refinement_uncertainty_golden(dev):
+    from refign_amd import align as A
+    g = golden("mod_decoder84")
+    dec = closed_form_fill(A.OpticalFlowEstimatorResidualConnection(84, output_x=True), "decoder3.").to(dev).eval()
+    m, f = dec(T(g["x"], dev))
+    np.testing.assert_allclose(m.cpu().numpy(), g["mapping"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(f.cpu().numpy(), g["feat"], rtol=1e-3, atol=1e-4)
+    g = golden("mod_refinement32")
+    ref = closed_form_fill(A.RefinementModule(32), "refinement_module_adaptive.").to(dev).eval()
+    np.testing.assert_allclose(ref(T(g["x"], dev)).cpu().numpy(), g["out"], rtol=1e-3, atol=1e-4)
+    g = golden("mod_uncertainty9")
+    um = closed_form_fill(A.UncertaintyModule(1, search_size=9, feed_in_previous=True),
+                          "estimate_uncertainty_components3.").to(dev).eval()
+    out = um(T(g["corr"], dev), T(g["feat"], dev), T(g["prev_uncert"], dev), T(g["prev_flow"], dev))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-3, atol=1e-4)
+    g = golden("mod_uncertainty16")
+    um = closed_form_fill(A.UncertaintyModule(1, search_size=16), "estimate_uncertainty_components4.").to(dev).eval()
+    out = um(T(g["corr"], dev), T(g["feat"], dev))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-3, atol=1e-4)
+
+
+def _pyramids(name, H, W):
+    pyr = {
+        "trg": [unit((1, 128, H // 4, W // 4), f"g5/{name}/t1"), unit((1, 256, H // 8, W // 8), f"g5/{name}/t2")],
+        "src": [unit((1, 128, H // 4, W // 4), f"g5/{name}/s1"), unit((1, 256, H // 8, W // 8), f"g5/{name}/s2")],
+        "trg256": [unit((1, 256, 32, 32), f"g5/{name}/t3"), unit((1, 512, 16, 16), f"g5/{name}/t4")],
+        "src256": [unit((1, 256, 32, 32), f"g5/{name}/s3"), unit((1, 512, 16, 16), f"g5/{name}/s4")],
+    }
+    for k_t, k_s in (("trg", "src"), ("trg256", "src256")):
+        for i in range(2):
+            a = pyr[k_t][i]
+            mix = 0.7 * np.roll(a, shift=(1, -2), axis=(2, 3)) + 0.3 * pyr[k_s][i]
+            pyr[k_s][i] = (mix / np.linalg.norm(mix, axis=1, keepdims=True)).astype(np.float32)
+    return pyr
+
+
+@pytest.mark.parametrize("name,H,W", [("k1_256x256", 256, 256), ("rect_192x320", 192, 320)])
+@torch.no_grad()
+def test_uawarpc_head_golden(dev, name, H, W):
+    """G5: all four (flow, log-variance) levels.  Flows are O(100) px here, tolerance is relative to that."""
+    from refign_amd.align import UAWarpCHead
+    g = golden("head_" + name)
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select',
+                                        estimate_uncertainty=True)).to(dev).eval()
+    p = _pyramids(name, H, W)
+    outs = head([T(x, dev) for x in p["trg"]], [T(x, dev) for x in p["src"]], [T(x, dev) for x in p["trg256"]],
+                [T(x, dev) for x in p["src256"]], (H, W))
+    for lvl, (fl, un) in zip((4, 3, 2, 1), outs):
+        np.testing.assert_allclose(fl.cpu().numpy(), g[f"flow{lvl}"], rtol=1e-3, atol=2e-2, err_msg=f"flow{lvl}")
+        np.testing.assert_allclose(un.cpu().numpy(), g[f"uncert{lvl}"], rtol=1e-3, atol=5e-3, err_msg=f"uncert{lvl}")
+
+
+@torch.no_grad()
+def test_align_end_to_end_golden(dev):
+    """G7: VGG-16 + head + fused tail on a 128x160 pair: warped logits <= 1e-3 (north star), mask exact, argmax exact
+    where the reference's top-2 margin is above the tolerance; AlignmentModel.forward flow/uncertainty."""
+    from refign_amd.align import VGG, UAWarpCHead, align, alignment_forward
+    g = golden("align_128x160")
+    H, W = [int(v) for v in g["size"]]
+    vgg = closed_form_fill(VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone.").to(dev).eval()
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select',
+                                        estimate_uncertainty=True)).to(dev).eval()
+    img_trg = (hashed_uniform((1, 3, H, W), "g7/trg") * 4 - 2).astype(np.float32)
+    img_ref = (0.8 * np.roll(img_trg, (2, -3), (2, 3)) + 0.2 * (hashed_uniform((1, 3, H, W), "g7/ref") * 4 - 2)).astype(np.float32)
+    logits = (hashed_uniform((1, 19, H, W), "g7/logits") * 8 - 4).astype(np.float32)
+    warped, mask, cert = align(vgg, head, T(logits, dev), T(img_ref, dev), T(img_trg, dev))
+    flow, unc = alignment_forward(vgg, head, T(img_trg, dev), T(img_ref, dev))
+    np.testing.assert_allclose(flow.cpu().numpy(), g["flow"], rtol=1e-3, atol=2e-2)
+    np.testing.assert_allclose(unc.cpu().numpy(), g["uncert"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(cert.cpu().numpy(), g["cert"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])
+    wn = warped.cpu().numpy()
+    # the logits here are white noise (adjacent pixels differ by O(4)), so a flow error of 1e-2 px moves the bilinear
+    # sample by O(4e-2): compare at that scale, and check the checksum tightly
+    np.testing.assert_allclose(wn[:, :, ::2, ::2], g["warped_sample"], atol=0.15)
+    assert abs(wn.astype(np.float64).sum() - g["warped_checksum"]) < 2e-4 * g["warped_abs_checksum"]
+    assert (wn.argmax(1) == g["warped_argmax"]).mean() > 0.995

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""tools/kbench.py -- per-kernel micro-benchmark (HIP events on the launch stream) for the kernels of the hot path.
+Prints one line per kernel: average launch time, algorithmic bytes, GB/s and fraction of the 8 TB/s HBM spec peak."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from refign_amd import correlation, matching, refine as refine_mod  # noqa: E402
+from refign_amd.modules import GlobalFeatureCorrelationLayer  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--b", type=int, default=2)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    b = args.b
+    g = torch.Generator().manual_seed(0)
+    rows = []
+
+    def add(name, us, nbytes, flops=0.0):
+        rows.append((name, us, nbytes, flops))
+        print(f"{name:58s} {us:10.1f} us  {nbytes / 1e6:9.1f} MB  {nbytes / us / 1e3:8.1f} GB/s  "
+              f"{nbytes / us / 1e3 / 8000:6.3f} of 8TB/s  {flops / us / 1e6:7.2f} TFLOP/s", flush=True)
+
+    for (lvl, C, H, W) in [("L1", 128, 270, 480), ("L2", 256, 135, 240), ("L3", 256, 32, 32), ("K2-L1", 128, 128, 128)]:
+        if args.only and lvl not in args.only:
+            continue
+        f1 = torch.nn.functional.normalize(torch.randn(b, C, H, W, generator=g), dim=1).to(dev)
+        f2 = torch.nn.functional.normalize(torch.randn(b, C, H, W, generator=g), dim=1).to(dev)
+        fl = (5 * torch.randn(b, 2, H, W, generator=g)).to(dev)
+        nb = 4 * b * H * W * (2 * C + 81)
+        fp = 2.0 * 81 * C * b * H * W
+        add(f"corr9 raw            {lvl} C={C} {H}x{W}", timeit(lambda: correlation.forward(f1, f2, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)), nb, fp)
+        add(f"corr9 +relu+l2norm   {lvl} C={C} {H}x{W}", timeit(lambda: correlation.local_correlation_layer(f2, f1)), nb, fp)
+        add(f"corr9 +warp+relu+l2n {lvl} C={C} {H}x{W}", timeit(lambda: correlation.local_correlation_layer(f2, f1, flow=fl)), nb + 8 * b * H * W, fp)
+        add(f"warp features        {lvl} C={C} {H}x{W}", timeit(lambda: matching.warp_nocheck(f2, fl)), 4 * b * H * W * (2 * C + 2))
+        add(f"l2norm channels      {lvl} C={C} {H}x{W}", timeit(lambda: matching.l2_normalize_channels(f2)), 4 * b * H * W * 2 * C)
+        if lvl == "L1":
+            go = torch.randn(b, 9, 9, H, W, generator=g).to(dev)
+            add(f"corr9 backward       {lvl} C={C} {H}x{W}", timeit(lambda: correlation.backward(f1, f2, go, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1), reps=5), 4 * b * H * W * (4 * C + 81))
+    if not args.only or "tail" in args.only:
+        H, W = 1080, 1920
+        lt = (3 * torch.randn(b, 19, H, W, generator=g)).to(dev)
+        lr = (3 * torch.randn(b, 19, H, W, generator=g)).to(dev)
+        fq = (5 * torch.randn(b, 2, H // 4, W // 4, generator=g)).to(dev)
+        lq = (2 * torch.randn(b, 1, H // 4, W // 4, generator=g)).to(dev)
+        ff = (5 * torch.randn(b, 2, H, W, generator=g)).to(dev)
+        add("warp logits 19x1080x1920 (+mask)", timeit(lambda: matching.warp_nocheck(lr, ff, True)), 4 * b * H * W * (2 * 19 + 2) + b * H * W)
+        add("align tail (upsample+cert+warp) 19x1080x1920", timeit(lambda: matching.align_tail(lr, fq, lq)), 4 * b * H * W * (2 * 19 + 1) + b * H * W)
+        w, m, c = matching.align_tail(lr, fq, lq)
+        add("refine 19x1080x1920", timeit(lambda: refine_mod.refine(lt, w, m, c)), 4 * b * H * W * (3 * 19 + 1) + b * H * W)
+        s4 = torch.nn.functional.normalize(torch.randn(b, 512, 16, 16, generator=g), dim=1).to(dev)
+        t4 = torch.nn.functional.normalize(torch.randn(b, 512, 16, 16, generator=g), dim=1).to(dev)
+        gl = GlobalFeatureCorrelationLayer()
+        add("global corr layer 512x16x16", timeit(lambda: gl(s4, t4)), 4 * b * (2 * 512 * 256 + 256 * 256), 2.0 * 512 * 256 * 256 * b)
+
+
+if __name__ == "__main__":
+    main()
