@@ -29,77 +29,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import matching
+from .layers import LEAKY_SLOPE, ConvBNReLU
 from .modules import GlobalFeatureCorrelationLayer, LocalFeatureCorrelationLayer
-
-LEAKY_SLOPE = 0.1   # activation_layer = partial(nn.LeakyReLU, negative_slope=0.1)  (modules.py:407,459,498)
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# building block: conv [+ BN] [+ activation]  (state_dict: conv.weight[, conv.bias], bn.*)
-# ---------------------------------------------------------------------------------------------------------------------
-class ConvBNReLU(nn.Module):
-    """Same constructor semantics and parameter names as models/modules.py:16-56 (non depthwise-separable case)."""
-
-    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, groups=1, padding=None,
-                 norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, bias='auto', depthwise_separable=False,
-                 inplace=True, affine=True):
-        super().__init__()
-        if depthwise_separable:
-            raise NotImplementedError("depthwise_separable ConvBNReLU is not on the align path")
-        self.padding = dilation * (kernel_size - 1) // 2 if padding is None else padding
-        self.stride, self.dilation, self.groups = stride, dilation, groups
-        self.use_norm = norm_layer is not None
-        if bias == 'auto':
-            bias = not self.use_norm
-        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, self.padding, dilation=dilation,
-                              groups=groups, bias=bias)
-        if self.use_norm:
-            self.bn = norm_layer(out_channels, affine=affine)
-        # activation: None, 'relu' or 'leaky' (negative slope 0.1)
-        if activation_layer is None:
-            self.act = None
-        else:
-            probe = activation_layer()
-            self.act = 'leaky' if isinstance(probe, nn.LeakyReLU) else 'relu'
-            self.act_slope = getattr(probe, 'negative_slope', 0.0)
-        self._folded = None
-
-    def folded(self):
-        """(weight, bias) with eval-mode BatchNorm folded in; cached until the module is put back in train()."""
-        if self._folded is None:
-            w, b = self.conv.weight, self.conv.bias
-            if self.use_norm:
-                bn = self.bn
-                inv = torch.rsqrt(bn.running_var + bn.eps)
-                g = inv if bn.weight is None else bn.weight * inv
-                w = w * g.view(-1, 1, 1, 1)
-                shift = -bn.running_mean * g
-                if bn.bias is not None:
-                    shift = shift + bn.bias
-                b = shift if b is None else b * g + shift
-            self._folded = (w.detach().contiguous(), None if b is None else b.detach().contiguous())
-        return self._folded
-
-    def train(self, mode=True):
-        self._folded = None
-        return super().train(mode)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._folded = None
-        return super()._load_from_state_dict(*args, **kwargs)
-
-    def forward(self, x, act=True):
-        if self.training or torch.is_grad_enabled():
-            x = self.conv(x)
-            if self.use_norm:
-                x = self.bn(x)
-        else:
-            w, b = self.folded()
-            x = F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
-        if act and self.act is not None:
-            x = F.leaky_relu(x, self.act_slope, inplace=True) if self.act == 'leaky' else F.relu(x, inplace=True)
-        return x
-
 
 def _leaky():
     return nn.LeakyReLU(LEAKY_SLOPE)

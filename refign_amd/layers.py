@@ -1,0 +1,121 @@
+"""Shared layer containers with the reference's parameter names (models/modules.py:16-68,564-596).
+
+These hold parameters under the same state_dict keys as the reference (`conv.weight`, `bn.running_mean`,
+`depthwise_conv.conv.weight`, `pointwise_conv.bn.bias`, `proj.weight`) and execute either the training formulation
+(conv -> BatchNorm with batch statistics -> activation) or, for frozen/eval networks under no_grad, a folded one
+(BatchNorm merged into the conv weights once, activation applied in place on the conv output).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+LEAKY_SLOPE = 0.1   # activation_layer = partial(nn.LeakyReLU, negative_slope=0.1)  (modules.py:407,459,498)
+
+
+class ConvBNReLU(nn.Module):
+    """Constructor semantics and parameter names of models/modules.py:16-56, including the depthwise-separable form
+    (a depthwise ConvBNReLU followed by a 1x1 pointwise ConvBNReLU, each with its own norm + activation)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, groups=1, padding=None,
+                 norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, bias='auto', depthwise_separable=False,
+                 inplace=True, affine=True):
+        super().__init__()
+        padding = dilation * (kernel_size - 1) // 2 if padding is None else padding
+        self.use_norm = norm_layer is not None
+        self.use_activation = activation_layer is not None
+        self.depthwise_separable = depthwise_separable
+        if bias == 'auto':
+            bias = not self.use_norm
+        if depthwise_separable:
+            assert kernel_size > 1 and groups == 1
+            self.depthwise_conv = ConvBNReLU(in_channels, in_channels, kernel_size, stride=stride, padding=padding,
+                                             dilation=dilation, groups=in_channels, norm_layer=norm_layer,
+                                             activation_layer=activation_layer)
+            self.pointwise_conv = ConvBNReLU(in_channels, out_channels, 1, norm_layer=norm_layer,
+                                             activation_layer=activation_layer)
+        else:
+            self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation=dilation,
+                                  groups=groups, bias=bias)
+            if self.use_norm:
+                self.bn = norm_layer(out_channels, affine=affine)
+        self.act, self.act_slope = None, 0.0
+        if self.use_activation:
+            probe = activation_layer()
+            self.act = 'leaky' if isinstance(probe, nn.LeakyReLU) else 'relu'
+            self.act_slope = getattr(probe, 'negative_slope', 0.0)
+        self._folded = None
+
+    # -- eval-time folding -------------------------------------------------------------------------------------------
+    def folded(self):
+        """(weight, bias) with eval-mode BatchNorm folded in; cached until train() / load_state_dict()."""
+        if self._folded is None:
+            w, b = self.conv.weight, self.conv.bias
+            if self.use_norm:
+                bn = self.bn
+                inv = torch.rsqrt(bn.running_var + bn.eps)
+                g = inv if bn.weight is None else bn.weight * inv
+                w = w * g.view(-1, 1, 1, 1)
+                shift = -bn.running_mean * g
+                if bn.bias is not None:
+                    shift = shift + bn.bias
+                b = shift if b is None else b * g + shift
+            self._folded = (w.detach().contiguous(), None if b is None else b.detach().contiguous())
+        return self._folded
+
+    def train(self, mode=True):
+        self._folded = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._folded = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._folded = None
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x):
+        if self.depthwise_separable:
+            return self.pointwise_conv(self.depthwise_conv(x))
+        c = self.conv
+        if self.use_norm and not self.training and not torch.is_grad_enabled():
+            w, b = self.folded()
+            x = F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
+        else:
+            x = c(x)
+            if self.use_norm:
+                x = self.bn(x)
+        if self.act == 'leaky':
+            x = F.leaky_relu(x, self.act_slope, inplace=True)
+        elif self.act == 'relu':
+            x = F.relu(x, inplace=True)
+        return x
+
+
+class MLP(nn.Module):
+    """Linear embedding of an NCHW map into tokens (models/modules.py:59-68): (B,C,H,W) -> (B,H*W,embed_dim)."""
+
+    def __init__(self, input_dim=2048, embed_dim=768):
+        super().__init__()
+        self.proj = nn.Linear(input_dim, embed_dim)
+
+    def forward(self, x):
+        return self.proj(x.flatten(2).transpose(1, 2))
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (models/modules.py:564-596)."""
+
+    def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask

@@ -1,0 +1,469 @@
+"""Segmentation networks of the Refign step: MiT encoder, DAFormer / SegFormer decode heads, HRDA multi-resolution
+fusion, pixel-weighted cross entropy.
+
+Host mirror of (brdav/refign):
+  models/backbones/mix_transformer.py   MixVisionTransformer(model_type, pretrained, ...)            (a18)
+  models/heads/daformer.py              DAFormerHead(in_channels, in_index, num_classes, ...)       (a19)
+  models/heads/segformer.py             SegFormerHead(...)  -- HRDA scale attention                 (a20)
+  models/hrda.py                        hrda_backbone / hrda_head decorators and crop helpers       (a21)
+  models/losses.py:10-22                PixelWeightedCrossEntropyLoss                               (a23)
+
+Module trees and state_dict keys are the reference's (`block3.17.attn.sr.weight`, `mlp.dwconv.dwconv.bias`,
+`fuse_layer.aspp_modules.2.depthwise_conv.bn.running_var`, `linear_fuse.conv.weight`, ...), so `mit_b5.pth` /
+Lightning checkpoints load with strict=True.  Execution differs from the reference where it matters on MI355X:
+tokens stay (B, N, C) with a single NCHW<->NHWC conversion per stage boundary, attention goes through one fused
+scaled-dot-product call (long Q, <=2040 keys after spatial reduction, head_dim 64) instead of materialising the N x Nkv
+score matrix, and K/V come from one fused projection.  Dense GEMM/conv/attention currently run on the ROCm libraries
+behind torch (hipBLASLt / MIOpen / fused SDPA); see DESIGN.md for which of them are scheduled to become hand-written
+MFMA kernels.
+"""
+import math
+import os
+import random
+from functools import partial, wraps
+from typing import Callable, List, Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .align import BaseHead
+from .layers import MLP, ConvBNReLU, DropPath
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MiT (SegFormer encoder)
+# ---------------------------------------------------------------------------------------------------------------------
+_MIT = {  # embed_dims, depths   (heads [1,2,5,8], mlp ratio 4, sr [8,4,2,1], qkv_bias, LN eps 1e-6 for all)
+    'mit_b0': ([32, 64, 160, 256], [2, 2, 2, 2]),
+    'mit_b1': ([64, 128, 320, 512], [2, 2, 2, 2]),
+    'mit_b2': ([64, 128, 320, 512], [3, 4, 6, 3]),
+    'mit_b3': ([64, 128, 320, 512], [3, 4, 18, 3]),
+    'mit_b4': ([64, 128, 320, 512], [3, 8, 27, 3]),
+    'mit_b5': ([64, 128, 320, 512], [3, 6, 40, 3]),
+}
+_MIT_HEADS = [1, 2, 5, 8]
+_MIT_SR = [8, 4, 2, 1]
+
+
+class DWConv(nn.Module):
+    """3x3 depthwise conv on tokens (mix_transformer.py:556-568); parameter path `dwconv.weight`."""
+
+    def __init__(self, dim=768):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+
+    def forward(self, x, H, W):
+        B, N, C = x.shape
+        y = self.dwconv(x.transpose(1, 2).reshape(B, C, H, W))
+        return y.flatten(2).transpose(1, 2)
+
+
+class Mlp(nn.Module):
+    """Mix-FFN (mix_transformer.py:79-103): fc1 -> depthwise 3x3 -> GELU (exact erf) -> fc2."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.dwconv = DWConv(hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x, H, W):
+        x = self.drop(self.act(self.dwconv(self.fc1(x), H, W)))
+        return self.drop(self.fc2(x))
+
+
+class Attention(nn.Module):
+    """Efficient self-attention with spatial-reduction K/V (mix_transformer.py:106-164)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., sr_ratio=1):
+        super().__init__()
+        assert dim % num_heads == 0, f'dim {dim} should be divided by num_heads {num_heads}.'
+        self.dim, self.num_heads = dim, num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.sr_ratio = sr_ratio
+        if sr_ratio > 1:
+            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x, H, W):
+        B, N, C = x.shape
+        h, d = self.num_heads, C // self.num_heads
+        q = self.q(x).view(B, N, h, d).transpose(1, 2)                       # (B,h,N,d)
+        if self.sr_ratio > 1:
+            r = self.sr(x.transpose(1, 2).reshape(B, C, H, W))               # (B,C,H/sr,W/sr)
+            x = self.norm(r.flatten(2).transpose(1, 2))
+        kv = self.kv(x).view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4)          # (2,B,h,Nkv,d)
+        p = self.attn_drop.p if self.training else 0.0
+        o = F.scaled_dot_product_attention(q, kv[0], kv[1], dropout_p=p, scale=self.scale)
+        return self.proj_drop(self.proj(o.transpose(1, 2).reshape(B, N, C)))
+
+
+class Block(nn.Module):
+    """Pre-norm transformer block with stochastic depth (mix_transformer.py:167-207)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, sr_ratio=1):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop, sr_ratio=sr_ratio)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x, H, W):
+        x = x + self.drop_path(self.attn(self.norm1(x), H, W))
+        return x + self.drop_path(self.mlp(self.norm2(x), H, W))
+
+
+class OverlapPatchEmbed(nn.Module):
+    """Overlapping patch embedding: strided conv (k=7/s=4 or k=3/s=2, pad k//2) + LayerNorm (default eps 1e-5)
+    (mix_transformer.py:210-242)."""
+
+    def __init__(self, img_size=224, patch_size=7, stride=4, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x):
+        x = self.proj(x)
+        H, W = x.shape[-2:]
+        return self.norm(x.flatten(2).transpose(1, 2)), H, W
+
+
+class MixVisionTransformer(nn.Module):
+    """mix_transformer.py:245-553.  forward(x) -> [C1@1/4, C2@1/8, C3@1/16, C4@1/32] NCHW maps."""
+
+    def __init__(self, model_type: str, pretrained: Optional[str] = None, img_size: int = 224, in_chans: int = 3,
+                 qk_scale: Optional[float] = None, drop_rate: float = 0., attn_drop_rate: float = 0.,
+                 drop_path_rate: float = 0.1, freeze_patch_embed: bool = False):
+        super().__init__()
+        dims, depths = _MIT[model_type]
+        self.model_type, self.depths = model_type, depths
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        dpr = torch.linspace(0, drop_path_rate, sum(depths)).tolist()        # stochastic depth decay rule
+        cur, cin = 0, in_chans
+        for s in range(4):
+            setattr(self, f"patch_embed{s + 1}",
+                    OverlapPatchEmbed(img_size // (1 if s == 0 else 2 ** (s + 1)), 7 if s == 0 else 3,
+                                      4 if s == 0 else 2, cin, dims[s]))
+            setattr(self, f"block{s + 1}", nn.ModuleList([
+                Block(dims[s], _MIT_HEADS[s], 4, True, qk_scale, drop_rate, attn_drop_rate, dpr[cur + i],
+                      norm_layer=norm_layer, sr_ratio=_MIT_SR[s]) for i in range(depths[s])]))
+            setattr(self, f"norm{s + 1}", norm_layer(dims[s]))
+            cur += depths[s]
+            cin = dims[s]
+        if freeze_patch_embed:
+            self.patch_embed1.requires_grad = False                          # (sic) mix_transformer.py:494-495
+        self.init_weights(pretrained)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Conv2d):
+            fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+            m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
+            if m.bias is not None:
+                m.bias.data.zero_()
+
+    def init_weights(self, pretrained=None):
+        """mix_transformer.py:445-479: local file (or $TORCH_HOME/hub/<path>); strips `backbone.`, drops `head.*`."""
+        if pretrained is None:
+            self.apply(self._init_weights)
+            return
+        names = {'imagenet': f'{self.model_type}.pth', 'cityscapes': f'{self.model_type}.pth'}
+        path = names.get(pretrained, pretrained)
+        for cand in (path, os.path.join(os.environ.get('TORCH_HOME', ''), 'hub', path),
+                     os.path.join('pretrained_models', path)):
+            if os.path.exists(cand):
+                ckpt = torch.load(cand, map_location='cpu')
+                break
+        else:
+            raise FileNotFoundError(f"MiT weights '{pretrained}' not found locally (no network access)")
+        sd = ckpt.get('state_dict', ckpt.get('model', ckpt))
+        if any(k.startswith('backbone.') for k in sd):
+            sd = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}
+        self.load_state_dict({k: v for k, v in sd.items() if not k.startswith('head.')}, strict=True)
+
+    def reset_drop_path(self, drop_path_rate):
+        dpr = torch.linspace(0, drop_path_rate, sum(self.depths)).tolist()
+        cur = 0
+        for s in range(4):
+            for i, blk in enumerate(getattr(self, f"block{s + 1}")):
+                blk.drop_path.drop_prob = dpr[cur + i]
+            cur += self.depths[s]
+
+    def forward_features(self, x):
+        B, outs = x.shape[0], []
+        for s in range(1, 5):
+            x, H, W = getattr(self, f"patch_embed{s}")(x)
+            for blk in getattr(self, f"block{s}"):
+                x = blk(x, H, W)
+            x = getattr(self, f"norm{s}")(x)
+            x = x.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+            outs.append(x)
+        return outs
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decode heads
+# ---------------------------------------------------------------------------------------------------------------------
+def _mmseg_init(module):
+    for m in module.modules():
+        if isinstance(m, ConvBNReLU) and not m.depthwise_separable:
+            nn.init.kaiming_normal_(m.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+            if m.conv.bias is not None:
+                nn.init.zeros_(m.conv.bias)
+            if m.use_norm and m.bn.weight is not None:
+                nn.init.ones_(m.bn.weight)
+                nn.init.zeros_(m.bn.bias)
+
+
+def _up(x, size):
+    return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
+
+
+class DepthwiseSeparableASPPModule(nn.ModuleList):
+    """daformer.py:10-62: branch 0 is a 1x1 ConvBNReLU, dilated branches are depthwise-separable 3x3."""
+
+    def __init__(self, dilations, in_channels, channels, norm_layer, activation_layer):
+        super().__init__()
+        self.dilations = dilations
+        for d in dilations:
+            if d == 1:
+                self.append(ConvBNReLU(in_channels, channels, 1, dilation=1, padding=0, norm_layer=norm_layer,
+                                       activation_layer=activation_layer))
+            else:
+                self.append(ConvBNReLU(in_channels, channels, 3, dilation=d, padding=d, norm_layer=norm_layer,
+                                       activation_layer=activation_layer, depthwise_separable=True))
+
+    def forward(self, x):
+        return [m(x) for m in self]
+
+
+class ASPPWrapper(nn.Module):
+    """daformer.py:65-126 with sep=True, pool=False, no context layer (the DAFormer configuration)."""
+
+    def __init__(self, in_channels, channels, sep, dilations, pool, norm_layer, activation_layer, context_cfg=None):
+        super().__init__()
+        if not sep or pool or context_cfg is not None:
+            raise NotImplementedError("DAFormer uses sep=True, pool=False, context_cfg=None (daformer.py:181-182)")
+        self.dilations = dilations
+        self.image_pool = None
+        self.context_layer = None
+        self.aspp_modules = DepthwiseSeparableASPPModule(dilations, in_channels, channels, norm_layer,
+                                                         activation_layer)
+        self.bottleneck = ConvBNReLU(len(dilations) * channels, channels, kernel_size=3, padding=1,
+                                     norm_layer=norm_layer, activation_layer=activation_layer)
+
+    def forward(self, x):
+        return self.bottleneck(torch.cat(self.aspp_modules(x), dim=1))
+
+
+class DAFormerHead(BaseHead):
+    """daformer.py:152-227: per-stage Linear embed -> bilinear to 1/4 -> concat -> sep-ASPP -> Dropout2d -> 1x1."""
+
+    def __init__(self, in_channels: List[int], in_index: Union[List[int], int], num_classes: int,
+                 input_transform: Optional[str] = None, channels: int = 256, dropout_ratio: float = 0.1,
+                 embed_dims: int = 256):
+        super().__init__(num_classes, in_index, input_transform)
+        self.in_channels, self.channels = in_channels, channels
+        if isinstance(embed_dims, int):
+            embed_dims = [embed_dims] * len(in_channels)
+        self.embed_layers = nn.ModuleDict({str(i): MLP(input_dim=c, embed_dim=e)
+                                           for i, (c, e) in enumerate(zip(in_channels, embed_dims))})
+        self.fuse_layer = ASPPWrapper(sum(embed_dims), channels, sep=True, dilations=(1, 6, 12, 18), pool=False,
+                                      norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU)
+        self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else None
+        self.conv_seg = nn.Conv2d(channels, num_classes, kernel_size=1)
+        nn.init.normal_(self.conv_seg.weight, mean=0, std=0.01)
+        nn.init.zeros_(self.conv_seg.bias)
+        _mmseg_init(self)
+
+    def forward(self, x):
+        x = self._transform_inputs(x)
+        size = x[0].shape[2:]
+        cs = []
+        for i, f in enumerate(x):
+            n, _, h, w = f.shape
+            c = self.embed_layers[str(i)](f).transpose(1, 2).reshape(n, -1, h, w)
+            cs.append(c if (h, w) == tuple(size) else _up(c, size))
+        y = self.fuse_layer(torch.cat(cs, dim=1))
+        if self.dropout is not None:
+            y = self.dropout(y)
+        return self.conv_seg(y)
+
+
+class SegFormerHead(BaseHead):
+    """segformer.py:15-111 (all-MLP decoder; used as HRDA's scale-attention head)."""
+
+    os: int = 4
+
+    def __init__(self, in_channels: List[int], in_index: Union[List[int], int], num_classes: int,
+                 input_transform: Optional[str] = None, channels: int = 256, dropout_ratio: float = 0.1):
+        super().__init__(num_classes, in_index, input_transform)
+        self.in_channels = in_channels
+        c1, c2, c3, c4 = in_channels
+        self.linear_c4 = MLP(input_dim=c4, embed_dim=channels)
+        self.linear_c3 = MLP(input_dim=c3, embed_dim=channels)
+        self.linear_c2 = MLP(input_dim=c2, embed_dim=channels)
+        self.linear_c1 = MLP(input_dim=c1, embed_dim=channels)
+        self.linear_fuse = ConvBNReLU(channels * 4, channels, kernel_size=1, norm_layer=nn.BatchNorm2d)
+        self.linear_pred = nn.Conv2d(channels, num_classes, kernel_size=1)
+        self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else None
+        nn.init.normal_(self.linear_pred.weight, mean=0, std=0.01)
+        nn.init.zeros_(self.linear_pred.bias)
+        _mmseg_init(self)
+
+    def forward(self, inputs):
+        c1, c2, c3, c4 = inputs                      # NB: takes the raw 4-tuple, no _transform_inputs (segformer.py:80)
+        size = c1.shape[2:]
+
+        def emb(layer, f):
+            n, _, h, w = f.shape
+            return layer(f).transpose(1, 2).reshape(n, -1, h, w)
+
+        parts = [_up(emb(self.linear_c4, c4), size), _up(emb(self.linear_c3, c3), size),
+                 _up(emb(self.linear_c2, c2), size), emb(self.linear_c1, c1)]
+        y = self.linear_fuse(torch.cat(parts, dim=1))
+        if self.dropout is not None:
+            y = self.dropout(y)
+        return self.linear_pred(y)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HRDA multi-resolution wrappers (models/hrda.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def extract_crop(img, crop_size, divisible=1):
+    """Random crop with offsets that are multiples of `divisible` (hrda.py:9-34).  Uses python `random` like the
+    reference, so the same seed gives the same box."""
+    H, W = img.shape[-2:]
+    assert crop_size[0] > 0 and crop_size[1] > 0
+    if H == crop_size[-2] and W == crop_size[-1]:
+        return (0, H, 0, W)                                                   # (sic) hrda.py:20-21
+    oy = random.randrange(0, int((max(H - crop_size[-2], 0) + 1) // divisible)) * divisible
+    ox = random.randrange(0, int((max(W - crop_size[-1], 0) + 1) // divisible)) * divisible
+    y1, y2, x1, x2 = int(oy), int(oy + crop_size[0]), int(ox), int(ox + crop_size[1])
+    return img[:, :, y1:y2, x1:x2], [[y1, y2, x1, x2]]
+
+
+def scale_box(box, scale):
+    """hrda.py:50-64 (int() truncation of each coordinate)."""
+    return tuple(int(v / scale) for v in box)
+
+
+def hr_crop_slice(crop_box, scale):
+    y1, y2, x1, x2 = scale_box(crop_box, scale)
+    return slice(y1, y2), slice(x1, x2)
+
+
+def extract_slide_crop(img, crop_size):
+    """Sliding crops with stride = crop/2, last crops clamped to the border (hrda.py:67-94)."""
+    hc, wc = crop_size
+    hs, ws = hc // 2, wc // 2
+    H, W = img.shape[-2:]
+    crops, boxes = [], []
+    for iy in range(max(H - hc + hs - 1, 0) // hs + 1):
+        for ix in range(max(W - wc + ws - 1, 0) // ws + 1):
+            y2, x2 = min(iy * hs + hc, H), min(ix * ws + wc, W)
+            y1, x1 = max(y2 - hc, 0), max(x2 - wc, 0)
+            crops.append(img[:, :, y1:y2, x1:x2])
+            boxes.append([y1, y2, x1, x2])
+    return torch.cat(crops, dim=0), boxes
+
+
+def hrda_backbone(self, head_os: int, is_teacher: bool = False) -> Callable:
+    """Decorator for backbone.forward (hrda.py:97-136): low-res (x0.5 bilinear) view + HR crop(s) in ONE backbone
+    pass; student in training = one random crop (offsets multiple of 2*head_os), teacher / eval = sliding crops."""
+    def deco(fn: Callable) -> Callable:
+        @wraps(fn)
+        def inner(x, *args, **kwargs):
+            lr = F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=False)
+            size = lr.shape[-2:]
+            if self.training and not is_teacher:
+                hr, boxes = extract_crop(x, size, head_os * 2.0)
+            else:
+                hr, boxes = extract_slide_crop(x, size)
+            nl, nh = lr.shape[0], hr.shape[0]
+            feats = fn(torch.cat((lr, hr)), *args, **kwargs)
+            lr_feats, hr_feats = zip(*(torch.split(f, [nl, nh]) for f in feats))
+            return lr_feats, hr_feats, boxes
+        return inner
+    return deco
+
+
+def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: bool = False) -> Callable:
+    """Decorator for head.forward (hrda.py:139-235): scale attention from the LR features, fusion of LR logits and
+    HR crop logits.  Student/train returns (logits, hr_logits, crop_box); teacher/eval returns logits."""
+    def deco(fn: Callable) -> Callable:
+        @wraps(fn)
+        def inner(inp, *args, **kwargs):
+            lr_feats, hr_feats, boxes = inp
+            att = torch.sigmoid(hrda_scale_attention(lr_feats))
+            nl, nh = lr_feats[0].shape[0], hr_feats[0].shape[0]
+            seg = fn([torch.cat(p) for p in zip(lr_feats, hr_feats)], *args, **kwargs)
+            lr_seg, hr_seg = torch.split(seg, [nl, nh])
+            if self.training and not is_teacher:
+                box = boxes[0]
+                crop_size = (box[1] - box[0], box[3] - box[2])
+                mask = lr_seg.new_zeros([nl, 1, *lr_seg.shape[2:]])
+                sy, sx = hr_crop_slice(box, 2.0 * head_os)
+                mask[:, :, sy, sx] = 1
+                att = att * mask
+                up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
+                up_att = F.interpolate(att, scale_factor=2, mode='bilinear', align_corners=False)
+                inserted = torch.zeros_like(up_lr)
+                sy, sx = hr_crop_slice(box, head_os)
+                inserted[:, :, sy, sx] = hr_seg
+                hr_logits = _up(hr_seg, crop_size)
+                return up_att * inserted + up_lr, hr_logits, box
+            up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
+            # overlap-average the sliding crops (the reference rescales `hr_boxes` in place, hrda.py:207-208)
+            for i in range(len(boxes)):
+                boxes[i] = scale_box(boxes[i], head_os)
+            Hh, Ww = max(b[1] for b in boxes), max(b[3] for b in boxes)
+            preds = lr_seg.new_zeros((nl, self.num_classes, Hh, Ww))
+            count = lr_seg.new_zeros((nl, 1, Hh, Ww))
+            for i, (y1, y2, x1, x2) in enumerate(boxes):
+                preds[:, :, y1:y2, x1:x2] += hr_seg[i * nl:(i + 1) * nl]
+                count[:, :, y1:y2, x1:x2] += 1
+            up_att = F.interpolate(att, scale_factor=2, mode='bilinear', align_corners=False)
+            return up_att * (preds / count) + up_lr
+        return inner
+    return deco
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# loss
+# ---------------------------------------------------------------------------------------------------------------------
+class PixelWeightedCrossEntropyLoss(nn.Module):
+    """models/losses.py:10-22: CE(ignore_index, reduction none) x optional pixel weight, mean over ALL pixels."""
+
+    def __init__(self, ignore_index: int = 255) -> None:
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, input, target, pixel_weight=None):
+        loss = F.cross_entropy(input, target, ignore_index=self.ignore_index, reduction='none')
+        if pixel_weight is not None:
+            assert pixel_weight.dim() == loss.dim()
+            loss = loss * pixel_weight.to(loss.dtype)
+        return loss.mean()

@@ -1,0 +1,121 @@
+"""Minimal one-process-per-GPU trainer that stands where PyTorch-Lightning's Trainer stands in the reference
+(SURVEY.md L4): it owns the optimiser/scheduler, drives `training_step`, and implements the data-parallel part.
+
+Data parallelism: image pairs are independent, so ranks shard the batch; align / refine / teacher are
+gradient-free replicas with ZERO communication.  The student's gradients of the three backward passes of a step are
+accumulated into one flat fp32 buffer (every `p.grad` is a view into it) and all-reduced ONCE per step with RCCL,
+averaged over ranks -- the reference's DDP does the same reduction three times per step (once per manual_backward).
+On xGMI (7 point-to-point links per GPU) one 342 MB all-reduce is bandwidth-bound; the flat buffer is reduced in
+`bucket_mb` chunks issued back to back on the RCCL stream so the first chunks overlap the tail of the backward pass.
+BatchNorm layers become SyncBatchNorm when the config says `sync_batchnorm: True` (student AND teacher, D9).
+"""
+import os
+from typing import List
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class LinearWarmupPolynomialLR(torch.optim.lr_scheduler.LRScheduler):
+    """helpers/lr_scheduler.py:10-57: linear warm-up from warmup_ratio*lr over warmup_iters, then polynomial decay to
+    min_lr at max_steps."""
+
+    def __init__(self, optimizer, max_steps: int = None, warmup_iters: int = 1500, warmup_ratio: float = 1e-6,
+                 power=0.9, min_lr=0., last_epoch=-1):
+        self.max_updates, self.warmup_iters, self.warmup_ratio = max_steps, warmup_iters, warmup_ratio
+        self.power, self.min_lr = power, min_lr
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self) -> List[float]:
+        t = self.last_epoch
+        if t < self.warmup_iters:
+            k = (1 - t / self.warmup_iters) * (1 - self.warmup_ratio)
+            return [lr * (1 - k) for lr in self.base_lrs]
+        coeff = (1 - (t - self.warmup_iters) / float(self.max_updates - self.warmup_iters)) ** self.power
+        return [(lr - self.min_lr) * coeff + self.min_lr for lr in self.base_lrs]
+
+
+class ValEveryNSteps:
+    """helpers/callbacks.py: validation every N steps (evaluation is out of scope here; kept so configs parse)."""
+
+    def __init__(self, every_n_steps):
+        self.every_n_steps = every_n_steps
+
+
+class FlatGradBuffer:
+    """All trainable parameters' gradients as views into one contiguous fp32 tensor."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, bucket_mb=64):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        step = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        works = [dist.all_reduce(self.flat[i:i + step], op=dist.ReduceOp.SUM, async_op=True)
+                 for i in range(0, self.flat.numel(), step)]
+        for w in works:
+            w.wait()
+        self.flat.div_(world)
+
+
+class Trainer:
+    """fit-loop subset: `step(batch)` = one reference training_step including EMA, three backward passes, the single
+    gradient all-reduce and the optimiser/scheduler step."""
+
+    def __init__(self, model, sync_batchnorm=False, bucket_mb=64, fused_optimizer=True):
+        self.model = model
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if sync_batchnorm and self.world > 1:
+            nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        if fused_optimizer and model.optimizer_init["class_path"].endswith("AdamW") and \
+                next(model.parameters()).is_cuda:
+            model.optimizer_init = {**model.optimizer_init,
+                                    "init_args": {**model.optimizer_init["init_args"], "fused": True}}
+        (opt,), (sch,) = model.configure_optimizers()
+        self.optimizer, self.scheduler = opt, sch
+        self.grads = FlatGradBuffer([p for g in opt.param_groups for p in g["params"]])
+        self.bucket_mb = bucket_mb
+        model._optimizer = _OptimizerProxy(self)
+        model._scheduler = sch
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self):
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            dist.broadcast(t.data, src=0)
+
+    def step(self, batch, batch_idx=0):
+        self.model.training_step(batch, batch_idx)
+        return {k: (float(v) if torch.is_tensor(v) else v) for k, v in self.model.logged.items()} \
+            if os.environ.get("RFN_LOG_LOSSES") else None
+
+
+class _OptimizerProxy:
+    """What `self.optimizers()` returns inside training_step: zero_grad() clears the flat buffer (keeping the views),
+    step() all-reduces once and then steps the real optimiser."""
+
+    def __init__(self, trainer):
+        self.t = trainer
+
+    def zero_grad(self):
+        self.t.grads.zero()
+
+    def step(self):
+        self.t.grads.all_reduce_mean(self.t.bucket_mb)
+        self.t.optimizer.step()
+
+    def __getattr__(self, name):
+        return getattr(self.t.optimizer, name)

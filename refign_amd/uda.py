@@ -1,0 +1,497 @@
+"""The Refign UDA training step on MI355X.
+
+Host mirror of models/segmentation_model.py (DomainAdaptationSegmentationModel): same constructor keywords (= the
+`model.init_args` of the reference's YAML configs), same `training_step` semantics (source CE, ImageNet feature
+distance, EMA teacher, align, refine, DACS class-mix, mixed CE, three backward passes, one optimiser step), same
+`forward` / `whole_inference` / `slide_inference`, `configure_optimizers`, `align`, `refine`, `eta`,
+`update_momentum_encoder`, `train`.  It is a plain nn.Module: PyTorch-Lightning is not part of the product (and not
+installed); refign_amd/trainer.py drives it one process per GPU.
+
+What is done differently, for the hardware:
+  * align / refine / the logits warp run in the HIP kernels of csrc/ (refign_amd.align / .refine / .matching);
+  * the EMA update is one multi-tensor op over ~1090 tensors instead of ~1090 tiny launches (a25);
+  * gradients of the three backward passes accumulate in ONE flat fp32 buffer and are all-reduced ONCE per step over
+    RCCL (the reference's DDP all-reduces after each of the three manual_backward calls; the mean of sums is the same
+    up to summation order) -- see refign_amd/trainer.py;
+  * the quirks the reference's numbers depend on are kept: teacher networks run in train mode (stochastic dropout /
+    drop-path and batch-statistics BatchNorm), refine() output is not renormalised (D8), the pseudo-label
+    weight is batch-global, get_class_masks draws classes from the whole batch.
+"""
+import copy
+import math
+import random
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import align as align_mod
+from . import refine as refine_mod
+from .config import instantiate_class
+from .seg import hrda_backbone, hrda_head
+
+IMNET_MEAN = (0.485, 0.456, 0.406)
+IMNET_STD = (0.229, 0.224, 0.225)
+
+
+def crop(img, crop_bbox):
+    """helpers/utils.py:44-56."""
+    y1, y2, x1, x2 = crop_bbox
+    if img.dim() == 4:
+        return img[:, :, y1:y2, x1:x2]
+    if img.dim() == 3:
+        return img[:, y1:y2, x1:x2]
+    if img.dim() == 2:
+        return img[y1:y2, x1:x2]
+    raise NotImplementedError(img.dim())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DACS strong augmentation (helpers/dacs_transforms.py).  The class-mix is exact; colour jitter / blur are random
+# augmentations (kornia 0.5.8 in the reference, not installed): restated with torch ops, parity unpinned.
+# ---------------------------------------------------------------------------------------------------------------------
+def get_class_masks(labels):
+    """dacs_transforms.py:81-92.  `labels`: (b,1,H,W).  NB the reference draws the candidate classes from
+    torch.unique over the WHOLE batch for every sample ("this seems to be a bug, we keep it for consistency")."""
+    masks = []
+    for label in labels:
+        classes = torch.unique(labels)
+        n = classes.shape[0]
+        choice = np.random.choice(n, int((n + n % 2) / 2), replace=False)
+        chosen = classes[torch.as_tensor(choice, dtype=torch.long, device=classes.device)]
+        masks.append((label.unsqueeze(0) == chosen.view(-1, 1, 1, 1)).sum(0, keepdim=False).unsqueeze(0))
+    return masks
+
+
+def one_mix(mask, data=None, target=None):
+    """dacs_transforms.py:102-112: mask selects element 0 (source), 1 - mask element 1 (target)."""
+    if mask is None:
+        return data, target
+    if data is not None:
+        m, _ = torch.broadcast_tensors(mask[0], data[0])
+        data = (m * data[0] + (1 - m) * data[1]).unsqueeze(0)
+    if target is not None:
+        m, _ = torch.broadcast_tensors(mask[0], target[0])
+        target = (m * target[0] + (1 - m) * target[1]).unsqueeze(0)
+    return data, target
+
+
+def _color_jitter(img01, s):
+    """brightness / contrast / saturation / hue jitter of strength s on a [0,1] RGB batch, random order."""
+    ops = [0, 1, 2, 3]
+    random.shuffle(ops)
+    x = img01
+    for op in ops:
+        f = random.uniform(max(0.0, 1 - s), 1 + s)
+        if op == 0:
+            x = x * f
+        elif op == 1:
+            mean = x.mean(dim=(1, 2, 3), keepdim=True)
+            x = (x - mean) * f + mean
+        elif op == 2:
+            gray = (0.299 * x[:, 0:1] + 0.587 * x[:, 1:2] + 0.114 * x[:, 2:3])
+            x = (x - gray) * f + gray
+        else:
+            h = random.uniform(-s, s) * 2 * math.pi           # rotate chroma in YIQ space
+            c, sn = math.cos(h), math.sin(h)
+            yiq = x.new_tensor([[0.299, 0.587, 0.114], [0.596, -0.274, -0.322], [0.211, -0.523, 0.312]])
+            rot = x.new_tensor([[1, 0, 0], [0, c, -sn], [0, sn, c]])
+            m = torch.linalg.inv(yiq) @ rot @ yiq
+            x = torch.einsum('ij,bjhw->bihw', m, x)
+        x = x.clamp(0, 1)
+    return x
+
+
+def _gaussian_blur(x, ksize, sigma):
+    def k1d(k):
+        r = torch.arange(k, dtype=x.dtype, device=x.device) - (k - 1) / 2
+        g = torch.exp(-r ** 2 / (2 * sigma ** 2))
+        return g / g.sum()
+    ky, kx = k1d(ksize[0]), k1d(ksize[1])
+    c = x.shape[1]
+    x = F.conv2d(F.pad(x, (0, 0, ksize[0] // 2, ksize[0] // 2), mode='reflect'),
+                 ky.view(1, 1, -1, 1).expand(c, 1, -1, 1), groups=c)
+    return F.conv2d(F.pad(x, (ksize[1] // 2, ksize[1] // 2, 0, 0), mode='reflect'),
+                    kx.view(1, 1, 1, -1).expand(c, 1, 1, -1), groups=c)
+
+
+def strong_transform(param, data=None, target=None):
+    """dacs_transforms.py:14-24: class-mix, then colour jitter (if param['color_jitter'] > p), then blur (> 0.5)."""
+    assert data is not None or target is not None
+    data, target = one_mix(mask=param['mix'], data=data, target=target)
+    if data is not None and data.shape[1] == 3:
+        mean = data.new_tensor(IMNET_MEAN).view(1, 3, 1, 1)
+        std = data.new_tensor(IMNET_STD).view(1, 3, 1, 1)
+        if param['color_jitter'] > param['color_jitter_p']:
+            data = (_color_jitter(data * std + mean, param['color_jitter_s']) - mean) / std
+        if param['blur'] > 0.5:
+            sigma = np.random.uniform(0.15, 1.15)
+            ks = tuple(int(np.floor(np.ceil(0.1 * d) - 0.5 + np.ceil(0.1 * d) % 2)) for d in data.shape[2:])
+            data = _gaussian_blur(data, ks, sigma)
+    return data, target
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class DomainAdaptationSegmentationModel(nn.Module):
+    """models/segmentation_model.py:25-701.  Constructor keywords are the reference's."""
+
+    def __init__(self,
+                 optimizer_init: dict,
+                 lr_scheduler_init: dict,
+                 backbone: nn.Module,
+                 head: nn.Module,
+                 loss: nn.Module,
+                 alignment_backbone: Optional[nn.Module] = None,
+                 alignment_head: Optional[nn.Module] = None,
+                 metrics: dict = {},
+                 backbone_lr_factor: float = 1.0,
+                 use_refign: bool = False,
+                 use_align: bool = True,
+                 gamma: float = 0.25,
+                 adapt_to_ref: bool = False,
+                 disable_M: bool = False,
+                 disable_P: bool = False,
+                 ema_momentum: float = 0.999,
+                 pseudo_label_threshold: float = 0.968,
+                 psweight_ignore_top: int = 0,
+                 psweight_ignore_bottom: int = 0,
+                 enable_fdist: bool = True,
+                 fdist_lambda: float = 0.005,
+                 fdist_classes: list = [6, 7, 11, 12, 13, 14, 15, 16, 17, 18],
+                 fdist_scale_min_ratio: float = 0.75,
+                 color_jitter_s: float = 0.2,
+                 color_jitter_p: float = 0.2,
+                 blur: bool = True,
+                 use_hrda: bool = False,
+                 hrda_output_stride: int = 4,
+                 hrda_scale_attention: Optional[nn.Module] = None,
+                 hr_loss_weight: float = 0.1,
+                 use_slide_inference: bool = False,
+                 inference_batched_slide: bool = True,
+                 inference_crop_size: list = [1080, 1080],
+                 inference_stride: list = [420, 420],
+                 pretrained: Optional[str] = None):
+        super().__init__()
+        self.backbone, self.head = backbone, head
+        self.hrda_scale_attention = hrda_scale_attention if use_hrda else None
+        self.alignment_backbone, self.alignment_head = alignment_backbone, alignment_head
+        for m in filter(None, [self.alignment_backbone, self.alignment_head]):
+            m.requires_grad_(False)
+        # EMA teacher and frozen ImageNet encoder are deep copies taken BEFORE the HRDA wrapping (:77-87)
+        self.m_backbone = copy.deepcopy(self.backbone)
+        self.m_head = copy.deepcopy(self.head)
+        self.m_hrda_scale_attention = copy.deepcopy(self.hrda_scale_attention)
+        for p in self.ema_parameters():
+            p.requires_grad = False
+        self.enable_fdist = enable_fdist
+        if enable_fdist:
+            self.imnet_backbone = copy.deepcopy(self.backbone)
+            self.imnet_backbone.requires_grad_(False)
+        self.loss = loss
+        self.metrics_cfg = metrics
+        self.optimizer_init, self.lr_scheduler_init = optimizer_init, lr_scheduler_init
+        self.backbone_lr_factor = backbone_lr_factor
+        self.use_refign, self.use_align, self.gamma = use_refign, use_align, gamma
+        self.adapt_to_ref, self.disable_M, self.disable_P = adapt_to_ref, disable_M, disable_P
+        self.ema_momentum = ema_momentum
+        self.pseudo_label_threshold = pseudo_label_threshold
+        self.psweight_ignore_top, self.psweight_ignore_bottom = psweight_ignore_top, psweight_ignore_bottom
+        self.fdist_lambda, self.fdist_classes = fdist_lambda, fdist_classes
+        self.fdist_scale_min_ratio = fdist_scale_min_ratio
+        self.color_jitter_s, self.color_jitter_p, self.blur = color_jitter_s, color_jitter_p, blur
+        self.use_hrda = use_hrda
+        if use_hrda:
+            os_ = hrda_output_stride
+            self.backbone.forward = hrda_backbone(self.backbone, os_)(self.backbone.forward)
+            self.head.forward = hrda_head(self.head, self.hrda_scale_attention, os_)(self.head.forward)
+            self.m_backbone.forward = hrda_backbone(self.m_backbone, os_, is_teacher=True)(self.m_backbone.forward)
+            self.m_head.forward = hrda_head(self.m_head, self.m_hrda_scale_attention, os_,
+                                            is_teacher=True)(self.m_head.forward)
+        self.hr_loss_weight = hr_loss_weight
+        self.use_slide_inference = use_slide_inference
+        self.inference_batched_slide = inference_batched_slide
+        self.inference_crop_size, self.inference_stride = inference_crop_size, inference_stride
+        self.automatic_optimization = False
+        # trainer-provided state
+        self.global_step = 0
+        self._optimizer = None
+        self._scheduler = None
+        self._backward = None           # set by the trainer: callable(loss, retain_graph)
+        self.logged = {}
+        self.load_weights(pretrained)
+
+    # -- trainer hooks (what Lightning provides in the reference) ---------------------------------------------------
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def optimizers(self):
+        return self._optimizer
+
+    def lr_schedulers(self):
+        return self._scheduler
+
+    def manual_backward(self, loss, retain_graph=False):
+        if self._backward is not None:
+            self._backward(loss, retain_graph)
+        else:
+            loss.backward(retain_graph=retain_graph)
+
+    def log(self, name, value, **kw):
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
+
+    # -- the step ------------------------------------------------------------------------------------------------
+    def training_step(self, batch, batch_idx):
+        """segmentation_model.py:146-253."""
+        opt, sch = self.optimizers(), self.lr_schedulers()
+        opt.zero_grad()
+        self.update_momentum_encoder()
+
+        # SOURCE (:156-179)
+        images_src, gt_src = batch['image_src'], batch['semantic_src']
+        feats_src = self.backbone(images_src)
+        logits_src = self.head(feats_src)
+        if self.use_hrda:
+            feats_src = feats_src[0]                                     # low-resolution features
+            logits_src, hr_logits_src, crop_box_src = logits_src
+            logits_src = F.interpolate(logits_src, images_src.shape[-2:], mode='bilinear', align_corners=False)
+            loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
+                self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
+        else:
+            logits_src = F.interpolate(logits_src, images_src.shape[-2:], mode='bilinear', align_corners=False)
+            loss_src = self.loss(logits_src, gt_src)
+        self.log("train_loss_src", loss_src)
+        self.manual_backward(loss_src, retain_graph=self.enable_fdist)
+        del loss_src, logits_src
+
+        # ImageNet feature distance (:181-189)
+        if self.enable_fdist:
+            loss_fd = self.calc_feat_dist(images_src, gt_src, feats_src)
+            self.log("train_loss_featdist_src", loss_fd)
+            self.manual_backward(loss_fd)
+            del loss_fd
+        del feats_src
+
+        # TARGET: teacher, align, refine, DACS mix (:194-224)
+        with torch.no_grad():
+            if self.adapt_to_ref and random.random() < 0.5:
+                adapt_to_ref, images_trg = True, batch['image_ref']
+            else:
+                adapt_to_ref, images_trg = False, batch['image_trg']
+            if self.use_refign and not adapt_to_ref:
+                images_ref = batch['image_ref']
+                b = images_trg.shape[0]
+                m_input = torch.cat((images_trg, images_ref))
+                m_logits = self.m_head(self.m_backbone(m_input))
+                m_logits = F.interpolate(m_logits, size=m_input.shape[-2:], mode='bilinear', align_corners=False)
+                m_logits_trg, m_logits_ref = torch.split(m_logits, [b, b], dim=0)
+                if self.use_align:
+                    warped, warp_mask, warp_certs = self.align(m_logits_ref.contiguous(), images_ref, images_trg)
+                    m_probs_trg = self.refine(m_logits_trg, warped, warp_mask, warp_certs)
+                else:
+                    m_probs_trg = self.refine(m_logits_trg, m_logits_ref, None, None)
+            else:
+                m_logits_trg = self.m_head(self.m_backbone(images_trg))
+                m_logits_trg = F.interpolate(m_logits_trg, size=images_trg.shape[-2:], mode='bilinear',
+                                             align_corners=False)
+                m_probs_trg = F.softmax(m_logits_trg, dim=1)
+            mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src)
+
+        # MIXED (:226-250)
+        mixed_pred = self.head(self.backbone(mixed_img))
+        if self.use_hrda:
+            mixed_pred, hr_mixed_pred, box = mixed_pred
+            mixed_pred = F.interpolate(mixed_pred, mixed_img.shape[-2:], mode='bilinear', align_corners=False)
+            mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
+                self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box),
+                                                pixel_weight=crop(mixed_weight, box))
+        else:
+            mixed_pred = F.interpolate(mixed_pred, mixed_img.shape[-2:], mode='bilinear', align_corners=False)
+            mixed_loss = self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight)
+        self.log("train_loss_uda_trg", mixed_loss)
+        self.manual_backward(mixed_loss)
+        del mixed_loss, mixed_pred
+
+        opt.step()
+        sch.step()
+        self.global_step += 1
+
+    # -- inference (:304-382) ------------------------------------------------------------------------------------
+    def forward(self, x, out_size=None):
+        logits = self.slide_inference(x) if self.use_slide_inference else self.whole_inference(x)
+        if out_size is not None:
+            logits = F.interpolate(logits, size=out_size, mode='bilinear', align_corners=False)
+        return logits
+
+    def whole_inference(self, x):
+        logits = self.head(self.backbone(x))
+        return F.interpolate(logits, x.shape[-2:], mode='bilinear', align_corners=False)
+
+    def slide_inference(self, img):
+        hs, ws = self.inference_stride
+        hc, wc = self.inference_crop_size
+        b, _, H, W = img.shape
+        boxes = []
+        for iy in range(max(H - hc + hs - 1, 0) // hs + 1):
+            for ix in range(max(W - wc + ws - 1, 0) // ws + 1):
+                y2, x2 = min(iy * hs + hc, H), min(ix * ws + wc, W)
+                boxes.append((max(y2 - hc, 0), y2, max(x2 - wc, 0), x2))
+        preds = img.new_zeros((b, self.head.num_classes, H, W))
+        count = img.new_zeros((b, 1, H, W))
+        if self.inference_batched_slide:
+            logits = self.whole_inference(torch.cat([img[:, :, y1:y2, x1:x2] for y1, y2, x1, x2 in boxes], dim=0))
+            for i, (y1, y2, x1, x2) in enumerate(boxes):
+                preds[:, :, y1:y2, x1:x2] += logits[i * b:(i + 1) * b]
+                count[:, :, y1:y2, x1:x2] += 1
+        else:
+            for y1, y2, x1, x2 in boxes:
+                preds[:, :, y1:y2, x1:x2] += self.whole_inference(img[:, :, y1:y2, x1:x2])
+                count[:, :, y1:y2, x1:x2] += 1
+        assert (count == 0).sum() == 0
+        return preds / count
+
+    # -- optimisation (:384-419) ---------------------------------------------------------------------------------
+    def optimizer_parameters(self):
+        groups = {k: [] for k in ('head_weight', 'head_bias', 'backbone_weight', 'backbone_bias')}
+        for name, p in self.named_parameters():
+            if not p.requires_grad:
+                continue
+            where = 'backbone' if name.startswith('backbone') else 'head'
+            groups[f"{where}_{'bias' if p.dim() == 1 else 'weight'}"].append(p)      # 1-D: biases and norm params
+        lr = self.optimizer_init['init_args']['lr']
+        wd = self.optimizer_init['init_args']['weight_decay']
+        return [
+            {'name': 'head_weight', 'params': groups['head_weight'], 'lr': lr, 'weight_decay': wd},
+            {'name': 'head_bias', 'params': groups['head_bias'], 'lr': lr, 'weight_decay': 0},
+            {'name': 'backbone_weight', 'params': groups['backbone_weight'], 'lr': self.backbone_lr_factor * lr,
+             'weight_decay': wd},
+            {'name': 'backbone_bias', 'params': groups['backbone_bias'], 'lr': self.backbone_lr_factor * lr,
+             'weight_decay': 0},
+        ]
+
+    def configure_optimizers(self):
+        optimizer = instantiate_class(self.optimizer_parameters(), self.optimizer_init)
+        scheduler = instantiate_class(optimizer, self.lr_scheduler_init)
+        return [optimizer], [scheduler]
+
+    def load_weights(self, pretrain_path):
+        if pretrain_path is None:
+            return
+        ckpt = torch.load(pretrain_path, map_location='cpu')
+        self.load_state_dict(ckpt.get('state_dict', ckpt), strict=True)
+
+    # -- refign (:438-523) ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def refine(self, logits_trg, logits_ref, warp_mask, certs):
+        return refine_mod.refine(logits_trg, logits_ref, warp_mask, certs, gamma=self.gamma, disable_M=self.disable_M,
+                                 disable_P=self.disable_P)
+
+    @staticmethod
+    @torch.no_grad()
+    def eta(logits):
+        """normalised entropy (:484-491)"""
+        ent = -(F.softmax(logits, dim=1) * F.log_softmax(logits, dim=1)).sum(dim=1)
+        return ent / math.log(logits.shape[1])
+
+    @torch.no_grad()
+    def align(self, logits_ref, images_ref, images_trg):
+        assert self.alignment_head is not None
+        return align_mod.align(self.alignment_backbone, self.alignment_head, logits_ref, images_ref, images_trg)
+
+    # -- DACS (:525-582) -----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_dacs_mix(self, images_trg, probs_trg, images_src, gt_src):
+        nb = images_trg.shape[0]
+        if images_src.shape[0] > nb:
+            images_src, gt_src = images_src[:nb], gt_src[:nb]
+        params = {'mix': None, 'color_jitter': random.uniform(0, 1), 'color_jitter_s': self.color_jitter_s,
+                  'color_jitter_p': self.color_jitter_p, 'blur': random.uniform(0, 1) if self.blur else 0}
+        pseudo_prob, pseudo_label = torch.max(probs_trg, dim=1)
+        # ONE scalar for the whole batch: fraction of confident pixels (:552-556)
+        weight = (pseudo_prob >= self.pseudo_label_threshold).sum() / pseudo_label.numel()
+        pseudo_weight = torch.full_like(pseudo_prob, 1.0) * weight
+        if self.psweight_ignore_top > 0:
+            pseudo_weight[:, :self.psweight_ignore_top, :] = 0
+        if self.psweight_ignore_bottom > 0:
+            pseudo_weight[:, -self.psweight_ignore_bottom:, :] = 0
+        gt_weight = torch.ones_like(pseudo_weight)
+        masks = get_class_masks(gt_src.unsqueeze(1))
+        mixed_img, mixed_lbl = [None] * nb, [None] * nb
+        for i in range(nb):
+            params['mix'] = masks[i]
+            mixed_img[i], mixed_lbl[i] = strong_transform(params, data=torch.stack((images_src[i], images_trg[i])),
+                                                          target=torch.stack((gt_src[i], pseudo_label[i])))
+            _, w = strong_transform(params, target=torch.stack((gt_weight[i], pseudo_weight[i])))
+            pseudo_weight[i] = w[0, 0] if w.dim() == 4 else w[0]
+        return torch.cat(mixed_img), torch.cat(mixed_lbl).squeeze(1), pseudo_weight
+
+    # -- feature distance (:584-668) -----------------------------------------------------------------------------
+    def calc_feat_dist(self, img, gt, feat=None):
+        assert self.enable_fdist
+        with torch.no_grad():
+            if self.use_hrda:
+                img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+            feat_imnet = self.imnet_backbone(img)
+            feat_imnet = [f.detach() for f in feat_imnet] if isinstance(feat_imnet, Sequence) else [feat_imnet.detach()]
+        if not isinstance(feat, Sequence):
+            feat = [feat]
+        if self.fdist_classes is not None:
+            scale = gt.shape[-1] // feat[-1].shape[-1]
+            gt_small = self.downscale_label_ratio(gt.unsqueeze(1), scale, self.fdist_scale_min_ratio,
+                                                  self.head.num_classes, 255).long()
+            cls = torch.tensor(self.fdist_classes, device=gt.device)
+            mask = torch.any(gt_small[..., None] == cls, -1)
+            dist = self.masked_feat_dist(feat[-1], feat_imnet[-1], mask)
+        else:
+            dist = self.masked_feat_dist(feat[-1], feat_imnet[-1])
+        return self.fdist_lambda * dist
+
+    @staticmethod
+    def masked_feat_dist(f1, f2, mask=None):
+        d = torch.norm(f1 - f2, dim=1, p=2)
+        if mask is not None:
+            d = d[mask.squeeze(1)]
+        return torch.mean(d)
+
+    @staticmethod
+    def downscale_label_ratio(gt, scale_factor, min_ratio, n_classes, ignore_index=255):
+        """(:637-668) majority class per scale x scale window if its share >= min_ratio, else ignore."""
+        assert scale_factor > 1
+        b, c, H, W = gt.shape
+        assert c == 1
+        out = gt.clone()
+        out[out == ignore_index] = n_classes
+        onehot = F.one_hot(out.squeeze(1), num_classes=n_classes + 1).permute(0, 3, 1, 2).float()
+        ratio, out = torch.max(F.avg_pool2d(onehot, kernel_size=scale_factor), dim=1, keepdim=True)
+        out[out == n_classes] = ignore_index
+        out[ratio < min_ratio] = ignore_index
+        return out
+
+    # -- EMA (:670-689) --------------------------------------------------------------------------------------------
+    def ema_parameters(self):
+        for m in filter(None, [self.m_backbone, self.m_head, self.m_hrda_scale_attention]):
+            yield from m.parameters()
+
+    def live_parameters(self):
+        for m in filter(None, [self.backbone, self.head, self.hrda_scale_attention]):
+            yield from m.parameters()
+
+    @torch.no_grad()
+    def update_momentum_encoder(self):
+        m = min(1.0 - 1 / (float(self.global_step) + 1.0), self.ema_momentum)
+        ema = [p.data for p in self.ema_parameters()]
+        live = [p.data for p in self.live_parameters()]
+        torch._foreach_mul_(ema, m)                   # one multi-tensor launch per op instead of ~1090 x 3
+        torch._foreach_add_(ema, live, alpha=1.0 - m)
+
+    def train(self, mode=True):
+        """(:691-701) alignment nets and the ImageNet encoder always in eval; the reference's attempt to disable
+        dropout/drop-path of the teacher tests the TOP-LEVEL modules only and therefore changes nothing (D7)."""
+        super().train(mode=mode)
+        for m in filter(None, [self.alignment_backbone, self.alignment_head]):
+            m.eval()
+        if self.enable_fdist:
+            self.imnet_backbone.eval()
+        return self

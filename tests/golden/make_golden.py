@@ -161,12 +161,14 @@ GROUPS = {"G1": g1, "G2": g2, "G3": g3, "G6": g6, "G8": g8}
 def main(argv):
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    torch.set_num_threads(8)
     corr = R.setup()
-    try:
-        import make_golden_modules as mm   # G4, G5, G7 (need the closed-form weight filler)
-        GROUPS.update(mm.GROUPS)
-    except ImportError:
-        pass
+    import make_golden_modules as mm   # G4, G5, G7 (need the closed-form weight filler)
+    import make_golden_seg as ms       # G9-G12
+    import make_golden_step as mst     # G13
+    GROUPS.update(mm.GROUPS)
+    GROUPS.update(ms.GROUPS)
+    GROUPS.update(mst.GROUPS)
     which = argv or sorted(GROUPS)
     for g in which:
         print(g)

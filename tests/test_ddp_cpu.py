@@ -1,0 +1,84 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of refign_amd/trainer.py -- every p.grad is a view into one
+flat buffer, one bucketed all-reduce per step gives the mean over ranks, parameters are broadcast from rank 0, and a
+2-rank step equals the 1-rank step on the concatenated batch for a batch-mean loss."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU())
+        self.head = nn.Conv2d(8, 4, 1)
+
+    def forward(self, x):
+        return self.head(self.backbone(x))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from refign_amd.trainer import FlatGradBuffer
+    torch.manual_seed(100 + rank)                 # different init per rank on purpose
+    model = Tiny()
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=0)
+    model = nn.SyncBatchNorm.convert_sync_batchnorm(model) if False else model   # gloo SyncBN is GPU-only; BN local
+    model.eval()                                   # eval BN => loss is a pure per-sample mean
+    grads = FlatGradBuffer(model.parameters())
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    y = torch.randn(4, 4, 8, 8, generator=g)
+    shard = slice(rank * 2, rank * 2 + 2)
+    for _ in range(3):                              # three backward passes accumulate into the flat buffer
+        ((model(x[shard]) - y[shard]) ** 2).mean().backward()
+    assert all(p.grad.data_ptr() >= grads.flat.data_ptr() for p in grads.params)   # still views
+    grads.all_reduce_mean(bucket_mb=0.0001)         # tiny buckets => many async all-reduces
+    if rank == 0:
+        torch.save({"flat": grads.flat.clone(), "w": model.head.weight.detach().clone()}, out)
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_equals_full_batch(tmp_path):
+    port, out = _free_port(), str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(100)
+    model = Tiny().eval()
+    assert torch.equal(model.head.weight, got["w"])          # rank-0 init was broadcast
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    y = torch.randn(4, 4, 8, 8, generator=g)
+    for _ in range(3):
+        ((model(x) - y) ** 2).mean().backward()
+    want = torch.cat([p.grad.flatten() for p in model.parameters()])
+    assert torch.allclose(got["flat"], want, rtol=1e-5, atol=1e-6)
+
+
+def test_lr_schedule_matches_reference_formula():
+    from refign_amd.trainer import LinearWarmupPolynomialLR
+    p = nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=6e-5)
+    sch = LinearWarmupPolynomialLR(opt, max_steps=40000, warmup_iters=1500, warmup_ratio=1e-6, power=1.0)
+    lrs = []
+    for _ in range(3000):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    assert abs(lrs[0] - 6e-5 * 1e-6) < 1e-15                       # helpers/lr_scheduler.py:47-50 at t=0
+    assert abs(lrs[750] - 6e-5 * (1 - 0.5 * (1 - 1e-6))) < 1e-12
+    assert abs(lrs[1500] - 6e-5) < 1e-12
+    assert abs(lrs[2500] - 6e-5 * (1 - 1000 / 38500)) < 1e-12       # :54-56, power 1

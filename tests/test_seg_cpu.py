@@ -1,0 +1,133 @@
+"""Segmentation networks (MiT, DAFormer / SegFormer heads, HRDA fusion, loss) against golden vectors captured from the
+imported reference.  These modules are compositions of torch ops, so the parity check runs on CPU here and again on the
+GPU in test_seg_gpu.py."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+from conftest import GOLDEN, golden
+from fill import closed_form_fill, hashed_uniform
+
+DIMS_B0 = [32, 64, 160, 256]
+
+
+def img(shape, key):
+    return (hashed_uniform(shape, key) * 4 - 2).astype(np.float32)
+
+
+def feats(key, b, h, w, dims, dev):
+    return [torch.from_numpy((hashed_uniform((b, c, h // s, w // s), f"{key}/f{i}") - 0.5).astype(np.float32)).to(dev)
+            for i, (c, s) in enumerate(zip(dims, (4, 8, 16, 32)))]
+
+
+def check_state_dicts():
+    from refign_amd import seg
+    man = json.load(open(os.path.join(GOLDEN, "state_dict_manifest.json")))
+    d = [64, 128, 320, 512]
+    for name, mod in [("MixVisionTransformer(mit_b5)", seg.MixVisionTransformer("mit_b5")),
+                      ("MixVisionTransformer(mit_b0)", seg.MixVisionTransformer("mit_b0")),
+                      ("DAFormerHead(b5)", seg.DAFormerHead(d, [0, 1, 2, 3], 19, 'multiple_select')),
+                      ("SegFormerHead(b5)", seg.SegFormerHead(d, [0, 1, 2, 3], 19, 'multiple_select'))]:
+        assert {k: list(v.shape) for k, v in mod.state_dict().items()} == man[name], name
+
+
+@torch.no_grad()
+def check_mit(dev, tol):
+    from refign_amd.seg import MixVisionTransformer
+    g = golden("mit_b0_64x96")
+    m = closed_form_fill(MixVisionTransformer("mit_b0"), "backbone.").to(dev).eval()
+    outs = m(torch.from_numpy(img((2, 3, 64, 96), "g9/b0")).to(dev))
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.cpu().numpy(), g[f"c{i + 1}"], rtol=tol, atol=tol, err_msg=f"c{i + 1}")
+    g = golden("mit_b5_64x64")
+    m = closed_form_fill(MixVisionTransformer("mit_b5"), "backbone.").to(dev).eval()
+    outs = m(torch.from_numpy(img((1, 3, 64, 64), "g9/b5")).to(dev))
+    for i, o in enumerate(outs):
+        o = o.cpu().numpy()
+        np.testing.assert_allclose(o[:, ::4], g[f"c{i + 1}_sample"], rtol=10 * tol, atol=10 * tol)
+        assert abs(np.abs(o.astype(np.float64)).sum() - g[f"c{i + 1}_abs_sum"]) < 1e-3 * g[f"c{i + 1}_abs_sum"]
+
+
+@torch.no_grad()
+def check_heads(dev, tol):
+    from refign_amd.seg import DAFormerHead, SegFormerHead
+    f = feats("g10", 2, 64, 96, DIMS_B0, dev)
+    head = closed_form_fill(DAFormerHead(DIMS_B0, [0, 1, 2, 3], 19, 'multiple_select'), "head.").to(dev).eval()
+    np.testing.assert_allclose(head(f).cpu().numpy(), golden("daformer_head")["out"], rtol=tol, atol=tol)
+    head = closed_form_fill(SegFormerHead(DIMS_B0, [0, 1, 2, 3], 19, 'multiple_select'),
+                            "hrda_scale_attention.").to(dev).eval()
+    np.testing.assert_allclose(head(f).cpu().numpy(), golden("segformer_head")["out"], rtol=tol, atol=tol)
+
+
+def _build(dev):
+    from refign_amd.seg import DAFormerHead, MixVisionTransformer, SegFormerHead
+    bb = closed_form_fill(MixVisionTransformer("mit_b0", drop_path_rate=0.0), "backbone.").to(dev)
+    hd = closed_form_fill(DAFormerHead(DIMS_B0, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0), "head.").to(dev)
+    sa = closed_form_fill(SegFormerHead(DIMS_B0, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0),
+                          "hrda_scale_attention.").to(dev)
+    return bb, hd, sa
+
+
+def check_hrda(dev, tol):
+    from refign_amd.seg import hrda_backbone, hrda_head
+    x = torch.from_numpy(img((2, 3, 128, 192), "g11/x")).to(dev)
+    bb, hd, sa = _build(dev)
+    bb.forward = hrda_backbone(bb, 4)(bb.forward)
+    hd.forward = hrda_head(hd, sa, 4)(hd.forward)
+    bb.train(); hd.train(); sa.train()
+    random.seed(1234)
+    with torch.no_grad():
+        logits, hr_logits, box = hd(bb(x))
+    g = golden("hrda_student")
+    assert list(box) == [int(v) for v in g["crop_box"]]
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(hr_logits.cpu().numpy()[:, :, ::2, ::2], g["hr_logits_sample"], rtol=tol, atol=tol)
+    bb, hd, sa = _build(dev)
+    bb.forward = hrda_backbone(bb, 4, is_teacher=True)(bb.forward)
+    hd.forward = hrda_head(hd, sa, 4, is_teacher=True)(hd.forward)
+    bb.eval(); hd.eval(); sa.eval()
+    with torch.no_grad():
+        out = hd(bb(x))
+    np.testing.assert_allclose(out.cpu().numpy(), golden("hrda_teacher")["logits"], rtol=tol, atol=tol)
+
+
+def check_loss(dev):
+    from refign_amd.seg import PixelWeightedCrossEntropyLoss
+    g = golden("pw_ce_loss")
+    lt = torch.from_numpy(g["logits"]).to(dev).requires_grad_()
+    loss = PixelWeightedCrossEntropyLoss()(lt, torch.from_numpy(g["target"]).to(dev),
+                                           pixel_weight=torch.from_numpy(g["weight"]).to(dev))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    np.testing.assert_allclose(lt.grad.cpu().numpy(), g["grad"], rtol=1e-4, atol=1e-7)
+    lt = torch.from_numpy(g["logits"]).to(dev).requires_grad_()
+    loss = PixelWeightedCrossEntropyLoss()(lt, torch.from_numpy(g["target"]).to(dev))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss_noweight"])) < 1e-5
+    np.testing.assert_allclose(lt.grad.cpu().numpy(), g["grad_noweight"], rtol=1e-4, atol=1e-7)
+
+
+CPU = torch.device("cpu")
+
+
+def test_state_dicts_match_reference():
+    check_state_dicts()
+
+
+def test_mit_golden_cpu():
+    check_mit(CPU, 2e-4)
+
+
+def test_heads_golden_cpu():
+    check_heads(CPU, 2e-4)
+
+
+def test_hrda_golden_cpu():
+    check_hrda(CPU, 5e-4)
+
+
+def test_loss_golden_cpu():
+    check_loss(CPU)

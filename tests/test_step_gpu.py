@@ -1,0 +1,77 @@
+"""GPU: one full UDA training_step of refign_amd.uda against the reference's (G13: three losses, per-group gradient
+norms, EMA / student checksums), with the model built through the same constructor keywords as the YAML configs."""
+import random
+
+import numpy as np
+import pytest
+import torch
+from conftest import golden
+from fill import closed_form_fill, hashed_uniform
+
+pytestmark = pytest.mark.gpu
+DIMS = [32, 64, 160, 256]
+OPT = {"class_path": "torch.optim.AdamW", "init_args": {"lr": 6e-5, "weight_decay": 0.01}}
+SCH = {"class_path": "helpers.lr_scheduler.LinearWarmupPolynomialLR",
+       "init_args": {"warmup_iters": 1500, "warmup_ratio": 1e-6, "power": 1.0, "max_steps": 40000}}
+
+
+def make_batch(b, H, W, blk, dev):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    img = lambda k: (hashed_uniform((b, 3, H, W), k) * 4 - 2).astype(np.float32)  # noqa: E731
+    trg = img("g13/trg")
+    ref = (0.8 * np.roll(trg, (2, -3), (2, 3)) + 0.2 * img("g13/ref")).astype(np.float32)
+    lbl = (hashed_uniform((b, H // blk, W // blk), "g13/lbl") * 19).astype(np.int64)
+    lbl = np.repeat(np.repeat(lbl, blk, axis=1), blk, axis=2)
+    lbl[hashed_uniform((b, H, W), "g13/ign") < 0.05] = 255
+    return {"image_src": t(img("g13/src")), "semantic_src": t(lbl), "image_trg": t(trg), "image_ref": t(ref)}
+
+
+def build(use_hrda, dev):
+    from refign_amd.align import VGG, UAWarpCHead
+    from refign_amd.seg import DAFormerHead, MixVisionTransformer, PixelWeightedCrossEntropyLoss, SegFormerHead
+    from refign_amd.uda import DomainAdaptationSegmentationModel
+    model = DomainAdaptationSegmentationModel(
+        OPT, SCH,
+        backbone=MixVisionTransformer("mit_b0", drop_path_rate=0.0),
+        head=DAFormerHead(DIMS, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0),
+        loss=PixelWeightedCrossEntropyLoss(),
+        alignment_backbone=VGG('vgg16', out_indices=[2, 3, 4]),
+        alignment_head=UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True),
+        backbone_lr_factor=0.1, use_refign=True, adapt_to_ref=False, gamma=0.25, enable_fdist=True,
+        color_jitter_p=1.0, blur=False, use_hrda=use_hrda, hrda_output_stride=4,
+        hrda_scale_attention=SegFormerHead(DIMS, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0))
+    closed_form_fill(model)
+    return model.to(dev).train()
+
+
+@pytest.mark.parametrize("use_hrda,name,blk", [(False, "step_daformer_96x128", 32), (True, "step_hrda_128x128", 64)])
+def test_training_step_matches_reference(dev, use_hrda, name, blk):
+    from refign_amd.trainer import Trainer
+    g = golden(name)
+    H, W = [int(v) for v in g["size"]]
+    model = build(use_hrda, dev)
+    trainer = Trainer(model, fused_optimizer=False)
+    trainer.scheduler = torch.optim.lr_scheduler.LambdaLR(trainer.optimizer, lambda s: 1.0)   # as in the golden run
+    model._scheduler = trainer.scheduler
+    batch = make_batch(2, H, W, blk, dev)
+    random.seed(77); np.random.seed(77); torch.manual_seed(77)
+    model.global_step = 3
+    norms = {}
+    real_step = trainer.optimizer.step
+
+    def recording_step(*a, **k):
+        norms["v"] = [float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in grp["params"])))
+                      for grp in trainer.optimizer.param_groups]
+        return real_step(*a, **k)
+
+    trainer.optimizer.step = recording_step
+    model.training_step(batch, 0)
+    losses = np.array([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src",
+                                                        "train_loss_uda_trg")])
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+    np.testing.assert_allclose(np.array(norms["v"]), g["grad_norms"], rtol=2e-2)
+    ema = float(sum(p.double().abs().sum() for p in model.ema_parameters()))
+    live = float(sum(p.double().abs().sum() for p in model.live_parameters()))
+    assert abs(ema - float(g["ema_abs_sum"])) < 1e-5 * float(g["ema_abs_sum"])
+    assert abs(live - float(g["live_abs_sum"])) < 1e-5 * float(g["live_abs_sum"])
+    assert model.global_step == 4
