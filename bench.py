@@ -37,7 +37,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="align_refine_kernels_1080x1920")
+    ap.add_argument("--workload", default="refign_hrda_step_1080x1920")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="segmentation networks: bf16 autocast (the reference trains with --trainer.precision 16) or "
+                         "fp32; the align/refine kernels are always fp32 (the reference forces fp32 there too)")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--pairs-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
@@ -144,7 +149,97 @@ class AlignRefineKernels:
         return time.perf_counter() - t0
 
 
-WORKLOADS = {AlignRefineKernels.name: AlignRefineKernels}
+
+# ------------------------------------------------------------------------------------------------------------------
+# workload: ONE FULL Refign training step (the metric's "align+seg fwd+bwd"): source fwd+bwd, ImageNet feature
+# distance, EMA, teacher fwd on (trg, ref), align (VGG-16 + UAWarpC + logits warp), refine, DACS mix, mixed fwd+bwd,
+# gradient all-reduce, AdamW + LR schedule -- HRDA MiT-B5 as configs/cityscapes_darkzurich/refign_hrda_star.yaml builds
+# it (random init: no checkpoints offline), b=2 source + 2 (target, reference) pairs per GPU at 1080x1920.
+# The Refign branch is pinned (adapt_to_ref=False): the reference skips align/refine on a random 50 % of steps.
+# ------------------------------------------------------------------------------------------------------------------
+REF_CFG = {  # the `model:` / `optimizer:` / `lr_scheduler:` sections of refign_hrda_star.yaml:83-190, verbatim values
+    "model": {"class_path": "models.DomainAdaptationSegmentationModel", "init_args": {
+        "backbone_lr_factor": 0.1, "enable_fdist": True, "use_hrda": True, "hrda_output_stride": 4,
+        "use_slide_inference": True, "use_refign": True, "adapt_to_ref": True, "gamma": 0.25,
+        "backbone": {"class_path": "models.backbones.MixVisionTransformer",
+                     "init_args": {"model_type": "mit_b5", "pretrained": "cityscapes"}},
+        "head": {"class_path": "models.heads.DAFormerHead", "init_args": {
+            "in_channels": [64, 128, 320, 512], "in_index": [0, 1, 2, 3], "num_classes": 19,
+            "input_transform": "multiple_select"}},
+        "hrda_scale_attention": {"class_path": "models.heads.SegFormerHead", "init_args": {
+            "in_channels": [64, 128, 320, 512], "in_index": [0, 1, 2, 3], "num_classes": 19,
+            "input_transform": "multiple_select"}},
+        "alignment_backbone": {"class_path": "models.backbones.VGG", "init_args": {
+            "model_type": "vgg16", "pretrained": "imagenet", "out_indices": [2, 3, 4]}},
+        "alignment_head": {"class_path": "models.heads.UAWarpCHead", "init_args": {
+            "in_index": [0, 1], "input_transform": "multiple_select", "estimate_uncertainty": True,
+            "pretrained": "pretrained_models/uawarpc_megadepth.ckpt"}},
+        "loss": {"class_path": "models.losses.PixelWeightedCrossEntropyLoss"}}},
+    "optimizer": {"class_path": "torch.optim.AdamW", "init_args": {"lr": 0.0006, "weight_decay": 0.01}},
+    "lr_scheduler": {"class_path": "helpers.lr_scheduler.LinearWarmupPolynomialLR", "init_args": {
+        "warmup_iters": 1500, "warmup_ratio": 0.000001, "power": 1.0, "max_steps": 40000}},
+}
+
+
+class RefignStep:
+    name = "refign_hrda_step_1080x1920"
+    use_hrda = True
+
+    def __init__(self, dev, b, seed, H=1080, W=1920, precision="bf16", sync_bn=True):
+        import copy
+        import random
+        import numpy as np
+        from refign_amd import config
+        from refign_amd.trainer import Trainer
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        cfg = copy.deepcopy(REF_CFG)
+        cfg["model"]["init_args"]["use_hrda"] = self.use_hrda
+        if not self.use_hrda:
+            cfg["model"]["init_args"].pop("hrda_scale_attention")
+        # offline: no checkpoints -> random init of the same architectures; pin the Refign branch
+        over = {"backbone.init_args.pretrained": None, "alignment_backbone.init_args.pretrained": None,
+                "alignment_head.init_args.pretrained": None, "adapt_to_ref": False}
+        self.model = config.build_model(cfg, over).to(dev).train()
+        self.trainer = Trainer(self.model, sync_batchnorm=sync_bn)
+        self.precision = precision
+        self.b, self.H, self.W = b, H, W
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        lbl = torch.randint(0, 19, (b, (H + 31) // 32, (W + 31) // 32), generator=g)
+        lbl = lbl.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :H, :W].contiguous()
+        lbl[torch.rand(b, H, W, generator=g) < 0.05] = 255
+        trg = torch.randn(b, 3, H, W, generator=g)
+        ref = 0.8 * torch.roll(trg, (3, -5), (2, 3)) + 0.2 * torch.randn(b, 3, H, W, generator=g)
+        self.batch = {"image_src": torch.randn(b, 3, H, W, generator=g).to(dev), "semantic_src": lbl.to(dev),
+                      "image_trg": trg.to(dev), "image_ref": ref.to(dev)}
+        self._kern = None
+
+    def step(self):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.precision == "bf16"):
+            self.trainer.step(self.batch)
+
+    # roofline kernel + CPU baseline are those of the align/refine kernel workload at the same image size
+    def _kernels(self):
+        if self._kern is None:
+            self._kern = AlignRefineKernels(self.batch["image_src"].device, self.b, 4321)
+        return self._kern
+
+    def roofline_launch(self):
+        return self._kernels().roofline_launch()
+
+    def roofline_bytes(self):
+        return self._kernels().roofline_bytes()
+
+    def cpu_step(self, kind, corr_fn):
+        return self._kernels().cpu_step(kind, corr_fn)
+
+
+class RefignDAFormerStep(RefignStep):
+    name = "refign_daformer_step_1080x1920"
+    use_hrda = False
+
+
+WORKLOADS = {AlignRefineKernels.name: AlignRefineKernels, RefignStep.name: RefignStep,
+             RefignDAFormerStep.name: RefignDAFormerStep}
 
 
 def cpu_baseline(wl):
@@ -191,7 +286,10 @@ def main():
 
     import refign_amd
     refign_amd.load_library()
-    wl = WORKLOADS[args.workload](dev, args.pairs_per_gpu, seed=1234 + rank)
+    if args.workload == AlignRefineKernels.name:
+        wl = AlignRefineKernels(dev, args.pairs_per_gpu, seed=1234 + rank)
+    else:
+        wl = WORKLOADS[args.workload](dev, args.pairs_per_gpu, 1234 + rank, args.height, args.width, args.precision)
 
     def barrier():
         if dist is not None:
@@ -241,12 +339,17 @@ def main():
     if rank == 0:
         pairs = args.pairs_per_gpu * world * args.steps
         line = {
-            "metric": "image-pairs/s (align+refine HIP kernels, 1080x1920)",
+            "metric": "image-pairs/s (align+seg fwd+bwd, 1080x1920)" if args.workload != AlignRefineKernels.name
+            else "image-pairs/s (align+refine HIP kernels only, 1080x1920)",
             "value": round(pairs / dt, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": "1080x1920",
-                       "parallelism": f"dp{world} (independent pairs, no data-path collective)"},
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if (args.workload == AlignRefineKernels.name or args.precision == "fp32") else "bf16",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": f"{args.height}x{args.width}",
+                       "model": "HRDA MiT-B5 + DAFormer head + VGG-16/UAWarpC align (random init)",
+                       "parallelism": f"dp{world}: pairs sharded, align/refine/teacher replica-local, one flat "
+                                      f"gradient all-reduce per step over RCCL"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -365,11 +365,15 @@ def align(alignment_backbone, alignment_head, logits_ref, images_ref, images_trg
     """DomainAdaptationSegmentationModel.align (segmentation_model.py:493-523).
     Returns (warped_ref_logits (b,C,h,w), trg_ref_mask (b,h,w) bool, trg_ref_cert (b,1,h,w))."""
     h, w = images_trg.shape[-2:]
-    pyr = extract_pyramids(alignment_backbone, images_ref, images_trg)
-    flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
     if tuple(logits_ref.shape[-2:]) != (h, w):
         raise RuntimeError("align: logits_ref must have the image resolution")
-    return matching.align_tail(logits_ref, flow_q, logvar_q)
+    # The matcher runs in fp32 even when the caller is inside a bf16 autocast region: the reference forces the
+    # correlation and the warp to fp32 under AMP (correlation_function.py:51, matching_utils.py:40-43) and sub-pixel
+    # flow accuracy is what the 1e-3 parity bound on the warped logits rests on.
+    with torch.autocast("cuda", enabled=False):
+        pyr = extract_pyramids(alignment_backbone, images_ref.float(), images_trg.float())
+        flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
+        return matching.align_tail(logits_ref, flow_q, logvar_q)
 
 
 @torch.no_grad()

@@ -84,9 +84,9 @@ def estimate_probability_of_confidence_interval_of_mixture_density(uncert_output
 def align_tail(logits_ref, flow_q, logvar_q, return_flow=False):
     """Fused tail of align() (segmentation_model.py:514-522): bilinear-upsample the quarter-res flow / log-variance
     to the logits' size, confidence P_R, warp the reference logits.  Returns (warped, mask, cert[, flow_up])."""
-    logits_ref = require_device_tensor(logits_ref.contiguous(), "logits_ref", torch.float32)
-    flow_q = require_device_tensor(flow_q.contiguous(), "flow_q", torch.float32)
-    logvar_q = require_device_tensor(logvar_q.contiguous(), "logvar_q", torch.float32)
+    logits_ref = require_device_tensor(logits_ref.float().contiguous(), "logits_ref", torch.float32)
+    flow_q = require_device_tensor(flow_q.float().contiguous(), "flow_q", torch.float32)
+    logvar_q = require_device_tensor(logvar_q.float().contiguous(), "logvar_q", torch.float32)
     dev = same_device(logits_ref, flow_q, logvar_q)
     B, C, H, W = logits_ref.shape
     h, w = flow_q.shape[-2:]
