@@ -113,6 +113,20 @@ int rfn_align_tail_f32(const float* logits_ref, const float* flow_q, const float
                        unsigned char* mask, float* cert, float* flow_up, int B, int C, int H, int W, int h,
                        int w, rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Depthwise 3x3 convolution on channels-last maps -- the DWConv of every Mix-FFN block
+ * (models/backbones/mix_transformer.py:96-103,556-568: nn.Conv2d(dim, dim, 3, 1, 1, groups=dim) between two token
+ * transposes) and the dilated depthwise branches of the DAFormer ASPP (models/heads/daformer.py:46-62).
+ * x, y, grad_y: (B,H,W,C) contiguous == the (B, N, C) token layout; dtype 0 = float32, 1 = bfloat16.
+ * weight / grad_weight: TAP-MAJOR (9, C) float32 (= conv.weight.view(C, 9).t()); bias / grad_bias: (C) float32,
+ * nullable.  Zero padding = dilation (same-size output).  flip = 1 applies the taps mirrored (that IS the
+ * backward-data pass: grad_x = fwd(grad_y, weight, NULL, flip = 1)).  bwd_weight zero-fills its outputs itself.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W,
+                           int C, int dilation, int dtype, int flip, rfn_stream_t stream);
+int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias, int B,
+                                  int H, int W, int C, int dilation, int dtype, rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,285 @@
+// refign_amd/csrc/dwconv.hip -- depthwise 3x3 convolution on channels-last maps, forward + both backward passes (gfx950).
+//
+// Where it sits in the reference: the Mix-FFN of every MiT block runs fc1 -> DWConv 3x3 -> GELU -> fc2
+// (models/backbones/mix_transformer.py:96-103,556-568: tokens are transposed to NCHW, nn.Conv2d(dim, dim, 3, 1, 1,
+// groups=dim), transposed back), and the DAFormer head's ASPP has three dilated depthwise 3x3 branches on 1024 channels
+// (models/heads/daformer.py:46-62).  On this stack the library path for those (MIOpen -> CK grouped conv) is a
+// dense-conv kernel with group size 1 and was measured at 59 % of the whole training step; the op itself is a pure
+// HBM-bound 9-tap stencil.
+//
+// Weights and weight gradients cross the ABI TAP-MAJOR, (9, C) fp32 (= weight.view(C, 9).t()), so that the 9 x VEC
+// weights of a thread are nine contiguous vectors.
+// Layout: x, y, grad tensors are (B, H, W, C) contiguous = the MiT token layout (B, N, C) itself, so no transposes at
+// all; lanes run along C (16-byte vectors: 8 bf16 or 4 fp32 channels per lane => a wave reads 1 KiB contiguous), each
+// thread produces 4 consecutive pixels along W and keeps its 9 x VEC weights in registers.  Halo re-reads between
+// neighbouring threads/blocks are served by L1/L2.  Accumulation is fp32; weights/bias/weight-gradients stay fp32
+// (master precision) while activations may be bf16.
+//   forward       y[b,h,w,c]  = bias[c] + sum_{ky,kx} wgt[c,ky,kx] * x[b, h+(ky-1)d, w+(kx-1)d, c]
+//   backward-data dx           = same stencil over gy with the taps flipped, no bias
+//   backward-wgt  dw[c,ky,kx]  = sum_{b,h,w} gy[b,h,w,c] * x[b, h+(ky-1)d, w+(kx-1)d, c];   db[c] = sum gy
+//                 (per-thread register partials over a pixel stripe -> LDS tree over the block's pixel lanes ->
+//                  one fp32 atomicAdd per (block, channel, tap))
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace rfn {
+
+template <typename T>
+struct VecIO;
+
+template <>
+struct VecIO<float> {
+  static constexpr int N = 4;
+  __device__ static void load(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ static void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+template <>
+struct VecIO<__hip_bfloat16> {
+  static constexpr int N = 8;
+  __device__ static void load(const __hip_bfloat16* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static unsigned pack(float lo, float hi) {
+    // round-to-nearest-even fp32 -> bf16 (matches torch's conversion)
+    auto rne = [](float f) -> unsigned {
+      unsigned u = __float_as_uint(f);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN
+      return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    return rne(lo) | (rne(hi) << 16);
+  }
+  __device__ static void store(__hip_bfloat16* p, const float (&v)[8]) {
+    uint4 t;
+    t.x = pack(v[0], v[1]); t.y = pack(v[2], v[3]); t.z = pack(v[4], v[5]); t.w = pack(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = t;
+  }
+};
+
+constexpr int kPX = 4;   // pixels along W per thread
+
+// grid-stride over work items (b, h, wq, cv); cv fastest so that a wave covers contiguous channels
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wgt,
+                                                            const float* __restrict__ bias, T* __restrict__ y, int B,
+                                                            int H, int W, int C, int dil, long total) {
+  constexpr int V = VecIO<T>::N;
+  const int CV = C / V, WQ = (W + kPX - 1) / kPX;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int cv = t % CV; t /= CV;
+    const int wq = t % WQ; t /= WQ;
+    const int h = t % H;
+    const int b = t / H;
+    const int c0 = cv * V, w0 = wq * kPX;
+    float wr[9][V];   // tap-major weights (9, C): one contiguous fp32 vector per tap
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float* wp = wgt + (size_t)(FLIP ? 8 - k : k) * C + c0;
+#pragma unroll
+      for (int i = 0; i < V; i += 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(wp + i);
+        wr[k][i] = t4.x; wr[k][i + 1] = t4.y; wr[k][i + 2] = t4.z; wr[k][i + 3] = t4.w;
+      }
+    }
+    float acc[kPX][V];
+#pragma unroll
+    for (int p = 0; p < kPX; ++p)
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[p][i] = (bias != nullptr) ? bias[c0 + i] : 0.0f;
+    const T* xb = x + (size_t)b * H * W * C + c0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = h + (ky - 1) * dil;
+      if (yy < 0 || yy >= H) continue;
+      const T* xr = xb + (size_t)yy * W * C;
+      if (dil == 1) {
+        // 6 loads feed 4 outputs x 3 taps
+        float v[kPX + 2][V];
+#pragma unroll
+        for (int j = 0; j < kPX + 2; ++j) {
+          const int xx = w0 - 1 + j;
+          if (xx >= 0 && xx < W) VecIO<T>::load(xr + (size_t)xx * C, v[j]);
+          else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) v[j][i] = 0.0f;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < kPX; ++p)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i], v[p + kx][i], acc[p][i]);
+      } else {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int p = 0; p < kPX; ++p) {
+            const int xx = w0 + p + (kx - 1) * dil;
+            if (xx < 0 || xx >= W) continue;
+            float v[V];
+            VecIO<T>::load(xr + (size_t)xx * C, v);
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i], v[i], acc[p][i]);
+          }
+      }
+    }
+    T* yo = y + ((size_t)b * H + h) * W * C + c0;
+#pragma unroll
+    for (int p = 0; p < kPX; ++p)
+      if (w0 + p < W) VecIO<T>::store(yo + (size_t)(w0 + p) * C, acc[p]);
+  }
+}
+
+// backward-weight: block = 256 threads = CVB channel-vectors x PL pixel lanes; each pixel lane walks a stripe of
+// (b,h,w) positions; 9*V + V register partials; LDS reduce over PL; atomics into dw/db.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                   float* __restrict__ dw, float* __restrict__ db,
+                                                                   int B, int H, int W, int C, int dil, int cvb,
+                                                                   int stripes) {
+  constexpr int V = VecIO<T>::N;
+  const int CV = C / V;
+  const int pl = 256 / cvb;                               // pixel lanes per block
+  const int cvi = threadIdx.x % cvb, pli = threadIdx.x / cvb;
+  const int cv = blockIdx.x * cvb + cvi;
+  const bool active = cv < CV;
+  const int c0 = cv * V;
+  float aw[9][V], ab[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    ab[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aw[k][i] = 0.0f;
+  }
+  if (active) {
+    const long npix = (long)B * H * W;
+    const long lane_id = (long)blockIdx.y * pl + pli, nlanes = (long)stripes * pl;
+    for (long pix = lane_id; pix < npix; pix += nlanes) {
+      const int w = pix % W;
+      const int h = (pix / W) % H;
+      const int b = pix / ((long)W * H);
+      float g[V];
+      VecIO<T>::load(gy + (size_t)pix * C + c0, g);
+#pragma unroll
+      for (int i = 0; i < V; ++i) ab[i] += g[i];
+      const T* xb = x + (size_t)b * H * W * C + c0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = h + (ky - 1) * dil;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = w + (kx - 1) * dil;
+          if (xx < 0 || xx >= W) continue;
+          float v[V];
+          VecIO<T>::load(xb + ((size_t)yy * W + xx) * C, v);
+#pragma unroll
+          for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[i], v[i], aw[ky * 3 + kx][i]);
+        }
+      }
+    }
+  }
+  // reduce over the pixel lanes of the block through LDS, one tap at a time
+  __shared__ float red[256 * 8];
+  for (int k = 0; k < 10; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[threadIdx.x * V + i] = (k < 9) ? aw[k][i] : ab[i];
+    __syncthreads();
+    if (pli == 0 && active) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float s = 0.0f;
+        for (int p = 0; p < pl; ++p) s += red[(p * cvb + cvi) * V + i];
+        if (k < 9) atomicAdd(&dw[(size_t)k * C + c0 + i], s);
+        else if (db != nullptr) atomicAdd(&db[c0 + i], s);
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,
+                      int flip, hipStream_t st) {
+  constexpr int V = VecIO<T>::N;
+  const long total = (long)B * H * ((W + kPX - 1) / kPX) * (C / V);
+  const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 64);
+  if (flip)
+    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, true>), dim3(grid), dim3(256), 0, st, (const T*)x, w, bias, (T*)y, B, H,
+                       W, C, dil, total);
+  else
+    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false>), dim3(grid), dim3(256), 0, st, (const T*)x, w, bias, (T*)y, B,
+                       H, W, C, dil, total);
+  return check_launch("dwconv3x3_fwd_kernel");
+}
+
+template <typename T>
+static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db, int B, int H, int W, int C, int dil,
+                             hipStream_t st) {
+  constexpr int V = VecIO<T>::N;
+  const int CV = C / V;
+  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * 9, st) != hipSuccess ||
+      (db && hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st) != hipSuccess))
+    return fail(RFN_ELAUNCH, "dwconv bwd weight: hipMemsetAsync failed");
+  const int cvb = CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV >= 16 ? 16 : 8));
+  const int gx = cdiv(CV, cvb);
+  // enough stripes to fill the chip (~8 blocks per CU) without drowning the atomics
+  const long npix = (long)B * H * W;
+  int stripes = (int)std::max<long>(1, std::min<long>(2048 / gx, npix / (4 * (256 / cvb)) + 1));
+  hipLaunchKernelGGL((dwconv3x3_bwd_weight_kernel<T>), dim3(gx, stripes), dim3(256), 0, st, (const T*)x, (const T*)gy,
+                     dw, db, B, H, W, C, dil, cvb, stripes);
+  return check_launch("dwconv3x3_bwd_weight_kernel");
+}
+
+}  // namespace rfn
+
+using namespace rfn;
+
+extern "C" {
+
+int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W, int C,
+                           int dilation, int dtype, int flip, rfn_stream_t stream) {
+  RFN_REQUIRE(x && weight && y, "rfn_dwconv3x3_nhwc_fwd: null pointer");
+  RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "rfn_dwconv3x3_nhwc_fwd: bad size");
+  if (dtype == 0) {
+    RFN_REQUIRE(C % 4 == 0, "rfn_dwconv3x3_nhwc_fwd: C must be a multiple of 4 for f32 (got %d)", C);
+    return launch_fwd<float>(x, weight, bias, y, B, H, W, C, dilation, flip, (hipStream_t)stream);
+  }
+  if (dtype == 1) {
+    RFN_REQUIRE(C % 8 == 0, "rfn_dwconv3x3_nhwc_fwd: C must be a multiple of 8 for bf16 (got %d)", C);
+    return launch_fwd<__hip_bfloat16>(x, weight, bias, y, B, H, W, C, dilation, flip, (hipStream_t)stream);
+  }
+  return fail(RFN_EINVAL, "rfn_dwconv3x3_nhwc_fwd: dtype must be 0 (f32) or 1 (bf16)");
+}
+
+int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias, int B, int H,
+                                  int W, int C, int dilation, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && grad_y && grad_weight, "rfn_dwconv3x3_nhwc_bwd_weight: null pointer");
+  RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "rfn_dwconv3x3_nhwc_bwd_weight: bad size");
+  if (dtype == 0) {
+    RFN_REQUIRE(C % 4 == 0, "rfn_dwconv3x3_nhwc_bwd_weight: C must be a multiple of 4 for f32");
+    return launch_bwd_weight<float>(x, grad_y, grad_weight, grad_bias, B, H, W, C, dilation, (hipStream_t)stream);
+  }
+  if (dtype == 1) {
+    RFN_REQUIRE(C % 8 == 0, "rfn_dwconv3x3_nhwc_bwd_weight: C must be a multiple of 8 for bf16");
+    return launch_bwd_weight<__hip_bfloat16>(x, grad_y, grad_weight, grad_bias, B, H, W, C, dilation,
+                                             (hipStream_t)stream);
+  }
+  return fail(RFN_EINVAL, "rfn_dwconv3x3_nhwc_bwd_weight: dtype must be 0 (f32) or 1 (bf16)");
+}
+
+}  // extern "C"

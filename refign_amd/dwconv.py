@@ -1,0 +1,72 @@
+"""Depthwise 3x3 convolution on channels-last / token layout, forward and backward in HIP (csrc/dwconv.hip).
+
+`dwconv3x3_tokens(x, weight, bias, H, W)` is the DWConv of the Mix-FFN (mix_transformer.py:556-568) WITHOUT the two
+NCHW transposes of the reference: x is (B, N=H*W, C) and stays that way.  `dwconv3x3_nhwc(x, weight, bias, dilation)`
+is the same on (B, H, W, C) maps with dilation (DAFormer ASPP branches, daformer.py:46-62).  `weight` is the reference
+parameter itself, shape (C, 1, 3, 3); activations float32 or bfloat16, accumulation fp32, weight grads fp32.
+"""
+import torch
+
+from . import _lib
+from ._tensor import current_stream, ptr, require_device_tensor
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _fwd(x, w_tap, bias, dilation, flip):
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.rfn_dwconv3x3_nhwc_fwd(ptr(x), ptr(w_tap), ptr(bias), ptr(y), B, H, W, C, dilation, _DT[x.dtype],
+                                        1 if flip else 0, current_stream(x.device))
+    _lib.check(rc, "dwconv3x3_nhwc_fwd")
+    return y
+
+
+class _DWConv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, dilation):
+        if x.dtype not in _DT:
+            x = x.float()
+        x = require_device_tensor(x.contiguous(), "x")
+        C = x.shape[-1]
+        w_tap = weight.detach().float().reshape(C, 9).t().contiguous()          # (9, C) tap-major
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        ctx.save_for_backward(x, w_tap)
+        ctx.dilation, ctx.has_bias = dilation, bias is not None
+        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        return _fwd(x, w_tap, b32, dilation, False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_tap = ctx.saved_tensors
+        gy = gy.to(x.dtype).contiguous()
+        B, H, W, C = x.shape
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _fwd(gy, w_tap, None, ctx.dilation, True)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
+            db = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            lib = _lib.load_library()
+            with torch.cuda.device(x.device):
+                rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), B, H, W, C, ctx.dilation,
+                                                       _DT[x.dtype], current_stream(x.device))
+            _lib.check(rc, "dwconv3x3_nhwc_bwd_weight")
+            gw = dw.t().reshape(ctx.wshape).to(ctx.wdtype)
+            gb = db
+        return gx, gw, gb, None
+
+
+def dwconv3x3_nhwc(x, weight, bias=None, dilation=1):
+    """x: (B,H,W,C) fp32/bf16; weight: (C,1,3,3); bias: (C) or None; same-size output (padding = dilation)."""
+    if x.dim() != 4 or weight.shape[0] != x.shape[-1]:
+        raise RuntimeError("dwconv3x3_nhwc: x must be (B,H,W,C) and weight (C,1,3,3)")
+    return _DWConv3x3.apply(x, weight, bias, int(dilation))
+
+
+def dwconv3x3_tokens(x, weight, bias, H, W):
+    """x: (B, N=H*W, C) tokens -> (B, N, C)."""
+    B, N, C = x.shape
+    return dwconv3x3_nhwc(x.reshape(B, H, W, C), weight, bias, 1).reshape(B, N, C)

@@ -74,15 +74,28 @@ class ConvBNReLU(nn.Module):
         self._folded = None
         return super()._apply(fn, *a, **k)
 
+    def _conv2d(self, x, w, b):
+        """The convolution itself.  Depthwise 3x3 (the DAFormer ASPP branches) goes to the hand-written channels-last
+        HIP kernel on the GPU -- the library's grouped-conv path for group size 1 is ~50x off the HBM roofline; every
+        other shape is a dense conv on the ROCm library."""
+        c = self.conv
+        if (x.is_cuda and c.groups == c.in_channels == c.out_channels and c.kernel_size == (3, 3)
+                and c.stride == (1, 1) and c.padding == c.dilation and c.dilation[0] == c.dilation[1]
+                and c.in_channels % 8 == 0):
+            from .dwconv import dwconv3x3_nhwc
+            xh = x.permute(0, 2, 3, 1)                       # free for channels_last inputs
+            y = dwconv3x3_nhwc(xh if xh.is_contiguous() else xh.contiguous(), w, b, c.dilation[0])
+            return y.permute(0, 3, 1, 2)                     # NCHW-shaped, channels_last strides
+        return F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
+
     def forward(self, x):
         if self.depthwise_separable:
             return self.pointwise_conv(self.depthwise_conv(x))
         c = self.conv
         if self.use_norm and not self.training and not torch.is_grad_enabled():
-            w, b = self.folded()
-            x = F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
+            x = self._conv2d(x, *self.folded())
         else:
-            x = c(x)
+            x = self._conv2d(x, c.weight, c.bias)
             if self.use_norm:
                 x = self.bn(x)
         if self.act == 'leaky':

@@ -54,7 +54,11 @@ class DWConv(nn.Module):
 
     def forward(self, x, H, W):
         B, N, C = x.shape
-        y = self.dwconv(x.transpose(1, 2).reshape(B, C, H, W))
+        if x.is_cuda and C % 8 == 0:
+            # tokens ARE the channels-last map: hand-written HIP stencil, no NCHW round trip (csrc/dwconv.hip)
+            from .dwconv import dwconv3x3_tokens
+            return dwconv3x3_tokens(x, self.dwconv.weight, self.dwconv.bias, H, W)
+        y = self.dwconv(x.transpose(1, 2).reshape(B, C, H, W))      # host-side formulation (CPU unit tests only)
         return y.flatten(2).transpose(1, 2)
 
 
@@ -275,6 +279,8 @@ class ASPPWrapper(nn.Module):
                                      norm_layer=norm_layer, activation_layer=activation_layer)
 
     def forward(self, x):
+        if x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)   # depthwise branches + 1x1 convs run channels-last
         return self.bottleneck(torch.cat(self.aspp_modules(x), dim=1))
 
 

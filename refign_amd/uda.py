@@ -464,7 +464,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
         out = gt.clone()
         out[out == ignore_index] = n_classes
         onehot = F.one_hot(out.squeeze(1), num_classes=n_classes + 1).permute(0, 3, 1, 2).float()
-        ratio, out = torch.max(F.avg_pool2d(onehot, kernel_size=scale_factor), dim=1, keepdim=True)
+        # ceil_mode only matters when H or W is not a multiple of scale_factor (e.g. 1080 rows at stride 64: the MiT
+        # stage-4 map has ceil(H/64) rows).  The reference asserts divisibility (:661-667) and trains on 1024^2 crops;
+        # for divisible sizes the result is identical, otherwise the border windows use their valid part.
+        ratio, out = torch.max(F.avg_pool2d(onehot, kernel_size=scale_factor, ceil_mode=True), dim=1, keepdim=True)
         out[out == n_classes] = ignore_index
         out[ratio < min_ratio] = ignore_index
         return out
