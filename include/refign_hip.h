@@ -120,12 +120,16 @@ int rfn_align_tail_f32(const float* logits_ref, const float* flow_q, const float
  * x, y, grad_y: (B,H,W,C) contiguous == the (B, N, C) token layout; dtype 0 = float32, 1 = bfloat16.
  * weight / grad_weight: TAP-MAJOR (9, C) float32 (= conv.weight.view(C, 9).t()); bias / grad_bias: (C) float32,
  * nullable.  Zero padding = dilation (same-size output).  flip = 1 applies the taps mirrored (that IS the
- * backward-data pass: grad_x = fwd(grad_y, weight, NULL, flip = 1)).  bwd_weight zero-fills its outputs itself.
+ * backward-data pass: grad_x = fwd(grad_y, weight, NULL, flip = 1)).  bwd_weight needs
+ * rfn_dwconv3x3_bwd_weight_workspace_bytes(C) bytes of device workspace (per-stripe partial sums, reduced in a fixed
+ * order: deterministic).
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W,
                            int C, int dilation, int dtype, int flip, rfn_stream_t stream);
-int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias, int B,
-                                  int H, int W, int C, int dilation, int dtype, rfn_stream_t stream);
+unsigned long rfn_dwconv3x3_bwd_weight_workspace_bytes(int C);
+int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias,
+                                  void* workspace, int B, int H, int W, int C, int dilation, int dtype,
+                                  rfn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -265,16 +265,26 @@ __global__ __launch_bounds__(TH * kStrips * 3) void corr9_tile_kernel(
 // --------------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int TH, int CC, bool FUSE, int MINW, int UNR>
-__global__ __launch_bounds__(TH * kStrips * 3, MINW) void corr9_dma_kernel(const float* __restrict__ in1,
-                                                                          const float* __restrict__ in2,
-                                                                          float* __restrict__ out, int C, int H,
-                                                                          int W, int tilesX, int tilesY) {
-  constexpr int NT = TH * kStrips * 3;
+template <int TH, int TW, int CC, bool FUSE, int MINW, int UNR>
+__global__ __launch_bounds__(TH * (TW / 4) * 3, MINW) void corr9_dma_kernel(const float* __restrict__ in1,
+                                                                           const float* __restrict__ in2,
+                                                                           float* __restrict__ out, int C, int H,
+                                                                           int W, int tilesX, int tilesY) {
+  static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
+  constexpr int STRIPS = TW / 4;                     // 4-pixel strips per tile row
+  constexpr int RPW = 64 / STRIPS;                   // tile rows covered by one wave (4 or 8)
+  constexpr int NT = TH * STRIPS * 3;
   constexpr int NW = NT / 64;
   constexpr int R2 = TH + 2 * kHalo;
   constexpr int ROWS = R2 + TH;
-  constexpr int V = kPitch / 4;                      // 18 float4 slots per row
+  // LDS row pitch in dwords.  It is chosen together with the lane->strip permutation below so that every
+  // ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31} and their +32 twins) covers all 64 banks once:
+  //   TW=64: pitch 72 (18 slots of 16 B), lanes of odd wave-rows take their strips rotated by 14;
+  //   TW=32: pitch 48 (12 slots, 10 used): row offsets 0,12,8,4 (mod 16 slots), lanes of wave-rows 1,2 (mod 4)
+  //          swap their strip halves (j ^ 4).
+  constexpr int PITCH = (TW == 64) ? 72 : 48;
+  constexpr int V = PITCH / 4;                       // float4 slots per LDS row
+  constexpr int VU2 = (TW + 2 * kHalo) / 4;          // slots of a source row that carry data
   constexpr int SLOTS = CC * ROWS * V;               // float4 slots per chunk
   constexpr int NINSTR = (SLOTS + 63) / 64;          // wave-level DMA instructions per chunk
   constexpr int K = (NINSTR + NW - 1) / NW;          // per wave
@@ -290,13 +300,13 @@ __global__ __launch_bounds__(TH * kStrips * 3, MINW) void corr9_dma_kernel(const
   const int tx = bid % tilesX; bid /= tilesX;
   const int ty = bid % tilesY;
   const int n = bid / tilesY;
-  const int h0 = ty * TH, w0 = tx * kTW;
+  const int h0 = ty * TH, w0 = tx * TW;
   const int lane = tid & 63, wave = tid >> 6;
-  constexpr int WPG = TH / 4;
+  constexpr int WPG = TH / RPW;                      // waves per vertical-shift group
   const int dyg = wave / WPG;
-  const int q = lane >> 4, j = lane & 15;
-  const int row = (wave % WPG) * 4 + q;
-  const int strip = (q & 1) ? ((j + 14) & 15) : j;
+  const int q = lane / STRIPS, j = lane % STRIPS;
+  const int row = (wave % WPG) * RPW + q;
+  const int strip = (TW == 64) ? ((q & 1) ? ((j + 14) & 15) : j) : (j ^ ((((q & 3) == 1) || ((q & 3) == 2)) ? 4 : 0));
 
   const size_t plane = (size_t)H * W;
   const float* p1 = in1 + (size_t)n * C * plane;
@@ -320,11 +330,11 @@ __global__ __launch_bounds__(TH * kStrips * 3, MINW) void corr9_dma_kernel(const
     const float* src;
     if (rr < R2) {
       const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
-      ok = ok && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+      ok = ok && v < VU2 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
       src = p2 + (size_t)c * plane + (long)gy * W + gx;
     } else {
       const int gy = h0 + rr - R2, gx = w0 + 4 * v;
-      ok = ok && v < 16 && gy < H && gx + 3 < W;
+      ok = ok && v < STRIPS && gy < H && gx + 3 < W;
       src = p1 + (size_t)c * plane + (long)gy * W + gx;
     }
     gsrc[k] = ok ? src : p1;
@@ -363,12 +373,12 @@ __global__ __launch_bounds__(TH * kStrips * 3, MINW) void corr9_dma_kernel(const
   auto compute = [&](const float* __restrict__ s2) {
 #pragma unroll UNR
     for (int c = 0; c < CC; ++c) {
-      const float* cb = s2 + c * ROWS * kPitch;
-      const float4 a = *reinterpret_cast<const float4*>(&cb[(R2 + row) * kPitch + 4 * strip]);
+      const float* cb = s2 + c * ROWS * PITCH;
+      const float4 a = *reinterpret_cast<const float4*>(&cb[(R2 + row) * PITCH + 4 * strip]);
       const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int dyi = 0; dyi < 3; ++dyi) {
-        const float* rp = &cb[(row + dyg * 3 + dyi) * kPitch + 4 * strip];
+        const float* rp = &cb[(row + dyg * 3 + dyi) * PITCH + 4 * strip];
         const float4 b0 = *reinterpret_cast<const float4*>(rp);
         const float4 b1 = *reinterpret_cast<const float4*>(rp + 4);
         const float4 b2 = *reinterpret_cast<const float4*>(rp + 8);
@@ -418,12 +428,12 @@ __global__ __launch_bounds__(TH * kStrips * 3, MINW) void corr9_dma_kernel(const
         }
     __syncthreads();
     float* red = ring0;  // [3][TH][64]
-    *reinterpret_cast<float4*>(&red[(dyg * TH + row) * kTW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+    *reinterpret_cast<float4*>(&red[(dyg * TH + row) * TW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float tot = red[(0 * TH + row) * kTW + 4 * strip + i] + red[(1 * TH + row) * kTW + 4 * strip + i] +
-                        red[(2 * TH + row) * kTW + 4 * strip + i];
+      const float tot = red[(0 * TH + row) * TW + 4 * strip + i] + red[(1 * TH + row) * TW + 4 * strip + i] +
+                        red[(2 * TH + row) * TW + 4 * strip + i];
       scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
     }
   }
@@ -449,29 +459,31 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
   if constexpr (!WARP) {
     if ((W & 3) == 0 && (C % 8) == 0) {
       static const int variant = getenv("RFN_CORR_VARIANT") ? atoi(getenv("RFN_CORR_VARIANT")) : 0;  // tuning knob
-#define RFN_LAUNCH_DMA(TH_, CC_, MINW_, UNR_)                                                                     \
+#define RFN_LAUNCH_DMA(TH_, TW_, CC_, MINW_, UNR_)                                                                \
   {                                                                                                               \
-    const int tilesX = cdiv(W, kTW), tilesY = cdiv(H, TH_);                                                       \
+    const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
     const long blocks = (long)B * tilesX * tilesY;                                                                \
     if (blocks <= 0 || blocks > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
-    hipLaunchKernelGGL((corr9_dma_kernel<TH_, CC_, FUSE, MINW_, UNR_>), dim3((unsigned)blocks),                   \
-                       dim3(TH_ * kStrips * 3), 0, st, in1, in2, out, C, H, W, tilesX, tilesY);                   \
+    hipLaunchKernelGGL((corr9_dma_kernel<TH_, TW_, CC_, FUSE, MINW_, UNR_>), dim3((unsigned)blocks),              \
+                       dim3(TH_ * (TW_ / 4) * 3), 0, st, in1, in2, out, C, H, W, tilesX, tilesY);                 \
     return check_launch("corr9_dma_kernel");                                                                      \
   }
-      // Tile height: a 16x64 tile is one 12-wave workgroup per CU (3 waves per SIMD), an 8x64 tile a 6-wave one.
-      // Pick the height whose (rounds over 256 CUs) x (rows per tile + fixed cost) is smallest for this shape.
-      if (variant == 0) {
-        const long b8 = (long)B * cdiv(W, kTW) * cdiv(H, 8), b16 = (long)B * cdiv(W, kTW) * cdiv(H, 16);
-        const long c8 = ((b8 + 255) / 256) * (8 + 2), c16 = ((b16 + 255) / 256) * (16 + 2);
-        if (c16 < c8) RFN_LAUNCH_DMA(16, 4, 3, 2)
-        RFN_LAUNCH_DMA(8, 4, 3, 2)
-      }
+      // Tile shape: a workgroup is 3 x (TH*TW/256) waves.  16x64 = 12 waves (one workgroup per CU, 3 waves/SIMD),
+      // 8x64 = 6 waves, 8x32 = 3 waves (up to four co-resident per CU).  Pick the shape whose
+      // (rounds over the CU slots) x (tile cost) is smallest for this image size.
+      // Measured on MI355X (profiles/r01_kbench_corr_tiles.txt): 16x32 tiles are the best or tied at both K4 levels
+      // (L1 270x480: 145 us vs 166 us for 16x64; L2 135x240: 102 us) because 510 tiles fill 256 CUs in two even rounds.
+      if (variant == 0) RFN_LAUNCH_DMA(16, 32, 4, 3, 2)
       switch (variant) {
-        case 2: RFN_LAUNCH_DMA(8, 4, 3, 1)
-        case 3: RFN_LAUNCH_DMA(8, 4, 3, 2)
-        case 4: RFN_LAUNCH_DMA(16, 4, 3, 1)
-        case 5: RFN_LAUNCH_DMA(16, 4, 3, 2)
-        case 7: RFN_LAUNCH_DMA(4, 4, 3, 1)
+        case 2: RFN_LAUNCH_DMA(8, 64, 4, 3, 1)
+        case 3: RFN_LAUNCH_DMA(8, 64, 4, 3, 2)
+        case 4: RFN_LAUNCH_DMA(16, 64, 4, 3, 1)
+        case 5: RFN_LAUNCH_DMA(16, 64, 4, 3, 2)
+        case 7: RFN_LAUNCH_DMA(4, 64, 4, 3, 1)
+        case 10: RFN_LAUNCH_DMA(8, 32, 4, 3, 1)
+        case 11: RFN_LAUNCH_DMA(8, 32, 4, 3, 2)
+        case 12: RFN_LAUNCH_DMA(16, 32, 4, 3, 2)
+        case 13: RFN_LAUNCH_DMA(32, 32, 4, 3, 2)
         default: break;   // 9: register-staged kernel below
       }
 #undef RFN_LAUNCH_DMA

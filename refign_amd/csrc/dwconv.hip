@@ -17,8 +17,8 @@
 //   forward       y[b,h,w,c]  = bias[c] + sum_{ky,kx} wgt[c,ky,kx] * x[b, h+(ky-1)d, w+(kx-1)d, c]
 //   backward-data dx           = same stencil over gy with the taps flipped, no bias
 //   backward-wgt  dw[c,ky,kx]  = sum_{b,h,w} gy[b,h,w,c] * x[b, h+(ky-1)d, w+(kx-1)d, c];   db[c] = sum gy
-//                 (per-thread register partials over a pixel stripe -> LDS tree over the block's pixel lanes ->
-//                  one fp32 atomicAdd per (block, channel, tap))
+//                 (per-thread register partials over its pixel quads -> LDS tree over the block's pixel lanes ->
+//                  one workspace row per stripe -> fixed-order reduction kernel: deterministic, no atomics)
 #include <hip/hip_bf16.h>
 
 #include "common.h"
@@ -70,35 +70,49 @@ struct VecIO<__hip_bfloat16> {
 
 constexpr int kPX = 4;   // pixels along W per thread
 
-// grid-stride over work items (b, h, wq, cv); cv fastest so that a wave covers contiguous channels
+__device__ __forceinline__ void quad_coords(long quad, int WQ, int H, int& b, int& h, int& w0) {
+  const int wq = (int)(quad % WQ);
+  const long t = quad / WQ;
+  h = (int)(t % H);
+  b = (int)(t / H);
+  w0 = wq * kPX;
+}
+
+// Thread layout (all three kernels): blockDim = 256 = cvb channel-vectors (fastest, so a wave reads contiguous
+// channels) x pl pixel lanes.  A thread keeps ONE channel vector for its whole life -- its 9 x V weights are loaded
+// once -- and walks "quads" (4 consecutive pixels of one image row) with stride gridDim.y * pl.
 template <typename T, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, T* __restrict__ y, int B,
-                                                            int H, int W, int C, int dil, long total) {
+                                                            int H, int W, int C, int dil, int cvb) {
   constexpr int V = VecIO<T>::N;
   const int CV = C / V, WQ = (W + kPX - 1) / kPX;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long t = idx;
-    const int cv = t % CV; t /= CV;
-    const int wq = t % WQ; t /= WQ;
-    const int h = t % H;
-    const int b = t / H;
-    const int c0 = cv * V, w0 = wq * kPX;
-    float wr[9][V];   // tap-major weights (9, C): one contiguous fp32 vector per tap
+  const int pl = 256 / cvb;
+  const int cv = blockIdx.x * cvb + threadIdx.x % cvb;
+  if (cv >= CV) return;
+  const int c0 = cv * V;
+  float wr[9][V];   // tap-major weights (9, C): one contiguous fp32 vector per tap
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const float* wp = wgt + (size_t)(FLIP ? 8 - k : k) * C + c0;
+  for (int k = 0; k < 9; ++k) {
+    const float* wp = wgt + (size_t)(FLIP ? 8 - k : k) * C + c0;
 #pragma unroll
-      for (int i = 0; i < V; i += 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(wp + i);
-        wr[k][i] = t4.x; wr[k][i + 1] = t4.y; wr[k][i + 2] = t4.z; wr[k][i + 3] = t4.w;
-      }
+    for (int i = 0; i < V; i += 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(wp + i);
+      wr[k][i] = t4.x; wr[k][i + 1] = t4.y; wr[k][i + 2] = t4.z; wr[k][i + 3] = t4.w;
     }
+  }
+  float bs[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) bs[i] = (bias != nullptr) ? bias[c0 + i] : 0.0f;
+  const long nquads = (long)B * H * WQ;
+  for (long quad = (long)blockIdx.y * pl + threadIdx.x / cvb; quad < nquads; quad += (long)gridDim.y * pl) {
+    int b, h, w0;
+    quad_coords(quad, WQ, H, b, h, w0);
     float acc[kPX][V];
 #pragma unroll
     for (int p = 0; p < kPX; ++p)
 #pragma unroll
-      for (int i = 0; i < V; ++i) acc[p][i] = (bias != nullptr) ? bias[c0 + i] : 0.0f;
+      for (int i = 0; i < V; ++i) acc[p][i] = bs[i];
     const T* xb = x + (size_t)b * H * W * C + c0;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -106,8 +120,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
       if (yy < 0 || yy >= H) continue;
       const T* xr = xb + (size_t)yy * W * C;
       if (dil == 1) {
-        // 6 loads feed 4 outputs x 3 taps
-        float v[kPX + 2][V];
+        float v[kPX + 2][V];   // 6 loads feed 4 outputs x 3 taps
 #pragma unroll
         for (int j = 0; j < kPX + 2; ++j) {
           const int xx = w0 - 1 + j;
@@ -144,16 +157,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
   }
 }
 
-// backward-weight: block = 256 threads = CVB channel-vectors x PL pixel lanes; each pixel lane walks a stripe of
-// (b,h,w) positions; 9*V + V register partials; LDS reduce over PL; atomics into dw/db.
+// backward-weight, stage 1: register partials over the thread's quads, LDS tree over the block's pixel lanes, one
+// partial row per (stripe = blockIdx.y) in the workspace: ws[stripe][k][C], k = 0..8 taps, 9 = bias.  No atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ gy,
-                                                                   float* __restrict__ dw, float* __restrict__ db,
-                                                                   int B, int H, int W, int C, int dil, int cvb,
-                                                                   int stripes) {
+                                                                   float* __restrict__ ws, int B, int H, int W, int C,
+                                                                   int dil, int cvb) {
   constexpr int V = VecIO<T>::N;
-  const int CV = C / V;
-  const int pl = 256 / cvb;                               // pixel lanes per block
+  const int CV = C / V, WQ = (W + kPX - 1) / kPX;
+  const int pl = 256 / cvb;
   const int cvi = threadIdx.x % cvb, pli = threadIdx.x / cvb;
   const int cv = blockIdx.x * cvb + cvi;
   const bool active = cv < CV;
@@ -166,35 +178,63 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
     for (int k = 0; k < 9; ++k) aw[k][i] = 0.0f;
   }
   if (active) {
-    const long npix = (long)B * H * W;
-    const long lane_id = (long)blockIdx.y * pl + pli, nlanes = (long)stripes * pl;
-    for (long pix = lane_id; pix < npix; pix += nlanes) {
-      const int w = pix % W;
-      const int h = (pix / W) % H;
-      const int b = pix / ((long)W * H);
-      float g[V];
-      VecIO<T>::load(gy + (size_t)pix * C + c0, g);
+    const long nquads = (long)B * H * WQ;
+    for (long quad = (long)blockIdx.y * pl + pli; quad < nquads; quad += (long)gridDim.y * pl) {
+      int b, h, w0;
+      quad_coords(quad, WQ, H, b, h, w0);
+      float g[kPX][V];
+      const T* gp = gy + (((size_t)b * H + h) * W) * C + c0;
 #pragma unroll
-      for (int i = 0; i < V; ++i) ab[i] += g[i];
+      for (int p = 0; p < kPX; ++p) {
+        if (w0 + p < W) VecIO<T>::load(gp + (size_t)(w0 + p) * C, g[p]);
+        else {
+#pragma unroll
+          for (int i = 0; i < V; ++i) g[p][i] = 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) ab[i] += g[p][i];
+      }
       const T* xb = x + (size_t)b * H * W * C + c0;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int yy = h + (ky - 1) * dil;
         if (yy < 0 || yy >= H) continue;
+        const T* xr = xb + (size_t)yy * W * C;
+        if (dil == 1) {
+          float v[kPX + 2][V];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int xx = w + (kx - 1) * dil;
-          if (xx < 0 || xx >= W) continue;
-          float v[V];
-          VecIO<T>::load(xb + ((size_t)yy * W + xx) * C, v);
+          for (int j = 0; j < kPX + 2; ++j) {
+            const int xx = w0 - 1 + j;
+            if (xx >= 0 && xx < W) VecIO<T>::load(xr + (size_t)xx * C, v[j]);
+            else {
 #pragma unroll
-          for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[i], v[i], aw[ky * 3 + kx][i]);
+              for (int i = 0; i < V; ++i) v[j][i] = 0.0f;
+            }
+          }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int p = 0; p < kPX; ++p)
+#pragma unroll
+              for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[p][i], v[p + kx][i], aw[ky * 3 + kx][i]);
+        } else {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int p = 0; p < kPX; ++p) {
+              const int xx = w0 + p + (kx - 1) * dil;
+              if (xx < 0 || xx >= W) continue;
+              float v[V];
+              VecIO<T>::load(xr + (size_t)xx * C, v);
+#pragma unroll
+              for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[p][i], v[i], aw[ky * 3 + kx][i]);
+            }
         }
       }
     }
   }
-  // reduce over the pixel lanes of the block through LDS, one tap at a time
   __shared__ float red[256 * 8];
+  float* wrow = ws + (size_t)blockIdx.y * 10 * C;
   for (int k = 0; k < 10; ++k) {
     __syncthreads();
 #pragma unroll
@@ -205,44 +245,57 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
       for (int i = 0; i < V; ++i) {
         float s = 0.0f;
         for (int p = 0; p < pl; ++p) s += red[(p * cvb + cvi) * V + i];
-        if (k < 9) atomicAdd(&dw[(size_t)k * C + c0 + i], s);
-        else if (db != nullptr) atomicAdd(&db[c0 + i], s);
+        wrow[(size_t)k * C + c0 + i] = s;
       }
     }
   }
 }
 
+// stage 2: dw[k][c] = sum over stripes (fixed order => deterministic); k = 9 -> bias gradient
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_reduce_kernel(const float* __restrict__ ws,
+                                                                          float* __restrict__ dw,
+                                                                          float* __restrict__ db, int C, int stripes) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 10 * C) return;
+  float s = 0.0f;
+  for (int t = 0; t < stripes; ++t) s += ws[(size_t)t * 10 * C + idx];
+  if (idx < 9 * C) dw[idx] = s;
+  else if (db != nullptr) db[idx - 9 * C] = s;
+}
+
+static inline int pick_cvb(int CV) { return CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV >= 16 ? 16 : 8)); }
+constexpr int kMaxStripes = 128;
+
 template <typename T>
 static int launch_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,
                       int flip, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
-  const long total = (long)B * H * ((W + kPX - 1) / kPX) * (C / V);
-  const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 64);
+  const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
+  const long nquads = (long)B * H * ((W + kPX - 1) / kPX);
+  const int gy = (int)std::max<long>(1, std::min<long>(cdiv(nquads, pl), (256L * 16) / gx));
   if (flip)
-    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, true>), dim3(grid), dim3(256), 0, st, (const T*)x, w, bias, (T*)y, B, H,
-                       W, C, dil, total);
+    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, true>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias, (T*)y, B,
+                       H, W, C, dil, cvb);
   else
-    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false>), dim3(grid), dim3(256), 0, st, (const T*)x, w, bias, (T*)y, B,
-                       H, W, C, dil, total);
+    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias, (T*)y,
+                       B, H, W, C, dil, cvb);
   return check_launch("dwconv3x3_fwd_kernel");
 }
 
 template <typename T>
-static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db, int B, int H, int W, int C, int dil,
-                             hipStream_t st) {
+static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db, float* ws, int B, int H, int W, int C,
+                             int dil, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
-  const int CV = C / V;
-  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * 9, st) != hipSuccess ||
-      (db && hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st) != hipSuccess))
-    return fail(RFN_ELAUNCH, "dwconv bwd weight: hipMemsetAsync failed");
-  const int cvb = CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV >= 16 ? 16 : 8));
-  const int gx = cdiv(CV, cvb);
-  // enough stripes to fill the chip (~8 blocks per CU) without drowning the atomics
-  const long npix = (long)B * H * W;
-  int stripes = (int)std::max<long>(1, std::min<long>(2048 / gx, npix / (4 * (256 / cvb)) + 1));
+  const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
+  const long nquads = (long)B * H * ((W + kPX - 1) / kPX);
+  const int stripes = (int)std::max<long>(1, std::min<long>(std::min<long>(kMaxStripes, cdiv(nquads, pl)),
+                                                            std::max<long>(1, (256L * 8) / gx)));
   hipLaunchKernelGGL((dwconv3x3_bwd_weight_kernel<T>), dim3(gx, stripes), dim3(256), 0, st, (const T*)x, (const T*)gy,
-                     dw, db, B, H, W, C, dil, cvb, stripes);
-  return check_launch("dwconv3x3_bwd_weight_kernel");
+                     ws, B, H, W, C, dil, cvb);
+  if (int rc = check_launch("dwconv3x3_bwd_weight_kernel")) return rc;
+  hipLaunchKernelGGL(dwconv3x3_bwd_weight_reduce_kernel, dim3(cdiv(10L * C, 256)), dim3(256), 0, st, ws, dw, db, C,
+                     stripes);
+  return check_launch("dwconv3x3_bwd_weight_reduce_kernel");
 }
 
 }  // namespace rfn
@@ -266,17 +319,23 @@ int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias
   return fail(RFN_EINVAL, "rfn_dwconv3x3_nhwc_fwd: dtype must be 0 (f32) or 1 (bf16)");
 }
 
-int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias, int B, int H,
-                                  int W, int C, int dilation, int dtype, rfn_stream_t stream) {
-  RFN_REQUIRE(x && grad_y && grad_weight, "rfn_dwconv3x3_nhwc_bwd_weight: null pointer");
+unsigned long rfn_dwconv3x3_bwd_weight_workspace_bytes(int C) {
+  return (unsigned long)kMaxStripes * 10ul * (unsigned long)(C > 0 ? C : 0) * sizeof(float);
+}
+
+int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias,
+                                  void* workspace, int B, int H, int W, int C, int dilation, int dtype,
+                                  rfn_stream_t stream) {
+  RFN_REQUIRE(x && grad_y && grad_weight && workspace, "rfn_dwconv3x3_nhwc_bwd_weight: null pointer");
   RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "rfn_dwconv3x3_nhwc_bwd_weight: bad size");
   if (dtype == 0) {
     RFN_REQUIRE(C % 4 == 0, "rfn_dwconv3x3_nhwc_bwd_weight: C must be a multiple of 4 for f32");
-    return launch_bwd_weight<float>(x, grad_y, grad_weight, grad_bias, B, H, W, C, dilation, (hipStream_t)stream);
+    return launch_bwd_weight<float>(x, grad_y, grad_weight, grad_bias, (float*)workspace, B, H, W, C, dilation,
+                                    (hipStream_t)stream);
   }
   if (dtype == 1) {
     RFN_REQUIRE(C % 8 == 0, "rfn_dwconv3x3_nhwc_bwd_weight: C must be a multiple of 8 for bf16");
-    return launch_bwd_weight<__hip_bfloat16>(x, grad_y, grad_weight, grad_bias, B, H, W, C, dilation,
+    return launch_bwd_weight<__hip_bfloat16>(x, grad_y, grad_weight, grad_bias, (float*)workspace, B, H, W, C, dilation,
                                              (hipStream_t)stream);
   }
   return fail(RFN_EINVAL, "rfn_dwconv3x3_nhwc_bwd_weight: dtype must be 0 (f32) or 1 (bf16)");

@@ -50,9 +50,10 @@ class _DWConv3x3(torch.autograd.Function):
             dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
             db = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
             lib = _lib.load_library()
+            ws = torch.empty(lib.rfn_dwconv3x3_bwd_weight_workspace_bytes(C), dtype=torch.uint8, device=x.device)
             with torch.cuda.device(x.device):
-                rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), B, H, W, C, ctx.dilation,
-                                                       _DT[x.dtype], current_stream(x.device))
+                rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), ptr(ws), B, H, W, C,
+                                                       ctx.dilation, _DT[x.dtype], current_stream(x.device))
             _lib.check(rc, "dwconv3x3_nhwc_bwd_weight")
             gw = dw.t().reshape(ctx.wshape).to(ctx.wdtype)
             gb = db

@@ -1,0 +1,44 @@
+"""CPU: the reference's YAML `class_path`/`init_args` trees build through refign_amd.config without modification (the
+model section of configs/cityscapes_darkzurich/refign_hrda_star.yaml is embedded verbatim in bench.REF_CFG), with the
+reference's trainable-parameter counts (85.69 M HRDA / 85.16 M DAFormer) and optimiser groups."""
+import copy
+
+import torch
+
+
+def _build(use_hrda):
+    import bench
+    from refign_amd import config
+    cfg = copy.deepcopy(bench.REF_CFG)
+    cfg["model"]["init_args"]["use_hrda"] = use_hrda
+    over = {"backbone.init_args.pretrained": None, "alignment_backbone.init_args.pretrained": None,
+            "alignment_head.init_args.pretrained": None}
+    return config.build_model(cfg, over)
+
+
+def test_hrda_config_builds_with_reference_param_count():
+    m = _build(True)
+    n = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert abs(n / 1e6 - 85.686) < 0.01
+    groups = m.optimizer_parameters()
+    assert [g["name"] for g in groups] == ["head_weight", "head_bias", "backbone_weight", "backbone_bias"]
+    assert groups[2]["lr"] == 0.1 * groups[0]["lr"] and groups[1]["weight_decay"] == 0
+    assert sum(p.numel() for g in groups for p in g["params"]) == n
+    # frozen: alignment nets, EMA teacher, ImageNet encoder
+    assert not any(p.requires_grad for p in m.alignment_head.parameters())
+    assert not any(p.requires_grad for p in m.m_backbone.parameters())
+    assert not any(p.requires_grad for p in m.imnet_backbone.parameters())
+    (opt,), (sch,) = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.AdamW) and type(sch).__name__ == "LinearWarmupPolynomialLR"
+
+
+def test_daformer_config_param_count():
+    m = _build(False)
+    assert abs(sum(p.numel() for p in m.parameters() if p.requires_grad) / 1e6 - 85.155) < 0.01
+    assert m.hrda_scale_attention is None
+
+
+def test_train_mode_keeps_frozen_nets_in_eval():
+    m = _build(False).train()
+    assert m.backbone.training and m.m_backbone.training          # teacher in train mode: reference quirk D7/D9
+    assert not m.alignment_backbone.training and not m.alignment_head.training and not m.imnet_backbone.training
