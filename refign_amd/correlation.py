@@ -110,12 +110,16 @@ def spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=1, stri
                                                    dilation, dilation_patch)
 
 
-def local_correlation_layer(feature_source, feature_target, flow=None):
+def local_correlation_layer(feature_source, feature_target, flow=None, single_kernel_warp=False):
     """LocalFeatureCorrelationLayer.forward (modules.py:266-274) as ONE kernel: patch-9 correlation (input1 = target,
     input2 = source) + ReLU + L2-normalisation over the 81 shifts -> (B,81,H,W).
 
-    With `flow` (B,2,H,W; pixels of this level) the source features are bilinearly warped on the fly while the tile is
-    staged in LDS, i.e. warp(feature_source, flow) of uawarpc.py:149-152 is fused in and never materialised.
+    With `flow` (B,2,H,W; pixels of this level) the source features are first bilinearly warped
+    (warp(feature_source, flow) of uawarpc.py:149-152).  Two implementations, same numbers:
+      * default: warp kernel into a scratch map (L2/Infinity-Cache resident at these sizes), then the LDS-DMA
+        correlation kernel -- measured faster (K4 level 1: 233 + 145 us) than
+      * single_kernel_warp=True: the register-staged kernel that warps while it stages the source tile and never
+        materialises the warped map (796 us: the per-element gathers cannot use the LDS-DMA path).
     Inference-only (the UDA step runs align under no_grad, segmentation_model.py:194).
     """
     require_device_tensor(feature_target, "feature_target", torch.float32)
@@ -128,6 +132,9 @@ def local_correlation_layer(feature_source, feature_target, flow=None):
     B, C, H, W = feature_target.shape
     if flow is not None and tuple(flow.shape) != (B, 2, H, W):
         raise RuntimeError("local_correlation_layer: flow must be (B,2,H,W)")
+    if flow is not None and not single_kernel_warp:
+        from .matching import warp_nocheck
+        feature_source, flow = warp_nocheck(feature_source, flow), None
     out = torch.empty((B, 81, H, W), dtype=torch.float32, device=dev)
     lib = _lib.load_library()
     with torch.cuda.device(dev):

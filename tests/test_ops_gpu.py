@@ -99,8 +99,9 @@ def test_local_layer_fused_warp_vs_oracle(dev, oracle):
     flo = (2.5 * rng.standard_normal((B, 2, H, W))).astype(np.float32)
     flo[0, :, :3, :3] = 40.0   # out of range region
     want = oracle.local_correlation_layer(oracle.warp(src, flo), trg)
-    out = local_correlation_layer(T(src, dev), T(trg, dev), flow=T(flo, dev))
-    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-3, atol=2e-5)
+    for single in (False, True):
+        out = local_correlation_layer(T(src, dev), T(trg, dev), flow=T(flo, dev), single_kernel_warp=single)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-3, atol=2e-5)
 
 
 # ------------------------------------------------------------------ GlobalFeatureCorrelationLayer (a7) -> G3
