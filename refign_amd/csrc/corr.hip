@@ -265,16 +265,19 @@ __global__ __launch_bounds__(TH * kStrips * 3) void corr9_tile_kernel(
 // --------------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int TH, int TW, int CC, bool FUSE, int MINW, int UNR>
-__global__ __launch_bounds__(TH * (TW / 4) * 3, MINW) void corr9_dma_kernel(const float* __restrict__ in1,
-                                                                           const float* __restrict__ in2,
-                                                                           float* __restrict__ out, int C, int H,
-                                                                           int W, int tilesX, int tilesY) {
+// NTILE = 2: the workgroup is two independent halves, each owning its own tile (ids 2b, 2b+1 of the launch's tile
+// order), its own LDS region and its own DMA stream; only the per-chunk barrier is shared.  This doubles the waves per
+// CU (6-wave workgroups do not co-reside: their 2,2,1,1 wave placement over the SIMDs leaves no room for a second one
+// at 168 VGPRs) while keeping the fine 16x32 tile granularity that fills 256 CUs evenly.
+template <int TH, int TW, int CC, bool FUSE, int MINW, int UNR, int NTILE>
+__global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_kernel(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
+    int tilesX, int tilesY, int ntiles, int xcd_remap) {
   static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
   constexpr int STRIPS = TW / 4;                     // 4-pixel strips per tile row
   constexpr int RPW = 64 / STRIPS;                   // tile rows covered by one wave (4 or 8)
-  constexpr int NT = TH * STRIPS * 3;
-  constexpr int NW = NT / 64;
+  constexpr int NT = TH * STRIPS * 3;                // threads per tile
+  constexpr int NW = NT / 64;                        // waves per tile
   constexpr int R2 = TH + 2 * kHalo;
   constexpr int ROWS = R2 + TH;
   // LDS row pitch in dwords.  It is chosen together with the lane->strip permutation below so that every
@@ -292,11 +295,27 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3, MINW) void corr9_dma_kernel(cons
   // TWO separate LDS objects on purpose: hipcc's waitcnt pass only lets a ds_read run past an in-flight LDS-DMA
   // when alias analysis proves they touch different objects; one array indexed by (chunk & 1) forces
   // s_waitcnt vmcnt(0) before the first ds_read of every chunk, i.e. no overlap at all.
-  __shared__ __attribute__((aligned(16))) float ring0[BUF];
-  __shared__ __attribute__((aligned(16))) float ring1[BUF];
+  __shared__ __attribute__((aligned(16))) float ring0_all[NTILE * BUF];
+  __shared__ __attribute__((aligned(16))) float ring1_all[NTILE * BUF];
 
-  const int tid = threadIdx.x;
-  int bid = blockIdx.x;
+  const int half = threadIdx.x / NT;                 // which of the workgroup's tiles (wave-uniform)
+  const int tid = threadIdx.x % NT;
+  float* const ring0 = ring0_all + half * BUF;
+  float* const ring1 = ring1_all + half * BUF;
+  // Tile order = dispatch order.  An XCD-aware remap (each XCD a contiguous band of tiles, T1) was measured and is
+  // WORSE here (16x32 single tile 145 -> 179 us at K4 level 1): the inputs are Infinity-Cache resident and spreading
+  // the eight XCDs over eight distant bands costs more in fabric/DRAM-page locality than the shared halos save.
+  int tile;
+  if (xcd_remap) {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int qq = nwg / 8, rr = nwg % 8, xcd = b % 8, loc = b / 8;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+    tile = wg * NTILE + half;
+  } else {
+    tile = blockIdx.x * NTILE + half;
+  }
+  const bool live = tile < ntiles;                   // odd tile count: the last half only keeps the barriers company
+  int bid = live ? tile : 0;
   const int tx = bid % tilesX; bid /= tilesX;
   const int ty = bid % tilesY;
   const int n = bid / tilesY;
@@ -326,7 +345,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3, MINW) void corr9_dma_kernel(cons
     const int wi = wave + k * NW;                    // wave-level instruction index
     const int slot = wi * 64 + lane;
     const int v = slot % V, rr = (slot / V) % ROWS, c = slot / (V * ROWS);
-    bool ok = (wi < NINSTR) && (slot < SLOTS);
+    bool ok = live && (wi < NINSTR) && (slot < SLOTS);
     const float* src;
     if (rr < R2) {
       const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3, MINW) void corr9_dma_kernel(cons
       scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
     }
   }
-  if (h < H && wx + 3 < W) {
+  if (live && h < H && wx + 3 < W) {
     float* obase = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
 #pragma unroll
     for (int dyi = 0; dyi < 3; ++dyi)
@@ -459,31 +478,36 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
   if constexpr (!WARP) {
     if ((W & 3) == 0 && (C % 8) == 0) {
       static const int variant = getenv("RFN_CORR_VARIANT") ? atoi(getenv("RFN_CORR_VARIANT")) : 0;  // tuning knob
-#define RFN_LAUNCH_DMA(TH_, TW_, CC_, MINW_, UNR_)                                                                \
+      static const int xcd_remap = getenv("RFN_CORR_XCD") ? atoi(getenv("RFN_CORR_XCD")) : 0;
+#define RFN_LAUNCH_DMA(TH_, TW_, CC_, MINW_, UNR_, NTILE_)                                                        \
   {                                                                                                               \
     const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
-    const long blocks = (long)B * tilesX * tilesY;                                                                \
-    if (blocks <= 0 || blocks > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
-    hipLaunchKernelGGL((corr9_dma_kernel<TH_, TW_, CC_, FUSE, MINW_, UNR_>), dim3((unsigned)blocks),              \
-                       dim3(TH_ * (TW_ / 4) * 3), 0, st, in1, in2, out, C, H, W, tilesX, tilesY);                 \
+    const long ntiles = (long)B * tilesX * tilesY;                                                                \
+    const long blocks = (ntiles + NTILE_ - 1) / NTILE_;                                                           \
+    if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
+    hipLaunchKernelGGL((corr9_dma_kernel<TH_, TW_, CC_, FUSE, MINW_, UNR_, NTILE_>), dim3((unsigned)blocks),      \
+                       dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
+                       (int)ntiles, xcd_remap);                                                                   \
     return check_launch("corr9_dma_kernel");                                                                      \
   }
-      // Tile shape: a workgroup is 3 x (TH*TW/256) waves.  16x64 = 12 waves (one workgroup per CU, 3 waves/SIMD),
-      // 8x64 = 6 waves, 8x32 = 3 waves (up to four co-resident per CU).  Pick the shape whose
-      // (rounds over the CU slots) x (tile cost) is smallest for this image size.
-      // Measured on MI355X (profiles/r01_kbench_corr_tiles.txt): 16x32 tiles are the best or tied at both K4 levels
-      // (L1 270x480: 145 us vs 166 us for 16x64; L2 135x240: 102 us) because 510 tiles fill 256 CUs in two even rounds.
-      if (variant == 0) RFN_LAUNCH_DMA(16, 32, 4, 3, 2)
+      // Default: two independent 16x32 tiles per 12-wave workgroup (3 waves/SIMD) when that yields enough workgroups
+      // to occupy the chip -- K4 level 1 (2 x 270x480): 510 tiles = 255 workgroups = one even round over 256 CUs,
+      // 141 us vs 166-200 us for 16x64 tiles (272 workgroups = two rounds, the second nearly empty).  Smaller maps
+      // (K4 level 2: 2 x 135x240) are wave-starved either way; 8x64 single tiles give the most workgroups per byte of
+      // halo (101 us vs 153 us paired).  Measurements: profiles/r01_kbench_corr_tiles*.txt.
+      if (variant == 0) {
+        const long pairs = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2;
+        if (pairs >= 192) RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2)
+        RFN_LAUNCH_DMA(8, 64, 4, 3, 2, 1)
+      }
       switch (variant) {
-        case 2: RFN_LAUNCH_DMA(8, 64, 4, 3, 1)
-        case 3: RFN_LAUNCH_DMA(8, 64, 4, 3, 2)
-        case 4: RFN_LAUNCH_DMA(16, 64, 4, 3, 1)
-        case 5: RFN_LAUNCH_DMA(16, 64, 4, 3, 2)
-        case 7: RFN_LAUNCH_DMA(4, 64, 4, 3, 1)
-        case 10: RFN_LAUNCH_DMA(8, 32, 4, 3, 1)
-        case 11: RFN_LAUNCH_DMA(8, 32, 4, 3, 2)
-        case 12: RFN_LAUNCH_DMA(16, 32, 4, 3, 2)
-        case 13: RFN_LAUNCH_DMA(32, 32, 4, 3, 2)
+        case 3: RFN_LAUNCH_DMA(8, 64, 4, 3, 2, 1)
+        case 5: RFN_LAUNCH_DMA(16, 64, 4, 3, 2, 1)
+        case 10: RFN_LAUNCH_DMA(8, 32, 4, 3, 1, 1)
+        case 12: RFN_LAUNCH_DMA(16, 32, 4, 3, 2, 1)
+        case 14: RFN_LAUNCH_DMA(8, 32, 4, 3, 1, 4)
+        case 15: RFN_LAUNCH_DMA(8, 64, 4, 3, 2, 2)
+        case 16: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2)
         default: break;   // 9: register-staged kernel below
       }
 #undef RFN_LAUNCH_DMA
