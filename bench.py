@@ -241,33 +241,65 @@ class RefignDAFormerStep(RefignStep):
     use_hrda = False
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md; separate passes) -- profiles/r01_pmc_traffic_corr9.json; null if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_corr9.json")) as f:
+            return int(json.load(f)["hbm_traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 WORKLOADS = {AlignRefineKernels.name: AlignRefineKernels, RefignStep.name: RefignStep,
              RefignDAFormerStep.name: RefignDAFormerStep}
 
 
-def cpu_baseline(wl):
-    """Reference CPU path on the host cores, 1 pair.  Returns the cpu_baseline object."""
+def cpu_baseline(wl, args):
+    """The reference's CPU path for the SAME step on the host cores, on a bounded sample: ONE pair at a reduced image
+    size (the step's cost is linear in pixels), extrapolated to the metric's unit.  kind "reference" when the
+    reference's own correlation.cpp (oracle/_ref) is available, else "port"; everything else is the reference's
+    algorithm restated on torch-CPU ops (oracle/cpu_align.py + the same module trees on CPU)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    kind, corr_fn = "port", None
-    try:
-        import build_ref
-        ref = build_ref.load_prebuilt()
-        if ref is not None:
-            kind = "reference"
-            corr_fn = lambda a, b: ref.forward(a, b, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)  # noqa: E731
-    except Exception:
-        ref = None
-    if corr_fn is None:
-        import cpu_oracle
-        corr_fn = lambda a, b: torch.from_numpy(cpu_oracle.corr_forward(a.numpy(), b.numpy(), patch_size=9))  # noqa: E731
-    dt = wl.cpu_step(kind, corr_fn)
-    return {"value": round(1.0 / dt, 5), "unit": "image-pairs/s", "cores": cores, "kind": kind,
-            "sample": f"1 image pair through the same step ({wl.name}) on the host, {dt:.2f} s wall: "
-                      f"correlation = {'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'}"
-                      f" with OpenMP, warp/refine = torch-CPU ATen ops"}
+    import cpu_align
+    kind, corr_fn = cpu_align._corr_fn_default()
+    if isinstance(wl, AlignRefineKernels):
+        dt = wl.cpu_step(kind, corr_fn)
+        return {"value": round(1.0 / dt, 5), "unit": "image-pairs/s", "cores": cores, "kind": kind,
+                "sample": f"1 pair through the align+refine kernel stage on the host, {dt:.2f} s wall"}
+    import copy
+    from refign_amd import config
+    from refign_amd.trainer import Trainer
+    h, w = args.height // 4, args.width // 4                   # 1/16 of the pixels
+    cfg = copy.deepcopy(REF_CFG)
+    cfg["model"]["init_args"]["use_hrda"] = wl.use_hrda
+    if not wl.use_hrda:
+        cfg["model"]["init_args"].pop("hrda_scale_attention")
+    over = {"backbone.init_args.pretrained": None, "alignment_backbone.init_args.pretrained": None,
+            "alignment_head.init_args.pretrained": None, "adapt_to_ref": False}
+    model = config.build_model(cfg, over).train()
+    model.align = lambda lr, ir, it: cpu_align.align(model.alignment_backbone, model.alignment_head, lr, ir, it, corr_fn)
+    model.refine = lambda lt, lr, m, c: cpu_align.refine(lt, lr, m, c, gamma=model.gamma)
+    trainer = Trainer(model, fused_optimizer=False)
+    g = torch.Generator().manual_seed(99)
+    lbl = torch.randint(0, 19, (1, (h + 31) // 32, (w + 31) // 32), generator=g)
+    lbl = lbl.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :h, :w].contiguous()
+    trg = torch.randn(1, 3, h, w, generator=g)
+    batch = {"image_src": torch.randn(1, 3, h, w, generator=g), "semantic_src": lbl, "image_trg": trg,
+             "image_ref": 0.8 * torch.roll(trg, (1, -1), (2, 3)) + 0.2 * torch.randn(1, 3, h, w, generator=g)}
+    t0 = time.perf_counter()
+    trainer.step(batch)
+    dt = time.perf_counter() - t0
+    scale = (h * w) / float(args.height * args.width)
+    return {"value": round(scale / dt, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind,
+            "sample": f"ONE full training step (same model/config, fp32) for 1 source image + 1 pair at {h}x{w} "
+                      f"(1/16 of the pixels of {args.height}x{args.width}) on the host: {dt:.2f} s wall; value = "
+                      f"(1 pair / {dt:.2f} s) x {scale:.4f} pixel ratio.  Correlation = "
+                      f"{'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'}"
+                      f" + OpenMP, all other ops torch-CPU ATen (what the reference's CPU path calls)"}
 
 
 def main():
@@ -330,12 +362,12 @@ def main():
         ach = wl.roofline_bytes() / (us * 1e-6) / 1e9
         roof = {"kernel": "corr9_dma_kernel<16x32 tiles, fused ReLU+L2norm> level 1 (C=128, 270x480, b=%d)" % wl.b,
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(us, 2),
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(), "avg_launch_us": round(us, 2),
                 "algorithmic_bytes_per_launch": wl.roofline_bytes()}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(wl)
+        cpu = cpu_baseline(wl, args)
 
     if dist is not None:
         dist.barrier()

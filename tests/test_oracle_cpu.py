@@ -93,3 +93,37 @@ def test_refine_oracle(oracle, name):
     np.testing.assert_array_equal(label, g["pseudo_label"])
     np.testing.assert_array_equal(prob, g["pseudo_prob"])
     assert abs(weight - g["pseudo_weight"]) < 1e-7
+
+
+# ------------------------------------------------------------------ head / align restatement (oracle/cpu_align.py)
+def _unit(shape, key):
+    from fill import hashed_uniform
+    x = hashed_uniform(shape, key) - 0.5
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_cpu_head_restatement_matches_reference_golden(oracle):
+    """The CPU restatement of the UAWarpC head (test infrastructure used by bench.py's cpu_baseline) reproduces the
+    reference's four (flow, log-variance) levels on the G5 fixture."""
+    import torch
+    import cpu_align
+    from fill import closed_form_fill
+    from refign_amd.align import UAWarpCHead
+    name, H, W = "rect_192x320", 192, 320
+    g = golden("head_" + name)
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select',
+                                        estimate_uncertainty=True)).eval()
+    p = {"trg": [_unit((1, 128, H // 4, W // 4), f"g5/{name}/t1"), _unit((1, 256, H // 8, W // 8), f"g5/{name}/t2")],
+         "src": [_unit((1, 128, H // 4, W // 4), f"g5/{name}/s1"), _unit((1, 256, H // 8, W // 8), f"g5/{name}/s2")],
+         "trg256": [_unit((1, 256, 32, 32), f"g5/{name}/t3"), _unit((1, 512, 16, 16), f"g5/{name}/t4")],
+         "src256": [_unit((1, 256, 32, 32), f"g5/{name}/s3"), _unit((1, 512, 16, 16), f"g5/{name}/s4")]}
+    for k_t, k_s in (("trg", "src"), ("trg256", "src256")):
+        for i in range(2):
+            mix = 0.7 * np.roll(p[k_t][i], shift=(1, -2), axis=(2, 3)) + 0.3 * p[k_s][i]
+            p[k_s][i] = (mix / np.linalg.norm(mix, axis=1, keepdims=True)).astype(np.float32)
+    t = lambda xs: [torch.from_numpy(x) for x in xs]  # noqa: E731
+    corr_fn = lambda a, b: torch.from_numpy(oracle.corr_forward(a.contiguous().numpy(), b.contiguous().numpy(), patch_size=9))  # noqa: E731
+    outs = cpu_align.head_forward(head, t(p["trg"]), t(p["src"]), t(p["trg256"]), t(p["src256"]), (H, W), corr_fn)
+    for lvl, (fl, un) in zip((4, 3, 2, 1), outs):
+        np.testing.assert_allclose(fl.numpy(), g[f"flow{lvl}"], rtol=1e-3, atol=2e-2, err_msg=f"flow{lvl}")
+        np.testing.assert_allclose(un.numpy(), g[f"uncert{lvl}"], rtol=1e-3, atol=5e-3, err_msg=f"uncert{lvl}")
