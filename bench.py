@@ -261,9 +261,11 @@ def cpu_baseline(wl, args):
     reference's own correlation.cpp (oracle/_ref) is available, else "port"; everything else is the reference's
     algorithm restated on torch-CPU ops (oracle/cpu_align.py + the same module trees on CPU)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    cores = os.cpu_count() or 1
+    # threads: all host cores up to 32 -- the step is thousands of small ops, and with 256 OpenMP threads per op the
+    # fork/join overhead dominates (measured: >7 min for one step on the 256-core box vs tens of seconds at 32)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     import cpu_align
     kind, corr_fn = cpu_align._corr_fn_default()
     if isinstance(wl, AlignRefineKernels):
@@ -273,7 +275,8 @@ def cpu_baseline(wl, args):
     import copy
     from refign_amd import config
     from refign_amd.trainer import Trainer
-    h, w = args.height // 4, args.width // 4                   # 1/16 of the pixels
+    # ~1/16 of the pixels, rounded to multiples of 32 (HRDA crop boxes need H/2 and W/2 divisible by 16)
+    h, w = max(64, args.height // 4 // 32 * 32), max(64, args.width // 4 // 32 * 32)
     cfg = copy.deepcopy(REF_CFG)
     cfg["model"]["init_args"]["use_hrda"] = wl.use_hrda
     if not wl.use_hrda:
@@ -296,7 +299,7 @@ def cpu_baseline(wl, args):
     scale = (h * w) / float(args.height * args.width)
     return {"value": round(scale / dt, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind,
             "sample": f"ONE full training step (same model/config, fp32) for 1 source image + 1 pair at {h}x{w} "
-                      f"(1/16 of the pixels of {args.height}x{args.width}) on the host: {dt:.2f} s wall; value = "
+                      f"({scale:.4f} of the pixels of {args.height}x{args.width}) on the host with {cores} threads: {dt:.2f} s wall; value = "
                       f"(1 pair / {dt:.2f} s) x {scale:.4f} pixel ratio.  Correlation = "
                       f"{'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'}"
                       f" + OpenMP, all other ops torch-CPU ATen (what the reference's CPU path calls)"}

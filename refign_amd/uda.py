@@ -440,7 +440,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if self.fdist_classes is not None:
             scale = gt.shape[-1] // feat[-1].shape[-1]
             gt_small = self.downscale_label_ratio(gt.unsqueeze(1), scale, self.fdist_scale_min_ratio,
-                                                  self.head.num_classes, 255).long()
+                                                  self.head.num_classes, 255, out_size=feat[-1].shape[-2:]).long()
             cls = torch.tensor(self.fdist_classes, device=gt.device)
             mask = torch.any(gt_small[..., None] == cls, -1)
             dist = self.masked_feat_dist(feat[-1], feat_imnet[-1], mask)
@@ -456,18 +456,23 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return torch.mean(d)
 
     @staticmethod
-    def downscale_label_ratio(gt, scale_factor, min_ratio, n_classes, ignore_index=255):
-        """(:637-668) majority class per scale x scale window if its share >= min_ratio, else ignore."""
+    def downscale_label_ratio(gt, scale_factor, min_ratio, n_classes, ignore_index=255, out_size=None):
+        """(:637-668) majority class per scale x scale window if its share >= min_ratio, else ignore.
+        `out_size` (extension): the feature-map size to match when H or W is not a multiple of scale_factor -- e.g.
+        1080 rows at stride 64, where the MiT stage-4 map has ceil(H/64) rows.  The reference asserts divisibility
+        (:661-667) and trains on 1024^2 crops; for divisible sizes the windows, hence the result, are identical."""
         assert scale_factor > 1
         b, c, H, W = gt.shape
         assert c == 1
         out = gt.clone()
         out[out == ignore_index] = n_classes
         onehot = F.one_hot(out.squeeze(1), num_classes=n_classes + 1).permute(0, 3, 1, 2).float()
-        # ceil_mode only matters when H or W is not a multiple of scale_factor (e.g. 1080 rows at stride 64: the MiT
-        # stage-4 map has ceil(H/64) rows).  The reference asserts divisibility (:661-667) and trains on 1024^2 crops;
-        # for divisible sizes the result is identical, otherwise the border windows use their valid part.
-        ratio, out = torch.max(F.avg_pool2d(onehot, kernel_size=scale_factor, ceil_mode=True), dim=1, keepdim=True)
+        if out_size is None or (H % scale_factor == 0 and W % scale_factor == 0
+                                and (H // scale_factor, W // scale_factor) == tuple(out_size)):
+            pooled = F.avg_pool2d(onehot, kernel_size=scale_factor)
+        else:
+            pooled = F.adaptive_avg_pool2d(onehot, tuple(out_size))
+        ratio, out = torch.max(pooled, dim=1, keepdim=True)
         out[out == n_classes] = ignore_index
         out[ratio < min_ratio] = ignore_index
         return out
