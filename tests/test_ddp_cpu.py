@@ -82,3 +82,70 @@ def test_lr_schedule_matches_reference_formula():
     assert abs(lrs[750] - 6e-5 * (1 - 0.5 * (1 - 1e-6))) < 1e-12
     assert abs(lrs[1500] - 6e-5) < 1e-12
     assert abs(lrs[2500] - 6e-5 * (1 - 1000 / 38500)) < 1e-12       # :54-56, power 1
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# whole Trainer.step on 2 ranks (gloo, CPU): the UDA model with a tiny MiT-b0, align/refine served by the CPU oracle
+# (test infrastructure) -- exercises parameter broadcast, the three backward passes into the flat buffer, the single
+# all-reduce, optimiser + scheduler + EMA on every rank, and checks the replicas stay bit-identical.
+# ----------------------------------------------------------------------------------------------------------------
+def _step_worker(rank, world, port, out):
+    import os
+    import random
+    import sys
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import cpu_align
+    from refign_amd.align import VGG, UAWarpCHead
+    from refign_amd.seg import DAFormerHead, MixVisionTransformer, PixelWeightedCrossEntropyLoss
+    from refign_amd.trainer import Trainer
+    from refign_amd.uda import DomainAdaptationSegmentationModel
+    dims = [32, 64, 160, 256]
+    torch.manual_seed(500 + rank)                     # different init per rank: the trainer must broadcast rank 0's
+    model = DomainAdaptationSegmentationModel(
+        {"class_path": "torch.optim.AdamW", "init_args": {"lr": 1e-3, "weight_decay": 0.01}},
+        {"class_path": "helpers.lr_scheduler.LinearWarmupPolynomialLR",
+         "init_args": {"warmup_iters": 2, "warmup_ratio": 0.1, "power": 1.0, "max_steps": 10}},
+        backbone=MixVisionTransformer("mit_b0", drop_path_rate=0.0),
+        head=DAFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0),
+        loss=PixelWeightedCrossEntropyLoss(),
+        alignment_backbone=VGG('vgg16', out_indices=[2, 3, 4]),
+        alignment_head=UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True),
+        backbone_lr_factor=0.1, use_refign=True, adapt_to_ref=False, enable_fdist=True, color_jitter_p=1.0,
+        blur=False).train()
+    _, corr_fn = cpu_align._corr_fn_default()
+    model.align = lambda lr, ir, it: cpu_align.align(model.alignment_backbone, model.alignment_head, lr, ir, it, corr_fn)
+    model.refine = lambda lt, lr, m, c: cpu_align.refine(lt, lr, m, c, gamma=model.gamma)
+    trainer = Trainer(model, sync_batchnorm=False, bucket_mb=1, fused_optimizer=False)
+    g = torch.Generator().manual_seed(1000 + rank)    # each rank its own shard of the global batch
+    H, W = 64, 64
+    lbl = torch.randint(0, 19, (1, 2, 2), generator=g).repeat_interleave(32, 1).repeat_interleave(32, 2)
+    batch = {"image_src": torch.randn(1, 3, H, W, generator=g), "semantic_src": lbl,
+             "image_trg": torch.randn(1, 3, H, W, generator=g), "image_ref": torch.randn(1, 3, H, W, generator=g)}
+    random.seed(3); np.random.seed(3)
+    for _ in range(2):
+        trainer.step(batch)
+    live = torch.cat([p.detach().flatten() for p in model.live_parameters()])
+    ema = torch.cat([p.detach().flatten() for p in model.ema_parameters()])
+    gathered = [torch.zeros_like(live) for _ in range(world)]
+    dist.all_gather(gathered, live)
+    gathered_ema = [torch.zeros_like(ema) for _ in range(world)]
+    dist.all_gather(gathered_ema, ema)
+    if rank == 0:
+        torch.save({"same_live": bool(torch.equal(gathered[0], gathered[1])),
+                    "same_ema": bool(torch.equal(gathered_ema[0], gathered_ema[1])),
+                    "finite": bool(torch.isfinite(live).all()), "step": model.global_step,
+                    "lr": trainer.optimizer.param_groups[0]["lr"]}, out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_keeps_replicas_identical(tmp_path):
+    port, out = _free_port(), str(tmp_path / "step.pt")
+    mp.spawn(_step_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["same_live"] and r["same_ema"] and r["finite"] and r["step"] == 2
+    assert abs(r["lr"] - 1e-3) < 1e-9       # warm-up of 2 iterations finished (LinearWarmupPolynomialLR)
