@@ -131,6 +131,22 @@ int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad
                                   void* workspace, int B, int H, int W, int C, int dilation, int dtype,
                                   rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim of a (rows, C) matrix, C <= 1024 -- the 213 LayerNorms of a MiT-B5 forward
+ * (models/backbones/mix_transformer.py:135,188-207,234,369-419; eps 1e-6 in blocks/stage norms, 1e-5 in
+ * patch-embed and spatial-reduction norms).  Statistics in fp32; activations float32 (dtype code 0) or bfloat16 (1),
+ * independently for input and output, so the residual stream can stay in bf16 with no separate cast passes.
+ * gamma, beta, grad_gamma, grad_beta: (C) float32; mean, rstd: (rows) float32 saved by fwd for bwd.
+ * bwd: grad_x has x's dtype; needs rfn_layernorm_bwd_workspace_bytes(C) bytes of workspace (deterministic two-stage
+ * reduction of the parameter gradients).
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      long rows, int C, float eps, int in_dtype, int out_dtype, rfn_stream_t stream);
+unsigned long rfn_layernorm_bwd_workspace_bytes(int C);
+int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, const float* mean, const float* rstd,
+                      void* grad_x, float* grad_gamma, float* grad_beta, void* workspace, long rows, int C,
+                      int x_dtype, int gy_dtype, rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

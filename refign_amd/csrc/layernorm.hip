@@ -1,0 +1,239 @@
+// refign_amd/csrc/layernorm.hip -- LayerNorm over the channel dim of (rows, C) token matrices, forward + backward.
+//
+// Where it sits in the reference: every MiT block has two LayerNorms (eps 1e-6) plus one per patch embedding, per
+// spatial-reduction branch and per stage output (models/backbones/mix_transformer.py:135,188-207,234,369-419): 213
+// LayerNorms per MiT-B5 forward.  Under bf16 autocast the library path runs them in fp32 and the surrounding linears in
+// bf16, so every LayerNorm is followed by a separate fp32->bf16 cast pass and the residual stream stays fp32
+// (14 bytes of traffic per element where 4-6 are needed; ~100 ms of a 600 ms step incl. the casts).  This kernel does
+// the statistics in fp32 registers and reads/writes the activation dtype directly (fp32 or bf16 in, fp32 or bf16 out),
+// so the residual stream can live in bf16.  Pure HBM-bound row reductions:
+//   * one wave per row, lanes strided over C (C <= 1024): the row lives in registers (<= 16 values per lane), mean and
+//     variance by two wave butterflies (two-pass variance, no E[x^2]-E[x]^2 cancellation);
+//   * backward: the same pass produces dx and per-wave register partials of dgamma/dbeta over the wave's rows; partials
+//     are combined per workgroup through LDS and written to a workspace row, reduced by a second tiny kernel in a
+//     fixed order (deterministic, no atomics).
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace rfn {
+
+constexpr int kLnMaxPerLane = 16;   // C <= 1024
+constexpr int kLnMaxBlocks = 1024;  // workspace rows for dgamma/dbeta partials
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld<__hip_bfloat16>(const __hip_bfloat16* p) {
+  return __uint_as_float(((unsigned)*reinterpret_cast<const unsigned short*>(p)) << 16);
+}
+template <typename T>
+__device__ __forceinline__ void st(T* p, float v);
+template <>
+__device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16* p, float v) {
+  unsigned u = __float_as_uint(v);
+  unsigned r = ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  *reinterpret_cast<unsigned short*>(p) = (unsigned short)r;
+}
+
+template <typename TI, typename TO, int NPL>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, TO* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g[NPL], b[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int c = lane + 64 * i;
+    g[i] = c < C ? gamma[c] : 0.0f;
+    b[i] = c < C ? beta[c] : 0.0f;
+  }
+  const float invC = 1.0f / (float)C;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const TI* xr = x + r * C;
+    float v[NPL];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < C ? ld<TI>(xr + c) : 0.0f;
+      s += v[i];
+    }
+    const float mu = wave_sum(s) * invC;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      const float d = c < C ? v[i] - mu : 0.0f;
+      q = fmaf(d, d, q);
+    }
+    const float rs = rsqrtf(wave_sum(q) * invC + eps);
+    TO* yr = y + r * C;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) st<TO>(yr + c, fmaf((v[i] - mu) * rs, g[i], b[i]));
+    }
+    if (lane == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+  }
+}
+
+// dx[r,c] = rstd * (g*gamma - (sum_c(g*gamma) + xhat * sum_c(g*gamma*xhat)) / C);  partial dgamma/dbeta per workgroup
+template <typename TX, typename TG, int NPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict__ x, const TG* __restrict__ gy,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, TX* __restrict__ dx,
+                                                            float* __restrict__ ws, long rows, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gm[NPL], dg[NPL], db[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = c < C ? gamma[c] : 0.0f;
+    dg[i] = 0.0f;
+    db[i] = 0.0f;
+  }
+  const float invC = 1.0f / (float)C;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const float mu = mean[r], rs = rstd[r];
+    float xh[NPL], gg[NPL];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = c < C;
+      const float xv = ok ? ld<TX>(x + r * C + c) : 0.0f;
+      const float gv = ok ? ld<TG>(gy + r * C + c) : 0.0f;
+      xh[i] = ok ? (xv - mu) * rs : 0.0f;
+      gg[i] = gv * gm[i];
+      s1 += gg[i];
+      s2 = fmaf(gg[i], xh[i], s2);
+      dg[i] = fmaf(gv, xh[i], dg[i]);
+      db[i] += gv;
+    }
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) st<TX>(dx + r * C + c, rs * (gg[i] - s1 - xh[i] * s2));
+    }
+  }
+  // combine the 4 waves' partials, one workspace row per workgroup: ws[block][2][C]
+  __shared__ float red[4][2][64 * NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    red[wave][0][lane + 64 * i] = dg[i];
+    red[wave][1][lane + 64 * i] = db[i];
+  }
+  __syncthreads();
+  float* row = ws + (size_t)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int which = c / C, cc = c % C;
+    row[c] = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ ws,
+                                                                   float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int C, int nblocks) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * C) return;
+  float s = 0.0f;
+  for (int b = 0; b < nblocks; ++b) s += ws[(size_t)b * 2 * C + idx];
+  if (idx < C) dgamma[idx] = s;
+  else dbeta[idx - C] = s;
+}
+
+static inline int ln_grid(long rows) { return (int)std::max<long>(1, std::min<long>(cdiv(rows, 4), kLnMaxBlocks)); }
+
+template <typename TI, typename TO>
+static int ln_fwd_dispatch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, long rows,
+                           int C, float eps, hipStream_t st) {
+  const int grid = ln_grid(rows), npl = cdiv(C, 64);
+#define RFN_LN_FWD(N)                                                                                             \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO, N>), dim3(grid), dim3(256), 0, st, (const TI*)x, g, b, (TO*)y, \
+                     mean, rstd, rows, C, eps)
+  if (npl <= 1) RFN_LN_FWD(1);
+  else if (npl <= 2) RFN_LN_FWD(2);
+  else if (npl <= 4) RFN_LN_FWD(4);
+  else if (npl <= 8) RFN_LN_FWD(8);
+  else RFN_LN_FWD(16);
+#undef RFN_LN_FWD
+  return check_launch("layernorm_fwd_kernel");
+}
+
+template <typename TX, typename TG>
+static int ln_bwd_dispatch(const void* x, const void* gy, const float* g, const float* mean, const float* rstd,
+                           void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, hipStream_t st) {
+  const int grid = ln_grid(rows), npl = cdiv(C, 64);
+#define RFN_LN_BWD(N)                                                                                              \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TG, N>), dim3(grid), dim3(256), 0, st, (const TX*)x, (const TG*)gy, \
+                     g, mean, rstd, (TX*)dx, ws, rows, C)
+  if (npl <= 1) RFN_LN_BWD(1);
+  else if (npl <= 2) RFN_LN_BWD(2);
+  else if (npl <= 4) RFN_LN_BWD(4);
+  else if (npl <= 8) RFN_LN_BWD(8);
+  else RFN_LN_BWD(16);
+#undef RFN_LN_BWD
+  if (int rc = check_launch("layernorm_bwd_kernel")) return rc;
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(2L * C, 256)), dim3(256), 0, st, ws, dgamma, dbeta, C,
+                     grid);
+  return check_launch("layernorm_bwd_reduce_kernel");
+}
+
+}  // namespace rfn
+
+using namespace rfn;
+
+extern "C" {
+
+unsigned long rfn_layernorm_bwd_workspace_bytes(int C) {
+  return (unsigned long)kLnMaxBlocks * 2ul * (unsigned long)(C > 0 ? C : 0) * sizeof(float);
+}
+
+// dtype codes: 0 = float32, 1 = bfloat16
+int rfn_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      long rows, int C, float eps, int in_dtype, int out_dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && gamma && beta && y && mean && rstd, "rfn_layernorm_fwd: null pointer");
+  RFN_REQUIRE(rows > 0 && C > 0 && C <= 64 * kLnMaxPerLane, "rfn_layernorm_fwd: need 0 < C <= 1024 (got %d)", C);
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == 0 && out_dtype == 0) return ln_fwd_dispatch<float, float>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
+  if (in_dtype == 0 && out_dtype == 1)
+    return ln_fwd_dispatch<float, __hip_bfloat16>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
+  if (in_dtype == 1 && out_dtype == 1)
+    return ln_fwd_dispatch<__hip_bfloat16, __hip_bfloat16>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
+  if (in_dtype == 1 && out_dtype == 0)
+    return ln_fwd_dispatch<__hip_bfloat16, float>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
+  return fail(RFN_EINVAL, "rfn_layernorm_fwd: dtype codes must be 0 (f32) or 1 (bf16)");
+}
+
+int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, const float* mean, const float* rstd,
+                      void* grad_x, float* grad_gamma, float* grad_beta, void* workspace, long rows, int C,
+                      int x_dtype, int gy_dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && grad_y && gamma && mean && rstd && grad_x && grad_gamma && grad_beta && workspace,
+              "rfn_layernorm_bwd: null pointer");
+  RFN_REQUIRE(rows > 0 && C > 0 && C <= 64 * kLnMaxPerLane, "rfn_layernorm_bwd: need 0 < C <= 1024 (got %d)", C);
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  if (x_dtype == 0 && gy_dtype == 0)
+    return ln_bwd_dispatch<float, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, st);
+  if (x_dtype == 0 && gy_dtype == 1)
+    return ln_bwd_dispatch<float, __hip_bfloat16>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, st);
+  if (x_dtype == 1 && gy_dtype == 1)
+    return ln_bwd_dispatch<__hip_bfloat16, __hip_bfloat16>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, st);
+  if (x_dtype == 1 && gy_dtype == 0)
+    return ln_bwd_dispatch<__hip_bfloat16, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, st);
+  return fail(RFN_EINVAL, "rfn_layernorm_bwd: dtype codes must be 0 (f32) or 1 (bf16)");
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""LayerNorm on the HIP kernel of csrc/layernorm.hip (fp32 statistics, fp32/bf16 activations, fwd + bwd).
+
+`LayerNorm` is a drop-in nn.LayerNorm subclass (same parameters / state_dict keys).  On HIP tensors with a 1-D
+normalized_shape <= 1024 it runs the hand-written kernel; inside a bf16 autocast region its OUTPUT is bf16 (the library
+path returns fp32 there and pays a separate cast pass before every following linear), which also makes the MiT residual
+stream bf16.  On CPU tensors (unit tests of the module trees only) it is torch's layer_norm.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._tensor import current_stream, ptr
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        C = x.shape[-1]
+        x2 = x.contiguous().view(-1, C)
+        rows = x2.shape[0]
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        lib = _lib.load_library()
+        with torch.cuda.device(x.device):
+            rc = lib.rfn_layernorm_fwd(ptr(x2), ptr(w32), ptr(b32), ptr(y), ptr(mean), ptr(rstd), rows, C, float(eps),
+                                       _DT[x2.dtype], _DT[out_dtype], current_stream(x.device))
+        _lib.check(rc, "layernorm_fwd")
+        ctx.save_for_backward(x2, w32, mean, rstd)
+        ctx.shape, ctx.wdtype = x.shape, weight.dtype
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w32, mean, rstd = ctx.saved_tensors
+        rows, C = x2.shape
+        if gy.dtype not in _DT:
+            gy = gy.float()
+        gy2 = gy.contiguous().view(rows, C)
+        dx = torch.empty_like(x2)
+        dg = torch.empty(C, dtype=torch.float32, device=x2.device)
+        db = torch.empty(C, dtype=torch.float32, device=x2.device)
+        lib = _lib.load_library()
+        ws = torch.empty(lib.rfn_layernorm_bwd_workspace_bytes(C), dtype=torch.uint8, device=x2.device)
+        with torch.cuda.device(x2.device):
+            rc = lib.rfn_layernorm_bwd(ptr(x2), ptr(gy2), ptr(w32), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db),
+                                       ptr(ws), rows, C, _DT[x2.dtype], _DT[gy2.dtype], current_stream(x2.device))
+        _lib.check(rc, "layernorm_bwd")
+        return dx.view(ctx.shape), dg.to(ctx.wdtype), db.to(ctx.wdtype), None, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
+    if x.dtype not in _DT:
+        x = x.float()
+    if out_dtype is None:
+        out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if out_dtype not in _DT:
+            out_dtype = x.dtype
+    return _LayerNormFn.apply(x, weight, bias, eps, out_dtype)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        if x.is_cuda and len(self.normalized_shape) == 1 and self.normalized_shape[0] <= 1024 \
+                and self.weight is not None and self.bias is not None:
+            return layer_norm(x, self.weight, self.bias, self.eps)
+        return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)

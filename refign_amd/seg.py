@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .align import BaseHead
+from .layernorm import LayerNorm
 from .layers import MLP, ConvBNReLU, DropPath
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -96,7 +97,7 @@ class Attention(nn.Module):
         self.sr_ratio = sr_ratio
         if sr_ratio > 1:
             self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
-            self.norm = nn.LayerNorm(dim)
+            self.norm = LayerNorm(dim)
 
     def forward(self, x, H, W):
         B, N, C = x.shape
@@ -115,7 +116,7 @@ class Block(nn.Module):
     """Pre-norm transformer block with stochastic depth (mix_transformer.py:167-207)."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
-                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, sr_ratio=1):
+                 drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm, sr_ratio=1):
         super().__init__()
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
@@ -136,7 +137,7 @@ class OverlapPatchEmbed(nn.Module):
     def __init__(self, img_size=224, patch_size=7, stride=4, in_chans=3, embed_dim=768):
         super().__init__()
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
-        self.norm = nn.LayerNorm(embed_dim)
+        self.norm = LayerNorm(embed_dim)
 
     def forward(self, x):
         x = self.proj(x)
@@ -153,7 +154,7 @@ class MixVisionTransformer(nn.Module):
         super().__init__()
         dims, depths = _MIT[model_type]
         self.model_type, self.depths = model_type, depths
-        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        norm_layer = partial(LayerNorm, eps=1e-6)
         dpr = torch.linspace(0, drop_path_rate, sum(depths)).tolist()        # stochastic depth decay rule
         cur, cin = 0, in_chans
         for s in range(4):

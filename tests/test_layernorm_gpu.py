@@ -1,0 +1,43 @@
+"""GPU: hand-written LayerNorm (csrc/layernorm.hip) forward/backward against torch's fp32 layer_norm, for the MiT
+channel widths, fp32 and bf16 activations, ragged row counts."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,C", [(1, 64), (7, 32), (1000, 128), (4097, 320), (513, 512), (33, 1024), (5, 160)])
+@pytest.mark.parametrize("in_dt,out_dt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                          (torch.bfloat16, torch.bfloat16)])
+def test_layernorm_fwd_bwd(dev, rows, C, in_dt, out_dt):
+    from refign_amd.layernorm import layer_norm
+    g = torch.Generator().manual_seed(rows + C)
+    x = (2 * torch.randn(rows, C, generator=g) + 0.5).to(dev).to(in_dt).requires_grad_()
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dev).requires_grad_()
+    b = (0.1 * torch.randn(C, generator=g)).to(dev).requires_grad_()
+    gy = torch.randn(rows, C, generator=g).to(dev).to(out_dt)
+    y = layer_norm(x, w, b, 1e-6, out_dt)
+    assert y.dtype == out_dt
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_()
+    wr, br = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    yr = F.layer_norm(xr, (C,), wr, br, 1e-6)
+    yr.backward(gy.float())
+    lo = out_dt == torch.bfloat16 or in_dt == torch.bfloat16
+    tol = dict(rtol=2e-2, atol=2e-2) if lo else dict(rtol=1e-4, atol=1e-5)
+    assert torch.allclose(y.float(), yr, **tol)
+    assert x.grad.dtype == in_dt
+    assert torch.allclose(x.grad.float(), xr.grad, **(dict(rtol=2e-2, atol=2e-2) if lo else dict(rtol=1e-3, atol=1e-4)))
+    rt = rows ** 0.5
+    assert torch.allclose(w.grad, wr.grad, rtol=2e-2 if lo else 1e-3, atol=(2e-2 if lo else 1e-4) * rt)
+    assert torch.allclose(b.grad, br.grad, rtol=2e-2 if lo else 1e-3, atol=(2e-2 if lo else 1e-4) * rt)
+
+
+def test_layernorm_module_autocast_outputs_bf16(dev):
+    from refign_amd.layernorm import LayerNorm
+    m = LayerNorm(64, eps=1e-6).to(dev)
+    x = torch.randn(3, 10, 64, device=dev)
+    assert m(x).dtype == torch.float32
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert m(x).dtype == torch.bfloat16
