@@ -19,7 +19,7 @@
 namespace rfn {
 
 constexpr int kLnMaxPerLane = 16;   // C <= 1024
-constexpr int kLnMaxBlocks = 1024;  // workspace rows for dgamma/dbeta partials
+constexpr int kLnMaxBlocks = 512;   // workspace rows for dgamma/dbeta partials (2 workgroups per CU)
 
 template <typename T>
 __device__ __forceinline__ float ld(const T* p);
@@ -146,20 +146,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ ws,
                                                                    float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta, int C, int nblocks) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 2 * C) return;
+  // 64 columns x 4 row segments per workgroup: coalesced 256 B reads, fixed summation order
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
   float s = 0.0f;
-  for (int b = 0; b < nblocks; ++b) s += ws[(size_t)b * 2 * C + idx];
-  if (idx < C) dgamma[idx] = s;
-  else dbeta[idx - C] = s;
+  if (col < 2 * C)
+    for (int b = seg; b < nblocks; b += 4) s += ws[(size_t)b * 2 * C + col];
+  part[seg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (seg == 0 && col < 2 * C) {
+    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (col < C) dgamma[col] = t;
+    else dbeta[col - C] = t;
+  }
 }
 
-static inline int ln_grid(long rows) { return (int)std::max<long>(1, std::min<long>(cdiv(rows, 4), kLnMaxBlocks)); }
+static inline int ln_grid(long rows, int cap) { return (int)std::max<long>(1, std::min<long>(cdiv(rows, 4), cap)); }
 
 template <typename TI, typename TO>
 static int ln_fwd_dispatch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, long rows,
                            int C, float eps, hipStream_t st) {
-  const int grid = ln_grid(rows), npl = cdiv(C, 64);
+  const int grid = ln_grid(rows, 256 * 16), npl = cdiv(C, 64);
 #define RFN_LN_FWD(N)                                                                                             \
   hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO, N>), dim3(grid), dim3(256), 0, st, (const TI*)x, g, b, (TO*)y, \
                      mean, rstd, rows, C, eps)
@@ -175,7 +182,7 @@ static int ln_fwd_dispatch(const void* x, const float* g, const float* b, void* 
 template <typename TX, typename TG>
 static int ln_bwd_dispatch(const void* x, const void* gy, const float* g, const float* mean, const float* rstd,
                            void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, hipStream_t st) {
-  const int grid = ln_grid(rows), npl = cdiv(C, 64);
+  const int grid = ln_grid(rows, kLnMaxBlocks), npl = cdiv(C, 64);
 #define RFN_LN_BWD(N)                                                                                              \
   hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TG, N>), dim3(grid), dim3(256), 0, st, (const TX*)x, (const TG*)gy, \
                      g, mean, rstd, (TX*)dx, ws, rows, C)
@@ -186,7 +193,7 @@ static int ln_bwd_dispatch(const void* x, const void* gy, const float* g, const 
   else RFN_LN_BWD(16);
 #undef RFN_LN_BWD
   if (int rc = check_launch("layernorm_bwd_kernel")) return rc;
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(2L * C, 256)), dim3(256), 0, st, ws, dgamma, dbeta, C,
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(2L * C, 64)), dim3(256), 0, st, ws, dgamma, dbeta, C,
                      grid);
   return check_launch("layernorm_bwd_reduce_kernel");
 }

@@ -38,4 +38,8 @@ if a.shapes:
     for e in rows[:a.rows]:
         print(f"{e.self_device_time_total / 1e3:9.2f} ms  n={e.count:4d}  {e.key:34s} {str(e.input_shapes)[:150]}")
 else:
-    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=a.rows, max_name_column_width=90))
+    evs = sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)
+    tot = sum(e.self_device_time_total for e in evs)
+    print(f"total self device time {tot / 1e3:.1f} ms")
+    for e in evs[:a.rows]:
+        print(f"{e.self_device_time_total / 1e3:9.2f} ms {100 * e.self_device_time_total / tot:5.1f}%  n={e.count:5d}  {e.key[:110]}")
