@@ -91,6 +91,10 @@ int rfn_global_corr_layer_f32(const float* feature_source, const float* feature_
 int rfn_warp_f32(const float* x, const float* flow, float* out, unsigned char* mask, int B, int C, int H,
                  int W, rfn_stream_t stream);
 
+/* F.interpolate(x, size=(OH,OW), mode='area') of align() (segmentation_model.py:498-501): adaptive average pooling
+ * with ATen's window rule [floor(o*I/O), ceil((o+1)*I/O)).  x: (planes,H,W) -> out: (planes,OH,OW). */
+int rfn_area_resize_f32(const float* x, float* out, int planes, int H, int W, int OH, int OW, rfn_stream_t stream);
+
 /* F.normalize(x, p=2, dim=1) on NCHW (uawarpc.py:101-108), eps 1e-12. */
 int rfn_l2norm_channels_f32(const float* x, float* out, int B, int C, int HW, rfn_stream_t stream);
 

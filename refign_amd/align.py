@@ -351,8 +351,8 @@ def extract_pyramids(alignment_backbone, images_ref, images_trg):
     """segmentation_model.py:497-510: full-resolution pyramid (1/4, 1/8) and the 256x256 pyramid (32^2, 16^2) for
     the concatenated (ref, trg) batch."""
     b = images_trg.shape[0]
-    ref_256 = F.interpolate(images_ref, size=(256, 256), mode='area')
-    trg_256 = F.interpolate(images_trg, size=(256, 256), mode='area')
+    ref_256 = matching.area_resize(images_ref, (256, 256))
+    trg_256 = matching.area_resize(images_trg, (256, 256))
     feats = alignment_backbone(torch.cat([images_ref, images_trg]), extract_only_indices=[-3, -2])
     feats_256 = alignment_backbone(torch.cat([ref_256, trg_256]), extract_only_indices=[-2, -1])
     pyr_ref, pyr_trg = zip(*[torch.split(f, [b, b]) for f in feats])

@@ -19,7 +19,7 @@
 namespace rfn {
 
 constexpr int kLnMaxPerLane = 16;   // C <= 1024
-constexpr int kLnMaxBlocks = 512;   // workspace rows for dgamma/dbeta partials (2 workgroups per CU)
+constexpr int kLnMaxBlocks = 256;   // workspace rows for dgamma/dbeta partials (one workgroup per CU)
 
 template <typename T>
 __device__ __forceinline__ float ld(const T* p);
@@ -150,8 +150,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
   __shared__ float part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
   float s = 0.0f;
-  if (col < 2 * C)
+  if (col < 2 * C) {
+#pragma unroll 8
     for (int b = seg; b < nblocks; b += 4) s += ws[(size_t)b * 2 * C + col];
+  }
   part[seg][threadIdx.x & 63] = s;
   __syncthreads();
   if (seg == 0 && col < 2 * C) {

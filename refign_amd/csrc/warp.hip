@@ -137,11 +137,38 @@ __global__ __launch_bounds__(256) void l2norm_channels_kernel(const float* __res
   for (int c = 0; c < C; ++c) o[(size_t)c * HW] = p[(size_t)c * HW] / d;
 }
 
+// F.interpolate(mode='area') == adaptive average pooling: out[oy,ox] = mean of in[floor(oy*H/OH) .. ceil((oy+1)*H/OH))
+// x the same along W (ATen start_index/end_index).  One thread per output element; windows are <= ~5x8 at 1080->256.
+__global__ __launch_bounds__(256) void area_resize_kernel(const float* __restrict__ x, float* __restrict__ out, int H,
+                                                          int W, int OH, int OW, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ox = idx % OW;
+  const int oy = (idx / OW) % OH;
+  const long plane = idx / ((long)OW * OH);
+  const int y0 = (int)(((long)oy * H) / OH), y1 = (int)((((long)oy + 1) * H + OH - 1) / OH);
+  const int x0 = (int)(((long)ox * W) / OW), x1 = (int)((((long)ox + 1) * W + OW - 1) / OW);
+  const float* p = x + plane * H * W;
+  float s = 0.0f;
+  for (int yy = y0; yy < y1; ++yy)
+    for (int xx = x0; xx < x1; ++xx) s += p[(size_t)yy * W + xx];
+  out[idx] = s / (float)((y1 - y0) * (x1 - x0));
+}
+
 }  // namespace rfn
 
 using namespace rfn;
 
 extern "C" {
+
+int rfn_area_resize_f32(const float* x, float* out, int planes, int H, int W, int OH, int OW, rfn_stream_t stream) {
+  RFN_REQUIRE(x && out, "rfn_area_resize_f32: null pointer");
+  RFN_REQUIRE(planes > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "rfn_area_resize_f32: non-positive size");
+  const long total = (long)planes * OH * OW;
+  hipLaunchKernelGGL(area_resize_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, H, W, OH,
+                     OW, total);
+  return check_launch("area_resize_kernel");
+}
 
 int rfn_warp_f32(const float* x, const float* flow, float* out, unsigned char* mask, int B, int C, int H, int W,
                  rfn_stream_t stream) {

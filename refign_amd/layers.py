@@ -110,7 +110,8 @@ class MLP(nn.Module):
 
     def __init__(self, input_dim=2048, embed_dim=768):
         super().__init__()
-        self.proj = nn.Linear(input_dim, embed_dim)
+        from .linear import Linear
+        self.proj = Linear(input_dim, embed_dim)
 
     def forward(self, x):
         return self.proj(x.flatten(2).transpose(1, 2))

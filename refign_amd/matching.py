@@ -56,6 +56,18 @@ def l2_normalize_channels(x):
     return out
 
 
+def area_resize(x, size):
+    """F.interpolate(x, size=size, mode='area') (segmentation_model.py:498-501) on the HIP kernel."""
+    x = require_device_tensor(x.float().contiguous(), "x", torch.float32)
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, size[0], size[1]), dtype=torch.float32, device=x.device)
+    lib = _lib.load_library()
+    with torch.cuda.device(x.device):
+        rc = lib.rfn_area_resize_f32(ptr(x), ptr(out), B * C, H, W, size[0], size[1], current_stream(x.device))
+    _lib.check(rc, "area_resize")
+    return out
+
+
 def unnormalise_and_convert_mapping_to_flow(map, output_channel_first=True):
     """matching_utils.py:77-103 (4-D case): mapping normalised to [-1,1] -> flow in pixels.  16x16 only on the hot
     path, so this stays a handful of tensor ops."""

@@ -30,6 +30,7 @@ import torch.nn.functional as F
 from .align import BaseHead
 from .layernorm import LayerNorm
 from .layers import MLP, ConvBNReLU, DropPath
+from .linear import Linear
 
 # ---------------------------------------------------------------------------------------------------------------------
 # MiT (SegFormer encoder)
@@ -70,10 +71,10 @@ class Mlp(nn.Module):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc1 = Linear(in_features, hidden_features)
         self.dwconv = DWConv(hidden_features)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.fc2 = Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
     def forward(self, x, H, W):
@@ -89,10 +90,10 @@ class Attention(nn.Module):
         assert dim % num_heads == 0, f'dim {dim} should be divided by num_heads {num_heads}.'
         self.dim, self.num_heads = dim, num_heads
         self.scale = qk_scale or (dim // num_heads) ** -0.5
-        self.q = nn.Linear(dim, dim, bias=qkv_bias)
-        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.q = Linear(dim, dim, bias=qkv_bias)
+        self.kv = Linear(dim, dim * 2, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.sr_ratio = sr_ratio
         if sr_ratio > 1:
@@ -312,7 +313,7 @@ class DAFormerHead(BaseHead):
         for i, f in enumerate(x):
             n, _, h, w = f.shape
             c = self.embed_layers[str(i)](f).transpose(1, 2).reshape(n, -1, h, w)
-            cs.append(c if (h, w) == tuple(size) else _up(c, size))
+            cs.append(c if (h, w) == tuple(size) else _up(c, size).to(c.dtype))
         y = self.fuse_layer(torch.cat(cs, dim=1))
         if self.dropout is not None:
             y = self.dropout(y)

@@ -41,3 +41,23 @@ def test_layernorm_module_autocast_outputs_bf16(dev):
     assert m(x).dtype == torch.float32
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert m(x).dtype == torch.bfloat16
+
+
+def test_linear_split_weight_grad_matches_nn_linear(dev):
+    """refign_amd.linear.Linear: forward identical, gradients equal to nn.Linear's (fp32), for a token count that
+    triggers the split-T batched weight-gradient GEMM"""
+    import torch.nn as nn
+    from refign_amd.linear import Linear
+    torch.manual_seed(0)
+    a, b = Linear(96, 160).to(dev), nn.Linear(96, 160).to(dev)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(4, 2040, 96, device=dev)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = a(xa), b(xb)
+    assert torch.equal(ya, yb)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-3, atol=1e-2)
+    assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-3, atol=1e-2)

@@ -196,3 +196,11 @@ def test_refine_full_size_properties(dev):
     assert torch.allclose(out, sm, rtol=1e-4, atol=1e-6)
     out = refine(lt, lr, mask, cert)
     assert torch.isfinite(out).all() and (out >= 0).all() and (out <= 1.0001).all()
+
+
+@pytest.mark.parametrize("shape,size", [((2, 3, 1080, 1920), (256, 256)), ((1, 3, 37, 53), (8, 16)), ((1, 2, 256, 256), (256, 256))])
+def test_area_resize_matches_interpolate_area(dev, shape, size):
+    from refign_amd.matching import area_resize
+    x = torch.randn(*shape, device=dev)
+    want = torch.nn.functional.interpolate(x, size=size, mode="area")
+    assert torch.allclose(area_resize(x, size), want, rtol=1e-5, atol=1e-6)
