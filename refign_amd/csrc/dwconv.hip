@@ -31,6 +31,9 @@ struct VecIO;
 template <>
 struct VecIO<float> {
   static constexpr int N = 4;
+  typedef float4 Raw;
+  __device__ static Raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  __device__ static void unpack(const Raw& t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
   __device__ static void load(const float* p, float (&v)[4]) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -43,6 +46,16 @@ struct VecIO<float> {
 template <>
 struct VecIO<__hip_bfloat16> {
   static constexpr int N = 8;
+  typedef uint4 Raw;
+  __device__ static Raw load_raw(const __hip_bfloat16* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static void unpack(const Raw& t, float (&v)[8]) {
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
   __device__ static void load(const __hip_bfloat16* p, float (&v)[8]) {
     const uint4 t = *reinterpret_cast<const uint4*>(p);
     const unsigned w[4] = {t.x, t.y, t.z, t.w};
@@ -114,29 +127,44 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
 #pragma unroll
       for (int i = 0; i < V; ++i) acc[p][i] = bs[i];
     const T* xb = x + (size_t)b * H * W * C + c0;
+    if (dil == 1) {
+      // branch-free window: all 18 loads (3 rows x 6 columns, clamped addresses) are issued back to back and the
+      // out-of-image taps are zeroed by a 0/1 factor -- per-tap `if`s made hipcc wait for each load in turn
+      typename VecIO<T>::Raw raw[3][kPX + 2];          // kept packed (bf16: 4 VGPRs per 8 channels) until used
+      float ok[3][kPX + 2];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = h + (ky - 1) * dil;
-      if (yy < 0 || yy >= H) continue;
-      const T* xr = xb + (size_t)yy * W * C;
-      if (dil == 1) {
-        float v[kPX + 2][V];   // 6 loads feed 4 outputs x 3 taps
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = h + ky - 1;
+        const bool rowok = yy >= 0 && yy < H;
+        const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
 #pragma unroll
         for (int j = 0; j < kPX + 2; ++j) {
           const int xx = w0 - 1 + j;
-          if (xx >= 0 && xx < W) VecIO<T>::load(xr + (size_t)xx * C, v[j]);
-          else {
+          ok[ky][j] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
+          raw[ky][j] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
+        }
+      }
 #pragma unroll
-            for (int i = 0; i < V; ++i) v[j][i] = 0.0f;
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int j = 0; j < kPX + 2; ++j) {
+          float v[V];
+          VecIO<T>::unpack(raw[ky][j], v);
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int p = j - kx;                      // output pixel fed by column j through tap kx
+            if (p < 0 || p >= kPX) continue;
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i] * ok[ky][j], v[i], acc[p][i]);
           }
         }
+    } else {
 #pragma unroll
-        for (int p = 0; p < kPX; ++p)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i], v[p + kx][i], acc[p][i]);
-      } else {
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = h + (ky - 1) * dil;
+        if (yy < 0 || yy >= H) continue;
+        const T* xr = xb + (size_t)yy * W * C;
+        {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -148,6 +176,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
 #pragma unroll
             for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i], v[i], acc[p][i]);
           }
+        }
       }
     }
     T* yo = y + ((size_t)b * H + h) * W * C + c0;

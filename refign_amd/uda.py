@@ -466,12 +466,15 @@ class DomainAdaptationSegmentationModel(nn.Module):
         assert c == 1
         out = gt.clone()
         out[out == ignore_index] = n_classes
-        onehot = F.one_hot(out.squeeze(1), num_classes=n_classes + 1).permute(0, 3, 1, 2).float()
-        if out_size is None or (H % scale_factor == 0 and W % scale_factor == 0
-                                and (H // scale_factor, W // scale_factor) == tuple(out_size)):
+        # one-hot directly in contiguous NCHW (the reference's F.one_hot(...).permute(...) is a channels-last int64
+        # tensor: 330 MB and a 14 ms pooling kernel at 1080x1920)
+        onehot = (out == torch.arange(n_classes + 1, device=gt.device).view(1, -1, 1, 1)).float()
+        if out_size is None or (H % scale_factor == 0 and W % scale_factor == 0):
             pooled = F.avg_pool2d(onehot, kernel_size=scale_factor)
         else:
-            pooled = F.adaptive_avg_pool2d(onehot, tuple(out_size))
+            pooled = F.avg_pool2d(onehot, kernel_size=scale_factor, ceil_mode=True)
+            if tuple(pooled.shape[-2:]) != tuple(out_size):
+                pooled = F.adaptive_avg_pool2d(onehot, tuple(out_size))
         ratio, out = torch.max(pooled, dim=1, keepdim=True)
         out[out == n_classes] = ignore_index
         out[ratio < min_ratio] = ignore_index

@@ -56,6 +56,22 @@ def main():
         if lvl == "L1":
             go = torch.randn(b, 9, 9, H, W, generator=g).to(dev)
             add(f"corr9 backward       {lvl} C={C} {H}x{W}", timeit(lambda: correlation.backward(f1, f2, go, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1), reps=5), 4 * b * H * W * (4 * C + 81))
+    if not args.only or "dw" in args.only:
+        from refign_amd.dwconv import dwconv3x3_nhwc
+        for (B_, H, W, C, dil, dt) in [(40, 135, 240, 1024, 6, torch.bfloat16), (40, 34, 60, 1280, 1, torch.bfloat16),
+                                       (40, 135, 240, 256, 1, torch.bfloat16), (4, 135, 240, 256, 1, torch.bfloat16),
+                                       (4, 34, 60, 1280, 1, torch.bfloat16), (4, 135, 240, 1024, 12, torch.float32)]:
+            x = torch.randn(B_, H, W, C, device=dev).to(dt)
+            w = torch.randn(C, 1, 3, 3, device=dev)
+            bb = torch.randn(C, device=dev)
+            es = x.element_size()
+            with torch.no_grad():
+                add(f"dwconv fwd {B_}x{H}x{W}x{C} d{dil} {str(dt)[6:]}", timeit(lambda: dwconv3x3_nhwc(x, w, bb, dil)), 2 * x.numel() * es)
+            xg = x.clone().requires_grad_()
+            wg = w.clone().requires_grad_()
+            y = dwconv3x3_nhwc(xg, wg, bb, dil)
+            gy = torch.randn_like(y)
+            add(f"dwconv fwd+bwd {B_}x{H}x{W}x{C} d{dil} {str(dt)[6:]}", timeit(lambda: torch.autograd.grad(dwconv3x3_nhwc(xg, wg, bb, dil), (xg, wg), gy), reps=5), 7 * x.numel() * es)
     if not args.only or "tail" in args.only:
         H, W = 1080, 1920
         lt = (3 * torch.randn(b, 19, H, W, generator=g)).to(dev)
