@@ -159,24 +159,31 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
           }
         }
     } else {
-#pragma unroll
+      // dilated taps (ASPP 6/12/18): no column reuse between the 4 pixels; one branch-free batch of 12 loads per row
+#pragma unroll 1
       for (int ky = 0; ky < 3; ++ky) {
         const int yy = h + (ky - 1) * dil;
-        if (yy < 0 || yy >= H) continue;
-        const T* xr = xb + (size_t)yy * W * C;
-        {
+        const bool rowok = yy >= 0 && yy < H;
+        const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
+        typename VecIO<T>::Raw raw[3][kPX];
+        float ok[3][kPX];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
           for (int p = 0; p < kPX; ++p) {
             const int xx = w0 + p + (kx - 1) * dil;
-            if (xx < 0 || xx >= W) continue;
-            float v[V];
-            VecIO<T>::load(xr + (size_t)xx * C, v);
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i], v[i], acc[p][i]);
+            ok[kx][p] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
+            raw[kx][p] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
           }
-        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int p = 0; p < kPX; ++p) {
+            float v[V];
+            VecIO<T>::unpack(raw[kx][p], v);
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i] * ok[kx][p], v[i], acc[p][i]);
+          }
       }
     }
     T* yo = y + ((size_t)b * H + h) * W * C + c0;
@@ -213,50 +220,79 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
       quad_coords(quad, WQ, H, b, h, w0);
       float g[kPX][V];
       const T* gp = gy + (((size_t)b * H + h) * W) * C + c0;
+      {
+        typename VecIO<T>::Raw graw[kPX];
 #pragma unroll
-      for (int p = 0; p < kPX; ++p) {
-        if (w0 + p < W) VecIO<T>::load(gp + (size_t)(w0 + p) * C, g[p]);
-        else {
+        for (int p = 0; p < kPX; ++p) graw[p] = VecIO<T>::load_raw(gp + (size_t)min(w0 + p, W - 1) * C);
 #pragma unroll
-          for (int i = 0; i < V; ++i) g[p][i] = 0.0f;
+        for (int p = 0; p < kPX; ++p) {
+          VecIO<T>::unpack(graw[p], g[p]);
+          const float m = (w0 + p < W) ? 1.0f : 0.0f;
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            g[p][i] *= m;
+            ab[i] += g[p][i];
+          }
         }
-#pragma unroll
-        for (int i = 0; i < V; ++i) ab[i] += g[p][i];
       }
       const T* xb = x + (size_t)b * H * W * C + c0;
+      if (dil == 1) {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yy = h + (ky - 1) * dil;
-        if (yy < 0 || yy >= H) continue;
-        const T* xr = xb + (size_t)yy * W * C;
-        if (dil == 1) {
-          float v[kPX + 2][V];
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = h + ky - 1;
+          const bool rowok = yy >= 0 && yy < H;
+          const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
+          typename VecIO<T>::Raw raw[kPX + 2];
+          float ok[kPX + 2];
 #pragma unroll
           for (int j = 0; j < kPX + 2; ++j) {
             const int xx = w0 - 1 + j;
-            if (xx >= 0 && xx < W) VecIO<T>::load(xr + (size_t)xx * C, v[j]);
-            else {
-#pragma unroll
-              for (int i = 0; i < V; ++i) v[j][i] = 0.0f;
-            }
+            ok[j] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
+            raw[j] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
           }
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
+          for (int j = 0; j < kPX + 2; ++j) {
+            float v[V];
+            VecIO<T>::unpack(raw[j], v);
 #pragma unroll
-            for (int p = 0; p < kPX; ++p)
+            for (int kx = 0; kx < 3; ++kx) {
+              const int p = j - kx;
+              if (p < 0 || p >= kPX) continue;
 #pragma unroll
-              for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[p][i], v[p + kx][i], aw[ky * 3 + kx][i]);
-        } else {
+              for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[p][i] * ok[j], v[i], aw[ky * 3 + kx][i]);
+            }
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = h + (ky - 1) * dil;
+          const bool rowok = yy >= 0 && yy < H;
+          const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
+          typename VecIO<T>::Raw raw[3][kPX];
+          float ok[3][kPX];
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int p = 0; p < kPX; ++p) {
               const int xx = w0 + p + (kx - 1) * dil;
-              if (xx < 0 || xx >= W) continue;
-              float v[V];
-              VecIO<T>::load(xr + (size_t)xx * C, v);
+              ok[kx][p] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
+              raw[kx][p] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
+            }
 #pragma unroll
-              for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[p][i], v[i], aw[ky * 3 + kx][i]);
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int p = 0; p < kPX; ++p) {
+              float v[V];
+              VecIO<T>::unpack(raw[kx][p], v);
+              // ky is a runtime index here (unroll 1): write the three taps of this row through a switch-free select
+#pragma unroll
+              for (int i = 0; i < V; ++i) {
+                const float t = g[p][i] * ok[kx][p] * v[i];
+                aw[0 + kx][i] += (ky == 0) ? t : 0.0f;
+                aw[3 + kx][i] += (ky == 1) ? t : 0.0f;
+                aw[6 + kx][i] += (ky == 2) ? t : 0.0f;
+              }
             }
         }
       }
