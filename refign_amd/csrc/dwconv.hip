@@ -83,12 +83,17 @@ struct VecIO<__hip_bfloat16> {
 
 constexpr int kPX = 4;   // pixels along W per thread
 
-__device__ __forceinline__ void quad_coords(long quad, int WQ, int H, int& b, int& h, int& w0) {
+// A "quad" is 4 pixels of one image row spaced by the dilation: w0, w0+d, w0+2d, w0+3d.  Their 3x3 dilated taps fall on
+// the 6 columns w0-d .. w0+4d, so 6 loads per row feed 4 outputs for ANY dilation (for d = 1 it is 4 adjacent pixels).
+// Per row there are d phases x ceil(ceil(W/d)/4) quads.
+__device__ __forceinline__ int quads_per_row(int W, int dil) { return dil * (((W + dil - 1) / dil + kPX - 1) / kPX); }
+
+__device__ __forceinline__ void quad_coords(long quad, int WQ, int H, int dil, int& b, int& h, int& w0) {
   const int wq = (int)(quad % WQ);
   const long t = quad / WQ;
   h = (int)(t % H);
   b = (int)(t / H);
-  w0 = wq * kPX;
+  w0 = (wq % dil) + (wq / dil) * kPX * dil;
 }
 
 // Thread layout (all three kernels): blockDim = 256 = cvb channel-vectors (fastest, so a wave reads contiguous
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ bias, T* __restrict__ y, int B,
                                                             int H, int W, int C, int dil, int cvb) {
   constexpr int V = VecIO<T>::N;
-  const int CV = C / V, WQ = (W + kPX - 1) / kPX;
+  const int CV = C / V, WQ = quads_per_row(W, dil);
   const int pl = 256 / cvb;
   const int cv = blockIdx.x * cvb + threadIdx.x % cvb;
   if (cv >= CV) return;
@@ -120,76 +125,47 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
   const long nquads = (long)B * H * WQ;
   for (long quad = (long)blockIdx.y * pl + threadIdx.x / cvb; quad < nquads; quad += (long)gridDim.y * pl) {
     int b, h, w0;
-    quad_coords(quad, WQ, H, b, h, w0);
+    quad_coords(quad, WQ, H, dil, b, h, w0);
     float acc[kPX][V];
 #pragma unroll
     for (int p = 0; p < kPX; ++p)
 #pragma unroll
       for (int i = 0; i < V; ++i) acc[p][i] = bs[i];
     const T* xb = x + (size_t)b * H * W * C + c0;
-    if (dil == 1) {
-      // branch-free window: all 18 loads (3 rows x 6 columns, clamped addresses) are issued back to back and the
-      // out-of-image taps are zeroed by a 0/1 factor -- per-tap `if`s made hipcc wait for each load in turn
-      typename VecIO<T>::Raw raw[3][kPX + 2];          // kept packed (bf16: 4 VGPRs per 8 channels) until used
-      float ok[3][kPX + 2];
+    // branch-free window: all 18 loads (3 rows x 6 columns, clamped addresses) are issued back to back and the
+    // out-of-image taps are zeroed by a 0/1 factor -- per-tap `if`s made hipcc wait for each load in turn
+    typename VecIO<T>::Raw raw[3][kPX + 2];            // kept packed (bf16: 4 VGPRs per 8 channels) until used
+    float ok[3][kPX + 2];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yy = h + ky - 1;
-        const bool rowok = yy >= 0 && yy < H;
-        const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = h + (ky - 1) * dil;
+      const bool rowok = yy >= 0 && yy < H;
+      const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
 #pragma unroll
-        for (int j = 0; j < kPX + 2; ++j) {
-          const int xx = w0 - 1 + j;
-          ok[ky][j] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
-          raw[ky][j] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
-        }
-      }
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int j = 0; j < kPX + 2; ++j) {
-          float v[V];
-          VecIO<T>::unpack(raw[ky][j], v);
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int p = j - kx;                      // output pixel fed by column j through tap kx
-            if (p < 0 || p >= kPX) continue;
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i] * ok[ky][j], v[i], acc[p][i]);
-          }
-        }
-    } else {
-      // dilated taps (ASPP 6/12/18): no column reuse between the 4 pixels; one branch-free batch of 12 loads per row
-#pragma unroll 1
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yy = h + (ky - 1) * dil;
-        const bool rowok = yy >= 0 && yy < H;
-        const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
-        typename VecIO<T>::Raw raw[3][kPX];
-        float ok[3][kPX];
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int p = 0; p < kPX; ++p) {
-            const int xx = w0 + p + (kx - 1) * dil;
-            ok[kx][p] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
-            raw[kx][p] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
-          }
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int p = 0; p < kPX; ++p) {
-            float v[V];
-            VecIO<T>::unpack(raw[kx][p], v);
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i] * ok[kx][p], v[i], acc[p][i]);
-          }
+      for (int j = 0; j < kPX + 2; ++j) {
+        const int xx = w0 + (j - 1) * dil;
+        ok[ky][j] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
+        raw[ky][j] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
       }
     }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int j = 0; j < kPX + 2; ++j) {
+        float v[V];
+        VecIO<T>::unpack(raw[ky][j], v);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int p = j - kx;                        // output pixel fed by column j through tap kx
+          if (p < 0 || p >= kPX) continue;
+#pragma unroll
+          for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i] * ok[ky][j], v[i], acc[p][i]);
+        }
+      }
     T* yo = y + ((size_t)b * H + h) * W * C + c0;
 #pragma unroll
     for (int p = 0; p < kPX; ++p)
-      if (w0 + p < W) VecIO<T>::store(yo + (size_t)(w0 + p) * C, acc[p]);
+      if (w0 + p * dil < W) VecIO<T>::store(yo + (size_t)(w0 + p * dil) * C, acc[p]);
   }
 }
 
@@ -200,7 +176,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
                                                                    float* __restrict__ ws, int B, int H, int W, int C,
                                                                    int dil, int cvb) {
   constexpr int V = VecIO<T>::N;
-  const int CV = C / V, WQ = (W + kPX - 1) / kPX;
+  const int CV = C / V, WQ = quads_per_row(W, dil);
   const int pl = 256 / cvb;
   const int cvi = threadIdx.x % cvb, pli = threadIdx.x / cvb;
   const int cv = blockIdx.x * cvb + cvi;
@@ -217,17 +193,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
     const long nquads = (long)B * H * WQ;
     for (long quad = (long)blockIdx.y * pl + pli; quad < nquads; quad += (long)gridDim.y * pl) {
       int b, h, w0;
-      quad_coords(quad, WQ, H, b, h, w0);
+      quad_coords(quad, WQ, H, dil, b, h, w0);
       float g[kPX][V];
       const T* gp = gy + (((size_t)b * H + h) * W) * C + c0;
       {
         typename VecIO<T>::Raw graw[kPX];
 #pragma unroll
-        for (int p = 0; p < kPX; ++p) graw[p] = VecIO<T>::load_raw(gp + (size_t)min(w0 + p, W - 1) * C);
+        for (int p = 0; p < kPX; ++p) graw[p] = VecIO<T>::load_raw(gp + (size_t)min(w0 + p * dil, W - 1) * C);
 #pragma unroll
         for (int p = 0; p < kPX; ++p) {
           VecIO<T>::unpack(graw[p], g[p]);
-          const float m = (w0 + p < W) ? 1.0f : 0.0f;
+          const float m = (w0 + p * dil < W) ? 1.0f : 0.0f;
 #pragma unroll
           for (int i = 0; i < V; ++i) {
             g[p][i] *= m;
@@ -236,64 +212,30 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
         }
       }
       const T* xb = x + (size_t)b * H * W * C + c0;
-      if (dil == 1) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int yy = h + ky - 1;
-          const bool rowok = yy >= 0 && yy < H;
-          const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
-          typename VecIO<T>::Raw raw[kPX + 2];
-          float ok[kPX + 2];
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = h + (ky - 1) * dil;
+        const bool rowok = yy >= 0 && yy < H;
+        const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
+        typename VecIO<T>::Raw raw[kPX + 2];
+        float ok[kPX + 2];
 #pragma unroll
-          for (int j = 0; j < kPX + 2; ++j) {
-            const int xx = w0 - 1 + j;
-            ok[j] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
-            raw[j] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
-          }
-#pragma unroll
-          for (int j = 0; j < kPX + 2; ++j) {
-            float v[V];
-            VecIO<T>::unpack(raw[j], v);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const int p = j - kx;
-              if (p < 0 || p >= kPX) continue;
-#pragma unroll
-              for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[p][i] * ok[j], v[i], aw[ky * 3 + kx][i]);
-            }
-          }
+        for (int j = 0; j < kPX + 2; ++j) {
+          const int xx = w0 + (j - 1) * dil;
+          ok[j] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
+          raw[j] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
         }
-      } else {
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-          const int yy = h + (ky - 1) * dil;
-          const bool rowok = yy >= 0 && yy < H;
-          const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
-          typename VecIO<T>::Raw raw[3][kPX];
-          float ok[3][kPX];
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
+        for (int j = 0; j < kPX + 2; ++j) {
+          float v[V];
+          VecIO<T>::unpack(raw[j], v);
 #pragma unroll
-            for (int p = 0; p < kPX; ++p) {
-              const int xx = w0 + p + (kx - 1) * dil;
-              ok[kx][p] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
-              raw[kx][p] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
-            }
+          for (int kx = 0; kx < 3; ++kx) {
+            const int p = j - kx;
+            if (p < 0 || p >= kPX) continue;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int p = 0; p < kPX; ++p) {
-              float v[V];
-              VecIO<T>::unpack(raw[kx][p], v);
-              // ky is a runtime index here (unroll 1): write the three taps of this row through a switch-free select
-#pragma unroll
-              for (int i = 0; i < V; ++i) {
-                const float t = g[p][i] * ok[kx][p] * v[i];
-                aw[0 + kx][i] += (ky == 0) ? t : 0.0f;
-                aw[3 + kx][i] += (ky == 1) ? t : 0.0f;
-                aw[6 + kx][i] += (ky == 2) ? t : 0.0f;
-              }
-            }
+            for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[p][i] * ok[j], v[i], aw[ky * 3 + kx][i]);
+          }
         }
       }
     }
@@ -336,7 +278,7 @@ static int launch_fwd(const void* x, const float* w, const float* bias, void* y,
                       int flip, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
   const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
-  const long nquads = (long)B * H * ((W + kPX - 1) / kPX);
+  const long nquads = (long)B * H * (dil * (((W + dil - 1) / dil + kPX - 1) / kPX));
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(nquads, pl), (256L * 16) / gx));
   if (flip)
     hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, true>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias, (T*)y, B,
@@ -352,7 +294,7 @@ static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db
                              int dil, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
   const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
-  const long nquads = (long)B * H * ((W + kPX - 1) / kPX);
+  const long nquads = (long)B * H * (dil * (((W + dil - 1) / dil + kPX - 1) / kPX));
   const int stripes = (int)std::max<long>(1, std::min<long>(std::min<long>(kMaxStripes, cdiv(nquads, pl)),
                                                             std::max<long>(1, (256L * 8) / gx)));
   hipLaunchKernelGGL((dwconv3x3_bwd_weight_kernel<T>), dim3(gx, stripes), dim3(256), 0, st, (const T*)x, (const T*)gy,
