@@ -265,14 +265,29 @@ __global__ __launch_bounds__(TH * kStrips * 3) void corr9_tile_kernel(
 // --------------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// One LDS-DMA instruction (global -> LDS, 16 bytes per lane, lane i lands at lds_wave_base + 16 i), issued through
+// inline asm ON PURPOSE.  With the `__builtin_amdgcn_global_load_lds` builtin hipcc tracks the pending LDS write and,
+// whenever it cannot prove that a later `ds_read` touches a different object, inserts `s_waitcnt vmcnt(0)` in front of
+// it -- measured here: the wait landed inside the channel loop, i.e. the DMA of chunk k+1 never overlapped the FMAs of
+// chunk k (DMA-only 62 us + FMA-only 81 us = 147 us total, profiles/r01_kbench_corr_ablation.txt).  Inline asm is
+// invisible to that pass; the hand-off is then entirely ours: `s_waitcnt vmcnt(N)` + barrier before the first read.
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_base) {
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base;
+  const unsigned sbase = __builtin_amdgcn_readfirstlane(base);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(sbase) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+
 // NTILE = 2: the workgroup is two independent halves, each owning its own tile (ids 2b, 2b+1 of the launch's tile
 // order), its own LDS region and its own DMA stream; only the per-chunk barrier is shared.  This doubles the waves per
 // CU (6-wave workgroups do not co-reside: their 2,2,1,1 wave placement over the SIMDs leaves no room for a second one
 // at 168 VGPRs) while keeping the fine 16x32 tile granularity that fills 256 CUs evenly.
-template <int TH, int TW, int CC, bool FUSE, int MINW, int UNR, int NTILE>
+template <int TH, int TW, int CC, bool FUSE, int MINW, int UNR, int NTILE, bool ILV>
 __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_kernel(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
-    int tilesX, int tilesY, int ntiles, int xcd_remap) {
+    int tilesX, int tilesY, int ntiles, int xcd_remap, int ablate) {
   static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
   constexpr int STRIPS = TW / 4;                     // 4-pixel strips per tile row
   constexpr int RPW = 64 / STRIPS;                   // tile rows covered by one wave (4 or 8)
@@ -361,15 +376,22 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_ker
   }
   __syncthreads();
 
+  // one DMA instruction of the next chunk (k-th of this wave); spread over the channel loop of the current chunk so
+  // that the 12 waves do not all queue on the CU's single address path right after the barrier
+  auto issue_one = [&](float* ring, int k) {
+    const int wi = wave + k * NW;
+    if (wi < NINSTR) {
+      if (gok[k]) lds_dma16(gsrc[k], ring + wi * 256);
+      gsrc[k] += (size_t)CC * plane;
+    }
+  };
   auto issue = [&](float* ring) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int wi = wave + k * NW;
       if (wi < NINSTR) {                               // wave-uniform
         float* ldst = ring + wi * 256;                 // wave-uniform LDS base; lane lands at +lane*16 B
-        if (gok[k])
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc[k],
-                                           (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+        if (gok[k]) lds_dma16(gsrc[k], ldst);
         gsrc[k] += (size_t)CC * plane;
       }
     }
@@ -389,9 +411,16 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_ker
       for (int p = 0; p < 4; ++p) accp[a][i][p] = f32x2{0.0f, 0.0f};
     }
 
-  auto compute = [&](const float* __restrict__ s2) {
+  auto compute = [&](const float* __restrict__ s2, float* next_ring, bool prefetch) {
 #pragma unroll UNR
     for (int c = 0; c < CC; ++c) {
+      if constexpr (ILV) {
+        if (prefetch) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            if (k % CC == c) issue_one(next_ring, k);
+        }
+      }
       const float* cb = s2 + c * ROWS * PITCH;
       const float4 a = *reinterpret_cast<const float4*>(&cb[(R2 + row) * PITCH + 4 * strip]);
       const float av[4] = {a.x, a.y, a.z, a.w};
@@ -419,13 +448,261 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_ker
   const int nchunks = C / CC;                          // even (checked by the launcher)
   issue(ring0);
   for (int ck = 0; ck < nchunks; ck += 2) {
-    __syncthreads();                                   // chunk ck landed in ring0; ring1 free
-    issue(ring1);
-    compute(ring0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my slots of chunk ck have landed ...
+    __syncthreads();                                   // ... and everybody's: chunk ck in ring0; ring1 free
+    if constexpr (ILV) {
+      compute(ring0, ring1, !(ablate & 1));
+    } else {
+      if (!(ablate & 1)) issue(ring1);
+      if (!(ablate & 2)) compute(ring0, ring1, false);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // chunk ck+1 landed in ring1; ring0 free
-    if (ck + 2 < nchunks) issue(ring0);
-    compute(ring1);
+    if constexpr (ILV) {
+      compute(ring1, ring0, (ck + 2 < nchunks) && !(ablate & 1));
+    } else {
+      if (ck + 2 < nchunks && !(ablate & 1)) issue(ring0);
+      if (!(ablate & 2)) compute(ring1, ring0, false);
+    }
   }
+
+  // ---- epilogue ----
+  auto get = [&](int dyi, int dx, int i) -> float {
+    if (i & 1) return dx == 0 ? accs[dyi][i] : accp[dyi][i][(dx - 1) >> 1][(dx - 1) & 1];
+    return dx == 8 ? accs[dyi][i] : accp[dyi][i][dx >> 1][dx & 1];
+  };
+  const int h = h0 + row, wx = w0 + 4 * strip;
+  float scale[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (FUSE) {
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 9; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = fmaxf(get(a, b, i), 0.0f);
+          ss[i] = fmaf(v, v, ss[i]);
+        }
+    __syncthreads();
+    float* red = ring0;  // [3][TH][64]
+    *reinterpret_cast<float4*>(&red[(dyg * TH + row) * TW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float tot = red[(0 * TH + row) * TW + 4 * strip + i] + red[(1 * TH + row) * TW + 4 * strip + i] +
+                        red[(2 * TH + row) * TW + 4 * strip + i];
+      scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+    }
+  }
+  if (live && h < H && wx + 3 < W && !(ablate & 4)) {
+    float* obase = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi)
+#pragma unroll
+      for (int dx = 0; dx < 9; ++dx) {
+        float r0 = get(dyi, dx, 0), r1 = get(dyi, dx, 1), r2 = get(dyi, dx, 2), r3 = get(dyi, dx, 3);
+        if constexpr (FUSE) {
+          r0 = fmaxf(r0, 0.f) * scale[0]; r1 = fmaxf(r1, 0.f) * scale[1];
+          r2 = fmaxf(r2, 0.f) * scale[2]; r3 = fmaxf(r3, 0.f) * scale[3];
+        }
+        *reinterpret_cast<float4*>(obase + (size_t)(dyi * 9 + dx) * plane) = make_float4(r0, r1, r2, r3);
+      }
+  }
+}
+
+// ---- 4-stage variant --------------------------------------------------------------------------------------------
+// Same decomposition, but the LDS ring is FOUR separate objects of 2-channel chunks and the DMA of chunk c+3 is issued
+// while chunk c is consumed.  `__syncthreads()` would drain every outstanding DMA (its fence carries vmcnt(0)), so the
+// chunk hand-off is: counted `s_waitcnt vmcnt(N)` (in-order completion: the wave's own slots of chunk c have landed
+// once at most the N instructions of chunks c+1, c+2 are still in flight) + raw `s_barrier` (every wave's slots landed,
+// and everybody finished reading chunk c-1 whose ring is about to be refilled).  Waves issue K or K-1 DMA instructions
+// per chunk; N = 2 (K-1) is the safe count for both.
+// NTILE = 2: the workgroup is two independent halves, each owning its own tile (ids 2b, 2b+1 of the launch's tile
+// order), its own LDS region and its own DMA stream; only the per-chunk barrier is shared.  This doubles the waves per
+// CU (6-wave workgroups do not co-reside: their 2,2,1,1 wave placement over the SIMDs leaves no room for a second one
+// at 168 VGPRs) while keeping the fine 16x32 tile granularity that fills 256 CUs evenly.
+template <int TH, int TW, bool FUSE, int MINW, int NTILE>
+__global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe_kernel(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
+    int tilesX, int tilesY, int ntiles, int xcd_remap) {
+  static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
+  constexpr int CC = 2;                              // channels per chunk
+  constexpr int STRIPS = TW / 4;                     // 4-pixel strips per tile row
+  constexpr int RPW = 64 / STRIPS;                   // tile rows covered by one wave (4 or 8)
+  constexpr int NT = TH * STRIPS * 3;                // threads per tile
+  constexpr int NW = NT / 64;                        // waves per tile
+  constexpr int R2 = TH + 2 * kHalo;
+  constexpr int ROWS = R2 + TH;
+  // LDS row pitch in dwords.  It is chosen together with the lane->strip permutation below so that every
+  // ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31} and their +32 twins) covers all 64 banks once:
+  //   TW=64: pitch 72 (18 slots of 16 B), lanes of odd wave-rows take their strips rotated by 14;
+  //   TW=32: pitch 48 (12 slots, 10 used): row offsets 0,12,8,4 (mod 16 slots), lanes of wave-rows 1,2 (mod 4)
+  //          swap their strip halves (j ^ 4).
+  constexpr int PITCH = (TW == 64) ? 72 : 48;
+  constexpr int V = PITCH / 4;                       // float4 slots per LDS row
+  constexpr int VU2 = (TW + 2 * kHalo) / 4;          // slots of a source row that carry data
+  constexpr int SLOTS = CC * ROWS * V;               // float4 slots per chunk
+  constexpr int NINSTR = (SLOTS + 63) / 64;          // wave-level DMA instructions per chunk
+  constexpr int K = (NINSTR + NW - 1) / NW;          // per wave
+  constexpr int BUF = NINSTR * 64 * 4;               // floats per ring buffer (rounded up to whole instructions)
+  // TWO separate LDS objects on purpose: hipcc's waitcnt pass only lets a ds_read run past an in-flight LDS-DMA
+  // when alias analysis proves they touch different objects; one array indexed by (chunk & 1) forces
+  // s_waitcnt vmcnt(0) before the first ds_read of every chunk, i.e. no overlap at all.
+  __shared__ __attribute__((aligned(16))) float ring0_all[NTILE * BUF];
+  __shared__ __attribute__((aligned(16))) float ring1_all[NTILE * BUF];
+  __shared__ __attribute__((aligned(16))) float ring2_all[NTILE * BUF];
+  __shared__ __attribute__((aligned(16))) float ring3_all[NTILE * BUF];
+
+  const int half = threadIdx.x / NT;                 // which of the workgroup's tiles (wave-uniform)
+  const int tid = threadIdx.x % NT;
+  float* const ring0 = ring0_all + half * BUF;
+  float* const ring1 = ring1_all + half * BUF;
+  float* const ring2 = ring2_all + half * BUF;
+  float* const ring3 = ring3_all + half * BUF;
+  // Tile order = dispatch order.  An XCD-aware remap (each XCD a contiguous band of tiles, T1) was measured and is
+  // WORSE here (16x32 single tile 145 -> 179 us at K4 level 1): the inputs are Infinity-Cache resident and spreading
+  // the eight XCDs over eight distant bands costs more in fabric/DRAM-page locality than the shared halos save.
+  int tile;
+  if (xcd_remap) {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int qq = nwg / 8, rr = nwg % 8, xcd = b % 8, loc = b / 8;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+    tile = wg * NTILE + half;
+  } else {
+    tile = blockIdx.x * NTILE + half;
+  }
+  const bool live = tile < ntiles;                   // odd tile count: the last half only keeps the barriers company
+  int bid = live ? tile : 0;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY;
+  const int n = bid / tilesY;
+  const int h0 = ty * TH, w0 = tx * TW;
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int WPG = TH / RPW;                      // waves per vertical-shift group
+  const int dyg = wave / WPG;
+  const int q = lane / STRIPS, j = lane % STRIPS;
+  const int row = (wave % WPG) * RPW + q;
+  const int strip = (TW == 64) ? ((q & 1) ? ((j + 14) & 15) : j) : (j ^ ((((q & 3) == 1) || ((q & 3) == 2)) ? 4 : 0));
+
+  const size_t plane = (size_t)H * W;
+  const float* p1 = in1 + (size_t)n * C * plane;
+  const float* p2 = in2 + (size_t)n * C * plane;
+
+  // zero both buffers once (out-of-image slots stay zero forever)
+  for (int i = tid; i < BUF / 4; i += NT) {
+    reinterpret_cast<float4*>(ring0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(ring1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(ring2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(ring3)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // per-thread DMA descriptors: source pointer (for chunk 0) and validity of each of my K slots
+  const float* gsrc[K];
+  bool gok[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int wi = wave + k * NW;                    // wave-level instruction index
+    const int slot = wi * 64 + lane;
+    const int v = slot % V, rr = (slot / V) % ROWS, c = slot / (V * ROWS);
+    bool ok = live && (wi < NINSTR) && (slot < SLOTS);
+    const float* src;
+    if (rr < R2) {
+      const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
+      ok = ok && v < VU2 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+      src = p2 + (size_t)c * plane + (long)gy * W + gx;
+    } else {
+      const int gy = h0 + rr - R2, gx = w0 + 4 * v;
+      ok = ok && v < STRIPS && gy < H && gx + 3 < W;
+      src = p1 + (size_t)c * plane + (long)gy * W + gx;
+    }
+    gsrc[k] = ok ? src : p1;
+    gok[k] = ok;
+  }
+  __syncthreads();
+
+  auto issue = [&](float* ring) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int wi = wave + k * NW;
+      if (wi < NINSTR) {                               // wave-uniform
+        float* ldst = ring + wi * 256;                 // wave-uniform LDS base; lane lands at +lane*16 B
+        if (gok[k]) lds_dma16(gsrc[k], ldst);
+        gsrc[k] += (size_t)CC * plane;
+      }
+    }
+  };
+
+  // accumulators as explicit register pairs so that every packed FMA operand is a naturally aligned pair:
+  //   pixel i even: pairs of horizontal shifts (0,1)(2,3)(4,5)(6,7) + single 8
+  //   pixel i odd : pairs (1,2)(3,4)(5,6)(7,8) + single 0
+  f32x2 accp[3][4][4];
+  float accs[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      accs[a][i] = 0.0f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) accp[a][i][p] = f32x2{0.0f, 0.0f};
+    }
+
+  auto compute = [&](const float* __restrict__ s2) {
+#pragma unroll 1
+    for (int c = 0; c < CC; ++c) {
+      const float* cb = s2 + c * ROWS * PITCH;
+      const float4 a = *reinterpret_cast<const float4*>(&cb[(R2 + row) * PITCH + 4 * strip]);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        const float* rp = &cb[(row + dyg * 3 + dyi) * PITCH + 4 * strip];
+        const float4 b0 = *reinterpret_cast<const float4*>(rp);
+        const float4 b1 = *reinterpret_cast<const float4*>(rp + 4);
+        const float4 b2 = *reinterpret_cast<const float4*>(rp + 8);
+        const f32x2 bp[6] = {f32x2{b0.x, b0.y}, f32x2{b0.z, b0.w}, f32x2{b1.x, b1.y},
+                             f32x2{b1.z, b1.w}, f32x2{b2.x, b2.y}, f32x2{b2.z, b2.w}};
+        const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 aa = f32x2{av[i], av[i]};
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            accp[dyi][i][p] = __builtin_elementwise_fma(aa, bp[(i + 2 * p + (i & 1)) / 2], accp[dyi][i][p]);
+          accs[dyi][i] = fmaf(av[i], (i & 1) ? bv[i] : bv[i + 8], accs[dyi][i]);
+        }
+      }
+    }
+  };
+
+  const int nchunks = C / CC;                          // multiple of 4 (checked by the launcher)
+  constexpr int NWAIT = 2 * (K - 1);                   // see header: chunk c landed once <= NWAIT newer DMAs in flight
+  auto handoff = [&]() {
+    if constexpr (NWAIT <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (NWAIT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (NWAIT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (NWAIT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  issue(ring0);
+  issue(ring1);
+  issue(ring2);
+  for (int ck = 0; ck < nchunks; ck += 4) {
+    handoff();                                         // chunk ck in ring0; ring3 (chunk ck-1) free
+    if (ck + 3 < nchunks) issue(ring3);
+    compute(ring0);
+    handoff();
+    if (ck + 4 < nchunks) issue(ring0);
+    compute(ring1);
+    handoff();
+    if (ck + 5 < nchunks) issue(ring1);
+    compute(ring2);
+    handoff();
+    if (ck + 6 < nchunks) issue(ring2);
+    compute(ring3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue ----
   auto get = [&](int dyi, int dx, int i) -> float {
@@ -479,17 +756,35 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
     if ((W & 3) == 0 && (C % 8) == 0) {
       static const int variant = getenv("RFN_CORR_VARIANT") ? atoi(getenv("RFN_CORR_VARIANT")) : 0;  // tuning knob
       static const int xcd_remap = getenv("RFN_CORR_XCD") ? atoi(getenv("RFN_CORR_XCD")) : 0;
-#define RFN_LAUNCH_DMA(TH_, TW_, CC_, MINW_, UNR_, NTILE_)                                                        \
+      // profiling only: bit0 no DMA, bit1 no FMAs, bit2 no stores (results are then meaningless)
+      static const int ablate = getenv("RFN_CORR_ABLATE") ? atoi(getenv("RFN_CORR_ABLATE")) : 0;
+#define RFN_LAUNCH_DMA(TH_, TW_, CC_, MINW_, UNR_, NTILE_, ILV_)                                                      \
   {                                                                                                               \
     const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
     const long ntiles = (long)B * tilesX * tilesY;                                                                \
     const long blocks = (ntiles + NTILE_ - 1) / NTILE_;                                                           \
     if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
-    hipLaunchKernelGGL((corr9_dma_kernel<TH_, TW_, CC_, FUSE, MINW_, UNR_, NTILE_>), dim3((unsigned)blocks),      \
+    hipLaunchKernelGGL((corr9_dma_kernel<TH_, TW_, CC_, FUSE, MINW_, UNR_, NTILE_, ILV_>), dim3((unsigned)blocks), \
                        dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
-                       (int)ntiles, xcd_remap);                                                                   \
+                       (int)ntiles, xcd_remap, ablate);                                                           \
     return check_launch("corr9_dma_kernel");                                                                      \
   }
+#define RFN_LAUNCH_PIPE(TH_, TW_, MINW_, NTILE_)                                                                  \
+  {                                                                                                               \
+    const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
+    const long ntiles = (long)B * tilesX * tilesY;                                                                \
+    const long blocks = (ntiles + NTILE_ - 1) / NTILE_;                                                           \
+    if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
+    hipLaunchKernelGGL((corr9_pipe_kernel<TH_, TW_, FUSE, MINW_, NTILE_>), dim3((unsigned)blocks),                \
+                       dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
+                       (int)ntiles, xcd_remap);                                                                   \
+    return check_launch("corr9_pipe_kernel");                                                                     \
+  }
+      if (variant == 20) RFN_LAUNCH_PIPE(16, 32, 3, 2)
+      if (variant == 21) RFN_LAUNCH_PIPE(16, 64, 3, 1)
+      if (variant == 22) RFN_LAUNCH_PIPE(8, 64, 3, 1)
+      if (variant == 23) RFN_LAUNCH_PIPE(8, 32, 3, 4)
+#undef RFN_LAUNCH_PIPE
       // Default: two independent 16x32 tiles per 12-wave workgroup (3 waves/SIMD) when that yields enough workgroups
       // to occupy the chip -- K4 level 1 (2 x 270x480): 510 tiles = 255 workgroups = one even round over 256 CUs,
       // 141 us vs 166-200 us for 16x64 tiles (272 workgroups = two rounds, the second nearly empty).  Smaller maps
@@ -497,17 +792,19 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
       // halo (101 us vs 153 us paired).  Measurements: profiles/r01_kbench_corr_tiles*.txt.
       if (variant == 0) {
         const long pairs = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2;
-        if (pairs >= 192) RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2)
-        RFN_LAUNCH_DMA(8, 64, 4, 3, 2, 1)
+        if (pairs >= 192) RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2, false)
+        RFN_LAUNCH_DMA(8, 64, 4, 3, 1, 1, false)
       }
       switch (variant) {
-        case 3: RFN_LAUNCH_DMA(8, 64, 4, 3, 2, 1)
-        case 5: RFN_LAUNCH_DMA(16, 64, 4, 3, 2, 1)
-        case 10: RFN_LAUNCH_DMA(8, 32, 4, 3, 1, 1)
-        case 12: RFN_LAUNCH_DMA(16, 32, 4, 3, 2, 1)
-        case 14: RFN_LAUNCH_DMA(8, 32, 4, 3, 1, 4)
-        case 15: RFN_LAUNCH_DMA(8, 64, 4, 3, 2, 2)
-        case 16: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2)
+        case 3: RFN_LAUNCH_DMA(8, 64, 4, 3, 1, 1, false)
+        case 5: RFN_LAUNCH_DMA(16, 64, 4, 3, 1, 1, false)
+        case 10: RFN_LAUNCH_DMA(8, 32, 4, 3, 1, 1, false)
+        case 12: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 1, false)
+        case 14: RFN_LAUNCH_DMA(8, 32, 4, 3, 1, 4, false)
+        case 16: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2, false)
+        case 17: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2, true)
+        case 18: RFN_LAUNCH_DMA(16, 64, 4, 3, 1, 1, true)
+        case 19: RFN_LAUNCH_DMA(8, 64, 4, 3, 1, 1, true)
         default: break;   // 9: register-staged kernel below
       }
 #undef RFN_LAUNCH_DMA
