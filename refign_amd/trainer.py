@@ -60,7 +60,7 @@ class FlatGradBuffer:
         self.flat.zero_()
 
     def all_reduce_mean(self, bucket_mb=64):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size()
         step = max(1, int(bucket_mb * 1024 * 1024 // 4))
@@ -78,8 +78,8 @@ class Trainer:
     def __init__(self, model, sync_batchnorm=False, bucket_mb=64, fused_optimizer=True):
         self.model = model
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if sync_batchnorm and self.world > 1:
-            nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        if sync_batchnorm and dist.is_available() and dist.is_initialized():
+            nn.SyncBatchNorm.convert_sync_batchnorm(model)   # student AND teacher BNs (reference: sync_batchnorm: True)
         if fused_optimizer and model.optimizer_init["class_path"].endswith("AdamW") and \
                 next(model.parameters()).is_cuda:
             model.optimizer_init = {**model.optimizer_init,
@@ -90,7 +90,7 @@ class Trainer:
         self.bucket_mb = bucket_mb
         model._optimizer = _OptimizerProxy(self)
         model._scheduler = sch
-        if self.world > 1:
+        if dist.is_available() and dist.is_initialized():
             self.broadcast_parameters()
 
     def broadcast_parameters(self):
