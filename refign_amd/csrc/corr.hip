@@ -31,6 +31,7 @@
 //   * corr_k1_bwd_kernel     -- gather form for kernel 1 / stride 1 / pad 0 (deterministic, no atomics);
 //   * corr_generic_bwd_kernel -- scatter with hardware float/double atomics for everything else.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -897,6 +898,76 @@ __global__ __launch_bounds__(256) void corr_k1_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// --------------------------------------------------------------------------------------------------------
+// Backward for the hot parameterisation (patch 9, kernel 1, stride 1, pad 0), f32: LDS-tiled gather.
+//   MODE 1: g1[n,c,q] = sum_d gout[n,d,q]     * in2[n,c,q+d]      (weights at q, taps forward)
+//   MODE 2: g2[n,c,q] = sum_d gout[n,d,q-d]   * in1[n,c,q-d]      (weights and taps mirrored)
+// The 81 weights of an output pixel do not depend on the channel: a thread owns ONE pixel, gathers its 81 weights into
+// registers once and then walks the channels; per channel chunk the (8+8) x (32+8) halo tile of the other input is
+// staged in LDS and every FMA costs one conflict-free ds_read_b32 (lanes = consecutive pixels).  Deterministic.
+// --------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void corr9_bwd_tile_kernel(const float* __restrict__ other,
+                                                             const float* __restrict__ gout,
+                                                             float* __restrict__ grad, int C, int H, int W,
+                                                             int tilesX, int tilesY) {
+  constexpr int TH = 8, TW = 32, CC = 8, RH = TH + 8, RW = TW + 8;
+  __shared__ float tile[CC][RH][RW + 1];
+  int bid = blockIdx.x;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY;
+  const int n = bid / tilesY;
+  const int h0 = ty * TH, w0 = tx * TW;
+  const int lx = threadIdx.x % TW, ly = threadIdx.x / TW;
+  const int qy = h0 + ly, qx = w0 + lx;
+  const bool inq = qy < H && qx < W;
+  const size_t plane = (size_t)H * W;
+  // my 81 weights
+  float wgt[81];
+  const float* go = gout + (size_t)n * 81 * plane;
+#pragma unroll
+  for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 9; ++dx) {
+      const int d = dy * 9 + dx;
+      float v = 0.0f;
+      if (MODE == 1) {
+        if (inq) v = go[(size_t)d * plane + (size_t)qy * W + qx];
+      } else {
+        const int py = qy - (dy - 4), px = qx - (dx - 4);
+        if (inq && py >= 0 && py < H && px >= 0 && px < W) v = go[(size_t)d * plane + (size_t)py * W + px];
+      }
+      wgt[d] = v;
+    }
+  const float* src = other + (size_t)n * C * plane;
+  float* dst = grad + (size_t)n * C * plane;
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < CC * RH * RW; idx += 256) {
+      const int x = idx % RW, r = (idx / RW) % RH, c = idx / (RW * RH);
+      const int gy = h0 - 4 + r, gx = w0 - 4 + x;
+      float v = 0.0f;
+      if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[(size_t)(c0 + c) * plane + (size_t)gy * W + gx];
+      tile[c][r][x] = v;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int c = 0; c < CC; ++c) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) {
+          // tile origin is (h0-4, w0-4): pixel q sits at [ly+4][lx+4]; MODE 1 taps q+d, MODE 2 taps q-d
+          const int r = (MODE == 1) ? ly + dy : ly + 8 - dy;
+          const int x = (MODE == 1) ? lx + dx : lx + 8 - dx;
+          acc = fmaf(wgt[dy * 9 + dx], tile[c][r][x], acc);
+        }
+      if (inq && c0 + c < C) dst[(size_t)(c0 + c) * plane + (size_t)qy * W + qx] = acc;
+    }
+  }
+}
+
 // Generic backward: scatter with hardware atomics, one thread per gout element (grads pre-zeroed by the caller).
 template <typename T>
 __global__ __launch_bounds__(256) void corr_generic_bwd_kernel(const T* __restrict__ in1,
@@ -967,6 +1038,19 @@ static int corr_fwd_any(const T* in1, const T* in2, T* out, const CorrParams& p,
 template <typename T>
 static int corr_bwd_any(const T* in1, const T* in2, const T* gout, T* g1, T* g2, const CorrParams& p,
                         hipStream_t st) {
+  if constexpr (std::is_same<T, float>::value) {
+    if (is_hot_param(p)) {
+      const int tilesX = cdiv(p.iW, 32), tilesY = cdiv(p.iH, 8);
+      const long blocks = (long)p.B * tilesX * tilesY;
+      if (blocks > 0x7fffffffL) return fail(RFN_EINVAL, "corr bwd: grid too large");
+      hipLaunchKernelGGL((corr9_bwd_tile_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, in2, gout, g1, p.C,
+                         p.iH, p.iW, tilesX, tilesY);
+      if (int rc = check_launch("corr9_bwd_tile_kernel<1>")) return rc;
+      hipLaunchKernelGGL((corr9_bwd_tile_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, in1, gout, g2, p.C,
+                         p.iH, p.iW, tilesX, tilesY);
+      return check_launch("corr9_bwd_tile_kernel<2>");
+    }
+  }
   if (is_k1(p)) {
     const long total = (long)p.B * p.C * p.iH * p.iW;
     const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 32);
