@@ -151,6 +151,19 @@ int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, con
                       void* grad_x, float* grad_gamma, float* grad_beta, void* workspace, long rows, int C,
                       int x_dtype, int gy_dtype, rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Front end of the UAWarpC UncertaintyModule for search size 9 (models/modules.py:529-551, eval mode): every pixel's
+ * 9x9 correlation patch -> conv3x3(1->32)+BN+LeakyReLU(0.1) -> conv3x3(32->32)+BN+LeakyReLU -> conv3x3(32->16)+BN+
+ * LeakyReLU -> conv3x3(16->6), all VALID, i.e. 9x9 -> 7x7 -> 5x5 -> 3x3 -> 1x1; one fused kernel, fp32 MFMA.
+ * corr (B,81,H,W), out (B,6,H,W) float32 contiguous.  weights: rfn_uncertainty9_weights_len() floats, BatchNorm
+ * folded in (w' = w*gamma/sqrt(var+eps), b' = beta - mean*gamma/sqrt(var+eps)), packed as
+ *   W0[tap9][c32] b0[32] | W1[k288][n32] b1[32] | W2[k288][n16] b2[16] | W3[k144][c6] b3[6]
+ * with k = (ky*3+kx)*Cin + ci, i.e. W[k][n] = conv.weight[n][ci][ky][kx].
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_uncertainty9_weights_len(void);
+int rfn_uncertainty9_frontend_f32(const float* corr, const float* weights, float* out, int B, int H, int W,
+                                  rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

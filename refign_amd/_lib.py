@@ -40,6 +40,8 @@ SIGNATURES = {
     "rfn_layernorm_bwd": (c_int, [c_void_p] * 9 + [ctypes.c_long, c_int, c_int, c_int, c_void_p]),
     "rfn_dwconv3x3_bwd_weight_workspace_bytes": (ctypes.c_ulong, [c_int]),
     "rfn_dwconv3x3_nhwc_bwd_weight": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "rfn_uncertainty9_weights_len": (c_int, []),
+    "rfn_uncertainty9_frontend_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }
 
 

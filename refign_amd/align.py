@@ -107,14 +107,46 @@ class UncertaintyModule(nn.Module):
         self.pred_conv_0 = ConvBNReLU(6 + 32 + add, 32, 3, norm_layer=nl, activation_layer=_leaky)
         self.pred_conv_1 = ConvBNReLU(32, 16, 3, norm_layer=nl, activation_layer=_leaky)
         self.predict_uncertainty_final = nn.Conv2d(16, 1, kernel_size=3, stride=1, padding=1, bias=True)
+        self._packed = None
 
     # micro-images per launch of the library conv chain: bounds the (N,32,7,7) intermediates to ~0.8 GB
     MICRO_BATCH = 131072
 
+    def packed_frontend_weights(self):
+        """The four front-end convs with eval-mode BatchNorm folded in, packed for rfn_uncertainty9_frontend_f32
+        (layout: include/refign_hip.h): W[k][n] with k = (ky*3+kx)*Cin + ci.  Cached until train()/load/_apply."""
+        if self._packed is None:
+            parts = []
+            for m in (self.conv_0, self.conv_1, self.conv_2):
+                w, b = m.folded()
+                parts += [w.permute(2, 3, 1, 0).reshape(-1), b.reshape(-1)]
+            pu = self.predict_uncertainty
+            parts += [pu.weight.detach().permute(2, 3, 1, 0).reshape(-1), pu.bias.detach().reshape(-1)]
+            self._packed = torch.cat([t.float() for t in parts]).contiguous()
+        return self._packed
+
+    def train(self, mode=True):
+        self._packed = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._packed = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
     def patch_statistics(self, corr):
-        """corr (B, s*s, H, W) -> (B, 6, H, W)."""
+        """corr (B, s*s, H, W) -> (B, 6, H, W).  Search size 9 in eval mode on the GPU (the frozen alignment head:
+        every call of the hot path) is ONE fused HIP kernel; training mode / search size 16 (the 16x16 level-4 map,
+        256 micro-images per image) run the library conv chain."""
         b, _, h, w = corr.shape
         s = self.search_size
+        if (s == 9 and corr.is_cuda and not self.training and not torch.is_grad_enabled()
+                and self.conv_0.use_norm and corr.dtype == torch.float32
+                and os.environ.get("RFN_UNCERT_FUSED", "1") != "0"):
+            return matching.uncertainty9_frontend(corr, self.packed_frontend_weights())
         x = corr.permute(0, 2, 3, 1).reshape(b * h * w, 1, s, s)
         outs = []
         for i in range(0, x.shape[0], self.MICRO_BATCH):

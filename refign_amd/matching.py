@@ -56,6 +56,25 @@ def l2_normalize_channels(x):
     return out
 
 
+def uncertainty9_frontend(corr, packed_weights):
+    """Front end of UncertaintyModule (search size 9, eval mode; models/modules.py:529-551): (B,81,H,W) correlation
+    volume -> (B,6,H,W), the 9x9 -> 7x7 -> 5x5 -> 3x3 -> 1x1 micro-conv chain of every pixel in one HIP kernel.
+    `packed_weights`: UncertaintyModule.packed_frontend_weights() (BatchNorm folded, layout in refign_hip.h)."""
+    corr = require_device_tensor(corr.contiguous(), "corr", torch.float32)
+    w = require_device_tensor(packed_weights.contiguous(), "packed_weights", torch.float32)
+    B, D, H, W = corr.shape
+    lib = _lib.load_library()
+    if D != 81 or w.numel() != lib.rfn_uncertainty9_weights_len():
+        raise RuntimeError("uncertainty9_frontend: corr must be (B,81,H,W) and the weight pack %d floats"
+                           % lib.rfn_uncertainty9_weights_len())
+    same_device(corr, w)
+    out = torch.empty((B, 6, H, W), dtype=torch.float32, device=corr.device)
+    with torch.cuda.device(corr.device):
+        rc = lib.rfn_uncertainty9_frontend_f32(ptr(corr), ptr(w), ptr(out), B, H, W, current_stream(corr.device))
+    _lib.check(rc, "uncertainty9_frontend")
+    return out
+
+
 def area_resize(x, size):
     """F.interpolate(x, size=size, mode='area') (segmentation_model.py:498-501) on the HIP kernel."""
     x = require_device_tensor(x.float().contiguous(), "x", torch.float32)

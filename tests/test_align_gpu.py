@@ -40,6 +40,25 @@ def test_decoder_refinement_uncertainty_golden(dev):
     np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 5, 7), (2, 33, 61), (1, 135, 240)])
+@torch.no_grad()
+def test_uncertainty9_frontend_fused_vs_library_chain(dev, monkeypatch, B, H, W):
+    """The fused fp32-MFMA kernel against the library micro-conv chain (same folded weights) on ragged pixel counts
+    (B*H*W not a multiple of the 8-pixel workgroup batch, pixels of one batch straddling images)."""
+    from refign_amd import align as A
+    um = closed_form_fill(A.UncertaintyModule(1, search_size=9, feed_in_previous=True),
+                          "estimate_uncertainty_components2.").to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H)
+    corr = (torch.rand((B, 81, H, W), generator=g) * 2 - 0.5).to(dev)
+    fused = um.patch_statistics(corr)
+    monkeypatch.setenv("RFN_UNCERT_FUSED", "0")
+    chain = um.patch_statistics(corr)
+    assert fused.shape == chain.shape == (B, 6, H, W)
+    scale = float(chain.abs().max())
+    assert scale > 1e-3
+    np.testing.assert_allclose(fused.cpu().numpy(), chain.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+
+
 def _pyramids(name, H, W):
     pyr = {
         "trg": [unit((1, 128, H // 4, W // 4), f"g5/{name}/t1"), unit((1, 256, H // 8, W // 8), f"g5/{name}/t2")],

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    from refign_amd import tuning
+    tuning.use_shipped_miopen_db()
     b = args.b
     g = torch.Generator().manual_seed(0)
     rows = []
@@ -72,6 +74,18 @@ def main():
             y = dwconv3x3_nhwc(xg, wg, bb, dil)
             gy = torch.randn_like(y)
             add(f"dwconv fwd+bwd {B_}x{H}x{W}x{C} d{dil} {str(dt)[6:]}", timeit(lambda: torch.autograd.grad(dwconv3x3_nhwc(xg, wg, bb, dil), (xg, wg), gy), reps=5), 7 * x.numel() * es)
+    if not args.only or "unc" in args.only:
+        from refign_amd import align as A
+        um = A.UncertaintyModule(1, search_size=9, feed_in_previous=True).to(dev).eval()
+        for (lvl, H, W) in [("L1", 270, 480), ("L2", 135, 240), ("L3", 32, 32)]:
+            corr = torch.rand(b, 81, H, W, generator=g).to(dev)
+            npx = b * H * W
+            fl = 2.0 * npx * (49 * 32 * 9 + 25 * 32 * 288 + 9 * 16 * 288 + 6 * 144)
+            with torch.no_grad():
+                add(f"uncertainty9 front end fused {lvl} {H}x{W}", timeit(lambda: um.patch_statistics(corr), reps=5), 4 * npx * 87, fl)
+                os.environ["RFN_UNCERT_FUSED"] = "0"
+                add(f"uncertainty9 front end library chain {lvl} {H}x{W}", timeit(lambda: um.patch_statistics(corr), reps=3), 4 * npx * 87, fl)
+                del os.environ["RFN_UNCERT_FUSED"]
     if not args.only or "tail" in args.only:
         H, W = 1080, 1920
         lt = (3 * torch.randn(b, 19, H, W, generator=g)).to(dev)
