@@ -31,3 +31,30 @@ def current_stream(device):
     """Raw hipStream_t of torch's current stream on `device` (the reference launches on the legacy default
     stream, correlation_cuda_kernel.cu:271; we honour torch's stream semantics instead so graphs/streams work)."""
     return torch.cuda.current_stream(device).cuda_stream
+
+
+_CONSTS = {}
+
+
+def const_tensor(values, like, dtype=None):
+    """A small constant tensor on `like`'s device, created ONCE per (values, dtype, device): `like.new_tensor([...])`
+    inside the step is a pageable host-to-device copy, i.e. a host synchronisation that drains the launch queue."""
+    dtype = dtype or like.dtype
+    flat = tuple(torch.as_tensor(values, dtype=torch.float64).flatten().tolist())
+    shape = tuple(torch.as_tensor(values).shape)
+    key = (flat, shape, dtype, like.device)
+    t = _CONSTS.get(key)
+    if t is None:
+        if len(_CONSTS) > 4096:
+            _CONSTS.clear()
+        t = _CONSTS[key] = torch.tensor(values, dtype=dtype, device=like.device)
+    return t
+
+
+def upload_async(values, dtype, device):
+    """Per-step host data (e.g. random class choices) to the device without a host synchronisation: staged through
+    pinned memory, copy enqueued on the current stream."""
+    t = torch.as_tensor(values, dtype=dtype)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)

@@ -29,6 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import matching
+from ._tensor import const_tensor
 from .layers import LEAKY_SLOPE, ConvBNReLU
 from .modules import GlobalFeatureCorrelationLayer, LocalFeatureCorrelationLayer
 
@@ -316,7 +317,7 @@ class UAWarpCHead(BaseHead):
         units refer to.  Returns (residual-corrected flow, decoder feature, log-variance)."""
         h, w = feat_trg.shape[-2:]
         oh, ow = orig_size
-        scale = flow_prev.new_tensor([w / float(ow), h / float(oh)]).view(1, 2, 1, 1)
+        scale = const_tensor([w / float(ow), h / float(oh)], flow_prev).view(1, 2, 1, 1)
         corr = self.local_corr(feat_src, feat_trg, flow=(flow_prev * scale).contiguous())   # warp fused in
         parts = [corr, flow_prev] + ([extra] if extra is not None else [])
         if self.estimate_uncertainty:
@@ -357,7 +358,7 @@ class UAWarpCHead(BaseHead):
         up_flow4 = _up(flow4_256, (32, 32))
         up_u4 = _up(u4_256, (32, 32)) if eu else None
         flow3, x3, u3 = self._level(3, c13, c23, up_flow4, up_u4, (256, 256))
-        flow3 = flow3 * flow3.new_tensor([W / 256.0, H / 256.0]).view(1, 2, 1, 1)
+        flow3 = flow3 * const_tensor([W / 256.0, H / 256.0], flow3).view(1, 2, 1, 1)
         diag_term = 2 * math.log(math.sqrt(H ** 2 + W ** 2) / math.sqrt(2 * 256.0 ** 2))
         if eu:
             u3 = u3 + diag_term
@@ -373,7 +374,7 @@ class UAWarpCHead(BaseHead):
         up_feat2 = self.reduce(_up(x2, s1))
         flow1, _, u1 = self._level(1, c11, c21, _up(flow2, s1), _up(u2, s1) if eu else None, (H, W), extra=up_feat2)
 
-        flow4 = flow4_256 * flow4_256.new_tensor([W / 256.0, H / 256.0]).view(1, 2, 1, 1)
+        flow4 = flow4_256 * const_tensor([W / 256.0, H / 256.0], flow4_256).view(1, 2, 1, 1)
         if eu:
             return (flow4, u4_256 + diag_term), (flow3, u3), (flow2, u2), (flow1, u1)
         return flow4, flow3, flow2, flow1

@@ -23,6 +23,7 @@
 //   [9568,14176) W2k[k288][n16]          [14176,14192) b2[16]
 //   [14192,15056) W3k[k144][c6]          [15056,15062) b3[6]          k144 = pos9*16 + ci
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -62,17 +63,17 @@ __device__ __forceinline__ void mfma_chain(const float* abase, const float (&wfr
 
 __global__ __launch_bounds__(256, 2) void uncert9_frontend_kernel(const float* __restrict__ corr,
                                                                const float* __restrict__ wts, float* __restrict__ out,
-                                                               int HW, long npix, int ngroups) {
-  // 81 624 B: two workgroups per CU (160 KB), so one group's VALU phases / barriers / global latency hide under the
-  // other's MFMA phases.  s_in is dead once L0 has run and s_a1 is first written by L1; s_a0 is dead once L1 has
-  // run and s_a2 is first written by L2 -- so they share storage.
-  __shared__ float smem[kUP * 49 * 33 + kUP * 25 * 33 + 144 * 6 + 6];
+                                                               int HW, long npix, int ngroups, int ablate) {
+  // 78 144 B: two workgroups per CU (160 KB), so one group's VALU phases / barriers hide under the other's MFMA
+  // phases.  Storage is shared where lifetimes allow: s_in is dead once L0 has run and s_a1 is first written by L1;
+  // s_a0 is dead once L1 has run, then holds s_a2 (written by L2) and the L3 weights (parked in registers between).
+  __shared__ float smem[kUP * 49 * 33 + kUP * 25 * 33];
   float* const s_a0 = smem;                        // [px][pos49][ci32] pitch 33
   float* const s_a1 = smem + kUP * 49 * 33;        // [px][pos25][ci32] pitch 33
-  float* const s_w3 = s_a1 + kUP * 25 * 33;
   float* const s_in = s_a1;                        // [px][81]
   float* const s_a2 = s_a0;                        // [px][pos9][ci16]  pitch 17
-
+  float* const s_w3 = s_a0 + 1280;                 // [k144][c6] + b3[6]
+  float* const s_part = s_a0 + 2176;               // [3][48] partial sums of L3
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
 
@@ -94,25 +95,40 @@ __global__ __launch_bounds__(256, 2) void uncert9_frontend_kernel(const float* _
 #pragma unroll
   for (int s = 0; s < 72; ++s) wC[s] = wts[kOffW2 + (4 * s + lk) * 16 + li];
   const float bias2 = wts[kOffB2 + li];
-  for (int i = tid; i < 144 * 6 + 6; i += 256) s_w3[i] = wts[kOffW3 + i];
+  float w3r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w3r[j] = (tid + 256 * j < 144 * 6 + 6) ? wts[kOffW3 + tid + 256 * j] : 0.0f;
+
+  // the 8 x 81 correlation patches of a group: corr is (B,81,H,W), pixel index = b*HW + hw; element i of the group is
+  // (pixel i & 7, shift i >> 3) -- 8 consecutive pixels of one shift plane.  Fetched one group ahead into registers.
+  float pre[3];
+  auto fetch_patches = [&](int g) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = tid + 256 * j;
+      const long pix = (long)g * kUP + (i & 7);
+      float v = 0.0f;
+      if (i < kUP * 81 && pix < npix) {
+        const long b = pix / HW, hw = pix - b * HW;
+        v = corr[(b * 81 + (i >> 3)) * HW + hw];
+      }
+      pre[j] = v;
+    }
+  };
+  if ((int)blockIdx.x < ngroups) fetch_patches(blockIdx.x);
 
   for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const long pix0 = (long)g * kUP;
-    __syncthreads();   // previous group fully consumed (also publishes s_w3 on the first trip)
-    // ---- load the 8 x 81 correlation patches: corr is (B,81,H,W); pixel index = b*HW + hw ------------------
-    for (int i = tid; i < kUP * 81; i += 256) {
-      const int p = i & 7, d = i >> 3;                    // 8 consecutive pixels of one shift plane
-      const long pix = pix0 + p;
-      float v = 0.0f;
-      if (pix < npix) {
-        const long b = pix / HW, hw = pix - b * HW;
-        v = corr[(b * 81 + d) * HW + hw];
-      }
-      s_in[p * 81 + d] = v;
+    __syncthreads();   // previous group fully consumed
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = tid + 256 * j;
+      if (i < kUP * 81) s_in[(i & 7) * 81 + (i >> 3)] = pre[j];
     }
     __syncthreads();
+    if (g + (int)gridDim.x < ngroups) fetch_patches(g + gridDim.x);
     // ---- L0: 1 -> 32 channels, 9x9 -> 7x7 -----------------------------------------------------------------
-    {
+    if (!(ablate & 2)) {
       const float* ip = s_in + p0 * 81;
       float* op = s_a0 + p0 * 49 * 33 + c0;
 #pragma unroll 7
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void uncert9_frontend_kernel(const float* _
     }
     __syncthreads();
     // ---- L1: 32 -> 32, 7x7 -> 5x5; rows m = p*25 + y*5 + x (200 valid of 13 x 16) ---------------------------
-    for (int mt = wave >> 1; mt < 13; mt += 2) {
+    for (int mt = wave >> 1; mt < ((ablate & 1) ? 0 : 13); mt += 2) {
       const int m = min(mt * 16 + li, kUP * 25 - 1);       // my A row (clamped for the ragged last tile)
       const int p = m / 25, r = m - p * 25, y = r / 5, x = r - y * 5;
       const float* abase = s_a0 + (p * 49 + y * 7 + x) * 33 + lk;
@@ -144,8 +160,12 @@ __global__ __launch_bounds__(256, 2) void uncert9_frontend_kernel(const float* _
       }
     }
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tid + 256 * j < 144 * 6 + 6) s_w3[tid + 256 * j] = w3r[j];     // s_a0 is dead: park the L3 weights there
     // ---- L2: 32 -> 16, 5x5 -> 3x3; rows m = p*9 + y*3 + x (72 valid of 5 x 16) ------------------------------
-    for (int mt = wave; mt < 5; mt += 4) {
+    // tiles 0..3 -> waves 0..3; the fifth tile goes to wave 3, which had 6 (not 7) L1 tiles: 8/8/7/8 MFMA tiles per wave
+    for (int mt = wave; mt < ((ablate & 4) ? 0 : (wave == 3 ? 5 : wave + 1)); ++mt) {
       const int m = min(mt * 16 + li, kUP * 9 - 1);
       const int p = m / 9, r = m - p * 9, y = r / 3, x = r - y * 3;
       const float* abase = s_a1 + (p * 25 + y * 5 + x) * 33 + lk;
@@ -158,15 +178,23 @@ __global__ __launch_bounds__(256, 2) void uncert9_frontend_kernel(const float* _
       }
     }
     __syncthreads();
-    // ---- L3: 16 -> 6 on the 3x3 map -> one value per (pixel, output channel) ---------------------------------
-    if (tid < kUP * 6) {
-      const int p = tid / 6, c = tid - p * 6;
-      float acc = s_w3[144 * 6 + c];
+    // ---- L3: 16 -> 6 on the 3x3 map -> one value per (pixel, output channel); K = 144 split over 4 thread groups -
+    float part = 0.0f;
+    const int o3 = tid % 48, ks = tid / 48;                 // output (p, c) = (o3 / 6, o3 % 6), k-slice
+    if (tid < 192 && !(ablate & 8)) {
+      const int p = o3 / 6, c = o3 - p * 6;
       const float* ap = s_a2 + p * 9 * 17;
-#pragma unroll 4
-      for (int pos = 0; pos < 9; ++pos)
-#pragma unroll
-        for (int ci = 0; ci < 16; ++ci) acc = fmaf(s_w3[(pos * 16 + ci) * 6 + c], ap[pos * 17 + ci], acc);
+#pragma unroll 6
+      for (int kk = 0; kk < 36; ++kk) {
+        const int k = ks * 36 + kk;
+        part = fmaf(s_w3[k * 6 + c], ap[(k >> 4) * 17 + (k & 15)], part);
+      }
+      if (ks > 0) s_part[(ks - 1) * 48 + o3] = part;
+    }
+    __syncthreads();
+    if (tid < 48) {
+      const int p = o3 / 6, c = o3 - p * 6;
+      const float acc = s_w3[144 * 6 + c] + ((part + s_part[o3]) + (s_part[48 + o3] + s_part[96 + o3]));
       const long pix = pix0 + p;
       if (pix < npix) {
         const long b = pix / HW, hw = pix - b * HW;
@@ -191,9 +219,12 @@ int rfn_uncertainty9_frontend_f32(const float* corr, const float* weights, float
   const long npix = (long)B * H * W;
   const long ngroups = (npix + kUP - 1) / kUP;
   RFN_REQUIRE(ngroups < 0x7fffffffL, "rfn_uncertainty9_frontend_f32: too many pixels");
-  const int grid = (int)std::min<long>(ngroups, 256L * 2);   // 2 resident workgroups per CU, grid-stride
+  // 2 resident workgroups per CU, grid-stride.  RFN_UNCERT_GRID / RFN_UNCERT_ABLATE: measurement knobs (tools/kbench.py)
+  const char* eg = getenv("RFN_UNCERT_GRID");
+  const char* ea = getenv("RFN_UNCERT_ABLATE");
+  const int grid = (int)std::min<long>(ngroups, eg ? atol(eg) : 256L * 2);
   hipLaunchKernelGGL(uncert9_frontend_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, corr, weights, out, H * W,
-                     npix, (int)ngroups);
+                     npix, (int)ngroups, ea ? atoi(ea) : 0);
   return check_launch("uncert9_frontend_kernel");
 }
 

@@ -29,6 +29,7 @@ import torch.nn.functional as F
 
 from . import align as align_mod
 from . import refine as refine_mod
+from ._tensor import const_tensor, upload_async
 from .config import instantiate_class
 from .seg import hrda_backbone, hrda_head
 
@@ -52,15 +53,18 @@ def crop(img, crop_bbox):
 # DACS strong augmentation (helpers/dacs_transforms.py).  The class-mix is exact; colour jitter / blur are random
 # augmentations (kornia 0.5.8 in the reference, not installed): restated with torch ops, parity unpinned.
 # ---------------------------------------------------------------------------------------------------------------------
-def get_class_masks(labels):
+def get_class_masks(labels, classes=None):
     """dacs_transforms.py:81-92.  `labels`: (b,1,H,W).  NB the reference draws the candidate classes from
-    torch.unique over the WHOLE batch for every sample ("this seems to be a bug, we keep it for consistency")."""
+    torch.unique over the WHOLE batch for every sample ("this seems to be a bug, we keep it for consistency") -- so
+    the set is computed once here; `classes` lets the caller compute it where the host synchronisation of
+    torch.unique is free (start of the step, see training_step).  The random draws are the reference's."""
+    if classes is None:
+        classes = torch.unique(labels)
+    n = classes.shape[0]
     masks = []
     for label in labels:
-        classes = torch.unique(labels)
-        n = classes.shape[0]
         choice = np.random.choice(n, int((n + n % 2) / 2), replace=False)
-        chosen = classes[torch.as_tensor(choice, dtype=torch.long, device=classes.device)]
+        chosen = classes[upload_async(choice, torch.long, classes.device)]
         masks.append((label.unsqueeze(0) == chosen.view(-1, 1, 1, 1)).sum(0, keepdim=False).unsqueeze(0))
     return masks
 
@@ -96,10 +100,11 @@ def _color_jitter(img01, s):
         else:
             h = random.uniform(-s, s) * 2 * math.pi           # rotate chroma in YIQ space
             c, sn = math.cos(h), math.sin(h)
-            yiq = x.new_tensor([[0.299, 0.587, 0.114], [0.596, -0.274, -0.322], [0.211, -0.523, 0.312]])
-            rot = x.new_tensor([[1, 0, 0], [0, c, -sn], [0, sn, c]])
-            m = torch.linalg.inv(yiq) @ rot @ yiq
-            x = torch.einsum('ij,bjhw->bihw', m, x)
+            yiq = np.array([[0.299, 0.587, 0.114], [0.596, -0.274, -0.322], [0.211, -0.523, 0.312]])
+            rot = np.array([[1, 0, 0], [0, c, -sn], [0, sn, c]])
+            m = (np.linalg.inv(yiq) @ rot @ yiq).tolist()      # 3x3 on the host: applied with scalar multipliers
+            r, g, b = x[:, 0:1], x[:, 1:2], x[:, 2:3]          # (no per-step host-to-device copy, no device inverse)
+            x = torch.cat([m[i][0] * r + m[i][1] * g + m[i][2] * b for i in range(3)], 1)
         x = x.clamp(0, 1)
     return x
 
@@ -122,8 +127,8 @@ def strong_transform(param, data=None, target=None):
     assert data is not None or target is not None
     data, target = one_mix(mask=param['mix'], data=data, target=target)
     if data is not None and data.shape[1] == 3:
-        mean = data.new_tensor(IMNET_MEAN).view(1, 3, 1, 1)
-        std = data.new_tensor(IMNET_STD).view(1, 3, 1, 1)
+        mean = const_tensor(IMNET_MEAN, data).view(1, 3, 1, 1)
+        std = const_tensor(IMNET_STD, data).view(1, 3, 1, 1)
         if param['color_jitter'] > param['color_jitter_p']:
             data = (_color_jitter(data * std + mean, param['color_jitter_s']) - mean) / std
         if param['blur'] > 0.5:
@@ -247,10 +252,15 @@ class DomainAdaptationSegmentationModel(nn.Module):
         """segmentation_model.py:146-253."""
         opt, sch = self.optimizers(), self.lr_schedulers()
         opt.zero_grad()
+        images_src, gt_src = batch['image_src'], batch['semantic_src']
+        # class set of the source labels for the DACS class-mix (dacs_transforms.py:84): torch.unique synchronises
+        # with the device, so it is taken HERE, with nothing of this step queued yet, not in the middle of the step
+        # where it would drain the launch queue (same values: gt_src does not change during the step)
+        nb_trg = batch['image_trg'].shape[0]
+        src_classes = torch.unique(gt_src[:nb_trg] if gt_src.shape[0] > nb_trg else gt_src)
         self.update_momentum_encoder()
 
         # SOURCE (:156-179)
-        images_src, gt_src = batch['image_src'], batch['semantic_src']
         feats_src = self.backbone(images_src)
         logits_src = self.head(feats_src)
         if self.use_hrda:
@@ -297,7 +307,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
                 m_logits_trg = F.interpolate(m_logits_trg, size=images_trg.shape[-2:], mode='bilinear',
                                              align_corners=False)
                 m_probs_trg = F.softmax(m_logits_trg, dim=1)
-            mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src)
+            mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src,
+                                                                   src_classes)
 
         # MIXED (:226-250)
         mixed_pred = self.head(self.backbone(mixed_img))
@@ -402,7 +413,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
 
     # -- DACS (:525-582) -----------------------------------------------------------------------------------------
     @torch.no_grad()
-    def get_dacs_mix(self, images_trg, probs_trg, images_src, gt_src):
+    def get_dacs_mix(self, images_trg, probs_trg, images_src, gt_src, src_classes=None):
         nb = images_trg.shape[0]
         if images_src.shape[0] > nb:
             images_src, gt_src = images_src[:nb], gt_src[:nb]
@@ -417,7 +428,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if self.psweight_ignore_bottom > 0:
             pseudo_weight[:, -self.psweight_ignore_bottom:, :] = 0
         gt_weight = torch.ones_like(pseudo_weight)
-        masks = get_class_masks(gt_src.unsqueeze(1))
+        masks = get_class_masks(gt_src.unsqueeze(1), src_classes)
         mixed_img, mixed_lbl = [None] * nb, [None] * nb
         for i in range(nb):
             params['mix'] = masks[i]
@@ -441,7 +452,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
             scale = gt.shape[-1] // feat[-1].shape[-1]
             gt_small = self.downscale_label_ratio(gt.unsqueeze(1), scale, self.fdist_scale_min_ratio,
                                                   self.head.num_classes, 255, out_size=feat[-1].shape[-2:]).long()
-            cls = torch.tensor(self.fdist_classes, device=gt.device)
+            cls = const_tensor(self.fdist_classes, gt, dtype=torch.long)
             mask = torch.any(gt_small[..., None] == cls, -1)
             dist = self.masked_feat_dist(feat[-1], feat_imnet[-1], mask)
         else:
@@ -452,7 +463,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def masked_feat_dist(f1, f2, mask=None):
         d = torch.norm(f1 - f2, dim=1, p=2)
         if mask is not None:
-            d = d[mask.squeeze(1)]
+            # mean over the masked pixels (reference: torch.mean(d[mask]); NaN for an empty mask either way) as a
+            # masked sum: boolean-mask indexing needs the element count on the host, i.e. a device synchronisation in
+            # the forward and another one in the backward
+            m = mask.squeeze(1)
+            return torch.where(m, d, torch.zeros_like(d)).sum() / m.sum().to(d.dtype)
         return torch.mean(d)
 
     @staticmethod

@@ -77,12 +77,15 @@ def main():
     if not args.only or "unc" in args.only:
         from refign_amd import align as A
         um = A.UncertaintyModule(1, search_size=9, feed_in_previous=True).to(dev).eval()
-        for (lvl, H, W) in [("L1", 270, 480), ("L2", 135, 240), ("L3", 32, 32)]:
+        quick = "uncL1x" in args.only                      # fused kernel at level 1 only (tools/unc_ablate.sh)
+        for (lvl, H, W) in [("L1", 270, 480), ("L2", 135, 240), ("L3", 32, 32)][:1 if quick else 3]:
             corr = torch.rand(b, 81, H, W, generator=g).to(dev)
             npx = b * H * W
             fl = 2.0 * npx * (49 * 32 * 9 + 25 * 32 * 288 + 9 * 16 * 288 + 6 * 144)
             with torch.no_grad():
                 add(f"uncertainty9 front end fused {lvl} {H}x{W}", timeit(lambda: um.patch_statistics(corr), reps=5), 4 * npx * 87, fl)
+                if quick:
+                    continue
                 os.environ["RFN_UNCERT_FUSED"] = "0"
                 add(f"uncertainty9 front end library chain {lvl} {H}x{W}", timeit(lambda: um.patch_statistics(corr), reps=3), 4 * npx * 87, fl)
                 del os.environ["RFN_UNCERT_FUSED"]
