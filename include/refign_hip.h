@@ -126,13 +126,15 @@ int rfn_align_tail_f32(const float* logits_ref, const float* flow_q, const float
  * nullable.  Zero padding = dilation (same-size output).  flip = 1 applies the taps mirrored (that IS the
  * backward-data pass: grad_x = fwd(grad_y, weight, NULL, flip = 1)).  bwd_weight needs
  * rfn_dwconv3x3_bwd_weight_workspace_bytes(C) bytes of device workspace (per-stripe partial sums, reduced in a fixed
- * order: deterministic).
+ * order: deterministic).  bwd_weight `flags`: bit 0 = ACCUMULATE into grad_weight / grad_bias (they are the
+ * parameters' .grad views of the flat gradient buffer: no separate add kernel); bit 1 = grad_weight in the parameter's
+ * own (C,1,3,3) layout instead of tap-major.
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W,
                            int C, int dilation, int dtype, int flip, rfn_stream_t stream);
 unsigned long rfn_dwconv3x3_bwd_weight_workspace_bytes(int C);
 int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias,
-                                  void* workspace, int B, int H, int W, int C, int dilation, int dtype,
+                                  void* workspace, int B, int H, int W, int C, int dilation, int dtype, int flags,
                                   rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -142,14 +144,14 @@ int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad
  * independently for input and output, so the residual stream can stay in bf16 with no separate cast passes.
  * gamma, beta, grad_gamma, grad_beta: (C) float32; mean, rstd: (rows) float32 saved by fwd for bwd.
  * bwd: grad_x has x's dtype; needs rfn_layernorm_bwd_workspace_bytes(C) bytes of workspace (deterministic two-stage
- * reduction of the parameter gradients).
+ * reduction of the parameter gradients); accumulate != 0 adds them to grad_gamma / grad_beta instead of overwriting.
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       long rows, int C, float eps, int in_dtype, int out_dtype, rfn_stream_t stream);
 unsigned long rfn_layernorm_bwd_workspace_bytes(int C);
 int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, const float* mean, const float* rstd,
                       void* grad_x, float* grad_gamma, float* grad_beta, void* workspace, long rows, int C,
-                      int x_dtype, int gy_dtype, rfn_stream_t stream);
+                      int x_dtype, int gy_dtype, int accumulate, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Front end of the UAWarpC UncertaintyModule for search size 9 (models/modules.py:529-551, eval mode): every pixel's
@@ -163,6 +165,19 @@ int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, con
 int rfn_uncertainty9_weights_len(void);
 int rfn_uncertainty9_frontend_f32(const float* corr, const float* weights, float* out, int B, int H, int W,
                                   rfn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * out[i] (+)= sum_{s < S} x[s*n + i]: sum over the leading dimension of a row-major (S, n) matrix into float32.
+ * Two uses on the training step, both formerly a library reduction followed by a separate gradient-accumulation add:
+ *   - bias gradient of every token-wise Linear: x = grad_y (tokens, features), S = tokens (8 160 ... 259 200)
+ *   - reduction of the split-T weight-gradient partials (refign_amd/linear.py): x = (S <= 64, N*K)
+ * x dtype 0 = float32, 1 = bfloat16; n must be a multiple of 8.  accumulate != 0: out += sum (out is the parameter's
+ * .grad view).  Tall inputs (S > 64) go through per-stripe partial sums in `workspace`
+ * (rfn_sum_rows_workspace_bytes(S, n) bytes; may be NULL when that is 0) reduced in a fixed order: deterministic.
+ * ---------------------------------------------------------------------------------------------------------- */
+unsigned long rfn_sum_rows_workspace_bytes(long S, long n);
+int rfn_sum_rows(const void* x, float* out, void* workspace, long S, long n, int x_dtype, int accumulate,
+                 rfn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -258,16 +258,26 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
   }
 }
 
-// stage 2: dw[k][c] = sum over stripes (fixed order => deterministic); k = 9 -> bias gradient
+// stage 2: dw[k][c] = sum over stripes (fixed order => deterministic); k = 9 -> bias gradient.
+// flags bit0: accumulate into dw/db (they are the parameters' .grad); bit1: dw in parameter layout (C,1,3,3) = [c][k]
+// instead of tap-major [k][c]
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_reduce_kernel(const float* __restrict__ ws,
                                                                           float* __restrict__ dw,
-                                                                          float* __restrict__ db, int C, int stripes) {
+                                                                          float* __restrict__ db, int C, int stripes,
+                                                                          int flags) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= 10 * C) return;
   float s = 0.0f;
   for (int t = 0; t < stripes; ++t) s += ws[(size_t)t * 10 * C + idx];
-  if (idx < 9 * C) dw[idx] = s;
-  else if (db != nullptr) db[idx - 9 * C] = s;
+  float* dst;
+  if (idx < 9 * C) {
+    const int k = idx / C, c = idx - k * C;
+    dst = (flags & 2) ? dw + c * 9 + k : dw + idx;
+  } else {
+    if (db == nullptr) return;
+    dst = db + (idx - 9 * C);
+  }
+  *dst = (flags & 1) ? *dst + s : s;
 }
 
 static inline int pick_cvb(int CV) { return CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV >= 16 ? 16 : 8)); }
@@ -291,7 +301,7 @@ static int launch_fwd(const void* x, const float* w, const float* bias, void* y,
 
 template <typename T>
 static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db, float* ws, int B, int H, int W, int C,
-                             int dil, hipStream_t st) {
+                             int dil, int flags, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
   const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
   const long nquads = (long)B * H * (dil * (((W + dil - 1) / dil + kPX - 1) / kPX));
@@ -301,7 +311,7 @@ static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db
                      ws, B, H, W, C, dil, cvb);
   if (int rc = check_launch("dwconv3x3_bwd_weight_kernel")) return rc;
   hipLaunchKernelGGL(dwconv3x3_bwd_weight_reduce_kernel, dim3(cdiv(10L * C, 256)), dim3(256), 0, st, ws, dw, db, C,
-                     stripes);
+                     stripes, flags);
   return check_launch("dwconv3x3_bwd_weight_reduce_kernel");
 }
 
@@ -331,19 +341,19 @@ unsigned long rfn_dwconv3x3_bwd_weight_workspace_bytes(int C) {
 }
 
 int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias,
-                                  void* workspace, int B, int H, int W, int C, int dilation, int dtype,
+                                  void* workspace, int B, int H, int W, int C, int dilation, int dtype, int flags,
                                   rfn_stream_t stream) {
   RFN_REQUIRE(x && grad_y && grad_weight && workspace, "rfn_dwconv3x3_nhwc_bwd_weight: null pointer");
   RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "rfn_dwconv3x3_nhwc_bwd_weight: bad size");
   if (dtype == 0) {
     RFN_REQUIRE(C % 4 == 0, "rfn_dwconv3x3_nhwc_bwd_weight: C must be a multiple of 4 for f32");
     return launch_bwd_weight<float>(x, grad_y, grad_weight, grad_bias, (float*)workspace, B, H, W, C, dilation,
-                                    (hipStream_t)stream);
+                                    flags, (hipStream_t)stream);
   }
   if (dtype == 1) {
     RFN_REQUIRE(C % 8 == 0, "rfn_dwconv3x3_nhwc_bwd_weight: C must be a multiple of 8 for bf16");
     return launch_bwd_weight<__hip_bfloat16>(x, grad_y, grad_weight, grad_bias, (float*)workspace, B, H, W, C, dilation,
-                                             (hipStream_t)stream);
+                                             flags, (hipStream_t)stream);
   }
   return fail(RFN_EINVAL, "rfn_dwconv3x3_nhwc_bwd_weight: dtype must be 0 (f32) or 1 (bf16)");
 }

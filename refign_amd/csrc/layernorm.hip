@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
 
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ ws,
                                                                    float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta, int C, int nblocks) {
+                                                                   float* __restrict__ dbeta, int C, int nblocks,
+                                                                   int accumulate) {
   // 64 columns x 4 row segments per workgroup: coalesced 256 B reads, fixed summation order
   __shared__ float part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
   __syncthreads();
   if (seg == 0 && col < 2 * C) {
     const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    if (col < C) dgamma[col] = t;
-    else dbeta[col - C] = t;
+    float* dst = col < C ? dgamma + col : dbeta + (col - C);
+    *dst = accumulate ? *dst + t : t;       // accumulate: straight into the parameter's .grad (flat gradient buffer)
   }
 }
 
@@ -183,7 +184,8 @@ static int ln_fwd_dispatch(const void* x, const float* g, const float* b, void* 
 
 template <typename TX, typename TG>
 static int ln_bwd_dispatch(const void* x, const void* gy, const float* g, const float* mean, const float* rstd,
-                           void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, hipStream_t st) {
+                           void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, int accumulate,
+                           hipStream_t st) {
   const int grid = ln_grid(rows, kLnMaxBlocks), npl = cdiv(C, 64);
 #define RFN_LN_BWD(N)                                                                                              \
   hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TG, N>), dim3(grid), dim3(256), 0, st, (const TX*)x, (const TG*)gy, \
@@ -196,7 +198,7 @@ static int ln_bwd_dispatch(const void* x, const void* gy, const float* g, const 
 #undef RFN_LN_BWD
   if (int rc = check_launch("layernorm_bwd_kernel")) return rc;
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(2L * C, 64)), dim3(256), 0, st, ws, dgamma, dbeta, C,
-                     grid);
+                     grid, accumulate);
   return check_launch("layernorm_bwd_reduce_kernel");
 }
 
@@ -228,20 +230,20 @@ int rfn_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
 
 int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, const float* mean, const float* rstd,
                       void* grad_x, float* grad_gamma, float* grad_beta, void* workspace, long rows, int C,
-                      int x_dtype, int gy_dtype, rfn_stream_t stream) {
+                      int x_dtype, int gy_dtype, int accumulate, rfn_stream_t stream) {
   RFN_REQUIRE(x && grad_y && gamma && mean && rstd && grad_x && grad_gamma && grad_beta && workspace,
               "rfn_layernorm_bwd: null pointer");
   RFN_REQUIRE(rows > 0 && C > 0 && C <= 64 * kLnMaxPerLane, "rfn_layernorm_bwd: need 0 < C <= 1024 (got %d)", C);
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   if (x_dtype == 0 && gy_dtype == 0)
-    return ln_bwd_dispatch<float, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, st);
+    return ln_bwd_dispatch<float, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st);
   if (x_dtype == 0 && gy_dtype == 1)
-    return ln_bwd_dispatch<float, __hip_bfloat16>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, st);
+    return ln_bwd_dispatch<float, __hip_bfloat16>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st);
   if (x_dtype == 1 && gy_dtype == 1)
-    return ln_bwd_dispatch<__hip_bfloat16, __hip_bfloat16>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, st);
+    return ln_bwd_dispatch<__hip_bfloat16, __hip_bfloat16>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st);
   if (x_dtype == 1 && gy_dtype == 0)
-    return ln_bwd_dispatch<__hip_bfloat16, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, st);
+    return ln_bwd_dispatch<__hip_bfloat16, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st);
   return fail(RFN_EINVAL, "rfn_layernorm_bwd: dtype codes must be 0 (f32) or 1 (bf16)");
 }
 

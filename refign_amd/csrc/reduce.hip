@@ -1,0 +1,176 @@
+// refign_amd/csrc/reduce.hip -- out[i] (+)= sum_{s<S} x[s*n + i]: the parameter-gradient reductions of the training step.
+//
+// The Refign step runs ~1 750 of these per step (one per token-wise Linear per backward pass: bias gradient =
+// column sum of grad_y (tokens x features), tokens = 8 160 ... 259 200, features = 64 ... 2 048; plus the reduction of
+// the split-T weight-gradient partials).  The library reduction needed 11-21 us for a 5 MB (8160 x 320) bf16 matrix
+// (0.25 TB/s, profiles/r01_step_shapes_elem.txt) and autograd followed every one with a separate `grad += g` kernel.
+// Here: pure HBM streaming with 16-byte loads, fp32 accumulation, deterministic two-stage reduction, and the result is
+// ADDED straight into the parameter's .grad view of the flat gradient buffer.
+//   tall (S > 64):   stage 1: grid = stripes of rows; a workgroup is (n/8 column vectors) x (rows in flight), every lane
+//                    owns 8 adjacent columns and walks rows with stride TY -> contiguous, fully coalesced reads;
+//                    LDS tree over the TY row groups; one partial row per stripe in the workspace.
+//                    stage 2 = the flat kernel on the (stripes, n) partials.
+//   flat (S <= 64):  one thread per 4 columns, loop over S.
+#include <hip/hip_bf16.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace rfn {
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<__hip_bfloat16>(const __hip_bfloat16* p, float (&v)[8]) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+
+constexpr int kMaxSumStripes = 512;
+constexpr int kFlatMaxS = 64;
+
+// stage 1 of the tall case.  blockDim.x = CVB * TY (<= 256) with CVB = column vectors handled by this workgroup
+// (blockIdx.y selects the column tile when n/8 > 256).  Rows [r0, r1) of stripe blockIdx.x.
+template <typename T>
+__global__ __launch_bounds__(256) void sum_rows_tall_kernel(const T* __restrict__ x, float* __restrict__ ws, long S,
+                                                            long n, int cvb, int ty_count, long rows_per_stripe) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int cx = tid % cvb, ty = tid / cvb;
+  const long cv = (long)blockIdx.y * cvb + cx;            // column vector index
+  const bool active = ty < ty_count && cv * 8 < n;
+  const long r0 = (long)blockIdx.x * rows_per_stripe, r1 = min(S, r0 + rows_per_stripe);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const T* p = x + cv * 8;
+    long r = r0 + ty;
+    // 4 rows in flight per lane
+    for (; r + 3L * ty_count < r1; r += 4L * ty_count) {
+      float a[8], b[8], c[8], d[8];
+      load8<T>(p + r * n, a);
+      load8<T>(p + (r + ty_count) * n, b);
+      load8<T>(p + (r + 2L * ty_count) * n, c);
+      load8<T>(p + (r + 3L * ty_count) * n, d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (a[j] + b[j]) + (c[j] + d[j]);
+    }
+    for (; r < r1; r += ty_count) {
+      float a[8];
+      load8<T>(p + r * n, a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += a[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+  __syncthreads();
+  if (ty == 0 && cv * 8 < n) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < ty_count; ++t) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += red[(t * cvb + cx) * 8 + j];
+    }
+    float* o = ws + (long)blockIdx.x * n + cv * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+  }
+}
+
+// flat case / stage 2: thread = 4 adjacent columns, serial over S (fixed order).
+template <typename T>
+__global__ __launch_bounds__(256) void sum_rows_flat_kernel(const T* __restrict__ x, float* __restrict__ out, int S, long n,
+                                                            int accumulate) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (long)s * n + i);
+      s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+  } else {
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) {
+      const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + (long)s * n + i);
+      s0 += __uint_as_float(v.x << 16); s1 += __uint_as_float(v.x & 0xffff0000u);
+      s2 += __uint_as_float(v.y << 16); s3 += __uint_as_float(v.y & 0xffff0000u);
+    }
+  }
+  float4* o = reinterpret_cast<float4*>(out + i);
+  if (accumulate) {
+    const float4 p = *o;
+    s0 += p.x; s1 += p.y; s2 += p.z; s3 += p.w;
+  }
+  *o = make_float4(s0, s1, s2, s3);
+}
+
+struct TallPlan {
+  int cvb, ty, gy, stripes;
+  long rows_per_stripe;
+};
+
+static TallPlan plan_tall(long S, long n) {
+  TallPlan p;
+  const long cv = n / 8;
+  p.cvb = (int)std::min<long>(cv, 256);
+  p.ty = std::max(1, 256 / p.cvb);
+  p.gy = (int)((cv + p.cvb - 1) / p.cvb);
+  // enough workgroups to fill 256 CUs a few times over, at least 4*ty rows each
+  long stripes = std::min<long>(kMaxSumStripes, std::max<long>(1, (256L * 6) / p.gy));
+  stripes = std::max<long>(1, std::min<long>(stripes, S / (4L * p.ty)));
+  p.rows_per_stripe = (S + stripes - 1) / stripes;
+  p.stripes = (int)((S + p.rows_per_stripe - 1) / p.rows_per_stripe);
+  return p;
+}
+
+template <typename T>
+static int launch_sum_rows(const void* x, float* out, float* ws, long S, long n, int accumulate, hipStream_t st) {
+  const int fgrid = cdiv(cdiv(n, 4), 256);
+  if (S <= kFlatMaxS) {
+    hipLaunchKernelGGL((sum_rows_flat_kernel<T>), dim3(fgrid), dim3(256), 0, st, (const T*)x, out, (int)S, n, accumulate);
+    return check_launch("sum_rows_flat_kernel");
+  }
+  const TallPlan p = plan_tall(S, n);
+  hipLaunchKernelGGL((sum_rows_tall_kernel<T>), dim3(p.stripes, p.gy), dim3(p.cvb * p.ty), 0, st, (const T*)x, ws, S, n,
+                     p.cvb, p.ty, p.rows_per_stripe);
+  if (int rc = check_launch("sum_rows_tall_kernel")) return rc;
+  hipLaunchKernelGGL((sum_rows_flat_kernel<float>), dim3(fgrid), dim3(256), 0, st, (const float*)ws, out, p.stripes, n,
+                     accumulate);
+  return check_launch("sum_rows_flat_kernel");
+}
+
+}  // namespace rfn
+
+using namespace rfn;
+
+extern "C" {
+
+unsigned long rfn_sum_rows_workspace_bytes(long S, long n) {
+  if (S <= kFlatMaxS || n <= 0 || n % 8 != 0) return 0;
+  return (unsigned long)plan_tall(S, n).stripes * (unsigned long)n * sizeof(float);
+}
+
+int rfn_sum_rows(const void* x, float* out, void* workspace, long S, long n, int x_dtype, int accumulate,
+                 rfn_stream_t stream) {
+  RFN_REQUIRE(x && out, "rfn_sum_rows: null pointer");
+  RFN_REQUIRE(S > 0 && n > 0 && n % 8 == 0, "rfn_sum_rows: need S > 0 and n a positive multiple of 8 (got %ld, %ld)", S, n);
+  RFN_REQUIRE(S <= kFlatMaxS || workspace, "rfn_sum_rows: workspace required for S > %d", kFlatMaxS);
+  if (x_dtype == 0) return launch_sum_rows<float>(x, out, (float*)workspace, S, n, accumulate, (hipStream_t)stream);
+  if (x_dtype == 1)
+    return launch_sum_rows<__hip_bfloat16>(x, out, (float*)workspace, S, n, accumulate, (hipStream_t)stream);
+  return fail(RFN_EINVAL, "rfn_sum_rows: x_dtype must be 0 (f32) or 1 (bf16)");
+}
+
+}  // extern "C"

@@ -9,6 +9,7 @@ import torch
 
 from . import _lib
 from ._tensor import current_stream, ptr, require_device_tensor
+from .params import as_dtype, derived, grad_sink
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
@@ -31,11 +32,13 @@ class _DWConv3x3(torch.autograd.Function):
             x = x.float()
         x = require_device_tensor(x.contiguous(), "x")
         C = x.shape[-1]
-        w_tap = weight.detach().float().reshape(C, 9).t().contiguous()          # (9, C) tap-major
-        b32 = None if bias is None else bias.detach().float().contiguous()
+        # (9, C) tap-major fp32 copy of the parameter, re-made only when the parameter changed
+        w_tap = derived(weight, "tap_major_f32", lambda t: t.float().reshape(C, 9).t().contiguous())
+        b32 = None if bias is None else as_dtype(bias, torch.float32).detach().contiguous()
         ctx.save_for_backward(x, w_tap)
         ctx.dilation, ctx.has_bias = dilation, bias is not None
         ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        ctx.weight, ctx.bias = weight, bias
         return _fwd(x, w_tap, b32, dilation, False)
 
     @staticmethod
@@ -47,16 +50,24 @@ class _DWConv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _fwd(gy, w_tap, None, ctx.dilation, True)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
-            db = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            # straight into the parameters' views of the flat gradient buffer when the trainer provides one
+            sw, sb = grad_sink(ctx.weight), grad_sink(ctx.bias) if ctx.has_bias else None
+            direct = sw is not None and (sb is not None or not ctx.has_bias)
+            if direct:
+                dw, db = sw, sb
+            else:
+                dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
+                db = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
             lib = _lib.load_library()
             ws = torch.empty(lib.rfn_dwconv3x3_bwd_weight_workspace_bytes(C), dtype=torch.uint8, device=x.device)
             with torch.cuda.device(x.device):
                 rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), ptr(ws), B, H, W, C,
-                                                       ctx.dilation, _DT[x.dtype], current_stream(x.device))
+                                                       ctx.dilation, _DT[x.dtype], 3 if direct else 0,
+                                                       current_stream(x.device))
             _lib.check(rc, "dwconv3x3_nhwc_bwd_weight")
-            gw = dw.t().reshape(ctx.wshape).to(ctx.wdtype)
-            gb = db
+            if not direct:
+                gw = dw.t().reshape(ctx.wshape).to(ctx.wdtype)
+                gb = db
         return gx, gw, gb, None
 
 

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._tensor import current_stream, ptr
+from .params import as_dtype, grad_sink
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
@@ -21,7 +22,8 @@ class _LayerNormFn(torch.autograd.Function):
         C = x.shape[-1]
         x2 = x.contiguous().view(-1, C)
         rows = x2.shape[0]
-        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        w32 = as_dtype(weight, torch.float32).detach().contiguous()
+        b32 = as_dtype(bias, torch.float32).detach().contiguous()
         y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -32,6 +34,7 @@ class _LayerNormFn(torch.autograd.Function):
         _lib.check(rc, "layernorm_fwd")
         ctx.save_for_backward(x2, w32, mean, rstd)
         ctx.shape, ctx.wdtype = x.shape, weight.dtype
+        ctx.weight, ctx.bias = weight, bias
         return y.view(x.shape)
 
     @staticmethod
@@ -42,14 +45,20 @@ class _LayerNormFn(torch.autograd.Function):
             gy = gy.float()
         gy2 = gy.contiguous().view(rows, C)
         dx = torch.empty_like(x2)
-        dg = torch.empty(C, dtype=torch.float32, device=x2.device)
-        db = torch.empty(C, dtype=torch.float32, device=x2.device)
+        # parameter gradients: straight into the flat gradient buffer when the trainer provides one
+        sg, sb = grad_sink(ctx.weight), grad_sink(ctx.bias)
+        direct = sg is not None and sb is not None
+        dg = sg if direct else torch.empty(C, dtype=torch.float32, device=x2.device)
+        db = sb if direct else torch.empty(C, dtype=torch.float32, device=x2.device)
         lib = _lib.load_library()
         ws = torch.empty(lib.rfn_layernorm_bwd_workspace_bytes(C), dtype=torch.uint8, device=x2.device)
         with torch.cuda.device(x2.device):
             rc = lib.rfn_layernorm_bwd(ptr(x2), ptr(gy2), ptr(w32), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db),
-                                       ptr(ws), rows, C, _DT[x2.dtype], _DT[gy2.dtype], current_stream(x2.device))
+                                       ptr(ws), rows, C, _DT[x2.dtype], _DT[gy2.dtype], 1 if direct else 0,
+                                       current_stream(x2.device))
         _lib.check(rc, "layernorm_bwd")
+        if direct:
+            return dx.view(ctx.shape), None, None, None, None
         return dx.view(ctx.shape), dg.to(ctx.wdtype), db.to(ctx.wdtype), None, None
 
 

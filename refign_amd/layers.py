@@ -133,3 +133,16 @@ class DropPath(nn.Module):
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
         return x * mask
+
+    def residual(self, x, y):
+        """x + drop_path(y) in ONE elementwise kernel (addcmul) instead of a broadcast multiply and an add: the MiT
+        residual stream is pure HBM traffic (2 x 52 blocks x 4 passes per step).  Same random draw as forward()."""
+        if self.drop_prob == 0. or not self.training:
+            return x + y
+        keep = 1 - self.drop_prob
+        mask = y.new_empty((y.shape[0],) + (1,) * (y.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        if x.dtype != y.dtype:
+            return x + y * mask
+        return torch.addcmul(x, y, mask)

@@ -1,15 +1,20 @@
-"""nn.Linear with a weight-gradient GEMM shaped for MI355X.
+"""nn.Linear with the weight-gradient path laid out for MI355X and the flat gradient buffer.
 
-The weight gradient of a token-wise Linear is dW[N,K] = dY[T,N]^T . X[T,K] with T = tokens (8 160 ... 129 600 on the
+The weight gradient of a token-wise Linear is dW[N,K] = dY[T,N]^T . X[T,K] with T = tokens (8 160 ... 259 200 on the
 Refign step) and N, K <= 2048: a "small output, very long reduction" GEMM.  The library picks a 64x64 macro-tile without
 split-K for it, i.e. 25-400 workgroups each walking the whole T: measured 24 TF/s on [320 x 8160] x [8160 x 320]
 (240 of those per step, 58 ms of wgrad GEMMs in total, profiles/r01_step_shapes_bf16_findnormal.txt).  Splitting T into
-S independent slabs turns it into a batched GEMM with S x more workgroups plus one (S, N, K) fp32 reduction.
-Forward and the input gradient stay ordinary library GEMMs.  Same parameters / state_dict keys as nn.Linear.
+S independent slabs turns it into a batched GEMM with S x more workgroups; the (S, N, K) partials are reduced by
+csrc/reduce.hip, which ADDS the result straight into the parameter's .grad view of the flat gradient buffer; the bias
+gradient (column sum of dY) goes through the same kernel.  Weights are used through their cached bf16 copies
+(params.derived) instead of being re-cast at every call.  Forward and the input gradient stay ordinary library GEMMs.
+Same parameters / state_dict keys as nn.Linear.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .params import as_dtype, compute_dtype, grad_sink, sum_rows
 
 
 def _split(T):
@@ -20,38 +25,59 @@ def _split(T):
 
 
 class _LinearFn(torch.autograd.Function):
+    """x, w_c, b_c are in the compute dtype; weight / bias are the fp32 parameters (gradient routing only)."""
+
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return F.linear(x, w, b)
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, w_c, b_c):
+        ctx.save_for_backward(x, w_c)
+        ctx.weight, ctx.bias = weight, bias
+        return F.linear(x, w_c, b_c)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        N, K = w.shape
+        x, w_c = ctx.saved_tensors
+        N, K = w_c.shape
         gx = gw = gb = None
+        gy = gy.to(w_c.dtype)
         if ctx.needs_input_grad[0]:
-            gx = torch.matmul(gy, w)
+            gx = torch.matmul(gy, w_c)
         g2 = gy.reshape(-1, N)
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, K)
             T = x2.shape[0]
             S = _split(T)
+            sink = grad_sink(ctx.weight)
             if S > 1:
                 part = torch.bmm(g2.view(S, T // S, N).transpose(1, 2), x2.view(S, T // S, K))     # (S, N, K)
-                gw = part.sum(0, dtype=torch.float32)
+                if sink is not None:
+                    sum_rows(part.view(S, N * K), out=sink.view(-1), accumulate=True)
+                else:
+                    gw = sum_rows(part.view(S, N * K)).view(N, K)
             else:
                 gw = g2.t().mm(x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0, dtype=torch.float32)
-        return gx, gw, gb
+                if sink is not None:
+                    sink.add_(gw)
+                    gw = None
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            sink = grad_sink(ctx.bias)
+            g2c = g2 if g2.is_contiguous() else g2.contiguous()
+            if sink is not None:
+                sum_rows(g2c, out=sink, accumulate=True)
+            else:
+                gb = sum_rows(g2c)
+        return gx, gw, gb, None, None
 
 
 class Linear(nn.Linear):
     def forward(self, x):
-        if x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad:
-            return _LinearFn.apply(x, self.weight, self.bias)
-        return F.linear(x, self.weight, self.bias)
+        if not x.is_cuda:
+            return F.linear(x, self.weight, self.bias)
+        cd = compute_dtype(x)
+        w_c, b_c = as_dtype(self.weight, cd), as_dtype(self.bias, cd)
+        if x.dtype != cd:
+            x = x.to(cd)
+        if torch.is_grad_enabled() and self.weight.requires_grad:
+            return _LinearFn.apply(x, self.weight, self.bias, w_c, b_c)
+        return F.linear(x, w_c, b_c)

@@ -1,0 +1,106 @@
+"""Parameter plumbing of the training step, laid out for the flat gradient buffer (trainer.FlatGradBuffer).
+
+Two things autograd + autocast do per parameter per pass, which on a MiT-B5 (1 000 parameters, 4 forward and 3 backward
+passes per Refign step) add up to ~7 000 launches of tiny kernels (profiles/r01_step_shapes_elem.txt):
+  * autocast re-casts every fp32 weight/bias to bf16 at every use              -> `derived()`: one versioned bf16 copy
+    per parameter, re-made only after the parameter changed in place (optimizer step, EMA update, load_state_dict);
+  * every weight gradient is materialised, cast to fp32 and added to `.grad`   -> `grad_sink()`: the hand-written
+    backward kernels (sum_rows, layernorm_bwd, dwconv3x3_bwd_weight) ACCUMULATE straight into the parameter's view of
+    the flat fp32 gradient buffer and return None to autograd.
+"""
+import torch
+from torch.optim.optimizer import register_optimizer_step_post_hook
+
+from . import _lib
+from ._tensor import current_stream, ptr
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def derived(p, key, fn):
+    """fn(p.detach()) cached on the parameter, recomputed when p was modified in place or re-allocated."""
+    cache = p.__dict__.setdefault("_rfn_derived", {})
+    ent = cache.get(key)
+    if ent is None or ent[1] != p._version or ent[2] != p.data_ptr():
+        with torch.no_grad():
+            t = fn(p.detach())
+        cache[key] = ent = (t, p._version, p.data_ptr())
+    return ent[0]
+
+
+def refresh(params):
+    """Bring the cached copies of `params` up to date after the parameters were updated in place by something that
+    does not bump their version counters (fused / foreach optimizers, EMA updates through `.data`): dtype copies are
+    re-filled with ONE multi-tensor copy, every other derived tensor is dropped and re-made on next use.  Called by an
+    optimizer-step post hook (every torch optimizer) and by update_momentum_encoder."""
+    dst, src = [], []
+    for p in params:
+        cache = p.__dict__.get("_rfn_derived")
+        if not cache:
+            continue
+        for key in list(cache):
+            t, _, dptr = cache[key]
+            if isinstance(key, torch.dtype) and dptr == p.data_ptr() and t.shape == p.shape:
+                dst.append(t)
+                src.append(p.detach())
+                cache[key] = (t, p._version, dptr)
+            else:
+                del cache[key]
+    if dst:
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+
+
+def _optimizer_step_post_hook(optimizer, args, kwargs):
+    refresh(p for g in optimizer.param_groups for p in g["params"])
+
+
+register_optimizer_step_post_hook(_optimizer_step_post_hook)
+
+
+def as_dtype(p, dtype):
+    """`p` in the compute dtype (None stays None): the parameter itself if it already has it, else the cached copy."""
+    if p is None or p.dtype == dtype:
+        return p
+    return derived(p, dtype, lambda t: t.to(dtype))
+
+
+def compute_dtype(x):
+    """dtype the dense ops run in: the autocast dtype inside an autocast region, else x's."""
+    if x.is_cuda and torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return x.dtype
+
+
+def mark_grad_sink(p):
+    """FlatGradBuffer: `p.grad` is a persistent fp32 view that kernels may accumulate into directly."""
+    p._rfn_grad_sink = True
+
+
+def grad_sink(p):
+    if p is None or not getattr(p, "_rfn_grad_sink", False):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
+        return None
+    return g
+
+
+def sum_rows(x, out=None, accumulate=False):
+    """out[n] (+)= sum over the leading dim of a contiguous (S, n) fp32/bf16 matrix, fp32 result (csrc/reduce.hip)."""
+    S, n = x.shape
+    if not x.is_cuda or n % 8 != 0 or x.dtype not in _DT or not x.is_contiguous():
+        r = x.sum(0, dtype=torch.float32)
+        if out is None:
+            return r
+        return out.add_(r) if accumulate else out.copy_(r)
+    if out is None:
+        out, accumulate = torch.empty(n, dtype=torch.float32, device=x.device), False
+    lib = _lib.load_library()
+    nb = lib.rfn_sum_rows_workspace_bytes(S, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+    with torch.cuda.device(x.device):
+        rc = lib.rfn_sum_rows(ptr(x), ptr(out), ptr(ws), S, n, _DT[x.dtype], 1 if accumulate else 0,
+                              current_stream(x.device))
+    _lib.check(rc, "sum_rows")
+    return out

@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .align import BaseHead
+from .conv import Conv2d
 from .layernorm import LayerNorm
 from .layers import MLP, ConvBNReLU, DropPath
 from .linear import Linear
@@ -97,7 +98,7 @@ class Attention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.sr_ratio = sr_ratio
         if sr_ratio > 1:
-            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.sr = Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = LayerNorm(dim)
 
     def forward(self, x, H, W):
@@ -127,8 +128,10 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def forward(self, x, H, W):
-        x = x + self.drop_path(self.attn(self.norm1(x), H, W))
-        return x + self.drop_path(self.mlp(self.norm2(x), H, W))
+        dp = self.drop_path
+        res = dp.residual if isinstance(dp, DropPath) else torch.add
+        x = res(x, self.attn(self.norm1(x), H, W))
+        return res(x, self.mlp(self.norm2(x), H, W))
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -137,7 +140,7 @@ class OverlapPatchEmbed(nn.Module):
 
     def __init__(self, img_size=224, patch_size=7, stride=4, in_chans=3, embed_dim=768):
         super().__init__()
-        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
+        self.proj = Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
         self.norm = LayerNorm(embed_dim)
 
     def forward(self, x):

@@ -16,6 +16,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .params import mark_grad_sink
+
 
 class LinearWarmupPolynomialLR(torch.optim.lr_scheduler.LRScheduler):
     """helpers/lr_scheduler.py:10-57: linear warm-up from warmup_ratio*lr over warmup_iters, then polynomial decay to
@@ -46,15 +48,19 @@ class ValEveryNSteps:
 class FlatGradBuffer:
     """All trainable parameters' gradients as views into one contiguous fp32 tensor."""
 
+    ALIGN = 64          # elements: every view starts on a 256-byte boundary (16-byte vector stores in csrc/reduce.hip)
+
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        pad = lambda k: (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN  # noqa: E731
+        n = sum(pad(p.numel()) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            mark_grad_sink(p)                       # backward kernels may accumulate into this view directly
+            off += pad(p.numel())
 
     def zero(self):
         self.flat.zero_()

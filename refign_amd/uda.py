@@ -30,6 +30,7 @@ import torch.nn.functional as F
 from . import align as align_mod
 from . import refine as refine_mod
 from ._tensor import const_tensor, upload_async
+from .params import refresh as refresh_derived
 from .config import instantiate_class
 from .seg import hrda_backbone, hrda_head
 
@@ -511,6 +512,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         live = [p.data for p in self.live_parameters()]
         torch._foreach_mul_(ema, m)                   # one multi-tensor launch per op instead of ~1090 x 3
         torch._foreach_add_(ema, live, alpha=1.0 - m)
+        refresh_derived(self.ema_parameters())        # cached bf16 copies of the teacher weights (params.py)
 
     def train(self, mode=True):
         """(:691-701) alignment nets and the ImageNet encoder always in eval; the reference's attempt to disable

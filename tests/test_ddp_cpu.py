@@ -48,7 +48,11 @@ def _worker(rank, world, port, out):
     assert all(p.grad.data_ptr() >= grads.flat.data_ptr() for p in grads.params)   # still views
     grads.all_reduce_mean(bucket_mb=0.0001)         # tiny buckets => many async all-reduces
     if rank == 0:
-        torch.save({"flat": grads.flat.clone(), "w": model.head.weight.detach().clone()}, out)
+        views = torch.cat([p.grad.flatten() for p in grads.params])     # the buffer minus its alignment padding
+        assert grads.flat.numel() % grads.ALIGN == 0 and grads.flat.numel() >= views.numel()
+        assert torch.equal(grads.flat.double().sum(), views.double().sum())             # padding stays zero
+        assert all((p.grad.data_ptr() - grads.flat.data_ptr()) % (4 * grads.ALIGN) == 0 for p in grads.params)
+        torch.save({"flat": views.clone(), "w": model.head.weight.detach().clone()}, out)
     dist.destroy_process_group()
 
 

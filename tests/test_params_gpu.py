@@ -1,0 +1,118 @@
+"""GPU: parameter plumbing of the training step (refign_amd/params.py, csrc/reduce.hip): leading-dimension sums with
+accumulation, versioned bf16 weight copies, and backward kernels that accumulate straight into the flat gradient
+buffer -- each against the stock autograd path."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("S,n", [(1, 8), (3, 24), (64, 4096), (65, 64), (1000, 320), (8160, 320), (4099, 1280),
+                                 (300, 2048), (129, 2056), (32640, 128), (200, 102400)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_sum_rows(dev, S, n, dt):
+    from refign_amd.params import sum_rows
+    g = torch.Generator().manual_seed(S * 7 + n)
+    x = torch.randn(S, n, generator=g).to(dev).to(dt)
+    want = x.double().sum(0)
+    got = sum_rows(x)
+    assert got.dtype == torch.float32 and got.shape == (n,)
+    tol = 2e-5 * (S ** 0.5) + 1e-6
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=tol), float((got.double() - want).abs().max())
+    # accumulate into an existing buffer; deterministic (bit-identical when repeated)
+    base = torch.randn(n, generator=g).to(dev)
+    out = base.clone()
+    sum_rows(x, out=out, accumulate=True)
+    assert torch.allclose(out.double(), base.double() + want, rtol=1e-5, atol=tol)
+    out2 = base.clone()
+    sum_rows(x, out=out2, accumulate=True)
+    assert torch.equal(out, out2)
+
+
+def test_sum_rows_rejects_bad_width_through_fallback(dev):
+    from refign_amd.params import sum_rows
+    x = torch.randn(10, 19, device=dev)                      # n % 8 != 0: library path
+    assert torch.allclose(sum_rows(x), x.sum(0), atol=1e-5)
+
+
+def test_derived_copy_follows_in_place_updates(dev):
+    from refign_amd.params import as_dtype, refresh
+    p = nn.Parameter(torch.randn(16, 8, device=dev))
+    a = as_dtype(p, torch.bfloat16)
+    assert a.dtype == torch.bfloat16 and as_dtype(p, torch.bfloat16) is a       # cached
+    assert as_dtype(p, torch.float32) is p
+    with torch.no_grad():
+        p.mul_(2.0)                                                             # what an optimizer step does
+    b = as_dtype(p, torch.bfloat16)
+    assert b is not a and torch.equal(b, p.detach().to(torch.bfloat16))
+    p.data.add_(1.0)                                   # through .data (EMA update): invisible to the version counter,
+    c = as_dtype(p, torch.bfloat16)                    # so the updater calls refresh(): same buffer, new contents
+    refresh([p])
+    assert as_dtype(p, torch.bfloat16) is c and torch.equal(c, p.detach().to(torch.bfloat16))
+    p.data = torch.zeros_like(p.data)                                           # re-allocation (load / .to())
+    assert torch.equal(as_dtype(p, torch.bfloat16), torch.zeros(16, 8, device=dev, dtype=torch.bfloat16))
+
+
+class _Net(nn.Module):
+    """every module type whose backward accumulates into the flat buffer"""
+
+    def __init__(self):
+        super().__init__()
+        from refign_amd.conv import Conv2d
+        from refign_amd.layernorm import LayerNorm
+        from refign_amd.linear import Linear
+        self.embed = Conv2d(3, 64, 3, stride=2, padding=1)
+        self.norm = LayerNorm(64)
+        self.fc1 = Linear(64, 128)
+        self.dw = nn.Conv2d(128, 128, 3, 1, 1, groups=128)
+        self.fc2 = Linear(128, 64)
+        self.sr = Conv2d(64, 64, 2, stride=2)
+
+    def forward(self, img):
+        from refign_amd.dwconv import dwconv3x3_tokens
+        x = self.embed(img)
+        B, C, H, W = x.shape
+        t = self.norm(x.flatten(2).transpose(1, 2))
+        h = dwconv3x3_tokens(self.fc1(t), self.dw.weight, self.dw.bias, H, W)
+        t = t + self.fc2(F.gelu(h))
+        return self.sr(t.transpose(1, 2).reshape(B, C, H, W))
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_backward_into_flat_gradient_buffer_equals_autograd(dev, autocast):
+    """three backward passes accumulated by the kernels into FlatGradBuffer views == stock autograd accumulation"""
+    from refign_amd.trainer import FlatGradBuffer
+    torch.manual_seed(3)
+    a = _Net().to(dev)
+    b = _Net().to(dev)
+    b.load_state_dict(a.state_dict())
+    flat = FlatGradBuffer(a.parameters())
+    assert all(getattr(p, "_rfn_grad_sink", False) for p in a.parameters())
+    imgs = [torch.randn(2, 3, 96, 80, device=dev) for _ in range(3)]
+    for m in (a, b):
+        for img in imgs:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                m(img).float().square().mean().backward()
+    assert all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in flat.params)              # still the views
+    tol = dict(rtol=3e-2, atol=3e-3) if autocast else dict(rtol=1e-3, atol=1e-5)
+    for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+        scale = float(pb.grad.abs().max())
+        assert scale > 0, name
+        assert torch.allclose(pa.grad / scale, pb.grad / scale, **tol), (name, float((pa.grad - pb.grad).abs().max()), scale)
+
+
+def test_optimizer_step_refreshes_bf16_weights(dev):
+    from refign_amd.linear import Linear
+    torch.manual_seed(0)
+    m = Linear(32, 16).to(dev)
+    opt = torch.optim.AdamW(m.parameters(), lr=0.1, fused=True)
+    x = torch.randn(64, 32, device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y0 = m(x)
+        y0.float().sum().backward()
+        opt.step()
+        y1 = m(x)
+        want = F.linear(x.bfloat16(), m.weight.detach().bfloat16(), m.bias.detach().bfloat16())
+    assert not torch.equal(y0, y1) and torch.equal(y1, want)

@@ -20,6 +20,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--workload", default="refign_hrda_step_1080x1920")
 ap.add_argument("--rows", type=int, default=45)
 ap.add_argument("--shapes", action="store_true")
+ap.add_argument("--ops", default="", help="comma-separated aten op names for --shapes (default: the dense ops)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 wl = bench.WORKLOADS[a.workload](dev, 2, 1234, a.height, a.width, a.precision)
@@ -30,10 +31,11 @@ with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_sh
     wl.step()
     torch.cuda.synchronize()
 if a.shapes:
+    keys = tuple(a.ops.split(",")) if a.ops else None
     rows = [e for e in prof.key_averages(group_by_input_shape=True)
-            if e.key in ("aten::miopen_convolution", "aten::convolution_backward", "aten::mm", "aten::addmm",
+            if e.key in (keys or ("aten::miopen_convolution", "aten::convolution_backward", "aten::mm", "aten::addmm",
                          "aten::bmm", "aten::copy_", "aten::native_layer_norm", "aten::_flash_attention_forward",
-                         "aten::_flash_attention_backward", "aten::native_batch_norm", "aten::upsample_bilinear2d")]
+                         "aten::_flash_attention_backward", "aten::native_batch_norm", "aten::upsample_bilinear2d"))]
     rows.sort(key=lambda e: -e.self_device_time_total)
     for e in rows[:a.rows]:
         print(f"{e.self_device_time_total / 1e3:9.2f} ms  n={e.count:4d}  {e.key:34s} {str(e.input_shapes)[:150]}")
