@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .params import as_dtype, compute_dtype, grad_sink
+from .params import _identity, as_dtype, compute_dtype, derived, grad_sink
 
 
 class _Conv2dFn(torch.autograd.Function):
@@ -54,7 +54,11 @@ class Conv2d(nn.Conv2d):
         if not x.is_cuda or self.padding_mode != 'zeros' or isinstance(self.padding, str):
             return super().forward(x)
         cd = compute_dtype(x)
-        w_c, b_c = as_dtype(self.weight, cd), as_dtype(self.bias, cd)
+        # the MiT token tensors reach the convolutions as channels-last views, and the library then wants the filter in
+        # channels-last too: keep the cached copy in that layout instead of converting it at every call
+        w_c = derived(self.weight, (cd, "channels_last"),
+                      lambda t: t.to(cd).contiguous(memory_format=torch.channels_last), _identity)
+        b_c = as_dtype(self.bias, cd)
         if x.dtype != cd:
             x = x.to(cd)
         if torch.is_grad_enabled() and self.weight.requires_grad:

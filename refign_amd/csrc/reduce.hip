@@ -9,7 +9,7 @@
 //   tall (S > 64):   stage 1: grid = stripes of rows; a workgroup is (n/8 column vectors) x (rows in flight), every lane
 //                    owns 8 adjacent columns and walks rows with stride TY -> contiguous, fully coalesced reads;
 //                    LDS tree over the TY row groups; one partial row per stripe in the workspace.
-//                    stage 2 = the flat kernel on the (stripes, n) partials.
+//                    stage 2: (stripes, n) partials, 32 columns x 8 stripe segments per workgroup.
 //   flat (S <= 64):  one thread per 4 columns, loop over S.
 #include <hip/hip_bf16.h>
 
@@ -116,6 +116,29 @@ __global__ __launch_bounds__(256) void sum_rows_flat_kernel(const T* __restrict_
   *o = make_float4(s0, s1, s2, s3);
 }
 
+// stage 2 of the tall case: the (stripes, n) fp32 partials.  n is small here (<= 2048 columns), so the parallelism
+// has to come from the stripe dimension too: a workgroup is 32 columns x 8 stripe segments (128-byte row reads),
+// LDS combine in a fixed order.
+__global__ __launch_bounds__(256) void sum_rows_partials_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                int stripes, long n, int accumulate) {
+  __shared__ float part[8][32];
+  const int lane = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const long col = (long)blockIdx.x * 32 + lane;
+  float s = 0.0f;
+  if (col < n) {
+#pragma unroll 4
+    for (int t = seg; t < stripes; t += 8) s += ws[(long)t * n + col];
+  }
+  part[seg][lane] = s;
+  __syncthreads();
+  if (seg == 0 && col < n) {
+    float t = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+              ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
+    if (accumulate) t += out[col];
+    out[col] = t;
+  }
+}
+
 struct TallPlan {
   int cvb, ty, gy, stripes;
   long rows_per_stripe;
@@ -127,9 +150,9 @@ static TallPlan plan_tall(long S, long n) {
   p.cvb = (int)std::min<long>(cv, 256);
   p.ty = std::max(1, 256 / p.cvb);
   p.gy = (int)((cv + p.cvb - 1) / p.cvb);
-  // enough workgroups to fill 256 CUs a few times over, at least 4*ty rows each
-  long stripes = std::min<long>(kMaxSumStripes, std::max<long>(1, (256L * 6) / p.gy));
-  stripes = std::max<long>(1, std::min<long>(stripes, S / (4L * p.ty)));
+  // enough workgroups to fill 256 CUs about three times over, at least 8*ty rows each
+  long stripes = std::min<long>(kMaxSumStripes, std::max<long>(1, (256L * 3) / p.gy));
+  stripes = std::max<long>(1, std::min<long>(stripes, S / (8L * p.ty)));
   p.rows_per_stripe = (S + stripes - 1) / stripes;
   p.stripes = (int)((S + p.rows_per_stripe - 1) / p.rows_per_stripe);
   return p;
@@ -146,9 +169,9 @@ static int launch_sum_rows(const void* x, float* out, float* ws, long S, long n,
   hipLaunchKernelGGL((sum_rows_tall_kernel<T>), dim3(p.stripes, p.gy), dim3(p.cvb * p.ty), 0, st, (const T*)x, ws, S, n,
                      p.cvb, p.ty, p.rows_per_stripe);
   if (int rc = check_launch("sum_rows_tall_kernel")) return rc;
-  hipLaunchKernelGGL((sum_rows_flat_kernel<float>), dim3(fgrid), dim3(256), 0, st, (const float*)ws, out, p.stripes, n,
+  hipLaunchKernelGGL(sum_rows_partials_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, (const float*)ws, out, p.stripes, n,
                      accumulate);
-  return check_launch("sum_rows_flat_kernel");
+  return check_launch("sum_rows_partials_kernel");
 }
 
 }  // namespace rfn

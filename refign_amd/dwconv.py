@@ -33,7 +33,8 @@ class _DWConv3x3(torch.autograd.Function):
         x = require_device_tensor(x.contiguous(), "x")
         C = x.shape[-1]
         # (9, C) tap-major fp32 copy of the parameter, re-made only when the parameter changed
-        w_tap = derived(weight, "tap_major_f32", lambda t: t.float().reshape(C, 9).t().contiguous())
+        w_tap = derived(weight, "tap_major_f32", lambda t: t.float().reshape(C, 9).t().contiguous(),
+                        lambda t: t.reshape(C, 9).t())
         b32 = None if bias is None else as_dtype(bias, torch.float32).detach().contiguous()
         ctx.save_for_backward(x, w_tap)
         ctx.dilation, ctx.has_bias = dilation, bias is not None

@@ -17,35 +17,43 @@ from ._tensor import current_stream, ptr
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
-def derived(p, key, fn):
-    """fn(p.detach()) cached on the parameter, recomputed when p was modified in place or re-allocated."""
+def derived(p, key, fn, refill=None):
+    """fn(p.detach()) cached on the parameter, recomputed when p was modified in place or re-allocated.
+    `refill(p.detach())`, if given, is a VIEW of the parameter with the cached tensor's shape: refresh() then updates
+    the cached tensor in place with one multi-tensor copy (dtype / layout conversions) instead of dropping it."""
     cache = p.__dict__.setdefault("_rfn_derived", {})
     ent = cache.get(key)
     if ent is None or ent[1] != p._version or ent[2] != p.data_ptr():
         with torch.no_grad():
             t = fn(p.detach())
-        cache[key] = ent = (t, p._version, p.data_ptr())
+        cache[key] = ent = (t, p._version, p.data_ptr(), refill)
     return ent[0]
+
+
+def _identity(t):
+    return t
 
 
 def refresh(params):
     """Bring the cached copies of `params` up to date after the parameters were updated in place by something that
-    does not bump their version counters (fused / foreach optimizers, EMA updates through `.data`): dtype copies are
-    re-filled with ONE multi-tensor copy, every other derived tensor is dropped and re-made on next use.  Called by an
-    optimizer-step post hook (every torch optimizer) and by update_momentum_encoder."""
+    does not bump their version counters (fused / foreach optimizers, EMA updates through `.data`): copies with a
+    refill view are re-filled with ONE multi-tensor copy, every other derived tensor is dropped and re-made on next
+    use.  Called by an optimizer-step post hook (every torch optimizer) and by update_momentum_encoder."""
     dst, src = [], []
     for p in params:
         cache = p.__dict__.get("_rfn_derived")
         if not cache:
             continue
         for key in list(cache):
-            t, _, dptr = cache[key]
-            if isinstance(key, torch.dtype) and dptr == p.data_ptr() and t.shape == p.shape:
-                dst.append(t)
-                src.append(p.detach())
-                cache[key] = (t, p._version, dptr)
-            else:
-                del cache[key]
+            t, _, dptr, refill = cache[key]
+            if refill is not None and dptr == p.data_ptr():
+                v = refill(p.detach())
+                if v.shape == t.shape:
+                    dst.append(t)
+                    src.append(v)
+                    cache[key] = (t, p._version, dptr, refill)
+                    continue
+            del cache[key]
     if dst:
         with torch.no_grad():
             torch._foreach_copy_(dst, src)
@@ -62,7 +70,7 @@ def as_dtype(p, dtype):
     """`p` in the compute dtype (None stays None): the parameter itself if it already has it, else the cached copy."""
     if p is None or p.dtype == dtype:
         return p
-    return derived(p, dtype, lambda t: t.to(dtype))
+    return derived(p, dtype, lambda t: t.to(dtype), _identity)
 
 
 def compute_dtype(x):

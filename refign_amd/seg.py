@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._tensor import const_tensor
 from .align import BaseHead
 from .conv import Conv2d
 from .layernorm import LayerNorm
@@ -127,7 +128,10 @@ class Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, masks=None):
+        if masks is not None:                       # pre-drawn stochastic-depth masks (MixVisionTransformer)
+            x = torch.addcmul(x, self.attn(self.norm1(x), H, W), masks[0])
+            return torch.addcmul(x, self.mlp(self.norm2(x), H, W), masks[1])
         dp = self.drop_path
         res = dp.residual if isinstance(dp, DropPath) else torch.add
         x = res(x, self.attn(self.norm1(x), H, W))
@@ -217,12 +221,30 @@ class MixVisionTransformer(nn.Module):
                 blk.drop_path.drop_prob = dpr[cur + i]
             cur += self.depths[s]
 
+    def _drop_path_masks(self, x):
+        """All stochastic-depth masks of one forward pass in three launches (Bernoulli, scale, cast) instead of two
+        tiny kernels per residual branch (2 x 52 branches x 4 passes per step on MiT-B5).  Per sample and per branch,
+        scaled by 1/keep, exactly what DropPath.forward draws (models/modules.py:564-596); only the order in which the
+        generator is consumed differs.  (n_branches, B, 1, 1) in the compute dtype, or None when nothing is dropped."""
+        blocks = [b for s in range(1, 5) for b in getattr(self, f"block{s}")]
+        keep = [1.0 - (b.drop_path.drop_prob if (isinstance(b.drop_path, DropPath) and b.training) else 0.0)
+                for b in blocks for _ in range(2)]
+        if not x.is_cuda or all(k == 1.0 for k in keep) or any(k <= 0.0 for k in keep) or \
+                not all(getattr(b.drop_path, "scale_by_keep", True) for b in blocks):
+            return None
+        k = const_tensor(keep, x, dtype=torch.float32).view(-1, 1)
+        m = torch.bernoulli(k.expand(-1, x.shape[0])) / k
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        return m.to(dt).view(len(keep), x.shape[0], 1, 1)
+
     def forward_features(self, x):
         B, outs = x.shape[0], []
+        masks, i = self._drop_path_masks(x), 0
         for s in range(1, 5):
             x, H, W = getattr(self, f"patch_embed{s}")(x)
             for blk in getattr(self, f"block{s}"):
-                x = blk(x, H, W)
+                x = blk(x, H, W, None if masks is None else masks[i:i + 2])
+                i += 2
             x = getattr(self, f"norm{s}")(x)
             x = x.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
             outs.append(x)
