@@ -388,6 +388,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": f"{args.height}x{args.width}",
                        "model": "HRDA MiT-B5 + DAFormer head + VGG-16/UAWarpC align (random init)",
+                       "precision_map": ("fp32 everywhere" if args.precision == "fp32" else
+                                         "reference AMP recipe: seg nets bf16 autocast (fp32 master weights, grads, "
+                                         "norm statistics, losses); align convolutions fp16 autocast; correlation, "
+                                         "warp, L2-norm, uncertainty and refine kernels fp32"),
                        "parallelism": f"dp{world}: pairs sharded, align/refine/teacher replica-local, one flat "
                                       f"gradient all-reduce per step over RCCL"},
             "roofline": roof, "cpu_baseline": cpu,

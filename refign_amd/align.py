@@ -317,6 +317,10 @@ class UAWarpCHead(BaseHead):
         units refer to.  Returns (residual-corrected flow, decoder feature, log-variance)."""
         h, w = feat_trg.shape[-2:]
         oh, ow = orig_size
+        # flows / log-variances travel between levels in fp32 whatever dtype the convolutions ran in: half precision
+        # resolves 1 px at |flow| >= 1024 px
+        flow_prev = flow_prev.float()
+        uncert_prev = None if uncert_prev is None else uncert_prev.float()
         scale = const_tensor([w / float(ow), h / float(oh)], flow_prev).view(1, 2, 1, 1)
         corr = self.local_corr(feat_src, feat_trg, flow=(flow_prev * scale).contiguous())   # warp fused in
         parts = [corr, flow_prev] + ([extra] if extra is not None else [])
@@ -326,11 +330,11 @@ class UAWarpCHead(BaseHead):
         refine = {3: self.refinement_at_adaptive_res and 'refinement_module_adaptive',
                   1: self.refinement_at_finest_level and 'refinement_module_finest'}.get(lvl)
         if refine:
-            res = res + getattr(self, refine)(x)
-        flow = res + flow_prev
+            res = res.float() + getattr(self, refine)(x).float()
+        flow = res.float() + flow_prev
         uncert = None
         if self.estimate_uncertainty:
-            uncert = getattr(self, f"estimate_uncertainty_components{lvl}")(corr, x, uncert_prev, flow_prev)
+            uncert = getattr(self, f"estimate_uncertainty_components{lvl}")(corr, x, uncert_prev, flow_prev).float()
         return flow, x, uncert
 
     def forward(self, trg, src, trg_256, src_256, out_size):
@@ -347,10 +351,10 @@ class UAWarpCHead(BaseHead):
         assert tuple(c14.shape[-2:]) == (16, 16), tuple(c14.shape[-2:])
         corr4 = self.global_corr(c24, c14)
         est_map4, x4 = self.decoder4(corr4)
-        flow4_256 = matching.unnormalise_and_convert_mapping_to_flow(est_map4) * (256.0 / 16.0)
+        flow4_256 = matching.unnormalise_and_convert_mapping_to_flow(est_map4.float()) * (256.0 / 16.0)
         u4_256 = None
         if eu:
-            u4_256 = self.estimate_uncertainty_components4(corr4, x4)
+            u4_256 = self.estimate_uncertainty_components4(corr4, x4).float()
             u4_256 = u4_256 + 2 * math.log(256.0 / 16.0)
 
         # level 3: 32x32, decoders work in 256-space pixels (uawarpc.py:132-173)
@@ -418,13 +422,27 @@ def align(alignment_backbone, alignment_head, logits_ref, images_ref, images_trg
     h, w = images_trg.shape[-2:]
     if tuple(logits_ref.shape[-2:]) != (h, w):
         raise RuntimeError("align: logits_ref must have the image resolution")
-    # The matcher runs in fp32 even when the caller is inside a bf16 autocast region: the reference forces the
-    # correlation and the warp to fp32 under AMP (correlation_function.py:51, matching_utils.py:40-43) and sub-pixel
-    # flow accuracy is what the 1e-3 parity bound on the warped logits rests on.
-    with torch.autocast("cuda", enabled=False):
+    # Precision map of the reference under its AMP recipe (`--trainer.precision 16`, README.md:262): the VGG and decoder
+    # convolutions run in fp16 autocast, correlation and warp are forced to fp32 (correlation_function.py:51,
+    # matching_utils.py:40-43).  Same here: inside a reduced-precision autocast region the matcher's convolutions run
+    # in fp16 (the reference's own dtype -- not bf16, sub-pixel flow accuracy rests on the mantissa), the HIP
+    # correlation / warp / L2-norm / uncertainty kernels always compute in fp32; outside autocast (fp32 parity mode)
+    # everything is fp32.  RFN_ALIGN_DTYPE=fp32|fp16|bf16 overrides.
+    dt = align_compute_dtype()
+    with torch.autocast("cuda", enabled=dt != torch.float32, dtype=dt if dt != torch.float32 else None):
         pyr = extract_pyramids(alignment_backbone, images_ref.float(), images_trg.float())
         flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
-        return matching.align_tail(logits_ref, flow_q, logvar_q)
+        return matching.align_tail(logits_ref, flow_q.float(), logvar_q.float())
+
+
+_ALIGN_DTYPES = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+def align_compute_dtype():
+    env = os.environ.get("RFN_ALIGN_DTYPE")
+    if env:
+        return _ALIGN_DTYPES[env]
+    return torch.float16 if torch.is_autocast_enabled("cuda") else torch.float32
 
 
 @torch.no_grad()

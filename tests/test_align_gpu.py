@@ -115,3 +115,39 @@ def test_align_end_to_end_golden(dev):
     np.testing.assert_allclose(wn[:, :, ::2, ::2], g["warped_sample"], atol=0.15)
     assert abs(wn.astype(np.float64).sum() - g["warped_checksum"]) < 2e-4 * g["warped_abs_checksum"]
     assert (wn.argmax(1) == g["warped_argmax"]).mean() > 0.995
+
+
+@torch.no_grad()
+def test_align_amp_precision_map(dev, monkeypatch):
+    """Inside a reduced-precision autocast region align() runs its convolutions in fp16 -- the reference's AMP dtype
+    (README.md:262) -- with correlation / warp / L2 norm / uncertainty kernels in fp32: close to the fp32 golden (G7),
+    and identical to forcing RFN_ALIGN_DTYPE=fp16; outside autocast it is the fp32 path bit for bit."""
+    from refign_amd.align import VGG, UAWarpCHead, align, align_compute_dtype
+    g = golden("align_128x160")
+    H, W = [int(v) for v in g["size"]]
+    vgg = closed_form_fill(VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone.").to(dev).eval()
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select',
+                                        estimate_uncertainty=True)).to(dev).eval()
+    img_trg = (hashed_uniform((1, 3, H, W), "g7/trg") * 4 - 2).astype(np.float32)
+    img_ref = (0.8 * np.roll(img_trg, (2, -3), (2, 3)) + 0.2 * (hashed_uniform((1, 3, H, W), "g7/ref") * 4 - 2)).astype(np.float32)
+    logits = (hashed_uniform((1, 19, H, W), "g7/logits") * 8 - 4).astype(np.float32)
+    args = (vgg, head, T(logits, dev), T(img_ref, dev), T(img_trg, dev))
+    assert align_compute_dtype() == torch.float32
+    w32, m32, c32 = align(*args)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert align_compute_dtype() == torch.float16
+        w16, m16, c16 = align(*args)
+    assert w16.dtype == torch.float32 and c16.dtype == torch.float32
+    assert float((c16 - c32).abs().max()) < 2e-2, float((c16 - c32).abs().max())
+    assert float((m16 != m32).float().mean()) < 1e-3
+    np.testing.assert_allclose(c16.cpu().numpy(), g["cert"], atol=2e-2)
+    # white-noise logits amplify flow differences (see G7): compare the checksum and the argmax agreement
+    assert abs(float(w16.double().sum()) - g["warped_checksum"]) < 5e-3 * g["warped_abs_checksum"]
+    assert float((w16.argmax(1) == w32.argmax(1)).float().mean()) > 0.97
+    monkeypatch.setenv("RFN_ALIGN_DTYPE", "fp16")
+    wf, mf, cf = align(*args)
+    assert torch.equal(wf, w16) and torch.equal(cf, c16)
+    monkeypatch.setenv("RFN_ALIGN_DTYPE", "fp32")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        wp, mp, cp = align(*args)
+    assert torch.equal(wp, w32) and torch.equal(cp, c32)
