@@ -179,6 +179,15 @@ unsigned long rfn_sum_rows_workspace_bytes(long S, long n);
 int rfn_sum_rows(const void* x, float* out, void* workspace, long S, long n, int x_dtype, int accumulate,
                  rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-tensor cast float32 -> bfloat16 (round to nearest even) in one launch: refresh of the cached bf16 copies of
+ * all parameters after an optimizer step / EMA update.  `table`: DEVICE array of nchunks entries
+ * { const float* src; uint16_t* dst; long n; } (24 bytes each), one per chunk of at most
+ * rfn_multi_cast_chunk_elems() elements; the host splits every tensor into such chunks once per parameter set.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_multi_cast_chunk_elems(void);
+int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,3 +197,56 @@ int rfn_sum_rows(const void* x, float* out, void* workspace, long S, long n, int
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-tensor cast fp32 -> bf16: refresh of the cached bf16 copies of ~1 000 parameter tensors after an optimizer step
+// / EMA update in ONE launch (torch._foreach_copy_ with a dtype change degenerates into one tiny kernel per tensor:
+// 2 x 1 000 launches per step).  `table` (device memory, built once per parameter set by the host) holds one entry per
+// chunk of <= kCastChunk elements: {src, dst, n}.  Round-to-nearest-even, as torch's conversion.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace rfn {
+
+struct CastChunk {
+  const float* src;
+  unsigned short* dst;
+  long n;
+};
+
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ __launch_bounds__(256) void multi_cast_f32_bf16_kernel(const CastChunk* __restrict__ table) {
+  const CastChunk c = table[blockIdx.x];
+  const bool aligned = (((size_t)c.src & 15) == 0) && (((size_t)c.dst & 7) == 0);
+  long i = (long)threadIdx.x * 4;
+  if (aligned) {
+    for (; i + 3 < c.n; i += 256 * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(c.src + i);
+      uint2 o;
+      o.x = f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16);
+      o.y = f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16);
+      *reinterpret_cast<uint2*>(c.dst + i) = o;
+    }
+  }
+  // tail (and unaligned tensors): scalar
+  for (long j = aligned ? (c.n & ~3L) + threadIdx.x : threadIdx.x; j < c.n; j += 256)
+    c.dst[j] = (unsigned short)f32_to_bf16_bits(c.src[j]);
+}
+
+}  // namespace rfn
+
+extern "C" {
+
+int rfn_multi_cast_chunk_elems(void) { return 16384; }
+
+int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream) {
+  RFN_REQUIRE(table && nchunks > 0, "rfn_multi_cast_f32_bf16: empty table");
+  hipLaunchKernelGGL(rfn::multi_cast_f32_bf16_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                     (const rfn::CastChunk*)table);
+  return rfn::check_launch("multi_cast_f32_bf16_kernel");
+}
+
+}  // extern "C"

@@ -54,9 +54,48 @@ def refresh(params):
                     cache[key] = (t, p._version, dptr, refill)
                     continue
             del cache[key]
-    if dst:
-        with torch.no_grad():
+    if not dst:
+        return
+    # plain fp32 -> bf16 casts of contiguous tensors: ONE launch of the multi-tensor cast kernel (csrc/reduce.hip);
+    # torch._foreach_copy_ with a dtype change is one tiny kernel per tensor.  Layout-changing copies stay per tensor.
+    fast = [i for i, (d, s_) in enumerate(zip(dst, src))
+            if d.is_cuda and d.dtype == torch.bfloat16 and s_.dtype == torch.float32 and d.is_contiguous()
+            and s_.is_contiguous() and d.numel() == s_.numel() and d.numel() > 0]
+    with torch.no_grad():
+        if len(fast) >= 4:
+            by_dev = {}
+            for i in fast:
+                by_dev.setdefault(dst[i].device, []).append(i)
+            for dev, idx in by_dev.items():
+                _multi_cast([dst[i] for i in idx], [src[i] for i in idx], dev)
+            skip = set(fast)
+            dst = [d for i, d in enumerate(dst) if i not in skip]
+            src = [s_ for i, s_ in enumerate(src) if i not in skip]
+        if dst:
             torch._foreach_copy_(dst, src)
+
+
+_CAST_TABLES = {}
+
+
+def _multi_cast(dst, src, dev):
+    key = (tuple(t.data_ptr() for t in src), tuple(t.data_ptr() for t in dst), tuple(t.numel() for t in src))
+    ent = _CAST_TABLES.get(key)
+    lib = _lib.load_library()
+    if ent is None:
+        import numpy as np
+        chunk = lib.rfn_multi_cast_chunk_elems()
+        rows = []
+        for s_, d in zip(src, dst):
+            n, sp, dp = s_.numel(), s_.data_ptr(), d.data_ptr()
+            rows += [(sp + 4 * off, dp + 2 * off, min(chunk, n - off)) for off in range(0, n, chunk)]
+        table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)       # {src*, dst*, n}: 24 bytes per chunk
+        if len(_CAST_TABLES) >= 16:
+            _CAST_TABLES.clear()
+        ent = _CAST_TABLES[key] = (table, len(rows))
+    with torch.cuda.device(dev):
+        rc = lib.rfn_multi_cast_f32_bf16(ptr(ent[0]), ent[1], current_stream(dev))
+    _lib.check(rc, "multi_cast_f32_bf16")
 
 
 def _optimizer_step_post_hook(optimizer, args, kwargs):

@@ -109,9 +109,11 @@ class Attention(nn.Module):
         if self.sr_ratio > 1:
             r = self.sr(x.transpose(1, 2).reshape(B, C, H, W))               # (B,C,H/sr,W/sr)
             x = self.norm(r.flatten(2).transpose(1, 2))
-        kv = self.kv(x).view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4)          # (2,B,h,Nkv,d)
+        # unbind, not kv[0] / kv[1]: its backward is ONE stack of (dK, dV) instead of two zero-fills, two slice
+        # copies and an add
+        k, v = self.kv(x).view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4).unbind(0)   # (B,h,Nkv,d) each
         p = self.attn_drop.p if self.training else 0.0
-        o = F.scaled_dot_product_attention(q, kv[0], kv[1], dropout_p=p, scale=self.scale)
+        o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
         return self.proj_drop(self.proj(o.transpose(1, 2).reshape(B, N, C)))
 
 

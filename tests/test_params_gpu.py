@@ -116,3 +116,30 @@ def test_optimizer_step_refreshes_bf16_weights(dev):
         y1 = m(x)
         want = F.linear(x.bfloat16(), m.weight.detach().bfloat16(), m.bias.detach().bfloat16())
     assert not torch.equal(y0, y1) and torch.equal(y1, want)
+
+
+def test_refresh_multi_tensor_cast_is_torch_rounding(dev):
+    """refresh() of many cached bf16 copies = one multi-tensor cast launch; bit-identical to tensor.to(bfloat16)
+    (round to nearest even, NaN / inf / denormals), ragged sizes, chunked large tensors, unaligned views."""
+    from refign_amd.params import as_dtype, refresh
+    g = torch.Generator().manual_seed(1)
+    sizes = [(19,), (1,), (3, 5), (320,), (320, 320), (257, 129), (40000,), (7, 11, 13), (1280, 320), (2,)]
+    flat = torch.randn(sum(int(torch.tensor(s).prod()) for s in sizes) + 3, generator=g).to(dev)
+    ps, off = [], 1                                              # views at odd element offsets: 4-byte aligned only
+    for s in sizes:
+        n = int(torch.tensor(s).prod())
+        ps.append(nn.Parameter(flat[off:off + n].view(s)))
+        off += n
+    ps.append(nn.Parameter(torch.tensor([float("nan"), float("inf"), -float("inf"), 1e-40, -0.0, 3.3895314e38, 1.0 + 2 ** -8,
+                                         1.0 + 3 * 2 ** -9], device=dev)))
+    copies = [as_dtype(p, torch.bfloat16) for p in ps]
+    with torch.no_grad():
+        for p in ps:
+            p.data.mul_(1.7).add_(0.123)                         # through .data: version counters do not move
+    refresh(ps)
+    for p, c in zip(ps, copies):
+        assert as_dtype(p, torch.bfloat16) is c
+        want = p.detach().to(torch.bfloat16)
+        assert torch.equal(c.view(torch.int16), want.view(torch.int16)) or \
+            (torch.isnan(want.float()) == torch.isnan(c.float())).all() and \
+            torch.equal(torch.nan_to_num(c.float(), nan=0.0), torch.nan_to_num(want.float(), nan=0.0))

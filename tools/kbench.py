@@ -89,6 +89,16 @@ def main():
                 os.environ["RFN_UNCERT_FUSED"] = "0"
                 add(f"uncertainty9 front end library chain {lvl} {H}x{W}", timeit(lambda: um.patch_statistics(corr), reps=3), 4 * npx * 87, fl)
                 del os.environ["RFN_UNCERT_FUSED"]
+    if not args.only or "sum" in args.only:
+        from refign_amd.params import sum_rows
+        for (S, n, dt) in [(8160, 320, torch.bfloat16), (8160, 1280, torch.bfloat16), (32640, 128, torch.bfloat16),
+                           (32640, 512, torch.bfloat16), (129600, 64, torch.bfloat16), (129600, 256, torch.bfloat16),
+                           (16, 320 * 1280, torch.bfloat16), (64, 64 * 256, torch.bfloat16)]:
+            x = torch.randn(S, n, device=dev).to(dt)
+            out = torch.zeros(n, device=dev)
+            nb = x.numel() * x.element_size() + 8 * n
+            add(f"sum_rows (+= into grad) {S}x{n} {str(dt)[6:]}", timeit(lambda: sum_rows(x, out=out, accumulate=True)), nb)
+            add(f"  torch: out += x.sum(0) {S}x{n}", timeit(lambda: out.add_(x.sum(0, dtype=torch.float32))), nb)
     if not args.only or "tail" in args.only:
         H, W = 1080, 1920
         lt = (3 * torch.randn(b, 19, H, W, generator=g)).to(dev)

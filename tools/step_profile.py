@@ -20,6 +20,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--workload", default="refign_hrda_step_1080x1920")
 ap.add_argument("--rows", type=int, default=45)
 ap.add_argument("--shapes", action="store_true")
+ap.add_argument("--stacks", default="", help="aten op name: list its call sites (python stacks) by launch count")
 ap.add_argument("--ops", default="", help="comma-separated aten op names for --shapes (default: the dense ops)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -27,10 +28,27 @@ wl = bench.WORKLOADS[a.workload](dev, 2, 1234, a.height, a.width, a.precision)
 for _ in range(2):
     wl.step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=a.shapes) as prof:
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=a.shapes or bool(a.stacks)) as prof:
     wl.step()
     torch.cuda.synchronize()
-if a.shapes:
+if a.stacks:
+    # call sites of an op, as the chain of enclosing profiler events (autograd node / aten op / module label)
+    from collections import Counter
+    cnt, dev_t = Counter(), Counter()
+    for e in prof.events():
+        if e.name != a.stacks:
+            continue
+        chain, p = [], e.cpu_parent
+        while p is not None and len(chain) < 5:
+            chain.append(p.name[:48])
+            p = p.cpu_parent
+        shp = str(e.input_shapes)[:60] if e.input_shapes else ""
+        key = "  <-  ".join(chain) + "   " + shp
+        cnt[key] += 1
+        dev_t[key] += e.device_time_total
+    for k, n in cnt.most_common(a.rows):
+        print(f"n={n:5d} {dev_t[k] / 1e3:8.2f} ms  {k}")
+elif a.shapes:
     keys = tuple(a.ops.split(",")) if a.ops else None
     rows = [e for e in prof.key_averages(group_by_input_shape=True)
             if e.key in (keys or ("aten::miopen_convolution", "aten::convolution_backward", "aten::mm", "aten::addmm",
