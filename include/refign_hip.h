@@ -178,6 +178,12 @@ int rfn_uncertainty9_frontend_f32(const float* corr, const float* weights, float
 unsigned long rfn_sum_rows_workspace_bytes(long S, long n);
 int rfn_sum_rows(const void* x, float* out, void* workspace, long S, long n, int x_dtype, int accumulate,
                  rfn_stream_t stream);
+/* Both of the above for one Linear in two launches instead of three: grad_bias (N) (+)= column sum of grad_y (T, N),
+ * T > 64, workspace = rfn_sum_rows_workspace_bytes(T, N) bytes; grad_weight (N*K) (+)= sum over the S <= 64 slabs of
+ * w_partials (S, N*K).  grad_y and w_partials share `dtype`. */
+int rfn_linear_param_grads(const void* grad_y, float* grad_bias, void* workspace, long T, long N, int acc_bias,
+                           const void* w_partials, float* grad_weight, int S, long NK, int acc_weight, int dtype,
+                           rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Multi-tensor cast float32 -> bfloat16 (round to nearest even) in one launch: refresh of the cached bf16 copies of

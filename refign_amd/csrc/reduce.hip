@@ -87,11 +87,11 @@ __global__ __launch_bounds__(256) void sum_rows_tall_kernel(const T* __restrict_
   }
 }
 
-// flat case / stage 2: thread = 4 adjacent columns, serial over S (fixed order).
+// flat case: thread = 4 adjacent columns, serial over S (fixed order).  `blk` = workgroup index within this job.
 template <typename T>
-__global__ __launch_bounds__(256) void sum_rows_flat_kernel(const T* __restrict__ x, float* __restrict__ out, int S, long n,
-                                                            int accumulate) {
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void sum_rows_flat_body(const T* __restrict__ x, float* __restrict__ out, int S, long n,
+                                                   int accumulate, long blk) {
+  const long i = (blk * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if constexpr (sizeof(T) == 4) {
@@ -116,14 +116,19 @@ __global__ __launch_bounds__(256) void sum_rows_flat_kernel(const T* __restrict_
   *o = make_float4(s0, s1, s2, s3);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void sum_rows_flat_kernel(const T* __restrict__ x, float* __restrict__ out, int S, long n,
+                                                            int accumulate) {
+  sum_rows_flat_body<T>(x, out, S, n, accumulate, blockIdx.x);
+}
+
 // stage 2 of the tall case: the (stripes, n) fp32 partials.  n is small here (<= 2048 columns), so the parallelism
 // has to come from the stripe dimension too: a workgroup is 32 columns x 8 stripe segments (128-byte row reads),
 // LDS combine in a fixed order.
-__global__ __launch_bounds__(256) void sum_rows_partials_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                                int stripes, long n, int accumulate) {
-  __shared__ float part[8][32];
+__device__ __forceinline__ void sum_rows_partials_body(const float* __restrict__ ws, float* __restrict__ out,
+                                                       int stripes, long n, int accumulate, long blk, float (*part)[32]) {
   const int lane = threadIdx.x & 31, seg = threadIdx.x >> 5;
-  const long col = (long)blockIdx.x * 32 + lane;
+  const long col = blk * 32 + lane;
   float s = 0.0f;
   if (col < n) {
 #pragma unroll 4
@@ -137,6 +142,24 @@ __global__ __launch_bounds__(256) void sum_rows_partials_kernel(const float* __r
     if (accumulate) t += out[col];
     out[col] = t;
   }
+}
+
+__global__ __launch_bounds__(256) void sum_rows_partials_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                int stripes, long n, int accumulate) {
+  __shared__ float part[8][32];
+  sum_rows_partials_body(ws, out, stripes, n, accumulate, blockIdx.x, part);
+}
+
+// Both parameter gradients of one Linear in one launch: workgroups [0, nb_bias) finish the bias gradient (stage 2 of
+// the tall column sum of grad_y), the rest reduce the (S, N*K) split-T weight-gradient partials.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_param_grads_kernel(const float* __restrict__ ws, float* __restrict__ gb,
+                                                                 int stripes, long n_b, int acc_b, int nb_bias,
+                                                                 const T* __restrict__ wpart, float* __restrict__ gw,
+                                                                 int S, long n_w, int acc_w) {
+  __shared__ float part[8][32];
+  if ((int)blockIdx.x < nb_bias) sum_rows_partials_body(ws, gb, stripes, n_b, acc_b, blockIdx.x, part);
+  else sum_rows_flat_body<T>(wpart, gw, S, n_w, acc_w, (long)blockIdx.x - nb_bias);
 }
 
 struct TallPlan {
@@ -183,6 +206,34 @@ extern "C" {
 unsigned long rfn_sum_rows_workspace_bytes(long S, long n) {
   if (S <= kFlatMaxS || n <= 0 || n % 8 != 0) return 0;
   return (unsigned long)plan_tall(S, n).stripes * (unsigned long)n * sizeof(float);
+}
+
+// Bias gradient (column sum of grad_y (T, N)) and reduction of the (S, N*K) weight-gradient partials of one Linear:
+// two launches (tall stage 1, then one combined kernel).  T must be > 64 (else call rfn_sum_rows twice).
+int rfn_linear_param_grads(const void* grad_y, float* grad_bias, void* workspace, long T, long N, int acc_bias,
+                           const void* w_partials, float* grad_weight, int S, long NK, int acc_weight, int dtype,
+                           rfn_stream_t stream) {
+  RFN_REQUIRE(grad_y && grad_bias && workspace && w_partials && grad_weight, "rfn_linear_param_grads: null pointer");
+  RFN_REQUIRE(T > kFlatMaxS && N > 0 && N % 8 == 0 && S > 0 && S <= kFlatMaxS && NK > 0 && NK % 8 == 0,
+              "rfn_linear_param_grads: need T > 64, 0 < S <= 64, N and N*K multiples of 8");
+  RFN_REQUIRE(dtype == 0 || dtype == 1, "rfn_linear_param_grads: dtype must be 0 (f32) or 1 (bf16)");
+  hipStream_t st = (hipStream_t)stream;
+  const TallPlan p = plan_tall(T, N);
+  const int nb_bias = cdiv(N, 32), nb_w = cdiv(cdiv(NK, 4), 256);
+  if (dtype == 0) {
+    hipLaunchKernelGGL((sum_rows_tall_kernel<float>), dim3(p.stripes, p.gy), dim3(p.cvb * p.ty), 0, st,
+                       (const float*)grad_y, (float*)workspace, T, N, p.cvb, p.ty, p.rows_per_stripe);
+    hipLaunchKernelGGL((linear_param_grads_kernel<float>), dim3(nb_bias + nb_w), dim3(256), 0, st,
+                       (const float*)workspace, grad_bias, p.stripes, N, acc_bias, nb_bias, (const float*)w_partials,
+                       grad_weight, S, NK, acc_weight);
+  } else {
+    hipLaunchKernelGGL((sum_rows_tall_kernel<__hip_bfloat16>), dim3(p.stripes, p.gy), dim3(p.cvb * p.ty), 0, st,
+                       (const __hip_bfloat16*)grad_y, (float*)workspace, T, N, p.cvb, p.ty, p.rows_per_stripe);
+    hipLaunchKernelGGL((linear_param_grads_kernel<__hip_bfloat16>), dim3(nb_bias + nb_w), dim3(256), 0, st,
+                       (const float*)workspace, grad_bias, p.stripes, N, acc_bias, nb_bias,
+                       (const __hip_bfloat16*)w_partials, grad_weight, S, NK, acc_weight);
+  }
+  return check_launch("linear_param_grads_kernel");
 }
 
 int rfn_sum_rows(const void* x, float* out, void* workspace, long S, long n, int x_dtype, int accumulate,

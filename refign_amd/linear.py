@@ -10,11 +10,16 @@ gradient (column sum of dY) goes through the same kernel.  Weights are used thro
 (params.derived) instead of being re-cast at every call.  Forward and the input gradient stay ordinary library GEMMs.
 Same parameters / state_dict keys as nn.Linear.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .params import as_dtype, compute_dtype, grad_sink, sum_rows
+from .params import as_dtype, compute_dtype, grad_sink, linear_param_grads, sum_rows
+
+
+_FUSED_GRADS = os.environ.get("RFN_LINEAR_FUSED_GRADS", "1") != "0"      # A/B switch (tools)
 
 
 def _split(T):
@@ -44,29 +49,33 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.matmul(gy, w_c)
         g2 = gy.reshape(-1, N)
-        if ctx.needs_input_grad[1]:
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        need_w, need_b = ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]
+        sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
+        part = None
+        if need_w:
             x2 = x.reshape(-1, K)
             T = x2.shape[0]
             S = _split(T)
-            sink = grad_sink(ctx.weight)
             if S > 1:
-                part = torch.bmm(g2.view(S, T // S, N).transpose(1, 2), x2.view(S, T // S, K))     # (S, N, K)
-                if sink is not None:
-                    sum_rows(part.view(S, N * K), out=sink.view(-1), accumulate=True)
-                else:
-                    gw = sum_rows(part.view(S, N * K)).view(N, K)
+                part = torch.bmm(g2.view(S, T // S, N).transpose(1, 2), x2.view(S, T // S, K)).view(S, N * K)
             else:
-                gw = g2.t().mm(x2)
-                if sink is not None:
-                    sink.add_(gw)
-                    gw = None
-        if ctx.bias is not None and ctx.needs_input_grad[2]:
-            sink = grad_sink(ctx.bias)
-            g2c = g2 if g2.is_contiguous() else g2.contiguous()
-            if sink is not None:
-                sum_rows(g2c, out=sink, accumulate=True)
+                part = g2.t().mm(x2).view(1, N * K)
+        # both gradients straight into the flat gradient buffer in two launches
+        if need_w and need_b and sink_w is not None and sink_b is not None and _FUSED_GRADS and \
+                linear_param_grads(g2, part, sink_b, sink_w.view(-1)):
+            return gx, None, None, None, None
+        if need_w:
+            if sink_w is not None:
+                sum_rows(part, out=sink_w.view(-1), accumulate=True)
             else:
-                gb = sum_rows(g2c)
+                gw = sum_rows(part).view(N, K).to(ctx.weight.dtype)
+        if need_b:
+            if sink_b is not None:
+                sum_rows(g2, out=sink_b, accumulate=True)
+            else:
+                gb = sum_rows(g2).to(ctx.bias.dtype)
         return gx, gw, gb, None, None
 
 

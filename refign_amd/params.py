@@ -151,3 +151,21 @@ def sum_rows(x, out=None, accumulate=False):
                               current_stream(x.device))
     _lib.check(rc, "sum_rows")
     return out
+
+
+def linear_param_grads(g2, part, gb_out, gw_out):
+    """One Linear's parameter gradients, accumulated in place: gb_out (N) += column sum of g2 (T, N);
+    gw_out (N*K) += sum over the leading dim of part (S, N*K).  Two launches (csrc/reduce.hip).  Returns False when
+    the shapes are outside the fused kernel's domain (caller falls back to two sum_rows calls)."""
+    T, N = g2.shape
+    S, NK = part.shape
+    if not (g2.is_cuda and g2.dtype == part.dtype and g2.dtype in _DT and T > 64 and S <= 64 and N % 8 == 0
+            and NK % 8 == 0 and g2.is_contiguous() and part.is_contiguous()):
+        return False
+    lib = _lib.load_library()
+    ws = torch.empty(lib.rfn_sum_rows_workspace_bytes(T, N), dtype=torch.uint8, device=g2.device)
+    with torch.cuda.device(g2.device):
+        rc = lib.rfn_linear_param_grads(ptr(g2), ptr(gb_out), ptr(ws), T, N, 1, ptr(part), ptr(gw_out), S, NK, 1,
+                                        _DT[g2.dtype], current_stream(g2.device))
+    _lib.check(rc, "linear_param_grads")
+    return True
