@@ -204,3 +204,18 @@ def test_area_resize_matches_interpolate_area(dev, shape, size):
     x = torch.randn(*shape, device=dev)
     want = torch.nn.functional.interpolate(x, size=size, mode="area")
     assert torch.allclose(area_resize(x, size), want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 128, 7, 9), (1, 128, 64, 65), (2, 256, 5, 13), (1, 256, 33, 31), (2, 512, 16, 16),
+                                     (1, 512, 3, 5), (2, 96, 9, 11), (1, 3, 4, 4)])
+def test_l2_normalize_channels(dev, B, C, H, W):
+    """F.normalize(x, p=2, dim=1) (uawarpc.py:101-108): register-resident kernels for the VGG widths, generic kernel
+    otherwise; ragged pixel counts; an all-zero pixel stays zero (eps = 1e-12 clamp)."""
+    from fill import hashed_uniform
+    from refign_amd.matching import l2_normalize_channels
+    x = T(hashed_uniform((B, C, H, W), f"l2n/{B}/{C}/{H}/{W}") * 4 - 2, dev)
+    x[0, :, 0, 0] = 0
+    got = l2_normalize_channels(x)
+    want = torch.nn.functional.normalize(x, p=2, dim=1)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), float((got - want).abs().max())
+    assert float(got[0, :, 0, 0].abs().max()) == 0.0
