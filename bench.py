@@ -241,6 +241,25 @@ class RefignDAFormerStep(RefignStep):
     use_hrda = False
 
 
+class RefignAlignRefine(RefignStep):
+    """The gradient-free half of the step only -- what the north star's "image-pairs/s align+refine" counts: EMA-teacher
+    forward on (target, reference), align (VGG-16 pyramid, UAWarpC head, logits warp), refine, pseudo-labels
+    (segmentation_model.py:194-224).  Secondary workload: `--workload refign_align_refine_1080x1920`."""
+    name = "refign_align_refine_1080x1920"
+
+    @torch.no_grad()
+    def step(self):
+        import torch.nn.functional as F
+        m, trg, ref = self.model, self.batch["image_trg"], self.batch["image_ref"]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.precision == "bf16"):
+            x = torch.cat((trg, ref))
+            logits = F.interpolate(m.m_head(m.m_backbone(x)), size=x.shape[-2:], mode="bilinear", align_corners=False)
+            l_trg, l_ref = torch.split(logits, [self.b, self.b], dim=0)
+            warped, mask, certs = m.align(l_ref.contiguous(), ref, trg)
+            probs = m.refine(l_trg, warped, mask, certs)
+            return torch.max(probs, dim=1)
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md; separate passes) -- profiles/r01_pmc_traffic_corr9.json; null if absent."""
@@ -252,7 +271,7 @@ def pmc_traffic():
 
 
 WORKLOADS = {AlignRefineKernels.name: AlignRefineKernels, RefignStep.name: RefignStep,
-             RefignDAFormerStep.name: RefignDAFormerStep}
+             RefignDAFormerStep.name: RefignDAFormerStep, RefignAlignRefine.name: RefignAlignRefine}
 
 
 def cpu_baseline(wl, args):
@@ -379,8 +398,10 @@ def main():
     if rank == 0:
         pairs = args.pairs_per_gpu * world * args.steps
         line = {
-            "metric": "image-pairs/s (align+seg fwd+bwd, 1080x1920)" if args.workload != AlignRefineKernels.name
-            else "image-pairs/s (align+refine HIP kernels only, 1080x1920)",
+            "metric": {AlignRefineKernels.name: "image-pairs/s (align+refine HIP kernels only, 1080x1920)",
+                       RefignAlignRefine.name: "image-pairs/s (teacher fwd + align + refine, no student fwd/bwd, "
+                                               "1080x1920)"}.get(args.workload,
+                                                                  "image-pairs/s (align+seg fwd+bwd, 1080x1920)"),
             "value": round(pairs / dt, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
