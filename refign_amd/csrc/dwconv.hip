@@ -34,6 +34,8 @@ struct VecIO<float> {
   typedef float4 Raw;
   __device__ static Raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
   __device__ static void unpack(const Raw& t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  typedef float Pair __attribute__((ext_vector_type(2)));
+  __device__ static void unpack2(const Raw& t, Pair (&v)[2]) { v[0] = Pair{t.x, t.y}; v[1] = Pair{t.z, t.w}; }
   __device__ static void load(const float* p, float (&v)[4]) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -55,6 +57,12 @@ struct VecIO<__hip_bfloat16> {
       v[2 * i] = __uint_as_float(w[i] << 16);
       v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
+  }
+  typedef float Pair __attribute__((ext_vector_type(2)));
+  __device__ static void unpack2(const Raw& t, Pair (&v)[4]) {      // adjacent channels land in adjacent registers
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = Pair{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
   }
   __device__ static void load(const __hip_bfloat16* p, float (&v)[8]) {
     const uint4 t = *reinterpret_cast<const uint4*>(p);
@@ -99,43 +107,53 @@ __device__ __forceinline__ void quad_coords(long quad, int WQ, int H, int dil, i
 // Thread layout (all three kernels): blockDim = 256 = cvb channel-vectors (fastest, so a wave reads contiguous
 // channels) x pl pixel lanes.  A thread keeps ONE channel vector for its whole life -- its 9 x V weights are loaded
 // once -- and walks "quads" (4 consecutive pixels of one image row) with stride gridDim.y * pl.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// zero a packed load when its tap is outside the image (true zero padding; 4 selects instead of one multiply per FMA)
+__device__ __forceinline__ float4 mask_raw(const float4& t, bool ok) {
+  return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ uint4 mask_raw(const uint4& t, bool ok) { return ok ? t : make_uint4(0u, 0u, 0u, 0u); }
+
 template <typename T, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, T* __restrict__ y, int B,
                                                             int H, int W, int C, int dil, int cvb) {
-  constexpr int V = VecIO<T>::N;
+  constexpr int V = VecIO<T>::N, V2 = V / 2;
   const int CV = C / V, WQ = quads_per_row(W, dil);
   const int pl = 256 / cvb;
   const int cv = blockIdx.x * cvb + threadIdx.x % cvb;
   if (cv >= CV) return;
   const int c0 = cv * V;
-  float wr[9][V];   // tap-major weights (9, C): one contiguous fp32 vector per tap
+  // weights, bias and accumulators live as adjacent-channel PAIRS: every multiply-add below is one v_pk_fma_f32
+  f32x2 wr[9][V2];   // tap-major weights (9, C): one contiguous fp32 vector per tap
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     const float* wp = wgt + (size_t)(FLIP ? 8 - k : k) * C + c0;
 #pragma unroll
     for (int i = 0; i < V; i += 4) {
       const float4 t4 = *reinterpret_cast<const float4*>(wp + i);
-      wr[k][i] = t4.x; wr[k][i + 1] = t4.y; wr[k][i + 2] = t4.z; wr[k][i + 3] = t4.w;
+      wr[k][i / 2] = f32x2{t4.x, t4.y};
+      wr[k][i / 2 + 1] = f32x2{t4.z, t4.w};
     }
   }
-  float bs[V];
+  f32x2 bs[V2];
 #pragma unroll
-  for (int i = 0; i < V; ++i) bs[i] = (bias != nullptr) ? bias[c0 + i] : 0.0f;
+  for (int i = 0; i < V2; ++i)
+    bs[i] = (bias != nullptr) ? f32x2{bias[c0 + 2 * i], bias[c0 + 2 * i + 1]} : f32x2{0.0f, 0.0f};
   const long nquads = (long)B * H * WQ;
   for (long quad = (long)blockIdx.y * pl + threadIdx.x / cvb; quad < nquads; quad += (long)gridDim.y * pl) {
     int b, h, w0;
     quad_coords(quad, WQ, H, dil, b, h, w0);
-    float acc[kPX][V];
+    f32x2 acc[kPX][V2];
 #pragma unroll
     for (int p = 0; p < kPX; ++p)
 #pragma unroll
-      for (int i = 0; i < V; ++i) acc[p][i] = bs[i];
+      for (int i = 0; i < V2; ++i) acc[p][i] = bs[i];
     const T* xb = x + (size_t)b * H * W * C + c0;
     // branch-free window: all 18 loads (3 rows x 6 columns, clamped addresses) are issued back to back and the
-    // out-of-image taps are zeroed by a 0/1 factor -- per-tap `if`s made hipcc wait for each load in turn
+    // out-of-image taps are zeroed by a select on the packed data -- per-tap `if`s made hipcc wait for each load in turn
     typename VecIO<T>::Raw raw[3][kPX + 2];            // kept packed (bf16: 4 VGPRs per 8 channels) until used
-    float ok[3][kPX + 2];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int yy = h + (ky - 1) * dil;
@@ -144,28 +162,33 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
 #pragma unroll
       for (int j = 0; j < kPX + 2; ++j) {
         const int xx = w0 + (j - 1) * dil;
-        ok[ky][j] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
-        raw[ky][j] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
+        raw[ky][j] = mask_raw(VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C),
+                              rowok && xx >= 0 && xx < W);
       }
     }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int j = 0; j < kPX + 2; ++j) {
-        float v[V];
-        VecIO<T>::unpack(raw[ky][j], v);
+        f32x2 v[V2];
+        VecIO<T>::unpack2(raw[ky][j], v);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int p = j - kx;                        // output pixel fed by column j through tap kx
           if (p < 0 || p >= kPX) continue;
 #pragma unroll
-          for (int i = 0; i < V; ++i) acc[p][i] = fmaf(wr[ky * 3 + kx][i] * ok[ky][j], v[i], acc[p][i]);
+          for (int i = 0; i < V2; ++i) acc[p][i] = __builtin_elementwise_fma(wr[ky * 3 + kx][i], v[i], acc[p][i]);
         }
       }
     T* yo = y + ((size_t)b * H + h) * W * C + c0;
 #pragma unroll
     for (int p = 0; p < kPX; ++p)
-      if (w0 + p * dil < W) VecIO<T>::store(yo + (size_t)(w0 + p * dil) * C, acc[p]);
+      if (w0 + p * dil < W) {
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V2; ++i) { o[2 * i] = acc[p][i].x; o[2 * i + 1] = acc[p][i].y; }
+        VecIO<T>::store(yo + (size_t)(w0 + p * dil) * C, o);
+      }
   }
 }
 
@@ -182,33 +205,31 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
   const int cv = blockIdx.x * cvb + cvi;
   const bool active = cv < CV;
   const int c0 = cv * V;
-  float aw[9][V], ab[V];
+  constexpr int V2 = V / 2;
+  f32x2 aw[9][V2], ab[V2];          // adjacent-channel pairs: every multiply-add is one v_pk_fma_f32
 #pragma unroll
-  for (int i = 0; i < V; ++i) {
-    ab[i] = 0.0f;
+  for (int i = 0; i < V2; ++i) {
+    ab[i] = f32x2{0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < 9; ++k) aw[k][i] = 0.0f;
+    for (int k = 0; k < 9; ++k) aw[k][i] = f32x2{0.0f, 0.0f};
   }
   if (active) {
     const long nquads = (long)B * H * WQ;
     for (long quad = (long)blockIdx.y * pl + pli; quad < nquads; quad += (long)gridDim.y * pl) {
       int b, h, w0;
       quad_coords(quad, WQ, H, dil, b, h, w0);
-      float g[kPX][V];
+      f32x2 g[kPX][V2];
       const T* gp = gy + (((size_t)b * H + h) * W) * C + c0;
       {
         typename VecIO<T>::Raw graw[kPX];
 #pragma unroll
-        for (int p = 0; p < kPX; ++p) graw[p] = VecIO<T>::load_raw(gp + (size_t)min(w0 + p * dil, W - 1) * C);
+        for (int p = 0; p < kPX; ++p)     // pixels past the row end contribute zero (select on the packed data)
+          graw[p] = mask_raw(VecIO<T>::load_raw(gp + (size_t)min(w0 + p * dil, W - 1) * C), w0 + p * dil < W);
 #pragma unroll
         for (int p = 0; p < kPX; ++p) {
-          VecIO<T>::unpack(graw[p], g[p]);
-          const float m = (w0 + p * dil < W) ? 1.0f : 0.0f;
+          VecIO<T>::unpack2(graw[p], g[p]);
 #pragma unroll
-          for (int i = 0; i < V; ++i) {
-            g[p][i] *= m;
-            ab[i] += g[p][i];
-          }
+          for (int i = 0; i < V2; ++i) ab[i] += g[p][i];
         }
       }
       const T* xb = x + (size_t)b * H * W * C + c0;
@@ -218,23 +239,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
         const bool rowok = yy >= 0 && yy < H;
         const T* xr = xb + (size_t)min(max(yy, 0), H - 1) * W * C;
         typename VecIO<T>::Raw raw[kPX + 2];
-        float ok[kPX + 2];
 #pragma unroll
         for (int j = 0; j < kPX + 2; ++j) {
           const int xx = w0 + (j - 1) * dil;
-          ok[j] = (rowok && xx >= 0 && xx < W) ? 1.0f : 0.0f;
-          raw[j] = VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C);
+          raw[j] = mask_raw(VecIO<T>::load_raw(xr + (size_t)min(max(xx, 0), W - 1) * C), rowok && xx >= 0 && xx < W);
         }
 #pragma unroll
         for (int j = 0; j < kPX + 2; ++j) {
-          float v[V];
-          VecIO<T>::unpack(raw[j], v);
+          f32x2 v[V2];
+          VecIO<T>::unpack2(raw[j], v);
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const int p = j - kx;
             if (p < 0 || p >= kPX) continue;
 #pragma unroll
-            for (int i = 0; i < V; ++i) aw[ky * 3 + kx][i] = fmaf(g[p][i] * ok[j], v[i], aw[ky * 3 + kx][i]);
+            for (int i = 0; i < V2; ++i) aw[ky * 3 + kx][i] = __builtin_elementwise_fma(g[p][i], v[i], aw[ky * 3 + kx][i]);
           }
         }
       }
@@ -245,7 +264,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
   for (int k = 0; k < 10; ++k) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < V; ++i) red[threadIdx.x * V + i] = (k < 9) ? aw[k][i] : ab[i];
+    for (int i = 0; i < V; ++i) {
+      const f32x2 t = (k < 9) ? aw[k][i / 2] : ab[i / 2];
+      red[threadIdx.x * V + i] = (i & 1) ? t.y : t.x;
+    }
     __syncthreads();
     if (pli == 0 && active) {
 #pragma unroll
@@ -265,10 +287,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_reduce_kernel(const 
                                                                           float* __restrict__ dw,
                                                                           float* __restrict__ db, int C, int stripes,
                                                                           int flags) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 10 * C) return;
+  // 32 columns x 8 stripe segments per workgroup (the stripe dimension has to supply parallelism: 10*C columns are
+  // only 50 workgroups of 256 at C = 1280), LDS combine in a fixed order
+  __shared__ float part[8][32];
+  const int lane = threadIdx.x & 31, seg = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + lane;
   float s = 0.0f;
-  for (int t = 0; t < stripes; ++t) s += ws[(size_t)t * 10 * C + idx];
+  if (idx < 10 * C) {
+#pragma unroll 4
+    for (int t = seg; t < stripes; t += 8) s += ws[(size_t)t * 10 * C + idx];
+  }
+  part[seg][lane] = s;
+  __syncthreads();
+  if (seg != 0 || idx >= 10 * C) return;
+  s = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+      ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
   float* dst;
   if (idx < 9 * C) {
     const int k = idx / C, c = idx - k * C;
@@ -310,7 +343,7 @@ static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db
   hipLaunchKernelGGL((dwconv3x3_bwd_weight_kernel<T>), dim3(gx, stripes), dim3(256), 0, st, (const T*)x, (const T*)gy,
                      ws, B, H, W, C, dil, cvb);
   if (int rc = check_launch("dwconv3x3_bwd_weight_kernel")) return rc;
-  hipLaunchKernelGGL(dwconv3x3_bwd_weight_reduce_kernel, dim3(cdiv(10L * C, 256)), dim3(256), 0, st, ws, dw, db, C,
+  hipLaunchKernelGGL(dwconv3x3_bwd_weight_reduce_kernel, dim3(cdiv(10L * C, 32)), dim3(256), 0, st, ws, dw, db, C,
                      stripes, flags);
   return check_launch("dwconv3x3_bwd_weight_reduce_kernel");
 }

@@ -84,6 +84,18 @@ class Mlp(nn.Module):
         return self.drop(self.fc2(x))
 
 
+def _sdpa_backend():
+    name = os.environ.get("RFN_SDPA_BACKEND")
+    if not name:
+        return None
+    from torch.nn.attention import SDPBackend
+    return {"flash": SDPBackend.FLASH_ATTENTION, "efficient": SDPBackend.EFFICIENT_ATTENTION,
+            "math": SDPBackend.MATH}[name]
+
+
+_SDPA_BACKEND = _sdpa_backend()
+
+
 class Attention(nn.Module):
     """Efficient self-attention with spatial-reduction K/V (mix_transformer.py:106-164)."""
 
@@ -113,7 +125,11 @@ class Attention(nn.Module):
         # copies and an add
         k, v = self.kv(x).view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4).unbind(0)   # (B,h,Nkv,d) each
         p = self.attn_drop.p if self.training else 0.0
-        o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
+        if _SDPA_BACKEND is None:
+            o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
+        else:                                          # measurement knob: RFN_SDPA_BACKEND=flash|efficient|math
+            with torch.nn.attention.sdpa_kernel([_SDPA_BACKEND]):
+                o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
         return self.proj_drop(self.proj(o.transpose(1, 2).reshape(B, N, C)))
 
 
