@@ -143,6 +143,202 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Vectorised layout (C % 8 == 0, every MiT width): a lane owns 8 ADJACENT channels per vector (one 16-byte load for
+// bf16, two for fp32) instead of 8 channels strided by 64 (eight 2-byte loads: 128 bytes per wave-load).  A row takes
+// LPR = 8/16/32/64 lanes, so narrow rows share a wave (C = 64: 8 rows per wave) and reductions are shuffles inside the
+// LPR-lane group.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void ld8<__hip_bfloat16>(const __hip_bfloat16* p, float (&v)[8]) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+  const unsigned u = __float_as_uint(f);
+  return ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void st8<__hip_bfloat16>(__hip_bfloat16* p, const float (&v)[8]) {
+  uint4 t;
+  t.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+  t.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+  t.z = bf16_rne(v[4]) | (bf16_rne(v[5]) << 16);
+  t.w = bf16_rne(v[6]) | (bf16_rne(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = t;
+}
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename TI, typename TO, int LPR, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, TO* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                long rows, int C, float eps) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
+  float g[NV][8], b[NV][8];
+  bool act[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (sub + LPR * j) * 8;
+    act[j] = c < C;
+    ld8<float>(gamma + (act[j] ? c : 0), g[j]);      // two 16-byte loads each (c is a multiple of 8)
+    ld8<float>(beta + (act[j] ? c : 0), b[j]);
+  }
+  const float invC = 1.0f / (float)C;
+  for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < rows; r0 += (long)gridDim.x * 4 * RPW) {
+    const long r = r0 + grp;
+    const bool valid = r < rows;
+    float v[NV][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (valid && act[j]) ld8<TI>(x + r * C + (sub + LPR * j) * 8, v[j]);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[j][i] = 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[j][i];
+    }
+    const float mu = group_sum<LPR>(s) * invC;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = act[j] ? v[j][i] - mu : 0.0f;
+        q = fmaf(d, d, q);
+      }
+    const float rs = rsqrtf(group_sum<LPR>(q) * invC + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (valid && act[j]) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaf((v[j][i] - mu) * rs, g[j][i], b[j][i]);
+        st8<TO>(y + r * C + (sub + LPR * j) * 8, o);
+      }
+    if (valid && sub == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+  }
+}
+
+template <typename TX, typename TG, int LPR, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TX* __restrict__ x, const TG* __restrict__ gy,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, TX* __restrict__ dx,
+                                                                float* __restrict__ ws, long rows, int C) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
+  float gm[NV][8], dg[NV][8], db[NV][8];
+  bool act[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (sub + LPR * j) * 8;
+    act[j] = c < C;
+    ld8<float>(gamma + (act[j] ? c : 0), gm[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dg[j][i] = 0.0f;
+      db[j][i] = 0.0f;
+    }
+  }
+  const float invC = 1.0f / (float)C;
+  for (long r0 = ((long)blockIdx.x * 4 + wave) * RPW; r0 < rows; r0 += (long)gridDim.x * 4 * RPW) {
+    const long r = r0 + grp;
+    const bool valid = r < rows;
+    const float mu = valid ? mean[r] : 0.0f, rs = valid ? rstd[r] : 0.0f;
+    float xh[NV][8], gg[NV][8];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float xv[8], gv[8];
+      if (valid && act[j]) {
+        ld8<TX>(x + r * C + (sub + LPR * j) * 8, xv);
+        ld8<TG>(gy + r * C + (sub + LPR * j) * 8, gv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xv[i] = mu; gv[i] = 0.0f; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xh[j][i] = (xv[i] - mu) * rs;
+        gg[j][i] = gv[i] * gm[j][i];
+        s1 += gg[j][i];
+        s2 = fmaf(gg[j][i], xh[j][i], s2);
+        dg[j][i] = fmaf(gv[i], xh[j][i], dg[j][i]);
+        db[j][i] += gv[i];
+      }
+    }
+    s1 = group_sum<LPR>(s1) * invC;
+    s2 = group_sum<LPR>(s2) * invC;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (valid && act[j]) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rs * (gg[j][i] - s1 - xh[j][i] * s2);
+        st8<TX>(dx + r * C + (sub + LPR * j) * 8, o);
+      }
+  }
+  // the RPW row groups of a wave hold partials for the same channels: fold them, then the 4 waves through LDS
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        dg[j][i] += __shfl_xor(dg[j][i], o, 64);
+        db[j][i] += __shfl_xor(db[j][i], o, 64);
+      }
+    }
+  __shared__ float red[4][2][64 * 8 * NV];
+  if (grp == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = (sub + LPR * j) * 8 + i;
+        red[wave][0][c] = dg[j][i];
+        red[wave][1][c] = db[j][i];
+      }
+  }
+  __syncthreads();
+  float* row = ws + (size_t)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int which = c / C, cc = c % C;
+    row[c] = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+  }
+}
+
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ ws,
                                                                    float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta, int C, int nblocks,
@@ -169,6 +365,19 @@ static inline int ln_grid(long rows, int cap) { return (int)std::max<long>(1, st
 template <typename TI, typename TO>
 static int ln_fwd_dispatch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, long rows,
                            int C, float eps, hipStream_t st) {
+  if (C % 8 == 0) {
+#define RFN_LN_FWDV(LPR, NV)                                                                                         \
+  hipLaunchKernelGGL((layernorm_fwd_vec_kernel<TI, TO, LPR, NV>),                                                    \
+                     dim3((int)std::max<long>(1, std::min<long>(cdiv(rows, 4 * (64 / LPR)), 256 * 16))), dim3(256), \
+                     0, st, (const TI*)x, g, b, (TO*)y, mean, rstd, rows, C, eps)
+    if (C <= 64) RFN_LN_FWDV(8, 1);
+    else if (C <= 128) RFN_LN_FWDV(16, 1);
+    else if (C <= 256) RFN_LN_FWDV(32, 1);
+    else if (C <= 512) RFN_LN_FWDV(64, 1);
+    else RFN_LN_FWDV(64, 2);
+#undef RFN_LN_FWDV
+    return check_launch("layernorm_fwd_vec_kernel");
+  }
   const int grid = ln_grid(rows, 256 * 16), npl = cdiv(C, 64);
 #define RFN_LN_FWD(N)                                                                                             \
   hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO, N>), dim3(grid), dim3(256), 0, st, (const TI*)x, g, b, (TO*)y, \
@@ -186,7 +395,20 @@ template <typename TX, typename TG>
 static int ln_bwd_dispatch(const void* x, const void* gy, const float* g, const float* mean, const float* rstd,
                            void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, int accumulate,
                            hipStream_t st) {
-  const int grid = ln_grid(rows, kLnMaxBlocks), npl = cdiv(C, 64);
+  int grid = ln_grid(rows, kLnMaxBlocks);
+  const int npl = cdiv(C, 64);
+  if (C % 8 == 0) {
+#define RFN_LN_BWDV(LPR, NV)                                                                                        \
+  grid = (int)std::max<long>(1, std::min<long>(cdiv(rows, 4 * (64 / LPR)), kLnMaxBlocks));                         \
+  hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TX, TG, LPR, NV>), dim3(grid), dim3(256), 0, st, (const TX*)x,      \
+                     (const TG*)gy, g, mean, rstd, (TX*)dx, ws, rows, C)
+    if (C <= 64) { RFN_LN_BWDV(8, 1); }
+    else if (C <= 128) { RFN_LN_BWDV(16, 1); }
+    else if (C <= 256) { RFN_LN_BWDV(32, 1); }
+    else if (C <= 512) { RFN_LN_BWDV(64, 1); }
+    else { RFN_LN_BWDV(64, 2); }
+#undef RFN_LN_BWDV
+  } else {
 #define RFN_LN_BWD(N)                                                                                              \
   hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TG, N>), dim3(grid), dim3(256), 0, st, (const TX*)x, (const TG*)gy, \
                      g, mean, rstd, (TX*)dx, ws, rows, C)
@@ -196,6 +418,7 @@ static int ln_bwd_dispatch(const void* x, const void* gy, const float* g, const 
   else if (npl <= 8) RFN_LN_BWD(8);
   else RFN_LN_BWD(16);
 #undef RFN_LN_BWD
+  }
   if (int rc = check_launch("layernorm_bwd_kernel")) return rc;
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(2L * C, 64)), dim3(256), 0, st, ws, dgamma, dbeta, C,
                      grid, accumulate);

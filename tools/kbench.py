@@ -89,6 +89,17 @@ def main():
                 os.environ["RFN_UNCERT_FUSED"] = "0"
                 add(f"uncertainty9 front end library chain {lvl} {H}x{W}", timeit(lambda: um.patch_statistics(corr), reps=3), 4 * npx * 87, fl)
                 del os.environ["RFN_UNCERT_FUSED"]
+    if not args.only or "ln" in args.only:
+        from refign_amd.layernorm import layer_norm
+        for (nrow, C) in [(129600, 64), (32640, 128), (8160, 320), (2040, 512), (8160, 1024)]:
+            x = torch.randn(nrow, C, device=dev).bfloat16().requires_grad_()
+            w = torch.ones(C, device=dev, requires_grad=True)
+            bb = torch.zeros(C, device=dev, requires_grad=True)
+            with torch.no_grad():
+                add(f"layernorm fwd {nrow}x{C} bf16", timeit(lambda: layer_norm(x, w, bb, 1e-6, torch.bfloat16)), 4 * nrow * C)
+            y = layer_norm(x, w, bb, 1e-6, torch.bfloat16)
+            gy = torch.randn_like(y)
+            add(f"layernorm bwd {nrow}x{C} bf16", timeit(lambda: torch.autograd.grad(y, (x, w, bb), gy, retain_graph=True)), 6 * nrow * C)
     if not args.only or "sum" in args.only:
         from refign_amd.params import sum_rows
         for (S, n, dt) in [(8160, 320, torch.bfloat16), (8160, 1280, torch.bfloat16), (32640, 128, torch.bfloat16),
