@@ -30,6 +30,7 @@ import torch.nn.functional as F
 from . import align as align_mod
 from . import refine as refine_mod
 from ._tensor import const_tensor, upload_async
+from .graphs import GraphedNoGrad
 from .params import refresh as refresh_derived
 from .config import instantiate_class
 from .seg import hrda_backbone, hrda_head
@@ -226,6 +227,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
         self._scheduler = None
         self._backward = None           # set by the trainer: callable(loss, retain_graph)
         self.logged = {}
+        # hipGraph replay of the gradient-free halves (eager until warmed up; eager for good if capture fails)
+        self._graphs = {"teacher_backbone": GraphedNoGrad(self._teacher_backbone, "teacher backbone"),
+                        "align_refine": GraphedNoGrad(self._align_refine, "align + refine")}
+        if self.enable_fdist:
+            self._graphs["imnet_features"] = GraphedNoGrad(self._imnet_features, "ImageNet features")
         self.load_weights(pretrained)
 
     # -- trainer hooks (what Lightning provides in the reference) ---------------------------------------------------
@@ -292,17 +298,9 @@ class DomainAdaptationSegmentationModel(nn.Module):
             else:
                 adapt_to_ref, images_trg = False, batch['image_trg']
             if self.use_refign and not adapt_to_ref:
-                images_ref = batch['image_ref']
-                b = images_trg.shape[0]
-                m_input = torch.cat((images_trg, images_ref))
-                m_logits = self.m_head(self.m_backbone(m_input))
-                m_logits = F.interpolate(m_logits, size=m_input.shape[-2:], mode='bilinear', align_corners=False)
-                m_logits_trg, m_logits_ref = torch.split(m_logits, [b, b], dim=0)
-                if self.use_align:
-                    warped, warp_mask, warp_certs = self.align(m_logits_ref.contiguous(), images_ref, images_trg)
-                    m_probs_trg = self.refine(m_logits_trg, warped, warp_mask, warp_certs)
-                else:
-                    m_probs_trg = self.refine(m_logits_trg, m_logits_ref, None, None)
+                # teacher forward on (target, reference) + align + refine: gradient-free and shape-static, mostly
+                # replayed from hipGraphs after the first eager call (refign_amd/graphs.py)
+                m_probs_trg = self._teacher_align_refine(images_trg, batch['image_ref'])
             else:
                 m_logits_trg = self.m_head(self.m_backbone(images_trg))
                 m_logits_trg = F.interpolate(m_logits_trg, size=images_trg.shape[-2:], mode='bilinear',
@@ -329,6 +327,44 @@ class DomainAdaptationSegmentationModel(nn.Module):
         opt.step()
         sch.step()
         self.global_step += 1
+
+    def _teacher_align_refine(self, images_trg, images_ref):
+        """segmentation_model.py:201-213: EMA-teacher logits of (target, reference), warp of the reference logits onto
+        the target (align), adaptive label correction (refine) -> refined target probabilities.  The teacher backbone
+        and align + refine replay from hipGraphs (refign_amd/graphs.py); the decode head in between stays eager: its
+        BatchNorms run in train mode (D9), i.e. they are collectives under DDP with sync_batchnorm."""
+        b = images_trg.shape[0]
+        m_input = torch.cat((images_trg, images_ref))
+        m_logits = self.m_head(self._graphs["teacher_backbone"](m_input))
+        m_logits = F.interpolate(m_logits, size=m_input.shape[-2:], mode='bilinear', align_corners=False)
+        m_logits_trg, m_logits_ref = torch.split(m_logits, [b, b], dim=0)
+        if self.use_align:
+            return self._graphs["align_refine"](m_logits_trg.contiguous(), m_logits_ref.contiguous(), images_ref,
+                                                images_trg)
+        return self.refine(m_logits_trg, m_logits_ref, None, None)
+
+    def _align_refine(self, logits_trg, logits_ref, images_ref, images_trg):
+        warped, warp_mask, warp_certs = self.align(logits_ref, images_ref, images_trg)
+        return self.refine(logits_trg, warped, warp_mask, warp_certs)
+
+    def _teacher_backbone(self, x):
+        return self.m_backbone(x)
+
+    def _imnet_features(self, img):
+        f = self.imnet_backbone(img)
+        return [t.detach() for t in f] if isinstance(f, Sequence) else [f.detach()]
+
+    def _reset_graphs(self):
+        for g in getattr(self, "_graphs", {}).values():
+            g.reset()
+
+    def _apply(self, fn, *a, **k):
+        self._reset_graphs()                         # .to() / .cuda() / .half(): cached copies and buffers move
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._reset_graphs()
+        return super().load_state_dict(*a, **k)
 
     # -- inference (:304-382) ------------------------------------------------------------------------------------
     def forward(self, x, out_size=None):
@@ -445,8 +481,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
         with torch.no_grad():
             if self.use_hrda:
                 img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
-            feat_imnet = self.imnet_backbone(img)
-            feat_imnet = [f.detach() for f in feat_imnet] if isinstance(feat_imnet, Sequence) else [feat_imnet.detach()]
+            feat_imnet = self._graphs["imnet_features"](img) if "imnet_features" in self._graphs \
+                else self._imnet_features(img)
         if not isinstance(feat, Sequence):
             feat = [feat]
         if self.fdist_classes is not None:
@@ -518,6 +554,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         """(:691-701) alignment nets and the ImageNet encoder always in eval; the reference's attempt to disable
         dropout/drop-path of the teacher tests the TOP-LEVEL modules only and therefore changes nothing (D7)."""
         super().train(mode=mode)
+        self._reset_graphs()                         # folded-BN caches and mode-dependent paths are re-made
         for m in filter(None, [self.alignment_backbone, self.alignment_head]):
             m.eval()
         if self.enable_fdist:

@@ -75,3 +75,52 @@ def test_training_step_matches_reference(dev, use_hrda, name, blk):
     assert abs(ema - float(g["ema_abs_sum"])) < 1e-5 * float(g["ema_abs_sum"])
     assert abs(live - float(g["live_abs_sum"])) < 1e-5 * float(g["live_abs_sum"])
     assert model.global_step == 4
+
+
+@pytest.mark.parametrize("use_hrda", [False, True])
+def test_hipgraph_replay_equals_eager(dev, use_hrda, monkeypatch):
+    """refign_amd/graphs.py: the captured teacher backbone, align + refine and ImageNet-feature graphs replay what the eager
+    code gives on the same inputs -- also after the weights were updated in place (EMA + cached bf16 copies) and for
+    inputs that differ from the ones seen at capture."""
+    monkeypatch.setenv("RFN_HIP_GRAPH", "1")
+    model = build(use_hrda, dev)
+    H, W = (128, 128) if use_hrda else (96, 128)
+    g = torch.Generator().manual_seed(5)
+    imnet = model._graphs["imnet_features"]
+
+    def pair(k):
+        trg = torch.randn(2, 3, H, W, generator=g)
+        ref = 0.8 * torch.roll(trg, (2, -3), (2, 3)) + 0.2 * torch.randn(2, 3, H, W, generator=g)
+        return trg.to(dev), ref.to(dev)
+
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for it in range(4):
+            trg, ref = pair(it)
+            if it == 2:                                  # in-place weight update between replays, as a step does
+                for p in model.ema_parameters():
+                    p.data.mul_(1.01)
+                from refign_amd.params import refresh
+                refresh(model.ema_parameters())
+            got = model._teacher_align_refine(trg, ref).clone().float()          # graphs on (env)
+            monkeypatch.setenv("RFN_HIP_GRAPH", "0")
+            want = model._teacher_align_refine(trg, ref).float()                  # pure eager, twice
+            again = model._teacher_align_refine(trg, ref).float()
+            monkeypatch.setenv("RFN_HIP_GRAPH", "1")
+            assert got.shape == want.shape == (2, 19, H, W)
+            # the eager path itself is not bit-reproducible (fp16 / bf16 library convolutions with atomics feed a
+            # sub-pixel flow): the replay has to sit inside the eager call-to-call noise
+            noise = float((again - want).abs().mean())
+            err = float((got - want).abs().mean())
+            assert err <= 3.0 * noise + 1e-4, (it, err, noise)
+            assert float((got.argmax(1) == want.argmax(1)).float().mean()) >= \
+                float((again.argmax(1) == want.argmax(1)).float().mean()) - 0.01
+            f_got = [t.clone() for t in imnet(trg)]
+            f_want = model._imnet_features(trg)
+            for a, b in zip(f_got, f_want):
+                assert float((a.float() - b.float()).abs().max()) <= 2e-2 * max(1.0, float(b.float().abs().max()))
+    for name, graphed in model._graphs.items():
+        st = [s for s in graphed.states.values()]
+        assert len(st) == 1 and st[0]["graph"] is not None and not st[0]["failed"], f"{name}: capture did not happen"
+    # train()/eval() (folded-BN caches are re-made) drops the captures
+    model.train()
+    assert all(len(g_.states) == 0 for g_ in model._graphs.values())

@@ -20,6 +20,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--workload", default="refign_hrda_step_1080x1920")
 ap.add_argument("--rows", type=int, default=45)
 ap.add_argument("--shapes", action="store_true")
+ap.add_argument("--cpu", action="store_true", help="rank ops by host (self CPU) time instead of device time")
 ap.add_argument("--stacks", default="", help="aten op name: list its call sites (python stacks) by launch count")
 ap.add_argument("--ops", default="", help="comma-separated aten op names for --shapes (default: the dense ops)")
 a = ap.parse_args()
@@ -57,6 +58,13 @@ elif a.shapes:
     rows.sort(key=lambda e: -e.self_device_time_total)
     for e in rows[:a.rows]:
         print(f"{e.self_device_time_total / 1e3:9.2f} ms  n={e.count:4d}  {e.key:34s} {str(e.input_shapes)[:150]}")
+elif a.cpu:
+    evs = sorted(prof.key_averages(), key=lambda e: -e.self_cpu_time_total)
+    tot = sum(e.self_cpu_time_total for e in evs)
+    print(f"total self CPU time {tot / 1e3:.1f} ms (all threads)")
+    for e in evs[:a.rows]:
+        print(f"{e.self_cpu_time_total / 1e3:9.2f} ms {100 * e.self_cpu_time_total / tot:5.1f}%  n={e.count:5d}  "
+              f"{e.self_cpu_time_total / max(e.count, 1):7.1f} us/call  {e.key[:90]}")
 else:
     evs = sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)
     tot = sum(e.self_device_time_total for e in evs)
