@@ -82,6 +82,8 @@ class GraphedNoGrad:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: calls made by other host threads during the capture (the RCCL watchdog of torch.distributed
+        # polls its events) must not invalidate it
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             outputs = self.fn(*inputs)
         st["graph"], st["inputs"], st["outputs"] = g, inputs, outputs
