@@ -27,10 +27,51 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
 def current_stream(device):
     """Raw hipStream_t of torch's current stream on `device` (the reference launches on the legacy default
-    stream, correlation_cuda_kernel.cu:271; we honour torch's stream semantics instead so graphs/streams work)."""
-    return torch.cuda.current_stream(device).cuda_stream
+    stream, correlation_cuda_kernel.cu:271; we honour torch's stream semantics instead so graphs/streams work).
+    Straight from the C binding: this sits on the launch path of ~3 000 kernel calls per training step."""
+    return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """`with on_device(dev):` == `with torch.cuda.device(dev):` without the guard's cost when `dev` already is the
+    current device (always, with one process per GPU)."""
+    if device.index is None or torch.cuda.current_device() == device.index:
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Scratch buffer for kernels that run back to back on one stream: a cached per-device allocation that only grows,
+    instead of a caching-allocator round trip per call.  NOT for results, and not while a graph is being captured
+    (captured kernels keep their pointers: they get a private allocation)."""
+    if nbytes <= 0:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    key = (device, _raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS[key] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
+    return buf
 
 
 _CONSTS = {}

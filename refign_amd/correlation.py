@@ -15,7 +15,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
 from . import _lib
-from ._tensor import current_stream, ptr, require_device_tensor, same_device
+from ._tensor import current_stream, ptr, require_device_tensor, same_device, on_device
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 
@@ -49,7 +49,7 @@ def forward(input1, input2, kH, kW, patchH, patchW, padH, padW, dilationH, dilat
     out = torch.empty((B, patchH, patchW, oH, oW), dtype=input1.dtype, device=dev)
     lib = _lib.load_library()
     fn = getattr(lib, "rfn_corr_fwd_" + _suffix(input1))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = fn(ptr(input1), ptr(input2), ptr(out), B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilationH,
                 dilationW, dilation_patchH, dilation_patchW, dH, dW, current_stream(dev))
     _lib.check(rc, "correlation.forward")
@@ -72,7 +72,7 @@ def backward(input1, input2, grad_output, kH, kW, patchH, patchW, padH, padW, di
     g2 = torch.empty_like(input2)
     lib = _lib.load_library()
     fn = getattr(lib, "rfn_corr_bwd_" + _suffix(input1))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = fn(ptr(input1), ptr(input2), ptr(grad_output), ptr(g1), ptr(g2), B, C, iH, iW, kH, kW, patchH, patchW,
                 padH, padW, dilationH, dilationW, dilation_patchH, dilation_patchW, dH, dW, current_stream(dev))
     _lib.check(rc, "correlation.backward")
@@ -137,7 +137,7 @@ def local_correlation_layer(feature_source, feature_target, flow=None, single_ke
         feature_source, flow = warp_nocheck(feature_source, flow), None
     out = torch.empty((B, 81, H, W), dtype=torch.float32, device=dev)
     lib = _lib.load_library()
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = lib.rfn_local_corr_layer_f32(ptr(feature_target), ptr(feature_source), ptr(flow), ptr(out), B, C, H, W,
                                           current_stream(dev))
     _lib.check(rc, "local_correlation_layer")

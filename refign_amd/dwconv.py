@@ -8,17 +8,18 @@ parameter itself, shape (C, 1, 3, 3); activations float32 or bfloat16, accumulat
 import torch
 
 from . import _lib
-from ._tensor import current_stream, ptr, require_device_tensor
+from ._tensor import current_stream, on_device, ptr, require_device_tensor, workspace
 from .params import as_dtype, derived, grad_sink
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
+_DW_WS_STRIPES = 128       # kMaxStripes in csrc/dwconv.hip (checked against the ABI in the GPU tests)
 
 
 def _fwd(x, w_tap, bias, dilation, flip):
     B, H, W, C = x.shape
     y = torch.empty_like(x)
     lib = _lib.load_library()
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         rc = lib.rfn_dwconv3x3_nhwc_fwd(ptr(x), ptr(w_tap), ptr(bias), ptr(y), B, H, W, C, dilation, _DT[x.dtype],
                                         1 if flip else 0, current_stream(x.device))
     _lib.check(rc, "dwconv3x3_nhwc_fwd")
@@ -60,8 +61,8 @@ class _DWConv3x3(torch.autograd.Function):
                 dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
                 db = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
             lib = _lib.load_library()
-            ws = torch.empty(lib.rfn_dwconv3x3_bwd_weight_workspace_bytes(C), dtype=torch.uint8, device=x.device)
-            with torch.cuda.device(x.device):
+            ws = workspace(_DW_WS_STRIPES * 10 * C * 4, x.device)   # == rfn_dwconv3x3_bwd_weight_workspace_bytes(C)
+            with on_device(x.device):
                 rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), ptr(ws), B, H, W, C,
                                                        ctx.dilation, _DT[x.dtype], 3 if direct else 0,
                                                        current_stream(x.device))

@@ -10,10 +10,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from ._tensor import current_stream, ptr
+from ._tensor import current_stream, on_device, ptr, workspace
 from .params import as_dtype, grad_sink
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
+_LN_WS_ROWS = 256          # kLnMaxBlocks in csrc/layernorm.hip (checked against the ABI in the GPU tests)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -28,7 +29,7 @@ class _LayerNormFn(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         lib = _lib.load_library()
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             rc = lib.rfn_layernorm_fwd(ptr(x2), ptr(w32), ptr(b32), ptr(y), ptr(mean), ptr(rstd), rows, C, float(eps),
                                        _DT[x2.dtype], _DT[out_dtype], current_stream(x.device))
         _lib.check(rc, "layernorm_fwd")
@@ -51,8 +52,8 @@ class _LayerNormFn(torch.autograd.Function):
         dg = sg if direct else torch.empty(C, dtype=torch.float32, device=x2.device)
         db = sb if direct else torch.empty(C, dtype=torch.float32, device=x2.device)
         lib = _lib.load_library()
-        ws = torch.empty(lib.rfn_layernorm_bwd_workspace_bytes(C), dtype=torch.uint8, device=x2.device)
-        with torch.cuda.device(x2.device):
+        ws = workspace(_LN_WS_ROWS * 2 * C * 4, x2.device)     # == rfn_layernorm_bwd_workspace_bytes(C)
+        with on_device(x2.device):
             rc = lib.rfn_layernorm_bwd(ptr(x2), ptr(gy2), ptr(w32), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db),
                                        ptr(ws), rows, C, _DT[x2.dtype], _DT[gy2.dtype], 1 if direct else 0,
                                        current_stream(x2.device))

@@ -3,7 +3,7 @@ backed by the HIP kernels in csrc/warp.hip.  Same names, argument meaning and re
 import torch
 
 from . import _lib
-from ._tensor import current_stream, ptr, require_device_tensor, same_device
+from ._tensor import current_stream, ptr, require_device_tensor, same_device, on_device
 
 
 def warp(x, flo, padding_mode='zeros', return_mask=False):
@@ -35,7 +35,7 @@ def warp_nocheck(x, flo, return_mask=False):
     out = torch.empty_like(x)
     mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev) if return_mask else None
     lib = _lib.load_library()
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = lib.rfn_warp_f32(ptr(x), ptr(flo), ptr(out), ptr(mask), B, C, H, W, current_stream(dev))
     _lib.check(rc, "warp")
     if return_mask:
@@ -50,7 +50,7 @@ def l2_normalize_channels(x):
     hw = x[0, 0].numel()
     out = torch.empty_like(x)
     lib = _lib.load_library()
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         rc = lib.rfn_l2norm_channels_f32(ptr(x), ptr(out), B, C, hw, current_stream(x.device))
     _lib.check(rc, "l2_normalize_channels")
     return out
@@ -69,7 +69,7 @@ def uncertainty9_frontend(corr, packed_weights):
                            % lib.rfn_uncertainty9_weights_len())
     same_device(corr, w)
     out = torch.empty((B, 6, H, W), dtype=torch.float32, device=corr.device)
-    with torch.cuda.device(corr.device):
+    with on_device(corr.device):
         rc = lib.rfn_uncertainty9_frontend_f32(ptr(corr), ptr(w), ptr(out), B, H, W, current_stream(corr.device))
     _lib.check(rc, "uncertainty9_frontend")
     return out
@@ -81,7 +81,7 @@ def area_resize(x, size):
     B, C, H, W = x.shape
     out = torch.empty((B, C, size[0], size[1]), dtype=torch.float32, device=x.device)
     lib = _lib.load_library()
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         rc = lib.rfn_area_resize_f32(ptr(x), ptr(out), B * C, H, W, size[0], size[1], current_stream(x.device))
     _lib.check(rc, "area_resize")
     return out
@@ -128,7 +128,7 @@ def align_tail(logits_ref, flow_q, logvar_q, return_flow=False):
     cert = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
     flow_up = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev) if return_flow else None
     lib = _lib.load_library()
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = lib.rfn_align_tail_f32(ptr(logits_ref), ptr(flow_q), ptr(logvar_q), ptr(warped), ptr(mask), ptr(cert),
                                     ptr(flow_up), B, C, H, W, h, w, current_stream(dev))
     _lib.check(rc, "align_tail")

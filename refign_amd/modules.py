@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._tensor import current_stream, ptr, require_device_tensor, same_device
+from ._tensor import current_stream, ptr, require_device_tensor, same_device, on_device
 from .correlation import local_correlation_layer, spatial_correlation_sample
 
 
@@ -50,7 +50,7 @@ class GlobalFeatureCorrelationLayer(nn.Module):
             raise RuntimeError("GlobalFeatureCorrelationLayer: batch/channel mismatch")
         out = torch.empty((B, hs * ws, ht, wt), dtype=torch.float32, device=dev)
         lib = _lib.load_library()
-        with torch.cuda.device(dev):
+        with on_device(dev):
             rc = lib.rfn_global_corr_layer_f32(ptr(fs), ptr(ft), ptr(out), B, C, hs, ws, ht, wt,
                                                1 if self.cyclic_consistency else 0, current_stream(dev))
         _lib.check(rc, "GlobalFeatureCorrelationLayer")

@@ -12,7 +12,7 @@ import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from . import _lib
-from ._tensor import current_stream, ptr
+from ._tensor import current_stream, on_device, ptr, workspace
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
@@ -93,7 +93,7 @@ def _multi_cast(dst, src, dev):
         if len(_CAST_TABLES) >= 16:
             _CAST_TABLES.clear()
         ent = _CAST_TABLES[key] = (table, len(rows))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = lib.rfn_multi_cast_f32_bf16(ptr(ent[0]), ent[1], current_stream(dev))
     _lib.check(rc, "multi_cast_f32_bf16")
 
@@ -145,8 +145,8 @@ def sum_rows(x, out=None, accumulate=False):
         out, accumulate = torch.empty(n, dtype=torch.float32, device=x.device), False
     lib = _lib.load_library()
     nb = lib.rfn_sum_rows_workspace_bytes(S, n)
-    ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
-    with torch.cuda.device(x.device):
+    ws = workspace(nb, x.device)
+    with on_device(x.device):
         rc = lib.rfn_sum_rows(ptr(x), ptr(out), ptr(ws), S, n, _DT[x.dtype], 1 if accumulate else 0,
                               current_stream(x.device))
     _lib.check(rc, "sum_rows")
@@ -163,8 +163,8 @@ def linear_param_grads(g2, part, gb_out, gw_out):
             and NK % 8 == 0 and g2.is_contiguous() and part.is_contiguous()):
         return False
     lib = _lib.load_library()
-    ws = torch.empty(lib.rfn_sum_rows_workspace_bytes(T, N), dtype=torch.uint8, device=g2.device)
-    with torch.cuda.device(g2.device):
+    ws = workspace(lib.rfn_sum_rows_workspace_bytes(T, N), g2.device)
+    with on_device(g2.device):
         rc = lib.rfn_linear_param_grads(ptr(g2), ptr(gb_out), ptr(ws), T, N, 1, ptr(part), ptr(gw_out), S, NK, 1,
                                         _DT[g2.dtype], current_stream(g2.device))
     _lib.check(rc, "linear_param_grads")

@@ -3,7 +3,7 @@ pseudo-label part of get_dacs_mix (segmentation_model.py:551-556), backed by csr
 import torch
 
 from . import _lib
-from ._tensor import current_stream, ptr, require_device_tensor, same_device
+from ._tensor import current_stream, ptr, require_device_tensor, same_device, on_device
 
 
 @torch.no_grad()
@@ -31,7 +31,7 @@ def refine(logits_trg, logits_ref, warp_mask, certs, gamma=0.25, disable_M=False
     ws = torch.empty(lib.rfn_refine_workspace_bytes(B), dtype=torch.uint8, device=dev)
     out = torch.empty_like(logits_trg)
     flags = (1 if disable_M else 0) | (2 if disable_P else 0)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         rc = lib.rfn_refine_f32(ptr(logits_trg), ptr(logits_ref), ptr(m8), ptr(certs), ptr(out), ptr(ws), B, C, H, W,
                                 float(gamma), flags, current_stream(dev))
     _lib.check(rc, "refine")

@@ -143,3 +143,12 @@ def test_refresh_multi_tensor_cast_is_torch_rounding(dev):
         assert torch.equal(c.view(torch.int16), want.view(torch.int16)) or \
             (torch.isnan(want.float()) == torch.isnan(c.float())).all() and \
             torch.equal(torch.nan_to_num(c.float(), nan=0.0), torch.nan_to_num(want.float(), nan=0.0))
+
+
+def test_python_side_workspace_sizes_match_the_abi(dev):
+    """layernorm.py / dwconv.py size their scratch buffers without an ABI round trip: same numbers as the library."""
+    from refign_amd import _lib, dwconv, layernorm
+    lib = _lib.load_library()
+    for C in (8, 64, 320, 1024, 1280):
+        assert lib.rfn_layernorm_bwd_workspace_bytes(C) == layernorm._LN_WS_ROWS * 2 * C * 4
+        assert lib.rfn_dwconv3x3_bwd_weight_workspace_bytes(C) == dwconv._DW_WS_STRIPES * 10 * C * 4
