@@ -14,7 +14,10 @@ Safety rules:
   * outputs are static buffers: valid until the next call.
   * no collectives inside a captured region: the teacher's decode head (SyncBatchNorm in train mode under DDP, D9) stays
     eager between the captured teacher backbone and the captured align + refine.
-Set RFN_HIP_GRAPH=0 to disable (pure eager).
+RFN_HIP_GRAPH=0 disables (pure eager); =1 forces on.  Default: on in a single-rank job, OFF when torch.distributed
+runs more than one rank -- a failed capture is not recoverable on this runtime (the stream stays invalidated) and a
+multi-rank capture (RCCL watchdog thread alongside) could not be exercised on the one-GPU development boxes, so the
+scaling runs stay on the path that was.
 """
 import os
 import warnings
@@ -23,7 +26,11 @@ import torch
 
 
 def enabled():
-    return os.environ.get("RFN_HIP_GRAPH", "1") != "0"
+    env = os.environ.get("RFN_HIP_GRAPH")
+    if env is not None:
+        return env != "0"
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
 def _fresh_containers(out):

@@ -9,6 +9,8 @@ import time
 
 import torch
 
+os.environ.setdefault("RFN_HIP_GRAPH", "0")      # per-phase host timing needs the eager path
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from refign_amd.tuning import use_shipped_miopen_db  # noqa: E402
