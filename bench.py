@@ -26,6 +26,8 @@ import time
 
 import torch
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see refign_amd/__init__.py (before the HIP runtime initialises)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -206,7 +208,7 @@ class RefignStep:
         over = {"backbone.init_args.pretrained": None, "alignment_backbone.init_args.pretrained": None,
                 "alignment_head.init_args.pretrained": None, "adapt_to_ref": False}
         self.model = config.build_model(cfg, over).to(dev).train()
-        self.trainer = Trainer(self.model, sync_batchnorm=sync_bn)
+        self.trainer = Trainer(self.model, sync_batchnorm=sync_bn and os.environ.get("RFN_BENCH_SYNC_BN", "1") != "0")
         self.precision = precision
         self.b, self.H, self.W = b, H, W
         g = torch.Generator(device="cpu").manual_seed(seed)

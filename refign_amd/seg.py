@@ -403,15 +403,38 @@ class SegFormerHead(BaseHead):
 # ---------------------------------------------------------------------------------------------------------------------
 # HRDA multi-resolution wrappers (models/hrda.py)
 # ---------------------------------------------------------------------------------------------------------------------
+_PREDRAWN_CROPS = []
+
+
+def draw_crop_offsets(H, W, crop_size, divisible=1):
+    """The two `random.randrange` draws of extract_crop (hrda.py:22-27), or None when no draw happens (crop == image)."""
+    if H == crop_size[-2] and W == crop_size[-1]:
+        return None
+    oy = random.randrange(0, int((max(H - crop_size[-2], 0) + 1) // divisible)) * divisible
+    ox = random.randrange(0, int((max(W - crop_size[-1], 0) + 1) // divisible)) * divisible
+    return int(oy), int(ox)
+
+
+def predraw_crop(H, W, crop_size, divisible=1):
+    """Draw the NEXT extract_crop's offsets now, keeping the position of those draws in the python `random` stream.
+    The training step needs its third draw (the adapt_to_ref coin, segmentation_model.py:195) before the source forward
+    that makes the first two, so that the teacher branch can start on a side stream; extract_crop then uses these."""
+    _PREDRAWN_CROPS.append(((H, W, tuple(crop_size), divisible), draw_crop_offsets(H, W, crop_size, divisible)))
+
+
 def extract_crop(img, crop_size, divisible=1):
     """Random crop with offsets that are multiples of `divisible` (hrda.py:9-34).  Uses python `random` like the
     reference, so the same seed gives the same box."""
     H, W = img.shape[-2:]
     assert crop_size[0] > 0 and crop_size[1] > 0
-    if H == crop_size[-2] and W == crop_size[-1]:
+    if _PREDRAWN_CROPS:
+        key, off = _PREDRAWN_CROPS.pop(0)
+        assert key == (H, W, tuple(crop_size), divisible), (key, (H, W, tuple(crop_size), divisible))
+    else:
+        off = draw_crop_offsets(H, W, crop_size, divisible)
+    if off is None:
         return (0, H, 0, W)                                                   # (sic) hrda.py:20-21
-    oy = random.randrange(0, int((max(H - crop_size[-2], 0) + 1) // divisible)) * divisible
-    ox = random.randrange(0, int((max(W - crop_size[-1], 0) + 1) // divisible)) * divisible
+    oy, ox = off
     y1, y2, x1, x2 = int(oy), int(oy + crop_size[0]), int(ox), int(ox + crop_size[1])
     return img[:, :, y1:y2, x1:x2], [[y1, y2, x1, x2]]
 

@@ -19,6 +19,7 @@ What is done differently, for the hardware:
 """
 import copy
 import math
+import os
 import random
 from typing import Optional, Sequence
 
@@ -33,7 +34,7 @@ from ._tensor import const_tensor, upload_async
 from .graphs import GraphedNoGrad
 from .params import refresh as refresh_derived
 from .config import instantiate_class
-from .seg import hrda_backbone, hrda_head
+from .seg import hrda_backbone, hrda_head, predraw_crop
 
 IMNET_MEAN = (0.485, 0.456, 0.406)
 IMNET_STD = (0.229, 0.224, 0.225)
@@ -217,6 +218,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
             self.m_head.forward = hrda_head(self.m_head, self.m_hrda_scale_attention, os_,
                                             is_teacher=True)(self.m_head.forward)
         self.hr_loss_weight = hr_loss_weight
+        self.hrda_output_stride = hrda_output_stride
         self.use_slide_inference = use_slide_inference
         self.inference_batched_slide = inference_batched_slide
         self.inference_crop_size, self.inference_stride = inference_crop_size, inference_stride
@@ -267,6 +269,15 @@ class DomainAdaptationSegmentationModel(nn.Module):
         src_classes = torch.unique(gt_src[:nb_trg] if gt_src.shape[0] > nb_trg else gt_src)
         self.update_momentum_encoder()
 
+        # The teacher branch (teacher forward on target + reference, align, refine) depends on nothing the student does
+        # in this step, only on the EMA update above: start it NOW on a side stream so that its kernels fill the gaps
+        # of the launch-bound student forward/backward (many small kernels, each well below 256 workgroups).
+        early = early_imnet = None
+        if self._overlap_teacher(images_src):
+            if self.enable_fdist:                                        # needed first (after the source backward)
+                early_imnet = self._start_imnet_features(images_src)
+            early = self._start_target_branch(batch, images_src)
+
         # SOURCE (:156-179)
         feats_src = self.backbone(images_src)
         logits_src = self.head(feats_src)
@@ -285,7 +296,12 @@ class DomainAdaptationSegmentationModel(nn.Module):
 
         # ImageNet feature distance (:181-189)
         if self.enable_fdist:
-            loss_fd = self.calc_feat_dist(images_src, gt_src, feats_src)
+            if early_imnet is not None:
+                early_imnet[1].wait()                                    # current stream waits for the side stream
+                for t in early_imnet[0]:
+                    t.record_stream(torch.cuda.current_stream())
+            loss_fd = self.calc_feat_dist(images_src, gt_src, feats_src,
+                                          feat_imnet=None if early_imnet is None else early_imnet[0])
             self.log("train_loss_featdist_src", loss_fd)
             self.manual_backward(loss_fd)
             del loss_fd
@@ -293,19 +309,13 @@ class DomainAdaptationSegmentationModel(nn.Module):
 
         # TARGET: teacher, align, refine, DACS mix (:194-224)
         with torch.no_grad():
-            if self.adapt_to_ref and random.random() < 0.5:
-                adapt_to_ref, images_trg = True, batch['image_ref']
+            if early is None:
+                images_trg, m_probs_trg = self._target_branch(batch)
             else:
-                adapt_to_ref, images_trg = False, batch['image_trg']
-            if self.use_refign and not adapt_to_ref:
-                # teacher forward on (target, reference) + align + refine: gradient-free and shape-static, mostly
-                # replayed from hipGraphs after the first eager call (refign_amd/graphs.py)
-                m_probs_trg = self._teacher_align_refine(images_trg, batch['image_ref'])
-            else:
-                m_logits_trg = self.m_head(self.m_backbone(images_trg))
-                m_logits_trg = F.interpolate(m_logits_trg, size=images_trg.shape[-2:], mode='bilinear',
-                                             align_corners=False)
-                m_probs_trg = F.softmax(m_logits_trg, dim=1)
+                images_trg, m_probs_trg = early
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(self._side_stream)
+                m_probs_trg.record_stream(cur)
             mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src,
                                                                    src_classes)
 
@@ -327,6 +337,45 @@ class DomainAdaptationSegmentationModel(nn.Module):
         opt.step()
         sch.step()
         self.global_step += 1
+
+    @torch.no_grad()
+    def _target_branch(self, batch):
+        """(:194-213) which image is adapted to, and the (refined) teacher probabilities for it."""
+        if self.adapt_to_ref and random.random() < 0.5:
+            adapt_to_ref, images_trg = True, batch['image_ref']
+        else:
+            adapt_to_ref, images_trg = False, batch['image_trg']
+        if self.use_refign and not adapt_to_ref:
+            # teacher forward on (target, reference) + align + refine: gradient-free and shape-static, mostly
+            # replayed from hipGraphs after the first eager call (refign_amd/graphs.py)
+            return images_trg, self._teacher_align_refine(images_trg, batch['image_ref'])
+        m_logits_trg = self.m_head(self.m_backbone(images_trg))
+        m_logits_trg = F.interpolate(m_logits_trg, size=images_trg.shape[-2:], mode='bilinear', align_corners=False)
+        return images_trg, F.softmax(m_logits_trg, dim=1)
+
+    def _overlap_teacher(self, x):
+        return x.is_cuda and os.environ.get("RFN_OVERLAP_TEACHER", "1") != "0"
+
+    def _start_target_branch(self, batch, images_src):
+        """_target_branch on the side stream.  The adapt_to_ref coin is the THIRD draw of the python `random` stream
+        in a step (after the two HRDA crop offsets of the source forward): those two are drawn here, in order, and
+        handed to the source forward (seg.predraw_crop), so a seeded run makes the same decisions as the reference."""
+        if self.adapt_to_ref and self.use_hrda and self.training:
+            H, W = images_src.shape[-2:]
+            predraw_crop(H, W, (int(H * 0.5), int(W * 0.5)), self.hrda_output_stride * 2.0)
+        cur = torch.cuda.current_stream()
+        self._ensure_side_stream(images_src.device)
+        self._side_stream.wait_stream(cur)                       # EMA update (and the batch) are ready
+        with torch.cuda.stream(self._side_stream):
+            return self._target_branch(batch)
+
+    def _ensure_side_stream(self, device):
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
+            # high priority: the runtime maps it to a hardware queue of its own.  With the default priority it can
+            # share a queue with the main stream once an RCCL communicator has taken its streams (4 hardware queues
+            # per process by default), and two streams on one queue do not overlap (measured: 328 vs 299 ms/step)
+            self._side_stream = torch.cuda.Stream(device=device,
+                                                  priority=int(os.environ.get("RFN_SIDE_PRIORITY", "-1")))
 
     def _teacher_align_refine(self, images_trg, images_ref):
         """segmentation_model.py:201-213: EMA-teacher logits of (target, reference), warp of the reference logits onto
@@ -476,13 +525,28 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return torch.cat(mixed_img), torch.cat(mixed_lbl).squeeze(1), pseudo_weight
 
     # -- feature distance (:584-668) -----------------------------------------------------------------------------
-    def calc_feat_dist(self, img, gt, feat=None):
+    @torch.no_grad()
+    def _imnet_forward(self, img):
+        if self.use_hrda:
+            img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+        return self._graphs["imnet_features"](img) if "imnet_features" in self._graphs else self._imnet_features(img)
+
+    def _start_imnet_features(self, images_src):
+        """ImageNet features of the source images (frozen encoder, no gradient) on the side stream, ahead of the
+        teacher branch; returns (features, event the consumer waits for)."""
+        cur = torch.cuda.current_stream()
+        self._ensure_side_stream(images_src.device)
+        self._side_stream.wait_stream(cur)
+        with torch.cuda.stream(self._side_stream):
+            feats = self._imnet_forward(images_src)
+            ev = torch.cuda.Event()
+            ev.record(self._side_stream)
+        return feats, ev
+
+    def calc_feat_dist(self, img, gt, feat=None, feat_imnet=None):
         assert self.enable_fdist
-        with torch.no_grad():
-            if self.use_hrda:
-                img = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
-            feat_imnet = self._graphs["imnet_features"](img) if "imnet_features" in self._graphs \
-                else self._imnet_features(img)
+        if feat_imnet is None:
+            feat_imnet = self._imnet_forward(img)
         if not isinstance(feat, Sequence):
             feat = [feat]
         if self.fdist_classes is not None:

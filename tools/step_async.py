@@ -24,6 +24,11 @@ ap.add_argument("--workload", default="refign_hrda_step_1080x1920")
 ap.add_argument("--steps", type=int, default=4)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+if "RANK" in os.environ:                                   # same path as bench.py under torchrun (1 rank here)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=dev)
 wl = bench.WORKLOADS[a.workload](dev, 2, 1234, a.height, a.width, a.precision)
 m = wl.model
 acc = {}

@@ -25,6 +25,11 @@ ap.add_argument("--stacks", default="", help="aten op name: list its call sites 
 ap.add_argument("--ops", default="", help="comma-separated aten op names for --shapes (default: the dense ops)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+if "RANK" in os.environ:                                   # same path as bench.py under torchrun (1 rank here)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=dev)
 wl = bench.WORKLOADS[a.workload](dev, 2, 1234, a.height, a.width, a.precision)
 for _ in range(2):
     wl.step()
