@@ -45,12 +45,13 @@ class _LinearFn(torch.autograd.Function):
         x, w_c = ctx.saved_tensors
         N, K = w_c.shape
         gx = gw = gb = None
-        gy = gy.to(w_c.dtype)
-        if ctx.needs_input_grad[0]:
-            gx = torch.matmul(gy, w_c)
+        if gy.dtype != w_c.dtype:
+            gy = gy.to(w_c.dtype)
         g2 = gy.reshape(-1, N)
         if not g2.is_contiguous():
             g2 = g2.contiguous()
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g2, w_c).view(x.shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]
         sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
         part = None

@@ -120,15 +120,15 @@ def compute_dtype(x):
 
 
 def mark_grad_sink(p):
-    """FlatGradBuffer: `p.grad` is a persistent fp32 view that kernels may accumulate into directly."""
+    """FlatGradBuffer: `p.grad` is a persistent, contiguous fp32 view that kernels may accumulate into directly."""
     p._rfn_grad_sink = True
 
 
 def grad_sink(p):
     if p is None or not getattr(p, "_rfn_grad_sink", False):
         return None
-    g = p.grad
-    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
+    g = p.grad                 # looked up every time: zero_grad(set_to_none=True) or a foreign p.grad must be seen
+    if g is None or g.dtype != torch.float32 or not g.is_cuda:
         return None
     return g
 
