@@ -131,3 +131,30 @@ def test_hrda_golden_cpu():
 
 def test_loss_golden_cpu():
     check_loss(CPU)
+
+
+def test_predrawn_hrda_crop_keeps_the_python_random_stream_order():
+    """seg.predraw_crop: the training step needs the adapt_to_ref coin (3rd draw of the `random` stream) before the
+    source forward makes the two crop draws; pre-drawing them must give the same offsets AND the same coin."""
+    import random
+    import torch
+    from refign_amd import seg
+    x = torch.zeros(1, 3, 96, 160)
+    size, div = (48, 80), 8.0
+    random.seed(123)
+    crop_a, box_a = seg.extract_crop(x, size, div)
+    coin_a, next_a = random.random(), random.random()
+    random.seed(123)
+    seg.predraw_crop(96, 160, size, div)
+    coin_b = random.random()                      # drawn BEFORE the crop is taken
+    crop_b, box_b = seg.extract_crop(x, size, div)
+    next_b = random.random()
+    assert box_a == box_b and coin_a == coin_b and next_a == next_b
+    assert not seg._PREDRAWN_CROPS
+    # crop == image: no draw happens in either order
+    random.seed(5)
+    seg.predraw_crop(96, 160, (96, 160), div)
+    c1 = random.random()
+    assert seg.extract_crop(x, (96, 160), div) == (0, 96, 0, 160)
+    random.seed(5)
+    assert random.random() == c1
