@@ -81,8 +81,11 @@ class Trainer:
     """fit-loop subset: `step(batch)` = one reference training_step including EMA, three backward passes, the single
     gradient all-reduce and the optimiser/scheduler step."""
 
-    def __init__(self, model, sync_batchnorm=False, bucket_mb=64, fused_optimizer=True):
+    def __init__(self, model, sync_batchnorm=False, bucket_mb=64, fused_optimizer=True, gc_interval=None):
         self.model = model
+        if gc_interval is None:
+            gc_interval = int(os.environ.get("RFN_GC_INTERVAL", "100"))
+        self.gc_interval, self._steps_done = gc_interval, 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if sync_batchnorm and dist.is_available() and dist.is_initialized():
             nn.SyncBatchNorm.convert_sync_batchnorm(model)   # student AND teacher BNs (reference: sync_batchnorm: True)
@@ -104,6 +107,17 @@ class Trainer:
             dist.broadcast(t.data, src=0)
 
     def step(self, batch, batch_idx=0):
+        # Python's cyclic collector fires on allocation counts; a step allocates ~10^5 autograd / tensor wrapper objects
+        # and a generation-2 pass in the middle of a step stalls the launch thread for ~100 ms (seen as one slow step in
+        # ten).  Collect at a step boundary every `gc_interval` steps instead, with the automatic collector off.
+        if self.gc_interval:
+            import gc
+            if self._steps_done == 0:
+                gc.collect()
+                gc.disable()
+            elif self._steps_done % self.gc_interval == 0:
+                gc.collect()
+            self._steps_done += 1
         self.model.training_step(batch, batch_idx)
         return {k: (float(v) if torch.is_tensor(v) else v) for k, v in self.model.logged.items()} \
             if os.environ.get("RFN_LOG_LOSSES") else None
