@@ -7,17 +7,19 @@ autograd, no host-side control flow that depends on data, and the same shapes ev
 captured once (after eager warm-up calls that populate every cache) and replayed with one host call.
 
 Safety rules:
-  * eager fallback, permanently, if capture throws (e.g. a library call that is not capturable);
+  * eager fallback, permanently, if capture throws (e.g. a library call that is not capturable) -- recoverable, see
+    _capture;
   * a capture is keyed on input shapes/dtypes/devices, the autocast state and a module "generation" that the owner
     bumps whenever cached derived tensors may have been re-allocated (train()/eval(), load_state_dict, .to());
   * parameters are only ever updated IN PLACE between replays (optimizer, EMA, params.refresh) -- same addresses;
   * outputs are static buffers: valid until the next call.
   * no collectives inside a captured region: the teacher's decode head (SyncBatchNorm in train mode under DDP, D9) stays
     eager between the captured teacher backbone and the captured align + refine.
-RFN_HIP_GRAPH=0 disables (pure eager); =1 forces on.  Default: on in a single-rank job, OFF when torch.distributed
-runs more than one rank -- a failed capture is not recoverable on this runtime (the stream stays invalidated) and a
-multi-rank capture (RCCL watchdog thread alongside) could not be exercised on the one-GPU development boxes, so the
-scaling runs stay on the path that was.
+RFN_HIP_GRAPH=0 disables (pure eager).  On by default for every world size: the captured regions contain no collective,
+the capture runs in thread-local error mode (the RCCL watchdog thread cannot invalidate it), and a capture that fails
+anyway is recoverable -- the thread is put back on its original stream and the region runs eagerly from then on
+(tests/test_step_gpu.py::test_failed_graph_capture_falls_back_to_eager).  Exercised on the GPU with a 1-rank RCCL
+process group (same module tree as N > 1: SyncBatchNorm everywhere); not with several ranks (one-GPU boxes).
 """
 import os
 import warnings
@@ -26,11 +28,7 @@ import torch
 
 
 def enabled():
-    env = os.environ.get("RFN_HIP_GRAPH")
-    if env is not None:
-        return env != "0"
-    import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    return os.environ.get("RFN_HIP_GRAPH", "1") != "0"
 
 
 def _fresh_containers(out):
@@ -91,6 +89,12 @@ class GraphedNoGrad:
         g = torch.cuda.CUDAGraph()
         # thread_local: calls made by other host threads during the capture (the RCCL watchdog of torch.distributed
         # polls its events) must not invalidate it
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            outputs = self.fn(*inputs)
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                outputs = self.fn(*inputs)
+        except BaseException:
+            # torch.cuda.graph.__exit__ raises from capture_end() BEFORE it restores the stream: the thread would stay
+            # on the (now invalidated) capture stream and every later launch would fail.  Put it back.
+            torch.cuda.set_stream(cur)
+            raise
         st["graph"], st["inputs"], st["outputs"] = g, inputs, outputs

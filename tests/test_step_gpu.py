@@ -124,3 +124,29 @@ def test_hipgraph_replay_equals_eager(dev, use_hrda, monkeypatch):
     # train()/eval() (folded-BN caches are re-made) drops the captures
     model.train()
     assert all(len(g_.states) == 0 for g_ in model._graphs.values())
+
+
+def test_failed_graph_capture_falls_back_to_eager(dev, monkeypatch):
+    """A region that cannot be captured (here: a host synchronisation inside it) must leave the process usable: warning,
+    eager results from then on, later launches on the original stream work."""
+    from refign_amd.graphs import GraphedNoGrad
+    monkeypatch.setenv("RFN_HIP_GRAPH", "1")
+
+    def fn(x):
+        y = x * 2.0
+        if float(y.sum()) > -1e30:                   # .item(): illegal while capturing
+            y = y + 1.0
+        return y
+
+    g = GraphedNoGrad(fn, "uncapturable")
+    x = torch.arange(8, device=dev, dtype=torch.float32)
+    with torch.no_grad():
+        assert torch.equal(g(x), x * 2 + 1)          # eager (warm-up call)
+        with pytest.warns(UserWarning, match="capture of 'uncapturable' failed"):
+            out = g(x)                               # capture attempt -> fallback
+        assert torch.equal(out, x * 2 + 1)
+        assert torch.equal(g(x + 1), (x + 1) * 2 + 1)
+    z = torch.ones(4, device=dev) + 1                # the stream is healthy
+    torch.cuda.synchronize()
+    assert float(z.sum()) == 8.0
+    assert all(s["failed"] for s in g.states.values())
