@@ -194,6 +194,20 @@ int rfn_linear_param_grads(const void* grad_y, float* grad_bias, void* workspace
 int rfn_multi_cast_chunk_elems(void);
 int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * The three GEMMs of a token-wise nn.Linear (mix_transformer.py: q / kv / proj / fc1 / fc2) on the ROCm library
+ * (hipBLASLt) through a per-problem plan cache: descriptors, layouts and the heuristic's algorithm are made once per
+ * (kind, T, N, K, S, dtype, bias) and reused, so a call costs a map lookup + hipblasLtMatmul instead of ~35 us of
+ * framework host time.  Row-major operands; dtype 1 = bfloat16 in/out (fp32 accumulate), 0 = float32.
+ *   kind 0  forward  C[T,N]     = B[T,K] . A[N,K]^T (+ bias[N], same dtype)      A = weight,  B = x
+ *   kind 1  dgrad    C[T,K]     = B[T,N] . A[N,K]                                A = weight,  B = grad_y
+ *   kind 2  wgrad    C[S][N,K]  = B_s[T/S,N]^T . A_s[T/S,K] for the S row slabs  A = x,       B = grad_y
+ * workspace: rfn_gemm_workspace_bytes() bytes of device memory.
+ * ---------------------------------------------------------------------------------------------------------- */
+unsigned long rfn_gemm_workspace_bytes(void);
+int rfn_linear_gemm(int kind, const void* A, const void* B, void* C, const void* bias, void* workspace, long T, long N,
+                    long K, int S, int dtype, rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .params import as_dtype, compute_dtype, grad_sink, linear_param_grads, sum_rows
+from .params import as_dtype, compute_dtype, grad_sink, linear_gemm, linear_param_grads, sum_rows
 
 
 _FUSED_GRADS = os.environ.get("RFN_LINEAR_FUSED_GRADS", "1") != "0"      # A/B switch (tools)
@@ -37,7 +37,10 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, w_c, b_c):
         ctx.save_for_backward(x, w_c)
         ctx.weight, ctx.bias = weight, bias
-        return F.linear(x, w_c, b_c)
+        N, K = w_c.shape
+        x2 = x.reshape(-1, K)
+        y = linear_gemm(0, w_c, x2, (x2.shape[0], N), b_c, x2.shape[0], N, K) if x2.is_contiguous() else None
+        return F.linear(x, w_c, b_c) if y is None else y.view(x.shape[:-1] + (N,))
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -51,7 +54,8 @@ class _LinearFn(torch.autograd.Function):
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = torch.mm(g2, w_c).view(x.shape)
+            gx = linear_gemm(1, w_c, g2, (g2.shape[0], K), None, g2.shape[0], N, K)
+            gx = (torch.mm(g2, w_c) if gx is None else gx).view(x.shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]
         sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
         part = None
@@ -59,10 +63,12 @@ class _LinearFn(torch.autograd.Function):
             x2 = x.reshape(-1, K)
             T = x2.shape[0]
             S = _split(T)
-            if S > 1:
-                part = torch.bmm(g2.view(S, T // S, N).transpose(1, 2), x2.view(S, T // S, K)).view(S, N * K)
-            else:
-                part = g2.t().mm(x2).view(1, N * K)
+            part = linear_gemm(2, x2, g2, (S, N * K), None, T, N, K, S) if x2.is_contiguous() else None
+            if part is None:
+                if S > 1:
+                    part = torch.bmm(g2.view(S, T // S, N).transpose(1, 2), x2.view(S, T // S, K)).view(S, N * K)
+                else:
+                    part = g2.t().mm(x2).view(1, N * K)
         # both gradients straight into the flat gradient buffer in two launches
         if need_w and need_b and sink_w is not None and sink_b is not None and _FUSED_GRADS and \
                 linear_param_grads(g2, part, sink_b, sink_w.view(-1)):
