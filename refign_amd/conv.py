@@ -65,3 +65,95 @@ class Conv2d(nn.Conv2d):
             return _Conv2dFn.apply(x, self.weight, self.bias, w_c, b_c, self.stride, self.padding, self.dilation,
                                    self.groups)
         return F.conv2d(x, w_c, b_c, self.stride, self.padding, self.dilation, self.groups)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Spatial-reduction convolution of the MiT attention (kernel = stride = sr_ratio, no padding: mix_transformer.py:128-134)
+# as what it is -- a Linear over non-overlapping r x r patches -- on the token layout, without the NCHW round trip.
+# Forward: one gather copy (tokens -> patches) + one GEMM with bias, output directly as (B, N', C) tokens for the
+# LayerNorm that follows.  Backward: the Linear's three GEMM-shaped ops (split-T weight gradient, parameter gradients
+# accumulated into the flat buffer) + one scatter copy; the library's convolution backward for this shape is five
+# launches of its own plus per-call zero-fill / cast tensor ops (~85 us of GPU time per layer per pass, 240 per step).
+# ---------------------------------------------------------------------------------------------------------------------
+def _to_patches(x, H, W, r):
+    B, N, C = x.shape
+    Hr, Wr = H // r, W // r
+    v = x.view(B, H, W, C)
+    if Hr * r != H or Wr * r != W:
+        v = v[:, :Hr * r, :Wr * r]                   # the strided conv drops the ragged border
+    return v.reshape(B, Hr, r, Wr, r, C).permute(0, 1, 3, 2, 4, 5).reshape(B * Hr * Wr, r * r * C), Hr, Wr
+
+
+def _from_patches(gp, B, H, W, C, r, Hr, Wr):
+    g = gp.view(B, Hr, Wr, r, r, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hr * r, Wr * r, C)
+    if Hr * r != H or Wr * r != W:
+        g = F.pad(g, (0, 0, 0, W - Wr * r, 0, H - Hr * r))
+    return g.reshape(B, H * W, C)
+
+
+class _PatchLinearFn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, w2, b_c, H, W, r):
+        patches, Hr, Wr = _to_patches(x, H, W, r)
+        ctx.save_for_backward(patches, w2)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.geom = (x.shape, H, W, r, Hr, Wr)
+        return F.linear(patches, w2, b_c).view(x.shape[0], Hr * Wr, w2.shape[0])
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        from .linear import _split
+        from .params import linear_param_grads, sum_rows
+        patches, w2 = ctx.saved_tensors
+        (B, N, C), H, W, r, Hr, Wr = ctx.geom
+        Co, K = w2.shape
+        g2 = gy.reshape(-1, Co)
+        if g2.dtype != w2.dtype:
+            g2 = g2.to(w2.dtype)
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _from_patches(torch.mm(g2, w2), B, H, W, C, r, Hr, Wr)
+        T = g2.shape[0]
+        S = _split(T)
+        if S > 1:
+            part = torch.bmm(g2.view(S, T // S, Co).transpose(1, 2), patches.view(S, T // S, K)).view(S, Co * K)
+        else:
+            part = g2.t().mm(patches).view(1, Co * K)
+        sw, sb = grad_sink(ctx.weight), grad_sink(ctx.bias)
+        # the parameter is (Co, C, r, r), the GEMM's weight is its (Co, r, r, C) permutation
+        gw2 = sum_rows(part).view(Co, r, r, C)
+        if sw is not None:
+            sw.permute(0, 2, 3, 1).add_(gw2)
+        else:
+            gw = gw2.permute(0, 3, 1, 2).to(ctx.weight.dtype)
+        if ctx.bias is not None:
+            if sb is not None:
+                sum_rows(g2, out=sb, accumulate=True)
+            else:
+                gb = sum_rows(g2).to(ctx.bias.dtype)
+        return gx, gw, gb, None, None, None, None, None
+
+
+def patch_conv_tokens(x, H, W, conv):
+    """`conv` (kernel == stride, no padding, groups 1) applied to the (B, H*W, C) token map `x`; returns the
+    (B, (H//r)*(W//r), C_out) token map -- what `conv(x.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)`
+    gives.  None when the layer / tensor is outside this path's domain."""
+    r = conv.kernel_size[0]
+    if not (x.is_cuda and conv.kernel_size == (r, r) and conv.stride == (r, r) and conv.padding == (0, 0)
+            and conv.dilation == (1, 1) and conv.groups == 1 and H >= r and W >= r and x.is_contiguous()):
+        return None
+    cd = compute_dtype(x)
+    Co, C = conv.weight.shape[:2]
+    w2 = derived(conv.weight, (cd, "patch_linear"), lambda t: t.to(cd).permute(0, 2, 3, 1).contiguous(),
+                 lambda t: t.permute(0, 2, 3, 1)).view(Co, r * r * C)
+    b_c = as_dtype(conv.bias, cd)
+    if x.dtype != cd:
+        x = x.to(cd)
+    if torch.is_grad_enabled() and conv.weight.requires_grad:
+        return _PatchLinearFn.apply(x, conv.weight, conv.bias, w2, b_c, H, W, r)
+    patches, Hr, Wr = _to_patches(x, H, W, r)
+    return F.linear(patches, w2, b_c).view(x.shape[0], Hr * Wr, Co)

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 
 from ._tensor import const_tensor
 from .align import BaseHead
-from .conv import Conv2d
+from .conv import Conv2d, patch_conv_tokens
 from .layernorm import LayerNorm
 from .layers import MLP, ConvBNReLU, DropPath
 from .linear import Linear
@@ -94,6 +94,7 @@ def _sdpa_backend():
 
 
 _SDPA_BACKEND = _sdpa_backend()
+_SR_AS_LINEAR = os.environ.get("RFN_SR_AS_LINEAR", "1") != "0"     # spatial-reduction conv as a Linear over patches
 
 
 class Attention(nn.Module):
@@ -119,8 +120,10 @@ class Attention(nn.Module):
         h, d = self.num_heads, C // self.num_heads
         q = self.q(x).view(B, N, h, d).transpose(1, 2)                       # (B,h,N,d)
         if self.sr_ratio > 1:
-            r = self.sr(x.transpose(1, 2).reshape(B, C, H, W))               # (B,C,H/sr,W/sr)
-            x = self.norm(r.flatten(2).transpose(1, 2))
+            r = patch_conv_tokens(x, H, W, self.sr) if _SR_AS_LINEAR else None   # (B, N/sr^2, C) tokens directly
+            if r is None:
+                r = self.sr(x.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
+            x = self.norm(r)
         # unbind, not kv[0] / kv[1]: its backward is ONE stack of (dK, dV) instead of two zero-fills, two slice
         # copies and an add
         k, v = self.kv(x).view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4).unbind(0)   # (B,h,Nkv,d) each

@@ -181,3 +181,33 @@ def test_linear_gemm_plan_cache_matches_framework_gemms(dev, dt):
                               atol=2.0 if dt == torch.bfloat16 else 1e-2)
     finally:
         params._GEMM_OK = False
+
+
+@pytest.mark.parametrize("H,W,r", [(16, 24, 2), (17, 30, 2), (34, 60, 4), (135, 50, 8), (8, 8, 8)])
+@pytest.mark.parametrize("sink", [False, True])
+def test_spatial_reduction_conv_as_patch_linear(dev, H, W, r, sink):
+    """conv.patch_conv_tokens == the strided convolution it replaces (forward, input / weight / bias gradients),
+    including maps whose size is not a multiple of the stride, with and without the flat gradient buffer."""
+    from refign_amd.conv import Conv2d, patch_conv_tokens
+    from refign_amd.trainer import FlatGradBuffer
+    torch.manual_seed(H * 100 + r)
+    C, B = 32, 2
+    a, b = Conv2d(C, C, r, stride=r).to(dev), nn.Conv2d(C, C, r, stride=r).to(dev)
+    b.load_state_dict(a.state_dict())
+    if sink:
+        FlatGradBuffer(a.parameters())
+    x = torch.randn(B, H * W, C, device=dev)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    for rep in range(2):                                          # twice: accumulation into .grad
+        ya = patch_conv_tokens(xa, H, W, a)
+        yb = b(xb.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
+        assert ya.shape == yb.shape
+        assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+        g = torch.randn_like(yb)
+        ya.backward(g)
+        yb.backward(g)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-3, atol=1e-3)
+    with torch.no_grad():
+        assert torch.allclose(patch_conv_tokens(x, H, W, a), yb, rtol=1e-4, atol=1e-4)
