@@ -208,6 +208,17 @@ unsigned long rfn_gemm_workspace_bytes(void);
 int rfn_linear_gemm(int kind, const void* A, const void* B, void* C, const void* bias, void* workspace, long T, long N,
                     long K, int S, int dtype, rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-resolution fusion front end of the decode heads (DAFormerHead.forward, models/heads/daformer.py:205-222;
+ * SegFormerHead.forward, models/heads/segformer.py:86-104): bilinear up-sampling (align_corners=False) of up to four
+ * embedded stage maps to (H, W) and their channel concatenation, one pass, channels-last output (n, H, W, sum C_l).
+ * src_l: TOKEN maps (n, hs[l]*ws[l], cs[l]) contiguous (= channels-last), cs[l] % 8 == 0; a level that already has
+ * (H, W) is copied.  hs / ws / cs: HOST arrays of nlev ints.  dtype 0 = float32, 1 = bfloat16 (fp32 blend).
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_upsample_concat_nhwc(const void* src0, const void* src1, const void* src2, const void* src3, const int* hs,
+                             const int* ws, const int* cs, int nlev, void* out, int n, int H, int W, int dtype,
+                             rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

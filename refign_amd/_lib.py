@@ -44,6 +44,8 @@ SIGNATURES = {
     "rfn_sum_rows": (c_int, [c_void_p] * 3 + [ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p]),
     "rfn_linear_param_grads": (c_int, [c_void_p] * 3 + [ctypes.c_long, ctypes.c_long, c_int, c_void_p, c_void_p, c_int,
                                        ctypes.c_long, c_int, c_int, c_void_p]),
+    "rfn_upsample_concat_nhwc": (c_int, [c_void_p] * 4 + [ctypes.POINTER(c_int)] * 3 + [c_int, c_void_p] + [c_int] * 4
+                                 + [c_void_p]),
     "rfn_gemm_workspace_bytes": (ctypes.c_ulong, []),
     "rfn_linear_gemm": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_long] * 3 + [c_int, c_int, c_void_p]),
     "rfn_multi_cast_chunk_elems": (c_int, []),

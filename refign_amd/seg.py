@@ -33,6 +33,7 @@ from .conv import Conv2d, patch_conv_tokens
 from .layernorm import LayerNorm
 from .layers import MLP, ConvBNReLU, DropPath
 from .linear import Linear
+from .upcat import upsample_concat
 
 # ---------------------------------------------------------------------------------------------------------------------
 # MiT (SegFormer encoder)
@@ -94,6 +95,7 @@ def _sdpa_backend():
 
 
 _SDPA_BACKEND = _sdpa_backend()
+_FUSED_UPCAT = os.environ.get("RFN_FUSED_UPCAT", "1") != "0"       # decode heads: up-sampling + concat in one kernel
 _SR_AS_LINEAR = os.environ.get("RFN_SR_AS_LINEAR", "1") != "0"     # spatial-reduction conv as a Linear over patches
 
 
@@ -355,12 +357,19 @@ class DAFormerHead(BaseHead):
     def forward(self, x):
         x = self._transform_inputs(x)
         size = x[0].shape[2:]
-        cs = []
-        for i, f in enumerate(x):
-            n, _, h, w = f.shape
-            c = self.embed_layers[str(i)](f).transpose(1, 2).reshape(n, -1, h, w)
-            cs.append(c if (h, w) == tuple(size) else _up(c, size).to(c.dtype))
-        y = self.fuse_layer(torch.cat(cs, dim=1))
+        toks = [self.embed_layers[str(i)](f) for i, f in enumerate(x)]          # (n, h_l*w_l, embed) token maps
+        # one pass (csrc/upcat.hip) on the gradient-free paths (teacher, inference); with autograd the library's bilinear
+        # backward on the channel slices of the fused gradient measured 34 ms/step slower than on the unfused graph
+        cat = upsample_concat(toks, [f.shape[2:] for f in x], size) \
+            if (_FUSED_UPCAT and not torch.is_grad_enabled()) else None
+        if cat is None:
+            cs = []
+            for c, f in zip(toks, x):
+                n, _, h, w = f.shape
+                c = c.transpose(1, 2).reshape(n, -1, h, w)
+                cs.append(c if (h, w) == tuple(size) else _up(c, size).to(c.dtype))
+            cat = torch.cat(cs, dim=1)
+        y = self.fuse_layer(cat)
         if self.dropout is not None:
             y = self.dropout(y)
         return self.conv_seg(y)
@@ -391,13 +400,18 @@ class SegFormerHead(BaseHead):
         c1, c2, c3, c4 = inputs                      # NB: takes the raw 4-tuple, no _transform_inputs (segformer.py:80)
         size = c1.shape[2:]
 
-        def emb(layer, f):
-            n, _, h, w = f.shape
-            return layer(f).transpose(1, 2).reshape(n, -1, h, w)
-
-        parts = [_up(emb(self.linear_c4, c4), size), _up(emb(self.linear_c3, c3), size),
-                 _up(emb(self.linear_c2, c2), size), emb(self.linear_c1, c1)]
-        y = self.linear_fuse(torch.cat(parts, dim=1))
+        feats = [c4, c3, c2, c1]                     # concat order of the reference (segformer.py:97)
+        toks = [layer(f) for layer, f in zip((self.linear_c4, self.linear_c3, self.linear_c2, self.linear_c1), feats)]
+        cat = upsample_concat(toks, [f.shape[2:] for f in feats], size) \
+            if (_FUSED_UPCAT and not torch.is_grad_enabled()) else None
+        if cat is None:
+            parts = []
+            for t, f in zip(toks, feats):
+                n, _, h, w = f.shape
+                t = t.transpose(1, 2).reshape(n, -1, h, w)
+                parts.append(t if (h, w) == tuple(size) else _up(t, size))
+            cat = torch.cat(parts, dim=1)
+        y = self.linear_fuse(cat)
         if self.dropout is not None:
             y = self.dropout(y)
         return self.linear_pred(y)

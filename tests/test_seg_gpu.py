@@ -1,5 +1,6 @@
 """GPU run of the segmentation-network parity checks of test_seg_cpu.py (same goldens, device = cuda:0)."""
 import pytest
+import torch
 import test_seg_cpu as S
 
 pytestmark = pytest.mark.gpu
@@ -19,3 +20,33 @@ def test_hrda_golden_gpu(dev):
 
 def test_loss_golden_gpu(dev):
     S.check_loss(dev)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("sizes,chans", [([(34, 60), (17, 30), (9, 15), (5, 8)], [32, 32, 32, 32]),
+                                         ([(5, 8), (9, 15), (17, 30), (34, 60)], [16, 24, 8, 40]),
+                                         ([(12, 12), (6, 6)], [64, 8])])
+def test_upsample_concat_fused_matches_interpolate_cat(dev, dt, sizes, chans):
+    """csrc/upcat.hip (decode-head fusion front end) == cat([interpolate(bilinear, align_corners=False)...], 1):
+    forward and the gradients w.r.t. every level's token map; ragged size ratios, levels in any order."""
+    import torch.nn.functional as F
+    from refign_amd.upcat import upsample_concat
+    g = torch.Generator().manual_seed(len(sizes) * 7 + chans[0])
+    n = 3
+    H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    toks = [torch.randn(n, h * w, c, generator=g).to(dev).to(dt).requires_grad_() for (h, w), c in zip(sizes, chans)]
+    refs = [t.detach().clone().requires_grad_() for t in toks]
+    got = upsample_concat(toks, sizes, (H, W))
+    parts = []
+    for t, (h, w), c in zip(refs, sizes, chans):
+        m = t.transpose(1, 2).reshape(n, c, h, w)
+        parts.append(m if (h, w) == (H, W) else F.interpolate(m, size=(H, W), mode='bilinear', align_corners=False))
+    want = torch.cat(parts, 1)
+    assert got.shape == want.shape and got.dtype == dt
+    tol = dict(rtol=2e-2, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    assert torch.allclose(got.float(), want.float(), **tol), float((got.float() - want.float()).abs().max())
+    go = torch.randn(want.shape, generator=g).to(dev).to(dt)
+    got.backward(go)
+    want.backward(go)
+    for a, b in zip(toks, refs):
+        assert torch.allclose(a.grad.float(), b.grad.float(), **tol)
