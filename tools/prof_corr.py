@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/prof_corr.py -- run ONE kernel of the hot path a few times (for rocprofv3 --kernel-trace / --pmc).
-usage: prof_corr.py [corr_l1|corr_l1_fused|corr_l1_warp|corr_l2_fused|tail|refine] [reps]"""
+usage: prof_corr.py [corr_l1|corr_l1_fused|corr_l1_warp|corr_l2_fused|uncert_l1|tail|refine] [reps]"""
 import os
 import sys
 
@@ -26,7 +26,15 @@ if what.startswith("corr_l1"):
     f1, f2, fl = feats(128, 270, 480)
 elif what.startswith("corr_l2"):
     f1, f2, fl = feats(256, 135, 240)
-if what in ("corr_l1", "corr_l2"):
+if what == "uncert_l1":
+    from refign_amd import align as A
+    um = A.UncertaintyModule(1, search_size=9, feed_in_previous=True).to(dev).eval()
+    corr = torch.rand(b, 81, 270, 480, generator=g).to(dev)
+
+    def fn():
+        with torch.no_grad():
+            return um.patch_statistics(corr)
+elif what in ("corr_l1", "corr_l2"):
     fn = lambda: correlation.forward(f1, f2, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)  # noqa: E731
 elif what.endswith("_fused"):
     fn = lambda: correlation.local_correlation_layer(f2, f1)  # noqa: E731
