@@ -105,7 +105,7 @@ class _PatchLinearFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         from .linear import _split
-        from .params import linear_param_grads, sum_rows
+        from .params import sum_rows
         patches, w2 = ctx.saved_tensors
         (B, N, C), H, W, r, Hr, Wr = ctx.geom
         Co, K = w2.shape
