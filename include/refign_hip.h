@@ -219,6 +219,12 @@ int rfn_upsample_concat_nhwc(const void* src0, const void* src1, const void* src
                              const int* ws, const int* cs, int nlev, void* out, int n, int H, int W, int dtype,
                              rfn_stream_t stream);
 
+/* Token map (B, H*W, C) -> non-overlapping r x r patches (B*(H/r)*(W/r), r*r*C) with (ry, rx, c) fastest (inverse = 0),
+ * or back (inverse = 1; a ragged border of the token map is NOT written -- zero it first): gather / scatter around the
+ * spatial-reduction convolution of the MiT attention run as a Linear (mix_transformer.py:128-134).  C % 8 == 0. */
+int rfn_patchify_tokens(const void* src, void* dst, int B, int H, int W, int C, int r, int dtype, int inverse,
+                        rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

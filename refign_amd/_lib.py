@@ -46,6 +46,7 @@ SIGNATURES = {
                                        ctypes.c_long, c_int, c_int, c_void_p]),
     "rfn_upsample_concat_nhwc": (c_int, [c_void_p] * 4 + [ctypes.POINTER(c_int)] * 3 + [c_int, c_void_p] + [c_int] * 4
                                  + [c_void_p]),
+    "rfn_patchify_tokens": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rfn_gemm_workspace_bytes": (ctypes.c_ulong, []),
     "rfn_linear_gemm": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_long] * 3 + [c_int, c_int, c_void_p]),
     "rfn_multi_cast_chunk_elems": (c_int, []),

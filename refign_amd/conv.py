@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+from ._tensor import current_stream, on_device, ptr
 from .params import _identity, as_dtype, compute_dtype, derived, grad_sink
 
 
@@ -75,9 +77,24 @@ class Conv2d(nn.Conv2d):
 # accumulated into the flat buffer) + one scatter copy; the library's convolution backward for this shape is five
 # launches of its own plus per-call zero-fill / cast tensor ops (~85 us of GPU time per layer per pass, 240 per step).
 # ---------------------------------------------------------------------------------------------------------------------
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _patchify(src, dst, B, H, W, C, r, inverse):
+    lib = _lib.load_library()
+    with on_device(src.device):
+        rc = lib.rfn_patchify_tokens(ptr(src), ptr(dst), B, H, W, C, r, _DT[src.dtype], 1 if inverse else 0,
+                                     current_stream(src.device))
+    _lib.check(rc, "patchify_tokens")
+
+
 def _to_patches(x, H, W, r):
     B, N, C = x.shape
     Hr, Wr = H // r, W // r
+    if x.is_cuda and x.dtype in _DT and C % 8 == 0 and x.is_contiguous():
+        out = torch.empty((B * Hr * Wr, r * r * C), dtype=x.dtype, device=x.device)
+        _patchify(x, out, B, H, W, C, r, False)                      # one vectorised gather (csrc/upcat.hip)
+        return out, Hr, Wr
     v = x.view(B, H, W, C)
     if Hr * r != H or Wr * r != W:
         v = v[:, :Hr * r, :Wr * r]                   # the strided conv drops the ragged border
@@ -85,6 +102,11 @@ def _to_patches(x, H, W, r):
 
 
 def _from_patches(gp, B, H, W, C, r, Hr, Wr):
+    if gp.is_cuda and gp.dtype in _DT and C % 8 == 0 and gp.is_contiguous():
+        ragged = Hr * r != H or Wr * r != W
+        out = (torch.zeros if ragged else torch.empty)((B, H * W, C), dtype=gp.dtype, device=gp.device)
+        _patchify(gp, out, B, H, W, C, r, True)
+        return out
     g = gp.view(B, Hr, Wr, r, r, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hr * r, Wr * r, C)
     if Hr * r != H or Wr * r != W:
         g = F.pad(g, (0, 0, 0, W - Wr * r, 0, H - Hr * r))

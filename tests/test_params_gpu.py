@@ -211,3 +211,20 @@ def test_spatial_reduction_conv_as_patch_linear(dev, H, W, r, sink):
     assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-3, atol=1e-3)
     with torch.no_grad():
         assert torch.allclose(patch_conv_tokens(x, H, W, a), yb, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,r", [(2, 16, 24, 64, 2), (1, 135, 50, 32, 8), (3, 17, 30, 320, 2), (2, 34, 61, 128, 4)])
+def test_patchify_tokens_kernel(dev, dt, B, H, W, C, r):
+    """csrc/upcat.hip patchify_kernel: gather to r x r patches and scatter back == the view/permute formulation."""
+    from refign_amd import conv
+    x = torch.randn(B, H * W, C, device=dev).to(dt)
+    Hr, Wr = H // r, W // r
+    want = x.view(B, H, W, C)[:, :Hr * r, :Wr * r].reshape(B, Hr, r, Wr, r, C).permute(0, 1, 3, 2, 4, 5) \
+        .reshape(B * Hr * Wr, r * r * C)
+    got, hr, wr = conv._to_patches(x, H, W, r)
+    assert (hr, wr) == (Hr, Wr) and torch.equal(got, want)
+    back = conv._from_patches(got, B, H, W, C, r, Hr, Wr)
+    ref = torch.zeros(B, H, W, C, device=dev, dtype=dt)
+    ref[:, :Hr * r, :Wr * r] = x.view(B, H, W, C)[:, :Hr * r, :Wr * r]
+    assert torch.equal(back, ref.view(B, H * W, C))
