@@ -3,7 +3,7 @@
 The weight gradient of a token-wise Linear is dW[N,K] = dY[T,N]^T . X[T,K] with T = tokens (8 160 ... 259 200 on the
 Refign step) and N, K <= 2048: a "small output, very long reduction" GEMM.  The library picks a 64x64 macro-tile without
 split-K for it, i.e. 25-400 workgroups each walking the whole T: measured 24 TF/s on [320 x 8160] x [8160 x 320]
-(240 of those per step, 58 ms of wgrad GEMMs in total, profiles/r01_step_shapes_bf16_findnormal.txt).  Splitting T into
+(240 of those per step, 58 ms of wgrad GEMMs in total, profiles/r01_step_shapes_bf16.txt).  Splitting T into
 S independent slabs turns it into a batched GEMM with S x more workgroups; the (S, N, K) partials are reduced by
 csrc/reduce.hip, which ADDS the result straight into the parameter's .grad view of the flat gradient buffer; the bias
 gradient (column sum of dY) goes through the same kernel.  Weights are used through their cached bf16 copies
