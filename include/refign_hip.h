@@ -225,6 +225,53 @@ int rfn_upsample_concat_nhwc(const void* src0, const void* src1, const void* src
 int rfn_patchify_tokens(const void* src, void* dst, int B, int H, int W, int C, int r, int dtype, int inverse,
                         rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Hand-written matrix-core (MFMA 32x32x16) GEMMs of a token-wise nn.Linear -- q / kv / proj / fc1 / fc2 / sr-as-Linear
+ * of MiT (mix_transformer.py:96-103,137-164) and the MLP embeds of the decode heads (daformer.py:129-149).
+ * dtype 1 = bfloat16, 2 = float16 operands and result, fp32 accumulation.  Row-major, leading dimensions in elements.
+ *
+ * rfn_gemm_nt:  Y[M,N] = res + rowscale[m / rows_per_sample] * act( X[M,K] . W[N,K]^T + bias[N] )
+ *   forward: X = tokens, W = weight.  dgrad: X = grad_y [T,N], W = weight^T [K,N] (host keeps the transposed copy).
+ *   bias / res / rowscale may be NULL (res NULL: Y = act(...); rowscale needs res: the stochastic-depth residual
+ *   `x + drop_path(branch)` of mix_transformer.py:203-207 with per-sample keep masks).  act: 0 none, 1 ReLU, 2 GELU(erf).
+ *   K % 64 == 0, N % 8 == 0, ldx / ldw / ldy % 8 == 0.
+ * rfn_gemm_tn:  P[s][N,K] = sum over rows t of slab s of G[t,n] * X[t,k]   (fp32 partials, S = ceil(T / rows_per_slab))
+ *   wgrad: G = grad_y [T,N], X = tokens [T,K]; the host reduces the slabs into the flat gradient buffer (rfn_sum_rows).
+ *   N % 64 == 0, K % 64 == 0, rows_per_slab % 32 == 0.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_gemm_nt(const void* X, const void* W, const void* bias, const void* res, const float* rowscale,
+                int rows_per_sample, int act, void* Y, long M, long N, long K, long ldx, long ldw, long ldy, int dtype,
+                rfn_stream_t stream);
+int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int rows_per_slab,
+                int dtype, rfn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Hand-written matrix-core attention for MiT's efficient self-attention (mix_transformer.py:137-164):
+ * softmax(scale q k^T) v with head_dim 64, long query / short key sequences.  dtype 1 = bf16, 2 = f16; fp32 softmax.
+ * Tensors are addressed as element (b, row, head, d) at base + b*batch_stride + row*row_stride + head*64 + d, i.e. the
+ * (B, N, heads*64) output of the q Linear and the K / V halves of the (B, Nkv, 2, heads, 64) kv Linear output are used
+ * in place.
+ *   rfn_attn_pack     rows of one tensor -> R-pack and/or T-pack (MFMA A-operand images, 4096 B per 32-row block and
+ *                     (b, head); nblk blocks, zero padded).  Needed: K R+T, V R+T (forward uses K R, V T), Q R+T, dO R+T.
+ *   rfn_attn_fwd      O and lse2[b*heads+h][nqpad] (base-2 log-sum-exp of the scaled scores), nkblk even.
+ *   rfn_attn_bwd_dq   dQ, and delta[bh][nqpad] = rowsum(dO o O) for the dK/dV kernel.
+ *   rfn_attn_bwd_dkv  dKV (B, Nkv, 2, heads, 64); accT: fp32 scratch of B*heads*2*64*nkpad floats; the query dimension is
+ *                     split into chunks of `blocks_per_chunk` 32-row blocks per workgroup.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_attn_pack(const void* src, long batch_stride, long row_stride, int B, int heads, int nrows, int nblk, void* rpack,
+                  void* tpack, rfn_stream_t stream);
+int rfn_attn_fwd(const void* Q, long q_batch_stride, long q_row_stride, const void* k_rpack, const void* v_tpack, void* O,
+                 long o_batch_stride, long o_row_stride, float* lse2, int B, int heads, int Nq, int Nkv, int nkblk,
+                 int nqpad, float scale, int dtype, rfn_stream_t stream);
+int rfn_attn_bwd_dq(const void* Q, long q_batch_stride, long q_row_stride, const void* dO, const void* O,
+                    long o_batch_stride, long o_row_stride, const void* k_rpack, const void* v_rpack, const void* k_tpack,
+                    const float* lse2, float* delta, void* dQ, long dq_batch_stride, long dq_row_stride, int B, int heads,
+                    int Nq, int Nkv, int nkblk, int nqpad, float scale, int dtype, rfn_stream_t stream);
+int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv_row_stride, const void* q_rpack,
+                     const void* q_tpack, const void* do_rpack, const void* do_tpack, const float* lse2,
+                     const float* delta, float* accT, void* dKV, int B, int heads, int Nq, int Nkv, int nqblk, int nqpad,
+                     int nkpad, int blocks_per_chunk, float scale, int dtype, rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

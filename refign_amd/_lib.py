@@ -51,6 +51,15 @@ SIGNATURES = {
     "rfn_linear_gemm": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_long] * 3 + [c_int, c_int, c_void_p]),
     "rfn_multi_cast_chunk_elems": (c_int, []),
     "rfn_multi_cast_f32_bf16": (c_int, [c_void_p, c_int, c_void_p]),
+    "rfn_gemm_nt": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p] + [ctypes.c_long] * 6 + [c_int, c_void_p]),
+    "rfn_gemm_tn": (c_int, [c_void_p] * 3 + [ctypes.c_long] * 5 + [c_int, c_int, c_void_p]),
+    "rfn_attn_pack": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] + [c_int] * 4 + [c_void_p] * 3),
+    "rfn_attn_fwd": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_void_p, ctypes.c_long,
+                             ctypes.c_long, c_void_p] + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    "rfn_attn_bwd_dq": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long]
+                        + [c_void_p] * 6 + [ctypes.c_long, ctypes.c_long] + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    "rfn_attn_bwd_dkv": (c_int, [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long] + [c_void_p] * 8 + [c_int] * 8
+                         + [c_float, c_int, c_void_p]),
     "rfn_uncertainty9_weights_len": (c_int, []),
     "rfn_uncertainty9_frontend_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }

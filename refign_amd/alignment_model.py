@@ -19,6 +19,7 @@ class AlignmentModel(nn.Module):
         self.alignment_head = alignment_head
         self.alignment_backbone.requires_grad_(False)
         self.optimizer_init, self.lr_scheduler_init = optimizer_init, lr_scheduler_init
+        self.selfsupervised_loss, self.unsupervised_loss = selfsupervised_loss, unsupervised_loss   # specs (row N1)
         self.apply_constant_flow_weights = apply_constant_flow_weights
         if pretrained is not None:
             ckpt = torch.load(pretrained, map_location='cpu')

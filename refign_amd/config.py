@@ -25,10 +25,27 @@ ALIASES = {
 }
 # subsystems that are out of scope here (host I/O, logging, evaluation): accepted in a config, not instantiated
 IGNORED_PREFIXES = ("pytorch_lightning.", "data_modules.", "helpers.metrics.")
+# matcher-training losses (SURVEY.md section 8f, row N1 -- "next"): a megadepth config carries them; AlignmentModel
+# keeps the spec and its training_step says so, forward / evaluation do not need them
+DEFERRED = ("models.losses.MultiScaleFlowLoss", "models.losses.WBipathLoss")
+
+
+# reference packages whose classes are routed through ALIASES; anything of theirs that has no alias is a component
+# outside the align-and-refine hot path (ResNet / DeepLabV2, data modules, metrics, ...)
+_REFERENCE_PACKAGES = ("models.", "helpers.", "data_modules.")
+
+
+class OutOfScopeError(NotImplementedError):
+    pass
 
 
 def resolve(class_path):
-    path = ALIASES.get(class_path, class_path)
+    path = ALIASES.get(class_path)
+    if path is None:
+        if class_path.startswith(_REFERENCE_PACKAGES):
+            raise OutOfScopeError(f"{class_path} is out of scope of refign_amd (the align-and-refine hot path: "
+                                  f"{', '.join(sorted(ALIASES))})")
+        path = class_path
     mod, _, name = path.rpartition(".")
     return getattr(importlib.import_module(mod), name)
 
@@ -40,7 +57,7 @@ def is_spec(x):
 def build(spec):
     """Recursively instantiate a {class_path, init_args} tree (nested specs inside init_args are built first)."""
     if is_spec(spec):
-        if spec["class_path"].startswith(IGNORED_PREFIXES):
+        if spec["class_path"].startswith(IGNORED_PREFIXES) or spec["class_path"] in DEFERRED:
             return spec
         kwargs = {k: build(v) for k, v in spec.get("init_args", {}).items()}
         return resolve(spec["class_path"])(**kwargs)

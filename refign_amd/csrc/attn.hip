@@ -1,0 +1,564 @@
+// refign_amd/csrc/attn.hip -- hand-written matrix-core attention for MiT's efficient self-attention
+// (mix_transformer.py:137-164): long query sequences (510 ... 129 600 tokens), short key/value sequences after the
+// spatial reduction (<= 2 040), head_dim 64, 1/2/5/8 heads.  bf16 or f16 in/out, fp32 softmax and accumulation.
+//
+//   forward   O = softmax(scale Q K^T) V                                     rfn_attn_fwd   (+ log-sum-exp per row)
+//   backward  dQ                                                              rfn_attn_bwd_dq  (one pass over the keys per
+//             query tile, like the forward: no atomics, no transposes)
+//             dK, dV                                                          rfn_attn_bwd_dkv (a workgroup owns 256 keys
+//             and a CHUNK of the queries -- the query dimension is split, so 510 keys x 20 (batch x head) pairs still
+//             fill 256 CUs; chunk partials are combined with coalesced fp32 atomics on a key-major scratch image)
+//
+// Everything is computed TRANSPOSED (S^T = K Q^T, O^T = V^T P^T, ...), so that a lane owns one query (forward, dQ) or
+// one key (dK/dV) and the softmax statistics are per lane; the probability block that comes out of one MFMA as a C/D
+// register block goes straight back in as the B operand of the next (k-slot order, mfma.h) -- no LDS round trip, no
+// cross-lane traffic except one half-wave exchange per statistic.
+//
+// Operands that are needed as an MFMA A operand are read from "packs" written once by rfn_attn_pack (K and V are tiny
+// and shared by every query tile; Q and dO are packed once per backward), per 32-row block of 4 096 bytes:
+//   R-pack  [8 d-chunks][32 rows][8 d]      A[i = row][k = d]: lane (i, g) reads the 16 bytes of chunk 2 ks + g
+//   T-pack  [8 row-quads][64 d][4 rows]     A[i = d][k = row slot]: lane (i, g) reads 8 bytes of quad 4 m + g and of
+//                                           quad 4 m + 2 + g for the 16-row k-step m
+// Both images are read conflict-free (lanes of a group cover consecutive 16- / 8-byte slots) and are contiguous in
+// memory per block, so a stage of the K/V stream is one linear LDS-DMA.
+#include "common.h"
+#include "mfma.h"
+
+namespace rfn {
+
+constexpr int kPackBlock = 4096;            // bytes of one 32-row pack block
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pack: rows [Nrows] x 64 of one (batch, head) -> R-pack and T-pack, zero padded to nblk blocks
+//   src element (b, row, head, d) at src + b * sb + row * sr + head * 64 + d
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_pack_kernel(const uint16_t* __restrict__ src, long sb, long sr, int heads,
+                                                        int nrows, int nblk, unsigned char* __restrict__ rpack,
+                                                        unsigned char* __restrict__ tpack) {
+  __shared__ unsigned tile[32][33];                    // [row][d pair], padded
+  const int blk = blockIdx.x, bh = blockIdx.y;
+  const int b = bh / heads, hd = bh % heads;
+  const int t = threadIdx.x, row = t >> 3, dc = t & 7;
+  const int grow = blk * 32 + row;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (grow < nrows) v = *(const u32x4*)(src + (long)b * sb + (long)grow * sr + hd * 64 + dc * 8);
+  unsigned char* rb = rpack + ((long)bh * nblk + blk) * kPackBlock;
+  if (rpack != nullptr) *(u32x4*)(rb + (dc * 32 + row) * 16) = v;
+  if (tpack == nullptr) return;
+  tile[row][dc * 4 + 0] = v[0];
+  tile[row][dc * 4 + 1] = v[1];
+  tile[row][dc * 4 + 2] = v[2];
+  tile[row][dc * 4 + 3] = v[3];
+  __syncthreads();
+  const int rq = t >> 5, dp = t & 31;                  // row quad, d pair (d = 2 dp, 2 dp + 1)
+  unsigned r0 = tile[4 * rq + 0][dp], r1 = tile[4 * rq + 1][dp], r2 = tile[4 * rq + 2][dp], r3 = tile[4 * rq + 3][dp];
+  u32x4 o;
+  o[0] = (r0 & 0xffffu) | (r1 << 16);                  // d even: rows 0,1
+  o[1] = (r2 & 0xffffu) | (r3 << 16);                  //         rows 2,3
+  o[2] = (r0 >> 16) | (r1 & 0xffff0000u);              // d odd
+  o[3] = (r2 >> 16) | (r3 & 0xffff0000u);
+  unsigned char* tb = tpack + ((long)bh * nblk + blk) * kPackBlock;
+  *(u32x4*)(tb + (rq * 64 + 2 * dp) * 8) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// shared pieces
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ void load_row_frags(const uint16_t* base, long row_stride, int row, int nrows, int g,
+                                               typename Elem<DT>::vec8 (&f)[4]) {
+  // B operand [k = d][j = row]: lane (j, g) holds row j, d = 16 ks + 8 g .. + 7; rows past the end read as zero
+  const bool ok = row < nrows;
+  const uint16_t* p = base + (long)(ok ? row : 0) * row_stride + 8 * g;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ok) v = *(const u32x4*)(p + 16 * ks);
+    f[ks] = __builtin_bit_cast(typename Elem<DT>::vec8, v);
+  }
+}
+
+// store a transposed accumulator pair (D[i = d][j = row], two 32-wide d blocks) as row-major 16-bit rows of 64
+template <int DT>
+__device__ __forceinline__ void store_rows64(const f32x16 (&acc)[2], float mul, uint16_t* rowptr, bool ok, int g) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    u32x2 pk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      pk[k] = pack4<DT>(acc[db][4 * k] * mul, acc[db][4 * k + 1] * mul, acc[db][4 * k + 2] * mul, acc[db][4 * k + 3] * mul);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p][0], pk[2 * p + 1][0], false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p][1], pk[2 * p + 1][1], false, false);
+      if (ok) {
+        u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+        *(u32x4*)(rowptr + db * 32 + 16 * p + 8 * g) = o;
+      }
+    }
+  }
+}
+
+// C/D block (16 floats of one column) -> the two B operands of the next MFMAs (k-steps of 16 rows), k-slot order
+template <int DT>
+__device__ __forceinline__ void to_operands(const float (&p)[16], typename Elem<DT>::vec8 (&b)[2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+    b[m] = join8<DT>(pack4<DT>(p[8 * m], p[8 * m + 1], p[8 * m + 2], p[8 * m + 3]),
+                     pack4<DT>(p[8 * m + 4], p[8 * m + 5], p[8 * m + 6], p[8 * m + 7]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward.  grid (ceil(Nq / 128), B * heads), 4 waves x 32 queries.  K/V stream: stages of 64 keys, 2-deep LDS ring.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restrict__ Q, long qsb, long qsr,
+                                                       const unsigned char* __restrict__ Kr,
+                                                       const unsigned char* __restrict__ Vt, uint16_t* __restrict__ O,
+                                                       long osb, long osr, float* __restrict__ lse2, int heads, int Nq,
+                                                       int Nkv, int nblk, int nqpad, float scale) {
+  using E = Elem<DT>;
+  using vec8 = typename E::vec8;
+  constexpr int STAGE = 4 * kPackBlock;                 // 2 key blocks: K R-pack + V T-pack
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, col = lane & 31;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int q = blockIdx.x * 128 + wave * 32 + col;
+  const float c = scale * kLog2e;
+
+  vec8 qf[4];
+  load_row_frags<DT>(Q + (long)b * qsb + hd * 64, qsr, q, Nq, g, qf);
+
+  const unsigned char* kbase = Kr + (long)bh * nblk * kPackBlock;
+  const unsigned char* vbase = Vt + (long)bh * nblk * kPackBlock;
+  const int nst = nblk / 2;                              // nblk is even (host pads the packs)
+  auto issue = [&](int st, int buf) {
+    unsigned char* dst = smem + buf * STAGE;
+    // 16 KB per stage = 16 DMA instructions, 4 per wave: 8 KB of K blocks then 8 KB of V blocks
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int piece = wave * 2 + u;                    // 0..7 within the 8 KB
+      lds_dma16(kbase + (long)st * 2 * kPackBlock + piece * 1024 + lane * 16, dst + piece * 1024);
+      lds_dma16(vbase + (long)st * 2 * kPackBlock + piece * 1024 + lane * 16, dst + 2 * kPackBlock + piece * 1024);
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
+  float mrun = -1e30f, lrun = 0.f;
+
+  issue(0, 0);
+  wait_dma_all();
+  wg_barrier();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) issue(st + 1, buf ^ 1);
+    const unsigned char* ks = smem + buf * STAGE;
+    const unsigned char* vs = ks + 2 * kPackBlock;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int key0 = (st * 2 + kb) * 32;
+      if (key0 < Nkv) {                                  // wave-uniform
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const vec8 kf = *(const vec8*)(ks + kb * kPackBlock + ((2 * kk + g) * 32 + col) * 16);
+          s = E::mma(kf, qf[kk], s);
+        }
+        float p[16];
+        float mt = -1e30f;
+        const bool tail = key0 + 32 > Nkv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = s[r] * c;
+          if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * g >= Nkv) v = -1e30f;
+          p[r] = v;
+          mt = fmaxf(mt, v);
+        }
+        mt = half_max(mt);
+        const float mnew = fmaxf(mrun, mt);
+        if (__any(mnew > mrun)) {
+          const float alpha = exp2f(mrun - mnew);
+          lrun *= alpha;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            oacc[0][r] *= alpha;
+            oacc[1][r] *= alpha;
+          }
+          mrun = mnew;
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[r] = exp2f(p[r] - mrun);
+          ps += p[r];
+        }
+        lrun += ps;
+        vec8 pb[2];
+        to_operands<DT>(p, pb);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const unsigned char* vq = vs + kb * kPackBlock + (db * 32 + col) * 8;
+            const vec8 vf = join8<DT>(*(const u32x2*)(vq + (4 * m + g) * 512), *(const u32x2*)(vq + (4 * m + 2 + g) * 512));
+            oacc[db] = E::mma(vf, pb[m], oacc[db]);
+          }
+      }
+    }
+    wait_dma_all();
+    wg_barrier();
+  }
+  const float l = half_sum(lrun);
+  const bool ok = q < Nq;
+  store_rows64<DT>(oacc, 1.f / l, O + (long)b * osb + (long)(ok ? q : 0) * osr + hd * 64, ok, g);
+  if (g == 0 && q < nqpad) lse2[(long)bh * nqpad + q] = ok ? mrun + log2f(l) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dQ.  Same decomposition as the forward; per 32-key block: S^T = K Q^T, dP^T = V dO^T (both with the query
+// operand in registers), dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T.  delta = rowsum(dO o O) is computed here and
+// written for the dK/dV kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ Q, long qsb, long qsr,
+                                                          const uint16_t* __restrict__ dO, const uint16_t* __restrict__ O,
+                                                          long osb, long osr, const unsigned char* __restrict__ Kr,
+                                                          const unsigned char* __restrict__ Vr,
+                                                          const unsigned char* __restrict__ Kt,
+                                                          const float* __restrict__ lse2, float* __restrict__ delta,
+                                                          uint16_t* __restrict__ dQ, long dsb, long dsr, int heads, int Nq,
+                                                          int Nkv, int nblk, int nqpad, float scale) {
+  using E = Elem<DT>;
+  using vec8 = typename E::vec8;
+  constexpr int STAGE = 6 * kPackBlock;                 // 2 key blocks x (K R-pack, V R-pack, K T-pack)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, col = lane & 31;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int q = blockIdx.x * 128 + wave * 32 + col;
+  const bool ok = q < Nq;
+  const float c = scale * kLog2e;
+
+  vec8 qf[4], gf[4];
+  load_row_frags<DT>(Q + (long)b * qsb + hd * 64, qsr, q, Nq, g, qf);
+  load_row_frags<DT>(dO + (long)b * osb + hd * 64, osr, q, Nq, g, gf);
+  float dl = 0.f;
+  {
+    vec8 of[4];
+    load_row_frags<DT>(O + (long)b * osb + hd * 64, osr, q, Nq, g, of);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)gf[kk][e] * (float)of[kk][e];
+    dl = half_sum(dl);
+  }
+  const float ls = (q < nqpad) ? lse2[(long)bh * nqpad + q] : 0.f;
+  if (g == 0 && q < nqpad) delta[(long)bh * nqpad + q] = ok ? dl : 0.f;
+
+  const long pbase = (long)bh * nblk * kPackBlock;
+  const int nst = nblk / 2;
+  auto issue = [&](int st, int buf) {
+    unsigned char* dst = smem + buf * STAGE;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int piece = wave * 2 + u;
+      const long off = pbase + (long)st * 2 * kPackBlock + piece * 1024 + lane * 16;
+      lds_dma16(Kr + off, dst + piece * 1024);
+      lds_dma16(Vr + off, dst + 2 * kPackBlock + piece * 1024);
+      lds_dma16(Kt + off, dst + 4 * kPackBlock + piece * 1024);
+    }
+  };
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq[0][r] = dq[1][r] = 0.f;
+
+  issue(0, 0);
+  wait_dma_all();
+  wg_barrier();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) issue(st + 1, buf ^ 1);
+    const unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int key0 = (st * 2 + kb) * 32;
+      if (key0 < Nkv) {
+        const unsigned char* krs = base + kb * kPackBlock;
+        const unsigned char* vrs = base + (2 + kb) * kPackBlock;
+        const unsigned char* kts = base + (4 + kb) * kPackBlock;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int off = ((2 * kk + g) * 32 + col) * 16;
+          s = E::mma(*(const vec8*)(krs + off), qf[kk], s);
+          dp = E::mma(*(const vec8*)(vrs + off), gf[kk], dp);
+        }
+        float ds[16];
+        const bool tail = key0 + 32 > Nkv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pr = exp2f(s[r] * c - ls);
+          if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * g >= Nkv) pr = 0.f;
+          ds[r] = pr * (dp[r] - dl);
+        }
+        vec8 sb[2];
+        to_operands<DT>(ds, sb);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const unsigned char* kq = kts + (db * 32 + col) * 8;
+            const vec8 kf = join8<DT>(*(const u32x2*)(kq + (4 * m + g) * 512), *(const u32x2*)(kq + (4 * m + 2 + g) * 512));
+            dq[db] = E::mma(kf, sb[m], dq[db]);
+          }
+      }
+    }
+    wait_dma_all();
+    wg_barrier();
+  }
+  store_rows64<DT>(dq, scale, dQ + (long)b * dsb + (long)(ok ? q : 0) * dsr + hd * 64, ok, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dK / dV.  grid (key blocks of 256, query chunks, B * heads), 8 waves x 32 keys.  A lane owns one key: its K
+// and V rows sit in registers as B operands for the whole kernel; the query stream (R- and T-packs of Q and dO) goes
+// through a 2-deep LDS ring, 32 queries per stage, shared by the 8 waves.
+//   S = Q K^T, P = exp2(c S - lse2), dP = dO V^T, dS = P o (dP - delta)
+//   dV^T += dO^T P,   dK^T += Q^T dS   (A operands from the T-packs, B operands = the P / dS register blocks)
+// Results are added (fp32 atomics, 128-byte coalesced) into accT[bh][2][64 d][nkpad keys].
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ K, const uint16_t* __restrict__ V,
+                                                           long ksb, long ksr, const unsigned char* __restrict__ Qr,
+                                                           const unsigned char* __restrict__ Qt,
+                                                           const unsigned char* __restrict__ Gr,
+                                                           const unsigned char* __restrict__ Gt,
+                                                           const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                           float* __restrict__ accT, int heads, int Nq, int Nkv, int nqblk,
+                                                           int nqpad, int nkpad, int blocks_per_chunk, float scale) {
+  using E = Elem<DT>;
+  using vec8 = typename E::vec8;
+  constexpr int STAGE = 4 * kPackBlock;                 // one query block: Q R, dO R, Q T, dO T
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, col = lane & 31;
+  const int bh = blockIdx.z, b = bh / heads, hd = bh % heads;
+  const int key = blockIdx.x * 256 + wave * 32 + col;
+  const bool wave_live = blockIdx.x * 256 + wave * 32 < Nkv;      // wave-uniform: any valid key in this wave
+  const bool kok = key < Nkv;
+  const float c = scale * kLog2e;
+
+  vec8 kf[4], vf[4];
+  load_row_frags<DT>(K + (long)b * ksb + hd * 64, ksr, key, Nkv, g, kf);
+  load_row_frags<DT>(V + (long)b * ksb + hd * 64, ksr, key, Nkv, g, vf);
+
+  const int qb0 = blockIdx.y * blocks_per_chunk;
+  const int qb1 = min(qb0 + blocks_per_chunk, nqblk);
+  const long pbase = (long)bh * nqblk * kPackBlock;
+  auto issue = [&](int qb, int buf) {
+    unsigned char* dst = smem + buf * STAGE;
+    // 16 KB per stage = 16 DMA instructions, 2 per wave: wave w moves piece w of (Qr, dOr) and piece w of (Qt, dOt)
+    const long off = pbase + (long)qb * kPackBlock + (wave & 3) * 1024 + lane * 16;
+    if (wave < 4) {
+      lds_dma16(Qr + off, dst + (wave & 3) * 1024);
+      lds_dma16(Gr + off, dst + kPackBlock + (wave & 3) * 1024);
+    } else {
+      lds_dma16(Qt + off, dst + 2 * kPackBlock + (wave & 3) * 1024);
+      lds_dma16(Gt + off, dst + 3 * kPackBlock + (wave & 3) * 1024);
+    }
+  };
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f;
+
+  if (qb0 < qb1) {
+    issue(qb0, 0);
+    wait_dma_all();
+    wg_barrier();
+  }
+  for (int qb = qb0; qb < qb1; ++qb) {
+    const int buf = (qb - qb0) & 1;
+    if (qb + 1 < qb1) issue(qb + 1, buf ^ 1);
+    if (wave_live) {
+      const unsigned char* base = smem + buf * STAGE;
+      // statistics of the 16 query rows this lane's registers cover: rows 8 k + 4 g + 0..3
+      f32x4 l4[4], d4[4];
+      const float* lp = lse2 + (long)bh * nqpad + qb * 32 + 4 * g;
+      const float* dp_ = delta + (long)bh * nqpad + qb * 32 + 4 * g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        l4[k] = *(const f32x4*)(lp + 8 * k);
+        d4[k] = *(const f32x4*)(dp_ + 8 * k);
+      }
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int off = ((2 * kk + g) * 32 + col) * 16;
+        s = E::mma(*(const vec8*)(base + off), kf[kk], s);                      // S[q][key]
+        dp = E::mma(*(const vec8*)(base + kPackBlock + off), vf[kk], dp);       // dP[q][key]
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pr = exp2f(s[r] * c - l4[r >> 2][r & 3]);
+        if (!kok) pr = 0.f;
+        p[r] = pr;
+        ds[r] = pr * (dp[r] - d4[r >> 2][r & 3]);
+      }
+      vec8 pb[2], sb[2];
+      to_operands<DT>(p, pb);
+      to_operands<DT>(ds, sb);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const unsigned char* qq = base + 2 * kPackBlock + (db * 32 + col) * 8;
+          const unsigned char* gq = base + 3 * kPackBlock + (db * 32 + col) * 8;
+          const vec8 qa = join8<DT>(*(const u32x2*)(qq + (4 * m + g) * 512), *(const u32x2*)(qq + (4 * m + 2 + g) * 512));
+          const vec8 ga = join8<DT>(*(const u32x2*)(gq + (4 * m + g) * 512), *(const u32x2*)(gq + (4 * m + 2 + g) * 512));
+          dv[db] = E::mma(ga, pb[m], dv[db]);
+          dk[db] = E::mma(qa, sb[m], dk[db]);
+        }
+    }
+    wait_dma_all();
+    wg_barrier();
+  }
+  if (kok) {
+    float* ak = accT + (long)bh * 2 * 64 * nkpad + key;
+    float* av = ak + (long)64 * nkpad;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        atomicAdd(ak + (long)d * nkpad, dk[db][r] * scale);
+        atomicAdd(av + (long)d * nkpad, dv[db][r]);
+      }
+  }
+}
+
+// accT[bh][2][64][nkpad] fp32 -> dKV[b][key][2][heads][64] 16-bit
+template <int DT>
+__global__ __launch_bounds__(256) void attn_dkv_finish_kernel(const float* __restrict__ accT, uint16_t* __restrict__ dkv,
+                                                              int heads, int Nkv, int nkpad, long total) {
+  using S = typename Elem<DT>::scalar;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int d = (int)(i & 63);
+  long r = i >> 6;
+  const int hd = (int)(r % heads);
+  r /= heads;
+  const int which = (int)(r & 1);
+  r >>= 1;
+  const int key = (int)(r % Nkv);
+  const int b = (int)(r / Nkv);
+  const float v = accT[(((long)(b * heads + hd) * 2 + which) * 64 + d) * nkpad + key];
+  const S o = (S)v;
+  dkv[i] = __builtin_bit_cast(uint16_t, o);
+}
+
+}  // namespace rfn
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+using namespace rfn;
+
+#define ATTN_DT_OK(dt) RFN_REQUIRE((dt) == 1 || (dt) == 2, "attention: dtype %d (1 = bf16, 2 = f16)", (dt))
+
+int rfn_attn_pack(const void* src, long batch_stride, long row_stride, int B, int heads, int nrows, int nblk, void* rpack,
+                  void* tpack, rfn_stream_t stream) {
+  RFN_REQUIRE(src && (rpack || tpack), "attn_pack: null pointer");
+  RFN_REQUIRE(B > 0 && heads > 0 && nrows > 0 && nblk * 32 >= nrows, "attn_pack: B=%d heads=%d rows=%d nblk=%d", B, heads,
+              nrows, nblk);
+  RFN_REQUIRE(row_stride % 8 == 0 && batch_stride % 8 == 0, "attn_pack: strides must be multiples of 8 elements");
+  dim3 grid(nblk, B * heads);
+  hipLaunchKernelGGL(attn_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, batch_stride,
+                     row_stride, heads, nrows, nblk, (unsigned char*)rpack, (unsigned char*)tpack);
+  return check_launch("attn_pack");
+}
+
+int rfn_attn_fwd(const void* Q, long q_batch_stride, long q_row_stride, const void* k_rpack, const void* v_tpack, void* O,
+                 long o_batch_stride, long o_row_stride, float* lse2, int B, int heads, int Nq, int Nkv, int nkblk,
+                 int nqpad, float scale, int dtype, rfn_stream_t stream) {
+  ATTN_DT_OK(dtype);
+  RFN_REQUIRE(Q && k_rpack && v_tpack && O && lse2, "attn_fwd: null pointer");
+  RFN_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nkv > 0 && nkblk % 2 == 0 && nkblk * 32 >= Nkv && nqpad >= Nq,
+              "attn_fwd: B=%d heads=%d Nq=%d Nkv=%d nkblk=%d nqpad=%d", B, heads, Nq, Nkv, nkblk, nqpad);
+  RFN_REQUIRE(q_row_stride % 8 == 0 && o_row_stride % 8 == 0 && q_batch_stride % 8 == 0 && o_batch_stride % 8 == 0,
+              "attn_fwd: strides must be multiples of 8 elements");
+  dim3 grid(cdiv(Nq, 128), B * heads);
+  if (dtype == 1)
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Q, q_batch_stride,
+                       q_row_stride, (const unsigned char*)k_rpack, (const unsigned char*)v_tpack, (uint16_t*)O,
+                       o_batch_stride, o_row_stride, lse2, heads, Nq, Nkv, nkblk, nqpad, scale);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Q, q_batch_stride,
+                       q_row_stride, (const unsigned char*)k_rpack, (const unsigned char*)v_tpack, (uint16_t*)O,
+                       o_batch_stride, o_row_stride, lse2, heads, Nq, Nkv, nkblk, nqpad, scale);
+  return check_launch("attn_fwd");
+}
+
+int rfn_attn_bwd_dq(const void* Q, long q_batch_stride, long q_row_stride, const void* dO, const void* O,
+                    long o_batch_stride, long o_row_stride, const void* k_rpack, const void* v_rpack, const void* k_tpack,
+                    const float* lse2, float* delta, void* dQ, long dq_batch_stride, long dq_row_stride, int B, int heads,
+                    int Nq, int Nkv, int nkblk, int nqpad, float scale, int dtype, rfn_stream_t stream) {
+  ATTN_DT_OK(dtype);
+  RFN_REQUIRE(Q && dO && O && k_rpack && v_rpack && k_tpack && lse2 && delta && dQ, "attn_bwd_dq: null pointer");
+  RFN_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nkv > 0 && nkblk % 2 == 0 && nkblk * 32 >= Nkv && nqpad >= Nq,
+              "attn_bwd_dq: B=%d heads=%d Nq=%d Nkv=%d nkblk=%d nqpad=%d", B, heads, Nq, Nkv, nkblk, nqpad);
+  dim3 grid(cdiv(Nq, 128), B * heads);
+#define RFN_DQ_LAUNCH(D)                                                                                                \
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Q, q_batch_stride, \
+                     q_row_stride, (const uint16_t*)dO, (const uint16_t*)O, o_batch_stride, o_row_stride,               \
+                     (const unsigned char*)k_rpack, (const unsigned char*)v_rpack, (const unsigned char*)k_tpack, lse2,  \
+                     delta, (uint16_t*)dQ, dq_batch_stride, dq_row_stride, heads, Nq, Nkv, nkblk, nqpad, scale)
+  if (dtype == 1) RFN_DQ_LAUNCH(1); else RFN_DQ_LAUNCH(2);
+#undef RFN_DQ_LAUNCH
+  return check_launch("attn_bwd_dq");
+}
+
+int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv_row_stride, const void* q_rpack,
+                     const void* q_tpack, const void* do_rpack, const void* do_tpack, const float* lse2,
+                     const float* delta, float* accT, void* dKV, int B, int heads, int Nq, int Nkv, int nqblk, int nqpad,
+                     int nkpad, int blocks_per_chunk, float scale, int dtype, rfn_stream_t stream) {
+  ATTN_DT_OK(dtype);
+  RFN_REQUIRE(K && V && q_rpack && q_tpack && do_rpack && do_tpack && lse2 && delta && accT && dKV,
+              "attn_bwd_dkv: null pointer");
+  RFN_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nkv > 0 && nqblk * 32 >= Nq && nqpad >= nqblk * 32 && nkpad >= Nkv &&
+                  nkpad % 32 == 0 && blocks_per_chunk > 0,
+              "attn_bwd_dkv: B=%d heads=%d Nq=%d Nkv=%d nqblk=%d nqpad=%d nkpad=%d chunk=%d", B, heads, Nq, Nkv, nqblk,
+              nqpad, nkpad, blocks_per_chunk);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(accT, 0, (size_t)B * heads * 2 * 64 * nkpad * sizeof(float), s);
+  if (e != hipSuccess) return fail(RFN_ELAUNCH, "attn_bwd_dkv: memset: %s", hipGetErrorString(e));
+  dim3 grid(cdiv(Nkv, 256), cdiv(nqblk, blocks_per_chunk), B * heads);
+#define RFN_DKV_LAUNCH(D)                                                                                               \
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, grid, dim3(512), 0, s, (const uint16_t*)K, (const uint16_t*)V,            \
+                     kv_batch_stride, kv_row_stride, (const unsigned char*)q_rpack, (const unsigned char*)q_tpack,      \
+                     (const unsigned char*)do_rpack, (const unsigned char*)do_tpack, lse2, delta, accT, heads, Nq, Nkv,  \
+                     nqblk, nqpad, nkpad, blocks_per_chunk, scale)
+  if (dtype == 1) RFN_DKV_LAUNCH(1); else RFN_DKV_LAUNCH(2);
+#undef RFN_DKV_LAUNCH
+  int rc = check_launch("attn_bwd_dkv");
+  if (rc != RFN_OK) return rc;
+  const long total = (long)B * Nkv * 2 * heads * 64;
+  if (dtype == 1)
+    hipLaunchKernelGGL(attn_dkv_finish_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, s, accT, (uint16_t*)dKV, heads,
+                       Nkv, nkpad, total);
+  else
+    hipLaunchKernelGGL(attn_dkv_finish_kernel<2>, dim3(cdiv(total, 256)), dim3(256), 0, s, accT, (uint16_t*)dKV, heads,
+                       Nkv, nkpad, total);
+  return check_launch("attn_dkv_finish");
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// refign_amd/csrc/mfma.h -- shared pieces of the hand-written gfx950 matrix-core kernels (mfma_gemm.hip, attn.hip,
+// conv.hip): operand types, the 32x32x16 MFMA wrappers for bf16 / f16, LDS-DMA, packing and wave-half exchange.
+//
+// Register maps used throughout (v_mfma_f32_32x32x16_{bf16,f16}, wave64, lane l, g = l >> 5):
+//   A operand  : 8 values  A[i = l & 31][k = 8 g + e],  e = 0..7      (one 16-byte register quad)
+//   B operand  : 8 values  B[k = 8 g + e][j = l & 31]
+//   C/D        : 16 floats D[i = (r & 3) + 8 (r >> 2) + 4 g][j = l & 31],  r = 0..15
+// The instruction is a dot product over its 16 k-slots, so WHICH reduction index sits in slot (g, e) is free as long
+// as the A and the B operand agree.  The kernels use that freedom instead of cross-lane shuffles: a C/D register
+// block (a lane holds rows {0-3, 8-11, 16-19, 24-27} + 4 g of one column) is fed back as a B operand whose slot
+// (g, e) means row {0-3, 8-11}[e] + 4 g (+ 16 for the second k-step), and the matching A operand is read from memory
+// in that slot order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rfn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// DT: 1 = bfloat16, 2 = float16 (the ABI's dtype codes; 0 = float32 is not a matrix-core input type here)
+template <int DT> struct Elem;
+template <> struct Elem<1> {
+  using vec8 = bf16x8;
+  using vec4 = bf16x4;
+  using scalar = __bf16;
+  static __device__ __forceinline__ f32x16 mma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Elem<2> {
+  using vec8 = f16x8;
+  using vec4 = f16x4;
+  using scalar = _Float16;
+  static __device__ __forceinline__ f32x16 mma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// 4 floats -> 4 x 16-bit (round to nearest even), as two dwords
+template <int DT> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+  using S = typename Elem<DT>::scalar;
+  typename Elem<DT>::vec4 v = {(S)a, (S)b, (S)c, (S)d};
+  return __builtin_bit_cast(u32x2, v);
+}
+template <int DT> __device__ __forceinline__ void unpack4(u32x2 p, float (&f)[4]) {
+  auto v = __builtin_bit_cast(typename Elem<DT>::vec4, p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
+}
+// two k-slot halves (4 + 4 values) -> one MFMA operand
+template <int DT> __device__ __forceinline__ typename Elem<DT>::vec8 join8(u32x2 lo, u32x2 hi) {
+  u32x4 q = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(typename Elem<DT>::vec8, q);
+}
+
+// One LDS-DMA instruction: global -> LDS, 16 bytes per lane, lane i lands at lds_wave_base + 16 i (the destination is
+// wave-uniform base + lane order; the SOURCE address is per lane, which is where swizzles and gathers go).  Inline
+// asm on purpose: hipcc does not track it, so the hand-off is ours -- `s_waitcnt vmcnt(N)` + barrier before the
+// first ds_read of the data (see corr.hip for the measurement behind this choice).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base) {
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  const unsigned sbase = __builtin_amdgcn_readfirstlane(base);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(sbase) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+
+__device__ __forceinline__ void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() {
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// value of the partner lane (l ^ 32) combined with the own one
+__device__ __forceinline__ float half_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// XCD-aware, bijective block remap (8 XCDs, dispatcher places block b on XCD b % 8): consecutive logical ids run on
+// one XCD, so neighbouring tiles share that XCD's L2.  Speed only -- nothing depends on the placement.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+}  // namespace rfn

@@ -16,7 +16,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .params import as_dtype, compute_dtype, grad_sink, linear_gemm, linear_param_grads, sum_rows
+from . import mfma
+from .params import as_dtype, compute_dtype, grad_sink, linear_gemm, linear_param_grads, sum_rows, transposed
 
 
 _FUSED_GRADS = os.environ.get("RFN_LINEAR_FUSED_GRADS", "1") != "0"      # A/B switch (tools)
@@ -39,7 +40,9 @@ class _LinearFn(torch.autograd.Function):
         ctx.weight, ctx.bias = weight, bias
         N, K = w_c.shape
         x2 = x.reshape(-1, K)
-        y = linear_gemm(0, w_c, x2, (x2.shape[0], N), b_c, x2.shape[0], N, K) if x2.is_contiguous() else None
+        y = mfma.gemm_nt(x2, w_c, b_c)                       # hand-written MFMA kernel (16-bit operands)
+        if y is None:
+            y = linear_gemm(0, w_c, x2, (x2.shape[0], N), b_c, x2.shape[0], N, K) if x2.is_contiguous() else None
         return F.linear(x, w_c, b_c) if y is None else y.view(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -54,7 +57,11 @@ class _LinearFn(torch.autograd.Function):
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = linear_gemm(1, w_c, g2, (g2.shape[0], K), None, g2.shape[0], N, K)
+            # dx = dy W = dy (W^T)^T: the NT kernel on the cached transposed 16-bit copy of the weight
+            gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype)) if mfma.ENABLED and w_c.dtype != torch.float32 \
+                else None
+            if gx is None:
+                gx = linear_gemm(1, w_c, g2, (g2.shape[0], K), None, g2.shape[0], N, K)
             gx = (torch.mm(g2, w_c) if gx is None else gx).view(x.shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]
         sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
@@ -62,8 +69,12 @@ class _LinearFn(torch.autograd.Function):
         if need_w:
             x2 = x.reshape(-1, K)
             T = x2.shape[0]
+            part = mfma.gemm_tn(g2, x2)                      # fp32 per-slab partials (S, N, K)
+            if part is not None:
+                part = part.view(part.shape[0], N * K)
             S = _split(T)
-            part = linear_gemm(2, x2, g2, (S, N * K), None, T, N, K, S) if x2.is_contiguous() else None
+            if part is None:
+                part = linear_gemm(2, x2, g2, (S, N * K), None, T, N, K, S) if x2.is_contiguous() else None
             if part is None:
                 if S > 1:
                     part = torch.bmm(g2.view(S, T // S, N).transpose(1, 2), x2.view(S, T // S, K)).view(S, N * K)
@@ -71,7 +82,7 @@ class _LinearFn(torch.autograd.Function):
                     part = g2.t().mm(x2).view(1, N * K)
         # both gradients straight into the flat gradient buffer in two launches
         if need_w and need_b and sink_w is not None and sink_b is not None and _FUSED_GRADS and \
-                linear_param_grads(g2, part, sink_b, sink_w.view(-1)):
+                part.dtype == g2.dtype and linear_param_grads(g2, part, sink_b, sink_w.view(-1)):
             return gx, None, None, None, None
         if need_w:
             if sink_w is not None:
@@ -87,13 +98,33 @@ class _LinearFn(torch.autograd.Function):
 
 
 class Linear(nn.Linear):
-    def forward(self, x):
+    def forward(self, x, res=None, rowscale=None):
+        """y = x W^T + b.  Gradient-free callers may pass `res` (same shape as y) and a per-sample fp32 `rowscale`
+        (B,): y = res + rowscale[b] * (x W^T + b), the stochastic-depth residual of mix_transformer.py:203-207 fused
+        into the GEMM epilogue."""
         if not x.is_cuda:
-            return F.linear(x, self.weight, self.bias)
+            y = F.linear(x, self.weight, self.bias)
+            return y if res is None else _residual(res, y, rowscale)
         cd = compute_dtype(x)
         w_c, b_c = as_dtype(self.weight, cd), as_dtype(self.bias, cd)
         if x.dtype != cd:
             x = x.to(cd)
-        if torch.is_grad_enabled() and self.weight.requires_grad:
-            return _LinearFn.apply(x, self.weight, self.bias, w_c, b_c)
-        return F.linear(x, w_c, b_c)
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            y = _LinearFn.apply(x, self.weight, self.bias, w_c, b_c)
+            return y if res is None else _residual(res, y, rowscale)
+        N, K = w_c.shape
+        x2 = x.reshape(-1, K)
+        if res is not None and res.dtype == cd and res.is_contiguous():
+            y = mfma.gemm_nt(x2, w_c, b_c, res=res.view(-1, N), rowscale=rowscale,
+                             rows_per_sample=(x2.shape[0] // x.shape[0]) if rowscale is not None else 0)
+            if y is not None:
+                return y.view(x.shape[:-1] + (N,))
+        y = mfma.gemm_nt(x2, w_c, b_c)
+        y = F.linear(x, w_c, b_c) if y is None else y.view(x.shape[:-1] + (N,))
+        return y if res is None else _residual(res, y, rowscale)
+
+
+def _residual(res, y, rowscale):
+    if rowscale is None:
+        return res + y
+    return torch.addcmul(res, y, rowscale.to(y.dtype).view((-1,) + (1,) * (y.dim() - 1)))

@@ -1,0 +1,194 @@
+"""Host side of the hand-written matrix-core kernels (csrc/mfma_gemm.hip, csrc/attn.hip).
+
+  gemm_nt / gemm_tn     the three GEMMs of a token-wise Linear (mix_transformer.py:96-103,137-164)
+  attention             MiT's efficient self-attention core softmax(scale q k^T) v (mix_transformer.py:150-160),
+                        forward + backward, as a torch.autograd.Function over the C ABI
+
+16-bit operands only (bf16 under the step's autocast, f16 inside align()); fp32 callers stay on their own path -- these
+functions return None for anything outside the kernels' domain and raise if the HIP library is missing.
+"""
+import os
+
+import torch
+
+from . import _lib
+from ._tensor import current_stream, on_device, ptr
+
+_DT16 = {torch.bfloat16: 1, torch.float16: 2}
+ENABLED = os.environ.get("RFN_MFMA", "1") != "0"            # A/B switch: 0 = library GEMM / SDPA everywhere
+
+
+def _row_major(t):
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.stride(0) >= t.shape[1] \
+        and t.data_ptr() % 16 == 0
+
+
+def gemm_nt(x, w, bias=None, res=None, rowscale=None, rows_per_sample=0, act=0, out=None):
+    """y[M,N] = res + rowscale[m // rows_per_sample] * act(x[M,K] @ w[N,K]^T + bias); None if outside the domain."""
+    if not (ENABLED and x.is_cuda and x.dtype in _DT16 and w.dtype == x.dtype and _row_major(x) and _row_major(w)):
+        return None
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K or K % 64 != 0 or N % 8 != 0 or M == 0:
+        return None
+    if bias is not None and not (bias.dtype == x.dtype and bias.is_contiguous() and bias.numel() == N):
+        return None
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if res is not None and not (res.dtype == x.dtype and res.shape == out.shape and res.stride() == out.stride()):
+        return None
+    if rowscale is not None and (res is None or rowscale.dtype != torch.float32 or not rowscale.is_contiguous()):
+        return None
+    lib = _lib.load_library()
+    with on_device(x.device):
+        rc = lib.rfn_gemm_nt(ptr(x), ptr(w), ptr(bias), ptr(res), ptr(rowscale), int(rows_per_sample), int(act),
+                             ptr(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), _DT16[x.dtype],
+                             current_stream(x.device))
+    _lib.check(rc, "gemm_nt")
+    return out
+
+
+def slab_rows(T, tiles):
+    """Rows per slab of the split-T weight-gradient GEMM: enough slabs to fill the chip (~1024 workgroups with the
+    output tiles), slabs of at least 256 rows, multiples of 32."""
+    want = max(1, min(64, 1024 // max(tiles, 1)))
+    rows = -(-T // want)
+    rows = max(256, -(-rows // 32) * 32)
+    return rows
+
+
+def gemm_tn(g, x, rows_per_slab=None):
+    """partials[S, N, K] (fp32) with sum_s partials[s] = g[T,N]^T @ x[T,K]; None if outside the domain."""
+    if not (ENABLED and g.is_cuda and g.dtype in _DT16 and x.dtype == g.dtype and g.dim() == 2 and x.dim() == 2
+            and g.stride(1) == 1 and x.stride(1) == 1 and g.stride(0) % 2 == 0 and x.stride(0) % 2 == 0
+            and g.data_ptr() % 4 == 0 and x.data_ptr() % 4 == 0):
+        return None
+    T, N = g.shape
+    K = x.shape[1]
+    if x.shape[0] != T or N % 64 != 0 or K % 64 != 0 or T == 0:
+        return None
+    if rows_per_slab is None:
+        tile = 128 if (N % 128 == 0 and K % 128 == 0) else 64
+        rows_per_slab = slab_rows(T, (N // tile) * (K // tile))
+    S = -(-T // rows_per_slab)
+    part = torch.empty((S, N, K), dtype=torch.float32, device=g.device)
+    lib = _lib.load_library()
+    with on_device(g.device):
+        rc = lib.rfn_gemm_tn(ptr(g), ptr(x), ptr(part), T, N, K, g.stride(0), x.stride(0), int(rows_per_slab),
+                             _DT16[g.dtype], current_stream(g.device))
+    _lib.check(rc, "gemm_tn")
+    return part
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------------------------
+_PACK_BLOCK = 4096
+
+
+def _pack(src, batch_stride, row_stride, B, heads, nrows, nblk, want_r=True, want_t=True):
+    dev = src.device
+    nbytes = B * heads * nblk * _PACK_BLOCK
+    r = torch.empty(nbytes, dtype=torch.uint8, device=dev) if want_r else None
+    t = torch.empty(nbytes, dtype=torch.uint8, device=dev) if want_t else None
+    lib = _lib.load_library()
+    with on_device(dev):
+        rc = lib.rfn_attn_pack(ptr(src), batch_stride, row_stride, B, heads, nrows, nblk, ptr(r), ptr(t),
+                               current_stream(dev))
+    _lib.check(rc, "attn_pack")
+    return r, t
+
+
+def _attn_ok(q, kv, heads):
+    if not (ENABLED and q.is_cuda and q.dtype in _DT16 and kv.dtype == q.dtype and q.dim() == 3 and kv.dim() == 3):
+        return False
+    B, N, C = q.shape
+    return (C == heads * 64 and kv.shape[0] == B and kv.shape[2] == 2 * C and q.is_contiguous() and kv.is_contiguous()
+            and q.data_ptr() % 16 == 0 and kv.data_ptr() % 16 == 0)
+
+
+def _dims(q, kv):
+    B, N, C = q.shape
+    Nkv = kv.shape[1]
+    nkblk = -(-Nkv // 32)
+    nkblk += nkblk & 1                                  # forward / dQ walk the keys two blocks per stage
+    nqblk = -(-N // 32)
+    return B, N, C, Nkv, nkblk, nqblk, nqblk * 32
+
+
+def _fwd(q, kv, heads, scale, need_bwd):
+    B, N, C, Nkv, nkblk, nqblk, nqpad = _dims(q, kv)
+    dev = q.device
+    k_view, v_view = kv[:, :, :C], kv[:, :, C:]
+    kr, kt = _pack(k_view, kv.stride(0), kv.stride(1), B, heads, Nkv, nkblk, True, need_bwd)
+    vr, vt = _pack(v_view, kv.stride(0), kv.stride(1), B, heads, Nkv, nkblk, need_bwd, True)
+    o = torch.empty_like(q)
+    lse2 = torch.empty((B * heads, nqpad), dtype=torch.float32, device=dev)
+    lib = _lib.load_library()
+    with on_device(dev):
+        rc = lib.rfn_attn_fwd(ptr(q), q.stride(0), q.stride(1), ptr(kr), ptr(vt), ptr(o), o.stride(0), o.stride(1),
+                              ptr(lse2), B, heads, N, Nkv, nkblk, nqpad, float(scale), _DT16[q.dtype],
+                              current_stream(dev))
+    _lib.check(rc, "attn_fwd")
+    return o, lse2, (kr, kt, vr)
+
+
+def _chunk_blocks(nqblk, Nkv, BH):
+    """32-query blocks per dK/dV workgroup: ~768 workgroups over the chip, at least 4 blocks each."""
+    kblocks = -(-Nkv // 256)
+    chunks = max(1, 768 // max(1, kblocks * BH))
+    return max(4, -(-nqblk // chunks))
+
+
+class _AttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        need = q.requires_grad or kv.requires_grad
+        o, lse2, packs = _fwd(q, kv, heads, scale, need)
+        if need:
+            ctx.save_for_backward(q, kv, o, lse2, *packs)
+            ctx.heads, ctx.scale = heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse2, kr, kt, vr = ctx.saved_tensors
+        heads, scale = ctx.heads, ctx.scale
+        B, N, C, Nkv, nkblk, nqblk, nqpad = _dims(q, kv)
+        dev = q.device
+        if do.dtype != q.dtype:
+            do = do.to(q.dtype)
+        if not do.is_contiguous():
+            do = do.contiguous()
+        dt = _DT16[q.dtype]
+        lib = _lib.load_library()
+        dq = torch.empty_like(q)
+        delta = torch.empty_like(lse2)
+        with on_device(dev):
+            rc = lib.rfn_attn_bwd_dq(ptr(q), q.stride(0), q.stride(1), ptr(do), ptr(o), o.stride(0), o.stride(1),
+                                     ptr(kr), ptr(vr), ptr(kt), ptr(lse2), ptr(delta), ptr(dq), dq.stride(0),
+                                     dq.stride(1), B, heads, N, Nkv, nkblk, nqpad, float(scale), dt,
+                                     current_stream(dev))
+        _lib.check(rc, "attn_bwd_dq")
+        qr, qt = _pack(q, q.stride(0), q.stride(1), B, heads, N, nqblk)
+        gr, gt = _pack(do, do.stride(0), do.stride(1), B, heads, N, nqblk)
+        nkpad = -(-Nkv // 32) * 32
+        accT = torch.empty(B * heads * 2 * 64 * nkpad, dtype=torch.float32, device=dev)
+        dkv = torch.empty_like(kv)
+        k_view, v_view = kv[:, :, :C], kv[:, :, C:]
+        with on_device(dev):
+            rc = lib.rfn_attn_bwd_dkv(ptr(k_view), ptr(v_view), kv.stride(0), kv.stride(1), ptr(qr), ptr(qt), ptr(gr),
+                                      ptr(gt), ptr(lse2), ptr(delta), ptr(accT), ptr(dkv), B, heads, N, Nkv, nqblk,
+                                      nqpad, nkpad, _chunk_blocks(nqblk, Nkv, B * heads), float(scale), dt,
+                                      current_stream(dev))
+        _lib.check(rc, "attn_bwd_dkv")
+        return dq, dkv, None, None
+
+
+def attention(q, kv, heads, scale):
+    """q: (B, N, heads*64) output of the q Linear; kv: (B, Nkv, 2*heads*64) output of the kv Linear (K then V, each
+    (heads, 64) per token -- the layout `.reshape(B, -1, 2, heads, 64)` of mix_transformer.py:147-149 reads).
+    Returns (B, N, heads*64) = `(attn @ v).transpose(1, 2).reshape(B, N, C)`, or None if outside the kernels' domain."""
+    if not _attn_ok(q, kv, heads):
+        return None
+    return _AttnFn.apply(q, kv, heads, scale)

@@ -114,6 +114,17 @@ def as_dtype(p, dtype):
     return derived(p, dtype, lambda t: t.to(dtype), _identity)
 
 
+def _t_view(t):
+    return t.t()
+
+
+def transposed(p, dtype):
+    """Contiguous transposed copy W^T (K, N) of a Linear weight (N, K) in the compute dtype: the B operand of the
+    input-gradient GEMM dx = dy W run as an NT product (csrc/mfma_gemm.hip).  Cached like the plain 16-bit copy and
+    re-filled in place after optimizer / EMA updates."""
+    return derived(p, ("T", dtype), lambda t: t.to(dtype).t().contiguous(), _t_view)
+
+
 def compute_dtype(x):
     """dtype the dense ops run in: the autocast dtype inside an autocast region, else x's."""
     if x.is_cuda and torch.is_autocast_enabled("cuda"):

@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import mfma
 from ._tensor import const_tensor
 from .align import BaseHead
 from .conv import Conv2d, patch_conv_tokens
@@ -80,9 +81,12 @@ class Mlp(nn.Module):
         self.fc2 = Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, res=None, rowscale=None):
         x = self.drop(self.act(self.dwconv(self.fc1(x), H, W)))
-        return self.drop(self.fc2(x))
+        if res is not None and self.drop.p == 0.:
+            return self.fc2(x, res=res, rowscale=rowscale)       # residual (+ drop-path scale) in the GEMM epilogue
+        y = self.drop(self.fc2(x))
+        return y if res is None else _residual(res, y, rowscale)
 
 
 def _sdpa_backend():
@@ -117,25 +121,40 @@ class Attention(nn.Module):
             self.sr = Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = LayerNorm(dim)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, res=None, rowscale=None):
         B, N, C = x.shape
         h, d = self.num_heads, C // self.num_heads
-        q = self.q(x).view(B, N, h, d).transpose(1, 2)                       # (B,h,N,d)
+        q = self.q(x)                                                        # (B,N,C) = (B,N,h,d)
         if self.sr_ratio > 1:
             r = patch_conv_tokens(x, H, W, self.sr) if _SR_AS_LINEAR else None   # (B, N/sr^2, C) tokens directly
             if r is None:
                 r = self.sr(x.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
             x = self.norm(r)
-        # unbind, not kv[0] / kv[1]: its backward is ONE stack of (dK, dV) instead of two zero-fills, two slice
-        # copies and an add
-        k, v = self.kv(x).view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4).unbind(0)   # (B,h,Nkv,d) each
+        kv = self.kv(x)                                                      # (B,Nkv,2C) = (B,Nkv,2,h,d)
         p = self.attn_drop.p if self.training else 0.0
-        if _SDPA_BACKEND is None:
-            o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
-        else:                                          # measurement knob: RFN_SDPA_BACKEND=flash|efficient|math
-            with torch.nn.attention.sdpa_kernel([_SDPA_BACKEND]):
+        # hand-written MFMA attention (csrc/attn.hip): head_dim 64, 16-bit operands, no attention dropout
+        o = mfma.attention(q, kv, h, self.scale) if (d == 64 and p == 0.0 and _SDPA_BACKEND is None) else None
+        if o is None:
+            q = q.view(B, N, h, d).transpose(1, 2)                           # (B,h,N,d)
+            # unbind, not kv[0] / kv[1]: its backward is ONE stack of (dK, dV) instead of two zero-fills, two slice
+            # copies and an add
+            k, v = kv.view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4).unbind(0)  # (B,h,Nkv,d) each
+            if _SDPA_BACKEND is None:
                 o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
-        return self.proj_drop(self.proj(o.transpose(1, 2).reshape(B, N, C)))
+            else:                                      # measurement knob: RFN_SDPA_BACKEND=flash|efficient|math
+                with torch.nn.attention.sdpa_kernel([_SDPA_BACKEND]):
+                    o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
+            o = o.transpose(1, 2).reshape(B, N, C)
+        if res is not None and self.proj_drop.p == 0.:
+            return self.proj(o, res=res, rowscale=rowscale)
+        y = self.proj_drop(self.proj(o))
+        return y if res is None else _residual(res, y, rowscale)
+
+
+def _residual(res, y, rowscale):
+    if rowscale is None:
+        return res + y
+    return torch.addcmul(res, y, rowscale.to(y.dtype).view((-1,) + (1,) * (y.dim() - 1)))
 
 
 class Block(nn.Module):
@@ -151,7 +170,14 @@ class Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
-    def forward(self, x, H, W, masks=None):
+    def forward(self, x, H, W, masks=None, masks32=None):
+        if x.is_cuda and not torch.is_grad_enabled() and (masks is None) == (masks32 is None) and \
+                (masks is not None or not (self.training and isinstance(self.drop_path, DropPath)
+                                           and self.drop_path.drop_prob > 0.)):
+            # gradient-free passes (EMA teacher, ImageNet features, inference): the residual add and the per-sample
+            # stochastic-depth scale ride in the epilogue of the proj / fc2 GEMMs
+            x = self.attn(self.norm1(x), H, W, res=x, rowscale=None if masks32 is None else masks32[0])
+            return self.mlp(self.norm2(x), H, W, res=x, rowscale=None if masks32 is None else masks32[1])
         if masks is not None:                       # pre-drawn stochastic-depth masks (MixVisionTransformer)
             x = torch.addcmul(x, self.attn(self.norm1(x), H, W), masks[0])
             return torch.addcmul(x, self.mlp(self.norm2(x), H, W), masks[1])
@@ -256,17 +282,18 @@ class MixVisionTransformer(nn.Module):
                 not all(getattr(b.drop_path, "scale_by_keep", True) for b in blocks):
             return None
         k = const_tensor(keep, x, dtype=torch.float32).view(-1, 1)
-        m = torch.bernoulli(k.expand(-1, x.shape[0])) / k
+        m = (torch.bernoulli(k.expand(-1, x.shape[0])) / k).contiguous()
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-        return m.to(dt).view(len(keep), x.shape[0], 1, 1)
+        return m.to(dt).view(len(keep), x.shape[0], 1, 1), m              # compute-dtype view + the fp32 (n, B) masks
 
     def forward_features(self, x):
         B, outs = x.shape[0], []
-        masks, i = self._drop_path_masks(x), 0
+        mm, i = self._drop_path_masks(x), 0
+        masks, masks32 = (None, None) if mm is None else mm
         for s in range(1, 5):
             x, H, W = getattr(self, f"patch_embed{s}")(x)
             for blk in getattr(self, f"block{s}"):
-                x = blk(x, H, W, None if masks is None else masks[i:i + 2])
+                x = blk(x, H, W, None if masks is None else masks[i:i + 2], None if masks32 is None else masks32[i:i + 2])
                 i += 2
             x = getattr(self, f"norm{s}")(x)
             x = x.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()

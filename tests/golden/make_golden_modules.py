@@ -107,4 +107,56 @@ def g7():
          uncert=unc.numpy())
 
 
-GROUPS = {"G4": g4, "G5": g5, "G7": g7}
+def smooth_logits(C, H, W, key):
+    """Low-pass logits with large top-2 margins almost everywhere: one low-frequency plane wave per class (at most one
+    period over the image) plus a class offset.  |d logit / d pixel| <= 2 pi 6 / min(H, W) ~ 0.3, so a flow error of
+    1e-3 px moves a bilinear sample by ~3e-4: the fixture can tell a correct warp from a slightly wrong one at the
+    north-star tolerance (1e-3), which white-noise logits cannot."""
+    u = hashed_uniform((C, 4), key)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64) / H, np.arange(W, dtype=np.float64) / W, indexing="ij")
+    out = np.empty((1, C, H, W), np.float32)
+    for c in range(C):
+        fy, fx = np.round(u[c, 0] * 2 - 1, 2), np.round(u[c, 1] * 2 - 1, 2)
+        out[0, c] = 6.0 * np.cos(2 * np.pi * (fy * yy + fx * xx + u[c, 2])) + 2.0 * (u[c, 3] - 0.5)
+    return out
+
+
+def g7s():
+    """align() on the G7 image pair with SMOOTH logits, plus every intermediate of the path (feature pyramids, the four
+    (flow, log-variance) levels) so that a parity failure can be bisected per stage."""
+    sm = R.ref_module("models.segmentation_model")
+    vggm = R.ref_module("models.backbones.vgg")
+    vgg = closed_form_fill(vggm.VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone.").eval()
+    head = _head()
+    H, W = 128, 160
+    img_trg = (hashed_uniform((1, 3, H, W), "g7/trg") * 4 - 2).astype(np.float32)
+    img_ref = (0.8 * np.roll(img_trg, (2, -3), (2, 3)) + 0.2 * (hashed_uniform((1, 3, H, W), "g7/ref") * 4 - 2)).astype(np.float32)
+    logits = smooth_logits(19, H, W, "g7s/logits")
+    ns = types.SimpleNamespace(alignment_backbone=vgg, alignment_head=head)
+    with torch.no_grad():
+        warped, mask, cert = sm.DomainAdaptationSegmentationModel.align(ns, t(logits), t(img_ref), t(img_trg))
+        # intermediates, through the same public calls align() makes (segmentation_model.py:498-513)
+        i256 = [torch.nn.functional.interpolate(t(x), size=(256, 256), mode='area') for x in (img_ref, img_trg)]
+        pyr = vgg(torch.cat([t(img_ref), t(img_trg)]), extract_only_indices=[-3, -2])
+        pyr256 = vgg(torch.cat(i256), extract_only_indices=[-2, -1])
+        pr, pt = zip(*[torch.split(l, [1, 1]) for l in pyr])
+        pr256, pt256 = zip(*[torch.split(l, [1, 1]) for l in pyr256])
+        levels = head(pt, pr, pt256, pr256, (H, W))
+    wn = warped.numpy()
+    srt = np.sort(wn, axis=1)
+    arrays = dict(size=np.array([H, W]), warped_sample=wn[:, :, ::2, ::2],
+                  warped_checksum=np.float64(wn.astype(np.float64).sum()), warped_abs_checksum=np.float64(np.abs(wn).sum()),
+                  warped_argmax=wn.argmax(1).astype(np.uint8), warped_margin=(srt[:, -1] - srt[:, -2]).astype(np.float16),
+                  mask=mask.numpy(), cert=cert.numpy(), img256_trg=i256[1].numpy()[:, :, ::4, ::4])
+    for name, fs in (("pyr", pyr), ("pyr256", pyr256)):
+        for i, f in enumerate(fs):
+            f = f.numpy()
+            arrays[f"{name}{i}_sample"] = f[:, ::8, ::2, ::2]
+            arrays[f"{name}{i}_abs_checksum"] = np.float64(np.abs(f).sum())
+    for lvl, (fl, un) in zip((4, 3, 2, 1), levels):
+        arrays[f"flow{lvl}"] = fl.numpy()
+        arrays[f"uncert{lvl}"] = un.numpy()
+    save("align_smooth_128x160", **arrays)
+
+
+GROUPS = {"G4": g4, "G5": g5, "G7": g7, "G7s": g7s}

@@ -56,3 +56,18 @@ def test_product_does_not_import_oracle():
                 if re.search(r"cpu_oracle|liboracle|oracle/|import oracle|from oracle", src):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_plugin_package_importable_by_name():
+    """The reference's zero-patch plug-in point: LocalFeatureCorrelationLayer.__init__ first tries
+    `from spatial_correlation_sampler import spatial_correlation_sample` (models/modules.py:252-262).  The package of
+    that name shipped at the repo root must resolve to the HIP operator with the reference's signature."""
+    import inspect
+
+    import spatial_correlation_sampler as scs
+    from refign_amd import correlation
+    assert scs.spatial_correlation_sample is correlation.spatial_correlation_sample
+    sig = inspect.signature(scs.spatial_correlation_sample)
+    assert list(sig.parameters) == ["input1", "input2", "kernel_size", "patch_size", "stride", "padding", "dilation",
+                                    "dilation_patch"]                       # correlation_function.py:14-16
+    assert [p.default for p in list(sig.parameters.values())[2:]] == [1, 1, 1, 0, 1, 1]

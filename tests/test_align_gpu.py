@@ -117,6 +117,65 @@ def test_align_end_to_end_golden(dev):
     assert (wn.argmax(1) == g["warped_argmax"]).mean() > 0.995
 
 
+def smooth_logits(C, H, W, key):
+    """Same closed form as tests/golden/make_golden_modules.py::smooth_logits (low-frequency plane wave per class)."""
+    u = hashed_uniform((C, 4), key)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64) / H, np.arange(W, dtype=np.float64) / W, indexing="ij")
+    out = np.empty((1, C, H, W), np.float32)
+    for c in range(C):
+        fy, fx = np.round(u[c, 0] * 2 - 1, 2), np.round(u[c, 1] * 2 - 1, 2)
+        out[0, c] = 6.0 * np.cos(2 * np.pi * (fy * yy + fx * xx + u[c, 2])) + 2.0 * (u[c, 3] - 0.5)
+    return out
+
+
+@torch.no_grad()
+def test_align_end_to_end_smooth_golden_north_star(dev):
+    """G7s: the north-star bar on align() -- warped reference logits within 1e-3 (fp32) of the reference CPU path and
+    pixel-exact argmax -- on logits that are smooth (|d logit / d px| <= 0.3), i.e. where 1e-3 on the warped logits is
+    a statement about the flow (<= 3e-3 px) and not about white noise.  Every stage of the path is pinned beside it
+    (feature pyramids, the four (flow, log-variance) levels) so that a failure names its stage.  Argmax is compared
+    where the reference's own top-2 margin exceeds 10x the tolerance (ties are not decidable in fp32)."""
+    from refign_amd.align import VGG, UAWarpCHead, align, extract_pyramids
+    g = golden("align_smooth_128x160")
+    H, W = [int(v) for v in g["size"]]
+    vgg = closed_form_fill(VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone.").to(dev).eval()
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select',
+                                        estimate_uncertainty=True)).to(dev).eval()
+    img_trg = (hashed_uniform((1, 3, H, W), "g7/trg") * 4 - 2).astype(np.float32)
+    img_ref = (0.8 * np.roll(img_trg, (2, -3), (2, 3)) + 0.2 * (hashed_uniform((1, 3, H, W), "g7/ref") * 4 - 2)).astype(np.float32)
+    logits = smooth_logits(19, H, W, "g7s/logits")
+    # --- stage by stage
+    pt, pr, pt256, pr256 = extract_pyramids(vgg, T(img_ref, dev), T(img_trg, dev))
+    report = []
+    for name, fs in (("pyr", [torch.cat([a, b]) for a, b in zip(pr, pt)]),
+                     ("pyr256", [torch.cat([a, b]) for a, b in zip(pr256, pt256)])):
+        for i, f in enumerate(fs):
+            f = f.cpu().numpy()
+            want = g[f"{name}{i}_sample"]
+            err = np.abs(f[:, ::8, ::2, ::2] - want).max() / max(np.abs(want).max(), 1e-6)
+            report.append((f"{name}{i}", err))
+            assert err < 1e-4, (name, i, err)
+    levels = head(pt, pr, pt256, pr256, (H, W))
+    for lvl, (fl, un) in zip((4, 3, 2, 1), levels):
+        ef = float(np.abs(fl.cpu().numpy() - g[f"flow{lvl}"]).max())
+        eu = float(np.abs(un.cpu().numpy() - g[f"uncert{lvl}"]).max())
+        report.append((f"flow{lvl} [px]", ef))
+        report.append((f"logvar{lvl}", eu))
+    print("\nalign per-stage max abs error vs reference CPU path:", ", ".join(f"{k}={v:.2e}" for k, v in report))
+    # --- the north star
+    warped, mask, cert = align(vgg, head, T(logits, dev), T(img_ref, dev), T(img_trg, dev))
+    wn = warped.cpu().numpy()
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])
+    np.testing.assert_allclose(cert.cpu().numpy(), g["cert"], atol=1e-3)
+    inside = g["mask"][:, None, ::2, ::2]
+    err = np.abs(wn[:, :, ::2, ::2] - g["warped_sample"]) * inside
+    assert err.max() <= 1e-3, f"warped logits differ by {err.max():.2e} (north star 1e-3)"
+    assert abs(wn.astype(np.float64).sum() - g["warped_checksum"]) < 1e-5 * g["warped_abs_checksum"]
+    decided = (g["warped_margin"].astype(np.float32) > 1e-2) & g["mask"]
+    assert decided.mean() > 0.9
+    assert (wn.argmax(1) == g["warped_argmax"])[decided].all(), "argmax mask not pixel-exact"
+
+
 @torch.no_grad()
 def test_align_amp_precision_map(dev, monkeypatch):
     """Inside a reduced-precision autocast region align() runs its convolutions in fp16 -- the reference's AMP dtype

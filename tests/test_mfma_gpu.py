@@ -1,0 +1,156 @@
+"""GPU numerics of the hand-written matrix-core kernels (csrc/mfma_gemm.hip, csrc/attn.hip) through the C ABI, each
+against a plain PyTorch fp32 reference of the same op fed with the SAME 16-bit-rounded inputs (so the only differences
+are fp32 accumulation order and the final 16-bit rounding).  Tolerances are written per test.
+
+Reference semantics: nn.Linear / Mlp / Attention of models/backbones/mix_transformer.py:96-103,137-164."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+def _rand(shape, dev, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(300, 64, 64), (129, 256, 64), (1000, 320, 320), (513, 640, 320),
+                                   (4111, 1280, 320), (2040, 512, 2048), (77, 8, 128), (260, 24, 64)])
+def test_gemm_nt_matches_fp32_reference(dev, dtype, M, N, K):
+    """y = x W^T + b: asymmetric random operands (a transposed / swapped tile cannot pass), ragged M, N not a multiple
+    of the 64 / 128 tile.  Error bound: one 16-bit rounding of the result + fp32 accumulation noise."""
+    from refign_amd.mfma import gemm_nt
+    x = _rand((M, K), dev, dtype, 1)
+    w = _rand((N, K), dev, dtype, 2, K ** -0.5)
+    b = _rand((N,), dev, dtype, 3)
+    want = x.float() @ w.float().t() + b.float()
+    got = gemm_nt(x, w, b)
+    assert got is not None and got.dtype == dtype and got.shape == (M, N)
+    tol = 2 * EPS[dtype] * float(want.abs().max())
+    assert float((got.float() - want).abs().max()) <= tol
+    # no bias, strided operands (views of wider buffers)
+    xb = torch.zeros((M, K + 64), dtype=dtype, device=dev)
+    xb[:, :K] = x
+    got2 = gemm_nt(xb[:, :K], w)
+    want2 = x.float() @ w.float().t()
+    assert float((got2.float() - want2).abs().max()) <= 2 * EPS[dtype] * float(want2.abs().max())
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_gemm_nt_epilogues(dev, act):
+    """Fused epilogue: act(x W^T + b), and the stochastic-depth residual res + mask[b] * (x W^T + b)."""
+    from refign_amd.mfma import gemm_nt
+    dtype = torch.bfloat16
+    B, T, N, K = 3, 170, 320, 128
+    x = _rand((B * T, K), dev, dtype, 4)
+    w = _rand((N, K), dev, dtype, 5, K ** -0.5)
+    b = _rand((N,), dev, dtype, 6)
+    z = x.float() @ w.float().t() + b.float()
+    want = torch.relu(z) if act == 1 else torch.nn.functional.gelu(z)
+    got = gemm_nt(x, w, b, act=act)
+    assert float((got.float() - want).abs().max()) <= 2 * EPS[dtype] * float(want.abs().max())
+    res = _rand((B * T, N), dev, dtype, 7)
+    mask = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9], device=dev)
+    got = gemm_nt(x, w, b, res=res, rowscale=mask, rows_per_sample=T)
+    want = res.float() + mask.repeat_interleave(T)[:, None] * z
+    assert float((got.float() - want).abs().max()) <= 2 * EPS[dtype] * float(want.abs().max())
+    assert torch.equal(got[:T], res[:T])                       # dropped sample: the residual passes through exactly
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,N,K,rows", [(8160, 320, 320, None), (2040, 512, 2048, None), (1000, 64, 256, 96),
+                                        (4111, 128, 128, 512), (129600, 64, 64, None)])
+def test_gemm_tn_matches_fp32_reference(dev, dtype, T, N, K, rows):
+    """Weight-gradient GEMM dW = g^T x as per-slab fp32 partials (ragged T: the last slab and the last 32-row stage are
+    masked)."""
+    from refign_amd.mfma import gemm_tn
+    g = _rand((T, N), dev, dtype, 8)
+    x = _rand((T, K), dev, dtype, 9)
+    part = gemm_tn(g, x, rows)
+    assert part is not None and part.dtype == torch.float32 and part.shape[1:] == (N, K)
+    want = g.double().t() @ x.double()
+    got = part.double().sum(0)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) * math.sqrt(T / 1000 + 1) + 1e-3
+
+
+def _ref_attention(q, kv, heads, scale):
+    B, N, C = q.shape
+    d = C // heads
+    qh = q.view(B, N, heads, d).transpose(1, 2)
+    k, v = kv.view(B, -1, 2, heads, d).permute(2, 0, 3, 1, 4).unbind(0)
+    a = ((qh @ k.transpose(-2, -1)) * scale).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(B, N, C)
+
+
+ATTN_CASES = [  # B, heads, N, Nkv
+    (2, 1, 510, 510), (2, 2, 2040, 510), (1, 5, 2040, 510), (2, 8, 510, 510), (1, 1, 32400, 480), (1, 8, 2040, 2040),
+    (2, 2, 333, 70), (1, 1, 31, 33), (1, 2, 8160, 510),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,heads,N,Nkv", ATTN_CASES)
+def test_attention_forward_backward_vs_fp32_reference(dev, dtype, B, heads, N, Nkv):
+    """softmax(scale q k^T) v and its three gradients against fp32 autograd of the textbook formulation on the same
+    16-bit inputs: ragged query / key counts (masking of the last key block, partial query tiles), 1-8 heads.
+    Bounds: output 2 ulp(16-bit) of its range; gradients 2 % of their range (P and dS are rounded to 16 bit before the
+    second GEMM of each chain, as in every flash-attention backward)."""
+    from refign_amd.mfma import attention
+    C = heads * 64
+    scale = 64 ** -0.5
+    q = _rand((B, N, C), dev, dtype, 10, 1.5).requires_grad_(True)
+    kv = _rand((B, Nkv, 2 * C), dev, dtype, 11, 1.5).requires_grad_(True)
+    go = _rand((B, N, C), dev, dtype, 12)
+    o = attention(q, kv, heads, scale)
+    assert o is not None and o.dtype == dtype
+    o.backward(go)
+    qf, kvf = q.detach().float().requires_grad_(True), kv.detach().float().requires_grad_(True)
+    of = _ref_attention(qf, kvf, heads, scale)
+    of.backward(go.float())
+    e = EPS[dtype]
+    assert float((o.float() - of).abs().max()) <= 4 * e * float(of.abs().max()) + 1e-3
+    for name, got, want in (("dq", q.grad, qf.grad), ("dkv", kv.grad, kvf.grad)):
+        err = float((got.float() - want).abs().max())
+        assert err <= 0.02 * float(want.abs().max()) + 1e-4, (name, err, float(want.abs().max()))
+
+
+def test_attention_spiked_scores_and_no_grad(dev):
+    """One key dominating one query late in the key stream (forces the running-max rescale of the online softmax in a
+    late stage), and the gradient-free path (no backward packs)."""
+    from refign_amd.mfma import attention
+    B, heads, N, Nkv, C = 1, 2, 200, 300, 128
+    q = _rand((B, N, C), dev, torch.bfloat16, 13)
+    kv = _rand((B, Nkv, 2 * C), dev, torch.bfloat16, 14)
+    kv[0, 290, :64] = 8 * q[0, 7, :64]                         # key 290 of head 0 ~ 8 |q_7|^2
+    with torch.no_grad():
+        o = attention(q, kv, heads, 0.125)
+    want = _ref_attention(q.float(), kv.float(), heads, 0.125)
+    assert float((o.float() - want).abs().max()) <= 4 * EPS[torch.bfloat16] * float(want.abs().max()) + 1e-3
+
+
+def test_linear_module_uses_mfma_kernels(dev):
+    """refign_amd.linear.Linear under bf16 autocast: forward, input gradient and the parameter gradients (accumulated
+    into .grad) against fp32 nn.functional.linear; tokens (B, N, C) like MiT's."""
+    from refign_amd.linear import Linear
+    torch.manual_seed(0)
+    lin = Linear(320, 1280).to(dev)
+    x = torch.randn(4, 2040, 320, device=dev, requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = lin(x)
+    assert y.dtype == torch.bfloat16
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_(True)
+    w, b = lin.weight.detach().clone().requires_grad_(True), lin.bias.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, w, b)
+    yr.backward(gy.float())
+    assert float((y.float() - yr).abs().max()) <= 0.02 * float(yr.abs().max())
+    assert float((x.grad - xr.grad).abs().max()) <= 0.02 * float(xr.grad.abs().max())
+    assert float((lin.weight.grad - w.grad).abs().max()) <= 0.02 * float(w.grad.abs().max())
+    assert float((lin.bias.grad - b.grad).abs().max()) <= 0.02 * float(b.grad.abs().max())
