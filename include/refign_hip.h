@@ -132,6 +132,11 @@ int rfn_align_tail_f32(const float* logits_ref, const float* flow_q, const float
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W,
                            int C, int dilation, int dtype, int flip, rfn_stream_t stream);
+/* The same convolution (dilation 1) followed by GELU (exact erf) -- the DWConv + act of the Mix-FFN
+ * (mix_transformer.py:99-101) in one pass: y_act = gelu(conv(x) + bias); y_pre (may be NULL) = the pre-activation,
+ * which the backward of GELU needs and a gradient-free pass does not. */
+int rfn_dwconv3x3_gelu_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y_pre, void* y_act, int B,
+                                int H, int W, int C, int dtype, rfn_stream_t stream);
 unsigned long rfn_dwconv3x3_bwd_weight_workspace_bytes(int C);
 int rfn_dwconv3x3_nhwc_bwd_weight(const void* x, const void* grad_y, float* grad_weight, float* grad_bias,
                                   void* workspace, int B, int H, int W, int C, int dilation, int dtype, int flags,
@@ -233,17 +238,30 @@ int rfn_patchify_tokens(const void* src, void* dst, int B, int H, int W, int C, 
  * rfn_gemm_nt:  Y[M,N] = res + rowscale[m / rows_per_sample] * act( X[M,K] . W[N,K]^T + bias[N] )
  *   forward: X = tokens, W = weight.  dgrad: X = grad_y [T,N], W = weight^T [K,N] (host keeps the transposed copy).
  *   bias / res / rowscale may be NULL (res NULL: Y = act(...); rowscale needs res: the stochastic-depth residual
- *   `x + drop_path(branch)` of mix_transformer.py:203-207 with per-sample keep masks).  act: 0 none, 1 ReLU, 2 GELU(erf).
+ *   `x + drop_path(branch)` of mix_transformer.py:203-207 with per-sample keep masks).  act: 0 none, 1 ReLU, 3 LeakyReLU(0.1).
  *   K % 64 == 0, N % 8 == 0, ldx / ldw / ldy % 8 == 0.
- * rfn_gemm_tn:  P[s][N,K] = sum over rows t of slab s of G[t,n] * X[t,k]   (fp32 partials, S = ceil(T / rows_per_slab))
- *   wgrad: G = grad_y [T,N], X = tokens [T,K]; the host reduces the slabs into the flat gradient buffer (rfn_sum_rows).
+ * rfn_gemm_tn:  sum over rows t of slab s of G[t,n] * X[t,k], S = ceil(T / rows_per_slab) slabs computed by separate
+ *   workgroups (the reduction of a weight gradient is the TOKEN dimension: 8 160 ... 259 200 rows for a <= 2048 x 2048
+ *   result).  wgrad: G = grad_y [T,N], X = tokens [T,K].
+ *     accumulate = 0: P[s][N,K] = fp32 partial of slab s (deterministic; caller reduces);
+ *     accumulate = 1: P[N,K] += every slab, fp32 atomics (the parameter's view of the flat gradient buffer);
+ *     grad_bias (may be NULL): [N] fp32, += column sums of G (the bias gradient), fp32 atomics.
  *   N % 64 == 0, K % 64 == 0, rows_per_slab % 32 == 0.
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_gemm_nt(const void* X, const void* W, const void* bias, const void* res, const float* rowscale,
                 int rows_per_sample, int act, void* Y, long M, long N, long K, long ldx, long ldw, long ldy, int dtype,
                 rfn_stream_t stream);
+/* Convolution as an implicit GEMM on the same kernel: channels-last activations X (B, H, W, C), weights W[n][(ky, kx, c)]
+ * with rows zero-padded to ldw >= roundup(KH*KW*C, 64), output Y (B, OH, OW, N) with row stride ldy (so a layer can write
+ * its channel slice of a concatenation buffer).  Y = res + act(conv(X) + bias); act 0 none, 1 ReLU, 3 LeakyReLU(0.1).
+ * Replaces F.conv2d for VGG-16 (vgg.py:108-120), the flow decoders / refinement modules (modules.py:395-477), the MiT patch
+ * embeddings (mix_transformer.py:210-242) and the decode-head convolutions (daformer.py:65-126) -- eval-mode BatchNorm is
+ * folded into W / bias by the host.  C % 8 == 0, N % 8 == 0, zero padding, any stride / dilation / kernel size. */
+int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* res, int act, void* Y, int B, int H,
+                    int Wd, int C, int N, int KH, int KW, int stride, int pad, int dil, long ldw, long ldy, int dtype,
+                    rfn_stream_t stream);
 int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int rows_per_slab,
-                int dtype, rfn_stream_t stream);
+                int accumulate, float* grad_bias, int dtype, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hand-written matrix-core attention for MiT's efficient self-attention (mix_transformer.py:137-164):

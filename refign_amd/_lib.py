@@ -35,6 +35,7 @@ SIGNATURES = {
     "rfn_refine_f32": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_int, c_void_p]),
     "rfn_align_tail_f32": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "rfn_dwconv3x3_nhwc_fwd": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    "rfn_dwconv3x3_gelu_nhwc_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rfn_layernorm_fwd": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
     "rfn_layernorm_bwd_workspace_bytes": (ctypes.c_ulong, [c_int]),
     "rfn_layernorm_bwd": (c_int, [c_void_p] * 9 + [ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p]),
@@ -52,7 +53,9 @@ SIGNATURES = {
     "rfn_multi_cast_chunk_elems": (c_int, []),
     "rfn_multi_cast_f32_bf16": (c_int, [c_void_p, c_int, c_void_p]),
     "rfn_gemm_nt": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p] + [ctypes.c_long] * 6 + [c_int, c_void_p]),
-    "rfn_gemm_tn": (c_int, [c_void_p] * 3 + [ctypes.c_long] * 5 + [c_int, c_int, c_void_p]),
+    "rfn_conv2d_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int,
+                                                                                       c_void_p]),
+    "rfn_gemm_tn": (c_int, [c_void_p] * 3 + [ctypes.c_long] * 5 + [c_int, c_int, c_void_p, c_int, c_void_p]),
     "rfn_attn_pack": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] + [c_int] * 4 + [c_void_p] * 3),
     "rfn_attn_fwd": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_void_p, ctypes.c_long,
                              ctypes.c_long, c_void_p] + [c_int] * 6 + [c_float, c_int, c_void_p]),

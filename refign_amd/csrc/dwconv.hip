@@ -115,10 +115,15 @@ __device__ __forceinline__ float4 mask_raw(const float4& t, bool ok) {
 }
 __device__ __forceinline__ uint4 mask_raw(const uint4& t, bool ok) { return ok ? t : make_uint4(0u, 0u, 0u, 0u); }
 
-template <typename T, bool FLIP>
+// ACT: the Mix-FFN applies GELU (exact erf) right after this convolution (mix_transformer.py:99-101): with ACT the
+// activation is computed on the fp32 accumulators and written to `ya`; the pre-activation goes to `y` only if that
+// pointer is given (the backward needs it, a gradient-free pass does not) -- the separate GELU kernel (one more read
+// and write of the 4C-wide hidden tensor) disappears.
+template <typename T, bool FLIP, bool ACT = false>
 __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, T* __restrict__ y, int B,
-                                                            int H, int W, int C, int dil, int cvb) {
+                                                            int H, int W, int C, int dil, int cvb,
+                                                            T* __restrict__ ya = nullptr) {
   constexpr int V = VecIO<T>::N, V2 = V / 2;
   const int CV = C / V, WQ = quads_per_row(W, dil);
   const int pl = 256 / cvb;
@@ -180,14 +185,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
           for (int i = 0; i < V2; ++i) acc[p][i] = __builtin_elementwise_fma(wr[ky * 3 + kx][i], v[i], acc[p][i]);
         }
       }
-    T* yo = y + ((size_t)b * H + h) * W * C + c0;
+    const size_t obase = ((size_t)b * H + h) * W * C + c0;
 #pragma unroll
     for (int p = 0; p < kPX; ++p)
       if (w0 + p * dil < W) {
         float o[V];
 #pragma unroll
         for (int i = 0; i < V2; ++i) { o[2 * i] = acc[p][i].x; o[2 * i + 1] = acc[p][i].y; }
-        VecIO<T>::store(yo + (size_t)(w0 + p * dil) * C, o);
+        if (!ACT || y != nullptr) VecIO<T>::store(y + obase + (size_t)(w0 + p * dil) * C, o);
+        if (ACT) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) o[i] = 0.5f * o[i] * (1.f + erff(o[i] * 0.70710678118654752440f));
+          VecIO<T>::store(ya + obase + (size_t)(w0 + p * dil) * C, o);
+        }
       }
   }
 }
@@ -317,6 +327,18 @@ static inline int pick_cvb(int CV) { return CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV
 constexpr int kMaxStripes = 128;
 
 template <typename T>
+static int launch_fwd_gelu(const void* x, const float* w, const float* bias, void* y, void* ya, int B, int H, int W,
+                           int C, hipStream_t st) {
+  constexpr int V = VecIO<T>::N;
+  const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
+  const long nquads = (long)B * H * ((W + kPX - 1) / kPX);
+  const int gy = (int)std::max<long>(1, std::min<long>(cdiv(nquads, pl), (256L * 16) / gx));
+  hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, true>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias,
+                     (T*)y, B, H, W, C, 1, cvb, (T*)ya);
+  return check_launch("dwconv3x3_fwd_kernel<gelu>");
+}
+
+template <typename T>
 static int launch_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,
                       int flip, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
@@ -367,6 +389,21 @@ int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias
     return launch_fwd<__hip_bfloat16>(x, weight, bias, y, B, H, W, C, dilation, flip, (hipStream_t)stream);
   }
   return fail(RFN_EINVAL, "rfn_dwconv3x3_nhwc_fwd: dtype must be 0 (f32) or 1 (bf16)");
+}
+
+int rfn_dwconv3x3_gelu_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y_pre, void* y_act, int B,
+                                int H, int W, int C, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && weight && y_act, "rfn_dwconv3x3_gelu_nhwc_fwd: null pointer");
+  RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "rfn_dwconv3x3_gelu_nhwc_fwd: bad size");
+  if (dtype == 0) {
+    RFN_REQUIRE(C % 4 == 0, "rfn_dwconv3x3_gelu_nhwc_fwd: C must be a multiple of 4 for f32 (got %d)", C);
+    return launch_fwd_gelu<float>(x, weight, bias, y_pre, y_act, B, H, W, C, (hipStream_t)stream);
+  }
+  if (dtype == 1) {
+    RFN_REQUIRE(C % 8 == 0, "rfn_dwconv3x3_gelu_nhwc_fwd: C must be a multiple of 8 for bf16 (got %d)", C);
+    return launch_fwd_gelu<__hip_bfloat16>(x, weight, bias, y_pre, y_act, B, H, W, C, (hipStream_t)stream);
+  }
+  return fail(RFN_EINVAL, "rfn_dwconv3x3_gelu_nhwc_fwd: dtype must be 0 (f32) or 1 (bf16)");
 }
 
 unsigned long rfn_dwconv3x3_bwd_weight_workspace_bytes(int C) {

@@ -19,6 +19,9 @@
 // row.  The DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address.
 #include <hip/hip_bf16.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 #include "mfma.h"
 
@@ -29,55 +32,125 @@ struct GemmEpi {
   const uint16_t* res;      // [M, ldy] residual added to the result, or null
   const float* rowscale;    // per-sample scale of the (acc + bias) term before the residual add, or null
   int rows_per_sample;      // sample of row m = m / rows_per_sample (for rowscale)
-  int act;                  // 0 none, 1 ReLU, 2 GELU (erf)
+  int act;                  // 0 none, 1 ReLU, 3 LeakyReLU(0.1)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
+  // 1 = ReLU, 3 = LeakyReLU(0.1) (the matcher's decoders); GELU is NOT offered here: in the Mix-FFN it follows the
+  // depthwise convolution (fused there, csrc/dwconv.hip), and its erf polynomial in this epilogue costs ~100 VGPRs
   if (act == 1) return fmaxf(v, 0.f);
-  if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  if (act == 3) return v > 0.f ? v : 0.1f * v;
   return v;
 }
 
-template <int DT, int BM, int BN>
+// Implicit-GEMM view of a convolution over a channels-last tensor (dense GEMM: 1x1, stride 1 -- GATHER = false):
+//   Y[m, n] = sum_{tap, c} X[b, oy s - p + ky d, ox s - p + kx d, c] * W[n, (tap, c)],   m = (b, oy, ox), zero padding.
+// The reduction index k = tap * C + c is walked in 64-wide steps; a 16-byte DMA piece is 8 channels of ONE tap, so C % 8
+// == 0 and the weight rows are [tap][c] zero-padded to a multiple of 64 (pieces past the last tap read the zero page).
+struct ConvGeom {
+  int H, W, C, OH, OW, KH, KW, stride, pad, dil;
+  int C8;                  // C / 8
+  unsigned c8_magic;       // ceil(2^32 / C8): piece index / C8 (exact for piece < 2^16)
+  unsigned kw_magic;       // ceil(2^32 / KW)
+  const void* zero;        // >= 16 bytes of zeros
+};
+
+// Persistent workgroups: a workgroup owns every G-th output tile (m-major, n fastest) and runs ONE software pipeline
+// over all their K-steps through an NS-deep
+// LDS ring: NS - 1 steps are in flight under the MFMAs of the current one -- also across tile boundaries, so the first
+// steps of tile i+1 stream in under the last MFMAs and the whole epilogue of tile i.  The hand-off is a COUNTED
+// `s_waitcnt vmcnt((NS - 2) * DMA instructions per step)` + one barrier per step; after an epilogue (its stores share the
+// counter and need not retire in order with the loads) the wait is vmcnt(0).  Measured on MI355X (profiles/): K-steps of
+// 64 (full 128-byte lines per row) with a 2-deep ring beat K-steps of 32 with a 4-deep ring by 1.3-1.6x on the K >= 512
+// shapes -- half-line requests double the L2 request count -- so BK = 64, NS = 2 is what the host launches.
+template <int N> __device__ __forceinline__ void wait_dma_upto() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int DT, int BM, int BN, int BK, int NS, bool GATHER>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                       uint16_t* __restrict__ Y, int M, int N, int K, long ldx, long ldw,
-                                                      long ldy, int tiles_n, GemmEpi epi) {
+                                                      long ldy, int tiles_n, int total_tiles, GemmEpi epi, ConvGeom cg) {
   using E = Elem<DT>;
   using vec8 = typename E::vec8;
+  static_assert(BK == 32 || BK == 64, "K-step of 32 or 64");
   constexpr int IB = BN / 64;              // 32-wide n blocks per wave (waves are 2 (m) x 2 (n))
   constexpr int JB = BM / 64;              // 32-wide m blocks per wave
-  constexpr int XBYTES = BM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
-  constexpr int XI = BM / 32, WI = BN / 32;          // DMA instructions per wave and tile (8 rows each, 4 waves)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  constexpr int ROWB = BK * 2;             // bytes per LDS row
+  constexpr int PPR = BK / 8;              // 16-byte pieces per row (4 or 8)
+  constexpr int RPI = 64 / PPR;            // tile rows per DMA instruction (16 or 8)
+  constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB, STAGE = XBYTES + WBYTES;
+  constexpr int XI = BM / (4 * RPI), WI = BN / (4 * RPI);   // DMA instructions per wave and step (4 waves)
+  constexpr int IPS = XI + WI;
+  // piece c of row r sits at c ^ swizzle(r): rows of 128 B: (r >> 1) & 7, rows of 64 B: (r >> 2) & 3 -- either way every
+  // ds_read_b128 lane group covers 16 distinct 16-byte slots of the 256-byte bank row
+  auto swizzle = [](int r) { return BK == 64 ? (r >> 1) & 7 : (r >> 2) & 3; };
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+  // tiles wg, wg + G, wg + 2 G, ...: at any time the resident workgroups work on CONSECUTIVE tiles, i.e. the n tiles of
+  // one X row panel run side by side on one XCD (xcd_remap) and share the panel in its L2.  (Contiguous per-workgroup
+  // ranges re-read the panel tiles_n times from HBM: the chip-wide working set of panels is far beyond 8 x 4 MB of L2
+  // -- measured 1.6x slower on 81600 x 1280 -> 320.)
+  const int G = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, G);
+  const int t_begin = wg;
+  if (t_begin >= total_tiles) return;
+  const int ntiles = (total_tiles - wg + G - 1) / G;
+  const int nk = K / BK;
 
-  // ---- per-lane DMA sources: instruction q of this wave covers tile rows 8 (4 q + wave) .. + 7
-  const int drow = lane >> 3, dchunk = lane & 7;
+  // ---- per-lane DMA sources: instruction q of this wave covers tile rows RPI (4 q + wave) .. + RPI - 1; lane = (row,
+  // 16-byte piece); the source piece of a lane is piece ^ swizzle(row), which does not depend on q
+  const int drow = lane / PPR;
+  const int dpiece = (lane % PPR) ^ swizzle(RPI * wave + drow);
   const unsigned char* xsrc[XI];
   const unsigned char* wsrc[WI];
+  int iy0[GATHER ? XI : 1], ix0[GATHER ? XI : 1];
+  auto setup = [&](int tile) {
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 #pragma unroll
-  for (int q = 0; q < XI; ++q) {
-    const int r = 8 * (4 * q + wave) + drow;
-    const int m = min(m0 + r, M - 1);
-    xsrc[q] = (const unsigned char*)(X + (long)m * ldx) + 16 * (dchunk ^ ((r >> 1) & 7));
-  }
+    for (int q = 0; q < XI; ++q) {
+      const int m = min(m0 + RPI * (4 * q + wave) + drow, M - 1);
+      if constexpr (GATHER) {
+        const int ohw = cg.OH * cg.OW;
+        const int b = m / ohw, rem = m - b * ohw, oy = rem / cg.OW, ox = rem - oy * cg.OW;
+        xsrc[q] = (const unsigned char*)(X + (long)b * cg.H * cg.W * cg.C);
+        iy0[q] = oy * cg.stride - cg.pad;
+        ix0[q] = ox * cg.stride - cg.pad;
+      } else {
+        xsrc[q] = (const unsigned char*)(X + (long)m * ldx) + 16 * dpiece;
+      }
+    }
 #pragma unroll
-  for (int q = 0; q < WI; ++q) {
-    const int r = 8 * (4 * q + wave) + drow;
-    const int n = min(n0 + r, N - 1);
-    wsrc[q] = (const unsigned char*)(W + (long)n * ldw) + 16 * (dchunk ^ ((r >> 1) & 7));
-  }
+    for (int q = 0; q < WI; ++q) {
+      const int n = min(n0 + RPI * (4 * q + wave) + drow, N - 1);
+      wsrc[q] = (const unsigned char*)(W + (long)n * ldw) + 16 * dpiece;
+    }
+  };
   auto issue = [&](int kt, int buf) {
     unsigned char* xs = smem + buf * STAGE;
     unsigned char* ws = xs + XBYTES;
+    if constexpr (GATHER) {
+      const unsigned j = (unsigned)(kt * PPR + dpiece);                     // 16-byte piece index along k
+      const unsigned tap = cg.C8 == 1 ? j : __umulhi(j, cg.c8_magic), c8 = j - tap * cg.C8;
+      const unsigned ky = cg.KW == 1 ? tap : __umulhi(tap, cg.kw_magic), kx = tap - ky * cg.KW;
+      const bool tap_ok = (int)ky < cg.KH;
+      const int dy = (int)ky * cg.dil, dx = (int)kx * cg.dil;
 #pragma unroll
-    for (int q = 0; q < XI; ++q) lds_dma16(xsrc[q] + (long)kt * 128, xs + 1024 * (4 * q + wave));
+      for (int q = 0; q < XI; ++q) {
+        const int iy = iy0[q] + dy, ix = ix0[q] + dx;
+        const bool ok = tap_ok && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
+        const unsigned char* src = ok ? xsrc[q] + ((long)(iy * cg.W + ix) * cg.C + c8 * 8) * 2
+                                      : (const unsigned char*)cg.zero;
+        lds_dma16(src, xs + 1024 * (4 * q + wave));
+      }
+    } else {
 #pragma unroll
-    for (int q = 0; q < WI; ++q) lds_dma16(wsrc[q] + (long)kt * 128, ws + 1024 * (4 * q + wave));
+      for (int q = 0; q < XI; ++q) lds_dma16(xsrc[q] + (long)kt * ROWB, xs + 1024 * (4 * q + wave));
+    }
+#pragma unroll
+    for (int q = 0; q < WI; ++q) lds_dma16(wsrc[q] + (long)kt * ROWB, ws + 1024 * (4 * q + wave));
   };
 
   f32x16 acc[IB][JB];
@@ -88,80 +161,119 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // fragment addresses: row (l & 31) of a 32-row block, chunk (2 ks + g) ^ swizzle(row); block offsets are multiples
+  // fragment addresses: row (l & 31) of a 32-row block, piece (2 ks + g) ^ swizzle(row); block offsets are multiples
   // of 32 rows and do not change the swizzle
-  const int g = lane >> 5, frow = lane & 31, swz = (frow >> 1) & 7;
-  const int xoff = (wm * (BM / 2) + frow) * 128, woff = XBYTES + (wn * (BN / 2) + frow) * 128;
+  const int g = lane >> 5, frow = lane & 31, swz = swizzle(frow);
+  const int xoff = (wm * (BM / 2) + frow) * ROWB, woff = XBYTES + (wn * (BN / 2) + frow) * ROWB;
 
-  const int nk = K / 64;
-  issue(0, 0);
-  wait_dma_all();
-  wg_barrier();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-    const unsigned char* st = smem + buf * STAGE;
+  // producer cursor: the next K-step to issue, over all tiles of this workgroup
+  const long S = (long)ntiles * nk;
+  long p = 0;
+  int p_tile = t_begin, p_kt = 0;
+  auto produce = [&]() {
+    if (p < S) {
+      if (p_kt == 0) setup(p_tile);
+      issue(p_kt, (int)(p % NS));
+      ++p;
+      if (++p_kt == nk) {
+        p_kt = 0;
+        p_tile += G;
+      }
+    }
+  };
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+  for (int q = 0; q < NS - 1; ++q) produce();
+
+  int c_tile = t_begin, c_kt = 0;
+  bool drained = false;                       // stores of an epilogue are outstanding: next wait is vmcnt(0)
+  for (long s = 0; s < S; ++s) {
+    // step s has landed once at most the two younger steps are still in flight (loads complete in order)
+    if (NS == 2 || drained || s + (NS - 2) >= S) wait_dma_all();
+    else wait_dma_upto<(NS - 2) * IPS>();
+    wg_barrier();                             // ... everybody's part of it; and everybody is done reading step s - 1
+    produce();                                // step s + 3 into the buffer step s - 1 occupied
+    drained = false;
+    const unsigned char* st = smem + (int)(s % NS) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
       const int coff = ((2 * ks + g) ^ swz) * 16;
       vec8 wf[IB], xf[JB];
 #pragma unroll
-      for (int i = 0; i < IB; ++i) wf[i] = *(const vec8*)(st + woff + i * 4096 + coff);
+      for (int i = 0; i < IB; ++i) wf[i] = *(const vec8*)(st + woff + i * 32 * ROWB + coff);
 #pragma unroll
-      for (int j = 0; j < JB; ++j) xf[j] = *(const vec8*)(st + xoff + j * 4096 + coff);
+      for (int j = 0; j < JB; ++j) xf[j] = *(const vec8*)(st + xoff + j * 32 * ROWB + coff);
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(wf[i], xf[j], acc[i][j]);
     }
-    wait_dma_all();      // tile kt+1 has landed (this wave's part) ...
-    wg_barrier();        // ... everybody's part, and everybody is done reading tile kt
-  }
-
-  // ---- epilogue, in registers: lane = one row m, register group k = 4 consecutive n
+    if (++c_kt == nk) {
+      // ---- epilogue.  Registers -> (bias, activation, 16-bit rounding) -> a per-wave LDS staging block -> row-contiguous
+      // 16-byte stores: an instruction then writes 8 rows x 128 B (or 16 x 64 B) instead of 64 scattered 16-byte runs
+      // (one cache-line request per run made the K <= 128 shapes store-bound).  The staging block lives in the LDS stage
+      // that was just consumed, hence the barrier; the next steps' DMA (other stage) is in flight meanwhile.  `tile` is
+      // laundered through an empty asm so that the address arithmetic below (loop-invariant for the step loop) is not
+      // hoisted out of this block, where it would hold ~80 VGPRs.
+      int tl = c_tile;
+      asm volatile("" : "+s"(tl));
+      const int m0 = (tl / tiles_n) * BM, n0 = (tl % tiles_n) * BN;
+      constexpr int WN = BN / 2;                       // columns of a wave's tile
+      constexpr int PITCH = WN * 2 + 16;               // staging row pitch in bytes (16-byte aligned, 2-way at worst)
+      constexpr int RPP = 64 / (WN / 8);               // rows per store instruction (8 pieces of 16 B per 64-column row)
+      static_assert(4 * 32 * PITCH <= STAGE, "staging block fits the consumed stage");
+      wg_barrier();                                    // every wave is done reading this stage's operands
+      unsigned char* stg = const_cast<unsigned char*>(st) + wave * 32 * PITCH;
 #pragma unroll
-  for (int j = 0; j < JB; ++j) {
-    const int m = m0 + wm * (BM / 2) + j * 32 + frow;
-    const bool mok = m < M;
-    const float rs = (epi.rowscale != nullptr && mok) ? epi.rowscale[m / epi.rows_per_sample] : 1.f;
+      for (int j = 0; j < JB; ++j) {
 #pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      const int nb = n0 + wn * (BN / 2) + i * 32;
-      u32x2 pk[4];
+        for (int i = 0; i < IB; ++i) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int n = nb + 8 * k + 4 * g;            // this lane's run: n .. n + 3
-        float v[4] = {acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]};
-        const bool ok = mok && n < N;               // N % 8 == 0: a run is all in or all out
-        if (epi.bias != nullptr && ok) {
-          float b[4];
-          unpack4<DT>(*(const u32x2*)(epi.bias + n), b);
+          for (int k = 0; k < 4; ++k) {
+            const int cl = i * 32 + 8 * k + 4 * g;       // this lane's run: local columns cl .. cl + 3 of row frow
+            const int n = n0 + wn * WN + cl;
+            float v[4] = {acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]};
+            if (epi.bias != nullptr && n < N) {          // N % 8 == 0: a run is all in or all out
+              float b[4];
+              unpack4<DT>(*(const u32x2*)(epi.bias + n), b);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
+              for (int e = 0; e < 4; ++e) v[e] += b[e];
+            }
+            if (epi.act != 0) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], epi.act);
+            }
+            *(u32x2*)(stg + frow * PITCH + cl * 2) = pack4<DT>(v[0], v[1], v[2], v[3]);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own staging writes (no other wave touches them)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], epi.act);
-        if (epi.res != nullptr && ok) {
-          float rr[4];
-          unpack4<DT>(*(const u32x2*)(epi.res + (long)m * ldy + n), rr);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rr[e] + rs * v[e];
+        for (int it = 0; it < 32 / RPP; ++it) {
+          const int row = it * RPP + lane / (WN / 8), piece = lane % (WN / 8);
+          const int m = m0 + wm * (BM / 2) + j * 32 + row, n = n0 + wn * WN + piece * 8;
+          u32x4 o = *(const u32x4*)(stg + row * PITCH + piece * 16);
+          if (m < M && n < N) {
+            if (epi.res != nullptr) {
+              const float rs = epi.rowscale != nullptr ? epi.rowscale[m / epi.rows_per_sample] : 1.f;
+              const u32x4 rr = *(const u32x4*)(epi.res + (long)m * ldy + n);
+              float a[4], b[4], c[4], d[4];
+              unpack4<DT>(u32x2{o[0], o[1]}, a);
+              unpack4<DT>(u32x2{o[2], o[3]}, b);
+              unpack4<DT>(u32x2{rr[0], rr[1]}, c);
+              unpack4<DT>(u32x2{rr[2], rr[3]}, d);
+              const u32x2 lo = pack4<DT>(c[0] + rs * a[0], c[1] + rs * a[1], c[2] + rs * a[2], c[3] + rs * a[3]);
+              const u32x2 hi = pack4<DT>(d[0] + rs * b[0], d[1] + rs * b[1], d[2] + rs * b[2], d[3] + rs * b[3]);
+              o = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+            *(u32x4*)(Y + (long)m * ldy + n) = o;
+          }
         }
-        pk[k] = pack4<DT>(v[0], v[1], v[2], v[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next j block overwrites
       }
-      // join the runs of lane l (g = 0) and lane l + 32 (g = 1): afterwards lanes 0-31 hold n = nb + 16 p .. + 7 and
-      // lanes 32-63 hold nb + 16 p + 8 .. + 15, 16 contiguous bytes each
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        u32x2 a = pk[2 * p], b = pk[2 * p + 1];
-        auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-        const int n = nb + 16 * p + 8 * g;
-        if (mok && n < N) {
-          u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-          *(u32x4*)(Y + (long)m * ldy + n) = o;
-        }
-      }
+      c_kt = 0;
+      c_tile += G;
+      drained = true;
     }
   }
 }
@@ -177,7 +289,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
 template <int DT, int BN, int BK>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
                                                       float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
-                                                      int R, int tiles_k) {
+                                                      int R, int tiles_k, int accumulate, float* __restrict__ gbias) {
   using E = Elem<DT>;
   constexpr int BT = 32;                   // rows of the reduction per stage (two 16-slot k-steps)
   constexpr int IB = BN / 64, JB = BK / 64;
@@ -199,6 +311,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
   constexpr int GPT = GITEMS / 256, XPT = XITEMS / 256;   // items per thread
   static_assert(GITEMS % 256 == 0 && XITEMS % 256 == 0, "tile/threads");
   unsigned greg[GPT][4], xreg[XPT][4];
+  // bias gradient = column sums of G: every thread stages the same column pair in every stage (256 % GP == 0), so it
+  // keeps the running sums of its two columns; only the k-tile-0 workgroups of each (n tile, slab) contribute
+  const bool do_bias = (gbias != nullptr) && (k0 == 0);
+  float bsum[2] = {0.f, 0.f};
   auto load_stage = [&](int it) {
     const long tb = t0 + (long)it * BT;
 #pragma unroll
@@ -229,6 +345,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
       o[2] = (greg[u][0] >> 16) | (greg[u][1] & 0xffff0000u);
       o[3] = (greg[u][2] >> 16) | (greg[u][3] & 0xffff0000u);
       *(u32x4*)(gs + (q * BN + 2 * cp) * 8) = o;
+      if (do_bias) {
+        float f[4];
+        unpack4<DT>(u32x2{o[0], o[1]}, f);
+        bsum[0] += (f[0] + f[1]) + (f[2] + f[3]);
+        unpack4<DT>(u32x2{o[2], o[3]}, f);
+        bsum[1] += (f[0] + f[1]) + (f[2] + f[3]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < XPT; ++u) {
@@ -285,7 +408,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
   }
 
   // D[i = n][j = k]: lane holds column k = .. + col, rows n = (r & 3) + 8 (r >> 2) + 4 g
-  float* out = P + (long)slab * N * K;
+  float* out = accumulate ? P : P + (long)slab * N * K;
 #pragma unroll
   for (int i = 0; i < IB; ++i)
 #pragma unroll
@@ -294,39 +417,75 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * (BN / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        out[(long)n * K + kk] = acc[i][j][r];
+        if (accumulate) atomicAdd(out + (long)n * K + kk, acc[i][j][r]);     // 128-byte coalesced fp32 atomics
+        else out[(long)n * K + kk] = acc[i][j][r];
       }
     }
+  if (do_bias) {                                   // reduce the per-thread column sums over the row quads, one atomic per column
+    float* red = (float*)smem;                     // the staging ring is free now (last __syncthreads above)
+    red[threadIdx.x * 2] = bsum[0];
+    red[threadIdx.x * 2 + 1] = bsum[1];
+    __syncthreads();
+    if (threadIdx.x < BN) {
+      const int cp = threadIdx.x >> 1, e = threadIdx.x & 1;
+      float sum = 0.f;
+      for (int t = cp; t < 256; t += GP) sum += red[t * 2 + e];
+      atomicAdd(gbias + n0 + threadIdx.x, sum);
+    }
+  }
 }
 
-template <int DT>
+__device__ uint4 g_zero_page[4];          // zero-initialised: DMA source of out-of-image / padding pieces
+
+template <int DT, bool GATHER>
 static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long K, long ldx, long ldw, long ldy,
-                     const GemmEpi& epi, hipStream_t s) {
-  const bool wide = (N % 128 == 0);
-  const int tiles_m = cdiv(M, 128), tiles_n = wide ? (int)(N / 128) : cdiv(N, 64);
-  dim3 grid(tiles_m * tiles_n), block(256);
-  if (wide)
-    hipLaunchKernelGGL((gemm_nt_kernel<DT, 128, 128>), grid, block, 0, s, (const uint16_t*)X, (const uint16_t*)W,
-                       (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tiles_n, epi);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<DT, 128, 64>), grid, block, 0, s, (const uint16_t*)X, (const uint16_t*)W,
-                       (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tiles_n, epi);
+                     const GemmEpi& epi, ConvGeom cg, hipStream_t s) {
+  if (GATHER) {
+    static void* zero_page = nullptr;        // looked up once (first call is an eager warm-up, never inside a capture)
+    if (zero_page == nullptr && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero_page)) != hipSuccess)
+      return fail(RFN_ELAUNCH, "conv2d_nhwc: zero page symbol");
+    cg.zero = zero_page;
+  }
+  // tile: the widest n the problem fills; m 128, or 64 when the problem would not give every CU a tile otherwise
+  const int bn = (N % 128 == 0) ? 128 : 64;
+  const int bm = ((long)cdiv(M, 128) * cdiv(N, bn) >= 256) ? 128 : 64;
+  const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
+  const long total = (long)tiles_m * tiles_n;
+  // workgroups per CU by LDS (2-deep ring of (bm + bn) * 128 bytes; 160 KB per CU), at most 4
+  const int ring = 2 * (bm + bn) * 128;
+  const int per_cu = std::min(160 * 1024 / ring, 4);
+  static const int persist_mode = getenv("RFN_GEMM_PERSIST") ? atoi(getenv("RFN_GEMM_PERSIST")) : -1;
+  // persistent (one pipeline across tiles) pays when a tile has only a few K-steps: the next tile's loads hide under the
+  // epilogue.  With many K-steps per tile the plain one-tile-per-workgroup launch measured faster (dispatcher refills a CU
+  // the moment a workgroup retires; its stores drain behind it).  RFN_GEMM_PERSIST=0/1 forces either (tools/mfma_bench.py).
+  const bool persistent = persist_mode < 0 ? (K <= 256) : persist_mode != 0;
+  const int slots = persistent ? 256 * per_cu : 0x7fffffff;
+  dim3 grid((unsigned)std::min<long>(total, slots)), block(256);
+#define RFN_NT(BM_, BN_)                                                                                                \
+  hipLaunchKernelGGL((gemm_nt_kernel<DT, BM_, BN_, 64, 2, GATHER>), grid, block, 0, s, (const uint16_t*)X,               \
+                     (const uint16_t*)W,                                                                                 \
+                     (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tiles_n, (int)total, epi, cg)
+  if (bm == 128 && bn == 128) RFN_NT(128, 128);
+  else if (bm == 128) RFN_NT(128, 64);
+  else if (bn == 128) RFN_NT(64, 128);
+  else RFN_NT(64, 64);
+#undef RFN_NT
   return check_launch("gemm_nt");
 }
 
 template <int DT>
 static int launch_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int R,
-                     hipStream_t s) {
+                     int accumulate, float* gbias, hipStream_t s) {
   const int S = cdiv(T, R);
   dim3 block(256);
   if (N % 128 == 0 && K % 128 == 0) {
     dim3 grid((unsigned)((N / 128) * (K / 128) * S));
     hipLaunchKernelGGL((gemm_tn_kernel<DT, 128, 128>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128));
+                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias);
   } else {
     dim3 grid((unsigned)((N / 64) * (K / 64) * S));
     hipLaunchKernelGGL((gemm_tn_kernel<DT, 64, 64>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64));
+                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias);
   }
   return check_launch("gemm_tn");
 }
@@ -346,15 +505,41 @@ int rfn_gemm_nt(const void* X, const void* W, const void* bias, const void* res,
               "gemm_nt: leading dimensions must be multiples of 8 elements");
   RFN_REQUIRE(M < (1L << 31) && N < (1L << 31), "gemm_nt: extent");
   RFN_REQUIRE(rowscale == nullptr || (res != nullptr && rows_per_sample > 0), "gemm_nt: rowscale needs res");
-  RFN_REQUIRE(act >= 0 && act <= 2, "gemm_nt: act");
+  RFN_REQUIRE(act == 0 || act == 1 || act == 3, "gemm_nt: act (0 none, 1 ReLU, 3 LeakyReLU 0.1)");
   GemmEpi epi{(const uint16_t*)bias, (const uint16_t*)res, rowscale, rows_per_sample > 0 ? rows_per_sample : 1, act};
   hipStream_t s = (hipStream_t)stream;
-  return dtype == 1 ? launch_nt<1>(X, W, Y, M, N, K, ldx, ldw, ldy, epi, s)
-                    : launch_nt<2>(X, W, Y, M, N, K, ldx, ldw, ldy, epi, s);
+  ConvGeom cg{};
+  return dtype == 1 ? launch_nt<1, false>(X, W, Y, M, N, K, ldx, ldw, ldy, epi, cg, s)
+                    : launch_nt<2, false>(X, W, Y, M, N, K, ldx, ldw, ldy, epi, cg, s);
+}
+
+int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* res, int act, void* Y, int B, int H,
+                    int Wd, int C, int N, int KH, int KW, int stride, int pad, int dil, long ldw, long ldy, int dtype,
+                    rfn_stream_t stream) {
+  using namespace rfn;
+  RFN_REQUIRE(X && W && Y, "conv2d_nhwc: null operand");
+  RFN_REQUIRE(dtype == 1 || dtype == 2, "conv2d_nhwc: dtype %d (1 = bf16, 2 = f16)", dtype);
+  RFN_REQUIRE(B > 0 && H > 0 && Wd > 0 && C > 0 && C % 8 == 0 && N > 0 && N % 8 == 0, "conv2d_nhwc: B=%d H=%d W=%d C=%d N=%d "
+              "(C %% 8, N %% 8)", B, H, Wd, C, N);
+  RFN_REQUIRE(KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d_nhwc: kernel %dx%d stride %d pad %d dil %d",
+              KH, KW, stride, pad, dil);
+  const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (Wd + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  RFN_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc: empty output");
+  const long K = ((long)KH * KW * C + 63) / 64 * 64, M = (long)B * OH * OW;
+  RFN_REQUIRE(ldw % 8 == 0 && ldw >= K && ldy % 8 == 0 && ldy >= N, "conv2d_nhwc: ldw=%ld (>= %ld, padded k) ldy=%ld", ldw,
+              K, ldy);
+  RFN_REQUIRE(M < (1L << 31) && K / 8 < 65536 && (long)H * Wd * C < (1L << 31), "conv2d_nhwc: extent");
+  RFN_REQUIRE(act == 0 || act == 1 || act == 3, "conv2d_nhwc: act (0 none, 1 ReLU, 3 LeakyReLU 0.1)");
+  GemmEpi epi{(const uint16_t*)bias, (const uint16_t*)res, nullptr, 1, act};
+  ConvGeom cg{H, Wd, C, OH, OW, KH, KW, stride, pad, dil, C / 8, (unsigned)((0x100000000ULL + C / 8 - 1) / (C / 8)),
+              (unsigned)((0x100000000ULL + KW - 1) / KW), nullptr};
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == 1 ? launch_nt<1, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s)
+                    : launch_nt<2, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s);
 }
 
 int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int rows_per_slab,
-                int dtype, rfn_stream_t stream) {
+                int accumulate, float* grad_bias, int dtype, rfn_stream_t stream) {
   using namespace rfn;
   RFN_REQUIRE(G && X && P, "gemm_tn: null operand");
   RFN_REQUIRE(dtype == 1 || dtype == 2, "gemm_tn: dtype %d", dtype);
@@ -362,8 +547,8 @@ int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, 
               "gemm_tn: T=%ld rows_per_slab=%d (%% 32)", T, rows_per_slab);
   RFN_REQUIRE(N % 64 == 0 && K % 64 == 0 && ldg % 2 == 0 && ldx % 2 == 0, "gemm_tn: N=%ld K=%ld (%% 64)", N, K);
   hipStream_t s = (hipStream_t)stream;
-  return dtype == 1 ? launch_tn<1>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, s)
-                    : launch_tn<2>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, s);
+  return dtype == 1 ? launch_tn<1>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, accumulate, grad_bias, s)
+                    : launch_tn<2>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, accumulate, grad_bias, s);
 }
 
 }  // extern "C"

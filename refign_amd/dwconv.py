@@ -73,6 +73,72 @@ class _DWConv3x3(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _DWConv3x3Gelu(torch.autograd.Function):
+    """gelu(dwconv3x3(x)) in one kernel; the backward is GELU' (on the saved pre-activation) followed by the backward
+    of the plain convolution."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        if x.dtype not in _DT:
+            x = x.float()
+        x = require_device_tensor(x.contiguous(), "x")
+        B, H, W, C = x.shape
+        w_tap = derived(weight, "tap_major_f32", lambda t: t.float().reshape(C, 9).t().contiguous(),
+                        lambda t: t.reshape(C, 9).t())
+        b32 = None if bias is None else as_dtype(bias, torch.float32).detach().contiguous()
+        need = any(ctx.needs_input_grad)
+        z = torch.empty_like(x) if need else None
+        a = torch.empty_like(x)
+        lib = _lib.load_library()
+        with on_device(x.device):
+            rc = lib.rfn_dwconv3x3_gelu_nhwc_fwd(ptr(x), ptr(w_tap), ptr(b32), ptr(z), ptr(a), B, H, W, C, _DT[x.dtype],
+                                                 current_stream(x.device))
+        _lib.check(rc, "dwconv3x3_gelu_nhwc_fwd")
+        if need:
+            ctx.save_for_backward(x, w_tap, z)
+            ctx.has_bias, ctx.wshape, ctx.wdtype = bias is not None, weight.shape, weight.dtype
+            ctx.weight, ctx.bias, ctx.dilation = weight, bias, 1
+        return a
+
+    @staticmethod
+    def backward(ctx, ga):
+        x, w_tap, z = ctx.saved_tensors
+        gz = torch.ops.aten.gelu_backward(ga.to(z.dtype).contiguous(), z)
+        ctx.saved = (x, w_tap)
+        return _dwconv_backward(ctx, x, w_tap, gz)[:3]
+
+
+def _dwconv_backward(ctx, x, w_tap, gy):
+    B, H, W, C = x.shape
+    gx = gw = gb = None
+    if ctx.needs_input_grad[0]:
+        gx = _fwd(gy, w_tap, None, ctx.dilation, True)
+    if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        sw, sb = grad_sink(ctx.weight), grad_sink(ctx.bias) if ctx.has_bias else None
+        direct = sw is not None and (sb is not None or not ctx.has_bias)
+        if direct:
+            dw, db = sw, sb
+        else:
+            dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
+            db = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        lib = _lib.load_library()
+        ws = workspace(_DW_WS_STRIPES * 10 * C * 4, x.device)
+        with on_device(x.device):
+            rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), ptr(ws), B, H, W, C, ctx.dilation,
+                                                   _DT[x.dtype], 3 if direct else 0, current_stream(x.device))
+        _lib.check(rc, "dwconv3x3_nhwc_bwd_weight")
+        if not direct:
+            gw = dw.t().reshape(ctx.wshape).to(ctx.wdtype)
+            gb = db
+    return gx, gw, gb, None
+
+
+def dwconv3x3_gelu_tokens(x, weight, bias, H, W):
+    """gelu(DWConv(x)) on tokens (B, N=H*W, C) -> (B, N, C): mix_transformer.py:99-101 in one pass."""
+    B, N, C = x.shape
+    return _DWConv3x3Gelu.apply(x.reshape(B, H, W, C), weight, bias).reshape(B, N, C)
+
+
 def dwconv3x3_nhwc(x, weight, bias=None, dilation=1):
     """x: (B,H,W,C) fp32/bf16; weight: (C,1,3,3); bias: (C) or None; same-size output (padding = dilation)."""
     if x.dim() != 4 or weight.shape[0] != x.shape[-1]:

@@ -51,7 +51,8 @@ class GraphedNoGrad:
         self.states.clear()
 
     def __call__(self, *tensors):
-        if not tensors[0].is_cuda or not enabled() or torch.is_grad_enabled():
+        if not tensors[0].is_cuda or not enabled() or torch.is_grad_enabled() or \
+                torch.cuda.is_current_stream_capturing():          # inside an enclosing capture: recorded inline
             return self.fn(*tensors)
         key = (tuple((tuple(t.shape), t.dtype, t.device) for t in tensors), torch.is_autocast_enabled("cuda"),
                torch.get_autocast_dtype("cuda"), self.generation)
@@ -97,4 +98,79 @@ class GraphedNoGrad:
             # on the (now invalidated) capture stream and every later launch would fail.  Put it back.
             torch.cuda.set_stream(cur)
             raise
+        st["graph"], st["inputs"], st["outputs"] = g, inputs, outputs
+
+
+class GraphedStep:
+    """hipGraph replay of a whole forward + backward pass of the student (source pass, mixed pass).
+
+    `fn(*tensors)` runs forward, loss and `backward()` and returns a tuple of loss tensors; its kernels -- including the
+    ones the autograd engine launches -- are recorded once and replayed with one host call per step afterwards.  What
+    makes that legal here: shapes never change; every per-step host decision of the pass is device data (the HRDA crop
+    offsets, seg.DeviceBox; stochastic depth / dropout masks come from the device generator, which torch re-seeds per
+    replay); parameter gradients accumulate IN PLACE into the flat gradient buffer (trainer.FlatGradBuffer) and
+    parameters / cached 16-bit copies are only updated in place between replays; BatchNorm statistics are in-place
+    buffer updates.  Not captured while a process group is active (SyncBatchNorm collectives of the decode heads).
+    The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
+    throws leaves the pass eager for good, like GraphedNoGrad."""
+
+    _pool = None                # one memory pool for all student passes: they are never live at the same time
+
+    def __init__(self, fn, name, warmup=2):
+        self.fn, self.name, self.warmup = fn, name, warmup
+        self.generation = 0
+        self.states = {}
+
+    def reset(self):
+        self.generation += 1
+        self.states.clear()
+
+    @staticmethod
+    def usable(t):
+        if not (t.is_cuda and enabled() and os.environ.get("RFN_GRAPH_STUDENT", "1") != "0"):
+            return False
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    def __call__(self, *tensors):
+        if not self.usable(tensors[0]):
+            return self.fn(*tensors)
+        key = (tuple((tuple(t.shape), t.dtype, t.device) for t in tensors), torch.is_autocast_enabled("cuda"),
+               torch.get_autocast_dtype("cuda"), self.generation)
+        st = self.states.get(key)
+        if st is None:
+            st = self.states[key] = {"calls": 0, "graph": None, "failed": False}
+        if st["failed"]:
+            return self.fn(*tensors)
+        if st["graph"] is None:
+            st["calls"] += 1
+            if st["calls"] <= self.warmup:
+                return self.fn(*tensors)
+            try:
+                self._capture(st, tensors)
+            except Exception as e:
+                st["failed"] = True
+                warnings.warn(f"refign_amd.graphs: capture of '{self.name}' failed ({type(e).__name__}: {e}); "
+                              f"running it eagerly")
+                torch.cuda.synchronize()
+                return self.fn(*tensors)
+        for s, t in zip(st["inputs"], tensors):
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t)
+        st["graph"].replay()
+        return st["outputs"]
+
+    def _capture(self, st, tensors):
+        inputs = [t.clone() for t in tensors]
+        cur = torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, pool=GraphedStep._pool, capture_error_mode="thread_local"):
+                outputs = self.fn(*inputs)
+        except BaseException:
+            torch.cuda.set_stream(cur)
+            raise
+        if GraphedStep._pool is None:
+            GraphedStep._pool = g.pool()
         st["graph"], st["inputs"], st["outputs"] = g, inputs, outputs

@@ -66,6 +66,10 @@ class _LinearFn(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]
         sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
         part = None
+        if need_w and sink_w is not None and (not need_b or sink_b is not None):
+            # hand-written split-T MFMA kernel accumulating straight into the flat gradient buffer (weight AND bias)
+            if mfma.gemm_tn(g2, x.reshape(-1, K), out=sink_w, bias_out=sink_b if need_b else None) is not None:
+                return gx, None, None, None, None
         if need_w:
             x2 = x.reshape(-1, K)
             T = x2.shape[0]

@@ -48,6 +48,50 @@ def gemm_nt(x, w, bias=None, res=None, rowscale=None, rows_per_sample=0, act=0, 
     return out
 
 
+def pack_conv_weight(w, dtype, scale=None):
+    """(N, C, KH, KW) conv weight -> (N, roundup(KH*KW*Cp, 64)) rows of [tap][channel], Cp = C rounded up to 8, zero
+    padded: the W operand of rfn_conv2d_nhwc.  `scale` (N,), if given, multiplies the rows (folded BatchNorm)."""
+    N, C, KH, KW = w.shape
+    Cp = -(-C // 8) * 8
+    K = KH * KW * Cp
+    Kp = -(-K // 64) * 64
+    wf = w.float() if scale is None else w.float() * scale.float().view(-1, 1, 1, 1)
+    out = torch.zeros((N, Kp), dtype=dtype, device=w.device)
+    t = torch.zeros((N, KH, KW, Cp), dtype=torch.float32, device=w.device)
+    t[..., :C] = wf.permute(0, 2, 3, 1)
+    out[:, :K] = t.reshape(N, K).to(dtype)
+    return out
+
+
+def conv2d_nhwc(x, wp, bias, KH, KW, stride=1, pad=0, dil=1, act=0, res=None, out=None):
+    """x (B, H, W, C) channels-last, C % 8 == 0; wp from pack_conv_weight; -> (B, OH, OW, N) (or into `out`, which may be
+    a channel slice of a wider buffer).  None if outside the kernel's domain."""
+    if not (ENABLED and x.is_cuda and x.dtype in _DT16 and wp.dtype == x.dtype and x.dim() == 4 and x.is_contiguous()
+            and x.shape[-1] % 8 == 0 and wp.is_contiguous()):
+        return None
+    B, H, W, C = x.shape
+    N = wp.shape[0]
+    if N % 8 != 0 or wp.shape[1] < KH * KW * C or wp.shape[1] % 64 != 0:
+        return None
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, OH, OW, N), dtype=x.dtype, device=x.device)
+    if tuple(out.shape) != (B, OH, OW, N) or out.stride(3) != 1 or out.stride(2) % 8 != 0 or \
+            out.stride(1) != OW * out.stride(2) or out.stride(0) != OH * out.stride(1):
+        return None
+    if res is not None and (res.dtype != x.dtype or res.shape != out.shape or res.stride() != out.stride()):
+        return None
+    if bias is not None and not (bias.dtype == x.dtype and bias.is_contiguous() and bias.numel() == N):
+        return None
+    lib = _lib.load_library()
+    with on_device(x.device):
+        rc = lib.rfn_conv2d_nhwc(ptr(x), ptr(wp), ptr(bias), ptr(res), int(act), ptr(out), B, H, W, C, N, KH, KW, stride,
+                                 pad, dil, wp.stride(0), out.stride(2), _DT16[x.dtype], current_stream(x.device))
+    _lib.check(rc, "conv2d_nhwc")
+    return out
+
+
 def slab_rows(T, tiles):
     """Rows per slab of the split-T weight-gradient GEMM: enough slabs to fill the chip (~1024 workgroups with the
     output tiles), slabs of at least 256 rows, multiples of 32."""
@@ -57,8 +101,11 @@ def slab_rows(T, tiles):
     return rows
 
 
-def gemm_tn(g, x, rows_per_slab=None):
-    """partials[S, N, K] (fp32) with sum_s partials[s] = g[T,N]^T @ x[T,K]; None if outside the domain."""
+def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None):
+    """g[T,N]^T @ x[T,K] with the token dimension split into slabs.  `out` None: returns the fp32 partials (S, N, K)
+    (deterministic; sum over S is the result).  `out` (N, K) fp32: every slab is ADDED into it with fp32 atomics (the
+    parameter's view of the flat gradient buffer) and `bias_out` (N,) fp32, if given, += the column sums of g.
+    None if outside the kernel's domain."""
     if not (ENABLED and g.is_cuda and g.dtype in _DT16 and x.dtype == g.dtype and g.dim() == 2 and x.dim() == 2
             and g.stride(1) == 1 and x.stride(1) == 1 and g.stride(0) % 2 == 0 and x.stride(0) % 2 == 0
             and g.data_ptr() % 4 == 0 and x.data_ptr() % 4 == 0):
@@ -71,11 +118,19 @@ def gemm_tn(g, x, rows_per_slab=None):
         tile = 128 if (N % 128 == 0 and K % 128 == 0) else 64
         rows_per_slab = slab_rows(T, (N // tile) * (K // tile))
     S = -(-T // rows_per_slab)
-    part = torch.empty((S, N, K), dtype=torch.float32, device=g.device)
+    if out is not None:
+        if not (out.dtype == torch.float32 and out.is_contiguous() and out.numel() == N * K and
+                (bias_out is None or (bias_out.dtype == torch.float32 and bias_out.is_contiguous()
+                                      and bias_out.numel() == N))):
+            return None
+        part = out
+    else:
+        part = torch.empty((S, N, K), dtype=torch.float32, device=g.device)
     lib = _lib.load_library()
     with on_device(g.device):
         rc = lib.rfn_gemm_tn(ptr(g), ptr(x), ptr(part), T, N, K, g.stride(0), x.stride(0), int(rows_per_slab),
-                             _DT16[g.dtype], current_stream(g.device))
+                             0 if out is None else 1, ptr(bias_out) if out is not None else None, _DT16[g.dtype],
+                             current_stream(g.device))
     _lib.check(rc, "gemm_tn")
     return part
 

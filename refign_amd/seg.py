@@ -82,7 +82,14 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x, H, W, res=None, rowscale=None):
-        x = self.drop(self.act(self.dwconv(self.fc1(x), H, W)))
+        x = self.fc1(x)
+        if x.is_cuda and x.shape[-1] % 8 == 0 and type(self.act) is nn.GELU and self.act.approximate == 'none' \
+                and os.environ.get("RFN_FUSED_DWGELU", "1") != "0":
+            from .dwconv import dwconv3x3_gelu_tokens           # depthwise conv + GELU in one pass (csrc/dwconv.hip)
+            dw = self.dwconv.dwconv
+            x = self.drop(dwconv3x3_gelu_tokens(x, dw.weight, dw.bias, H, W))
+        else:
+            x = self.drop(self.act(self.dwconv(x, H, W)))
         if res is not None and self.drop.p == 0.:
             return self.fc2(x, res=res, rowscale=rowscale)       # residual (+ drop-path scale) in the GEMM epilogue
         y = self.drop(self.fc2(x))
@@ -448,6 +455,51 @@ class SegFormerHead(BaseHead):
 # HRDA multi-resolution wrappers (models/hrda.py)
 # ---------------------------------------------------------------------------------------------------------------------
 _PREDRAWN_CROPS = []
+_DEVICE_CROPS = []          # crop offsets as DEVICE data (hipGraph replay of the student passes), see DeviceBox
+
+
+class DeviceBox:
+    """A crop box whose offset lives in device memory: `off` = int64 tensor (oy, ox), (h, w) python ints.
+    extract_crop / hr_crop_slice / crop() of the reference bake the random HRDA crop offsets (hrda.py:22-27) into
+    slices, i.e. into kernel arguments -- a captured graph would replay one fixed crop for ever.  With the offsets as
+    device data the same operations are gathers / comparisons against tensors the host refreshes before each replay.
+    Offsets are multiples of `divisible` (2 * head_os), so the reference's int(v / scale) box scaling
+    (hrda.py:50-64) is the exact integer division used here."""
+
+    def __init__(self, off, h, w, divisible):
+        self.off, self.h, self.w, self.divisible = off, int(h), int(w), int(divisible)
+
+    def _idx(self, n, which, scale=1):
+        return torch.arange(n, device=self.off.device) + self.off[which] // scale
+
+    def crop(self, x):
+        """x[..., y1:y2, x1:x2]"""
+        return x.index_select(-2, self._idx(self.h, 0)).index_select(-1, self._idx(self.w, 1))
+
+    def mask(self, H, W, scale, like):
+        """ones on the box scaled by 1/scale (hr_crop_slice), zeros elsewhere: (1, 1, H, W)"""
+        assert self.divisible % int(scale) == 0
+        hs, ws = int(self.h / scale), int(self.w / scale)
+        ry = torch.arange(H, device=self.off.device) - self.off[0] // int(scale)
+        rx = torch.arange(W, device=self.off.device) - self.off[1] // int(scale)
+        m = ((ry >= 0) & (ry < hs))[:, None] & ((rx >= 0) & (rx < ws))[None, :]
+        return m.to(like.dtype).view(1, 1, H, W)
+
+    def insert(self, patch, size, scale):
+        """zeros(size) with `patch` written at the box scaled by 1/scale (gather from the zero-padded patch)"""
+        assert self.divisible % int(scale) == 0
+        H, W = size
+        hs, ws = patch.shape[-2:]
+        ry = torch.arange(H, device=self.off.device) - self.off[0] // int(scale)
+        rx = torch.arange(W, device=self.off.device) - self.off[1] // int(scale)
+        ry = torch.where((ry >= 0) & (ry < hs), ry, torch.full_like(ry, hs))
+        rx = torch.where((rx >= 0) & (rx < ws), rx, torch.full_like(rx, ws))
+        return F.pad(patch, (0, 1, 0, 1)).index_select(-2, ry).index_select(-1, rx)
+
+
+def push_device_crop(off, divisible):
+    """The NEXT extract_crop takes its offsets from the device tensor `off` (int64, (oy, ox))."""
+    _DEVICE_CROPS.append((off, divisible))
 
 
 def draw_crop_offsets(H, W, crop_size, divisible=1):
@@ -471,6 +523,11 @@ def extract_crop(img, crop_size, divisible=1):
     reference, so the same seed gives the same box."""
     H, W = img.shape[-2:]
     assert crop_size[0] > 0 and crop_size[1] > 0
+    if _DEVICE_CROPS:
+        off, div = _DEVICE_CROPS.pop(0)
+        assert div == divisible, (div, divisible)
+        box = DeviceBox(off, crop_size[0], crop_size[1], divisible)
+        return box.crop(img), [box]
     if _PREDRAWN_CROPS:
         key, off = _PREDRAWN_CROPS.pop(0)
         assert key == (H, W, tuple(crop_size), divisible), (key, (H, W, tuple(crop_size), divisible))
@@ -539,6 +596,13 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
             nl, nh = lr_feats[0].shape[0], hr_feats[0].shape[0]
             seg = fn([torch.cat(p) for p in zip(lr_feats, hr_feats)], *args, **kwargs)
             lr_seg, hr_seg = torch.split(seg, [nl, nh])
+            if self.training and not is_teacher and isinstance(boxes[0], DeviceBox):
+                box = boxes[0]
+                att = att * box.mask(lr_seg.shape[2], lr_seg.shape[3], 2.0 * head_os, lr_seg)
+                up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
+                up_att = F.interpolate(att, scale_factor=2, mode='bilinear', align_corners=False)
+                inserted = box.insert(hr_seg, up_lr.shape[2:], head_os)
+                return up_att * inserted + up_lr, _up(hr_seg, (box.h, box.w)), box
             if self.training and not is_teacher:
                 box = boxes[0]
                 crop_size = (box[1] - box[0], box[3] - box[2])

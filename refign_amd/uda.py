@@ -31,10 +31,10 @@ import torch.nn.functional as F
 from . import align as align_mod
 from . import refine as refine_mod
 from ._tensor import const_tensor, upload_async
-from .graphs import GraphedNoGrad
+from .graphs import GraphedNoGrad, GraphedStep
 from .params import refresh as refresh_derived
 from .config import instantiate_class
-from .seg import hrda_backbone, hrda_head, predraw_crop
+from .seg import DeviceBox, draw_crop_offsets, hrda_backbone, hrda_head, predraw_crop, push_device_crop
 
 IMNET_MEAN = (0.485, 0.456, 0.406)
 IMNET_STD = (0.229, 0.224, 0.225)
@@ -42,6 +42,8 @@ IMNET_STD = (0.229, 0.224, 0.225)
 
 def crop(img, crop_bbox):
     """helpers/utils.py:44-56."""
+    if isinstance(crop_bbox, DeviceBox):                    # crop offsets as device data (graph replay)
+        return crop_bbox.crop(img)
     y1, y2, x1, x2 = crop_bbox
     if img.dim() == 4:
         return img[:, :, y1:y2, x1:x2]
@@ -234,6 +236,9 @@ class DomainAdaptationSegmentationModel(nn.Module):
                         "align_refine": GraphedNoGrad(self._align_refine, "align + refine")}
         if self.enable_fdist:
             self._graphs["imnet_features"] = GraphedNoGrad(self._imnet_features, "ImageNet features")
+        # forward + backward of the student passes (single process; eager under DDP: SyncBatchNorm collectives)
+        self._graphs["source_pass"] = GraphedStep(self._source_pass_device_crop, "student source pass")
+        self._graphs["mixed_pass"] = GraphedStep(self._mixed_pass_device_crop, "student mixed pass")
         self.load_weights(pretrained)
 
     # -- trainer hooks (what Lightning provides in the reference) ---------------------------------------------------
@@ -273,10 +278,13 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # in this step, only on the EMA update above: start it NOW on a side stream so that its kernels fill the gaps
         # of the launch-bound student forward/backward (many small kernels, each well below 256 workgroups).
         early = early_imnet = None
+        graphed = self._student_graphs(images_src)
         if self._overlap_teacher(images_src):
-            if self.enable_fdist:                                        # needed first (after the source backward)
+            if self.enable_fdist and not graphed:                        # needed first (after the source backward)
                 early_imnet = self._start_imnet_features(images_src)
             early = self._start_target_branch(batch, images_src)
+        if graphed:
+            return self._training_step_graphed(batch, images_src, gt_src, src_classes, early, opt, sch)
 
         # SOURCE (:156-179)
         feats_src = self.backbone(images_src)
@@ -334,6 +342,83 @@ class DomainAdaptationSegmentationModel(nn.Module):
         self.manual_backward(mixed_loss)
         del mixed_loss, mixed_pred
 
+        opt.step()
+        sch.step()
+        self.global_step += 1
+
+    # -- the student passes as replayable units (refign_amd/graphs.py: GraphedStep) ----------------------------------
+    def _student_graphs(self, x):
+        """Graph replay of the student passes: HRDA training on a GPU, one process (see GraphedStep.usable)."""
+        return self.use_hrda and self.training and GraphedStep.usable(x) and torch.is_grad_enabled()
+
+    def _crop_offsets(self, images, slot):
+        """Draw the HRDA crop offsets of the next student forward on the host (python `random`, the reference's stream
+        and order: hrda.py:22-27), or take the pre-drawn ones, and put them into the device tensor the pass reads."""
+        from . import seg
+        H, W = images.shape[-2:]
+        size, div = (int(H * 0.5), int(W * 0.5)), self.hrda_output_stride * 2.0
+        if seg._PREDRAWN_CROPS:
+            key, off = seg._PREDRAWN_CROPS.pop(0)
+            assert key == (H, W, size, div), (key, (H, W, size, div))
+        else:
+            off = draw_crop_offsets(H, W, size, div)
+        bufs = self.__dict__.setdefault("_crop_off", {})
+        dev = bufs.get(slot)
+        if dev is None or dev.device != images.device:
+            dev = bufs[slot] = torch.zeros(2, dtype=torch.long, device=images.device)
+        dev.copy_(upload_async(list(off), torch.long, images.device), non_blocking=True)
+        return dev
+
+    def _source_pass_device_crop(self, images_src, gt_src, off):
+        """SOURCE (:156-179) + ImageNet feature distance (:181-189), forward and both backward passes."""
+        push_device_crop(off, self.hrda_output_stride * 2.0)
+        feats_src = self.backbone(images_src)
+        logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
+        feats_src = feats_src[0]
+        logits_src = F.interpolate(logits_src, images_src.shape[-2:], mode='bilinear', align_corners=False)
+        loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
+            self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
+        self.manual_backward(loss_src, retain_graph=self.enable_fdist)
+        out = [loss_src.detach()]
+        if self.enable_fdist:
+            loss_fd = self.calc_feat_dist(images_src, gt_src, feats_src)
+            self.manual_backward(loss_fd)
+            out.append(loss_fd.detach())
+        return tuple(out)
+
+    def _mixed_pass_device_crop(self, mixed_img, mixed_lbl, mixed_weight, off):
+        """MIXED (:226-250), forward and backward."""
+        push_device_crop(off, self.hrda_output_stride * 2.0)
+        mixed_pred, hr_mixed_pred, box = self.head(self.backbone(mixed_img))
+        mixed_pred = F.interpolate(mixed_pred, mixed_img.shape[-2:], mode='bilinear', align_corners=False)
+        mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
+            self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
+        self.manual_backward(mixed_loss)
+        return (mixed_loss.detach(),)
+
+    def _training_step_graphed(self, batch, images_src, gt_src, src_classes, early, opt, sch):
+        """training_step with the two student passes replayed from hipGraphs.  Same order of host random draws as the
+        eager path: source crop (pre-drawn when the teacher branch started early), adapt_to_ref coin, DACS parameters,
+        mixed crop."""
+        off = self._crop_offsets(images_src, "src")
+        losses = self._graphs["source_pass"](images_src, gt_src, off)
+        self.log("train_loss_src", losses[0])
+        if self.enable_fdist:
+            self.log("train_loss_featdist_src", losses[1])
+        with torch.no_grad():
+            if early is None:
+                images_trg, m_probs_trg = self._target_branch(batch)
+            else:
+                images_trg, m_probs_trg = early
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(self._side_stream)
+                m_probs_trg.record_stream(cur)
+            mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src,
+                                                                   src_classes)
+        off = self._crop_offsets(mixed_img, "mix")
+        (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.contiguous(), mixed_lbl.contiguous(),
+                                                   mixed_weight.contiguous(), off)
+        self.log("train_loss_uda_trg", mixed_loss)
         opt.step()
         sch.step()
         self.global_step += 1

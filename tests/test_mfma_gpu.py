@@ -42,7 +42,7 @@ def test_gemm_nt_matches_fp32_reference(dev, dtype, M, N, K):
     assert float((got2.float() - want2).abs().max()) <= 2 * EPS[dtype] * float(want2.abs().max())
 
 
-@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("act", [1, 3])
 def test_gemm_nt_epilogues(dev, act):
     """Fused epilogue: act(x W^T + b), and the stochastic-depth residual res + mask[b] * (x W^T + b)."""
     from refign_amd.mfma import gemm_nt
@@ -52,7 +52,7 @@ def test_gemm_nt_epilogues(dev, act):
     w = _rand((N, K), dev, dtype, 5, K ** -0.5)
     b = _rand((N,), dev, dtype, 6)
     z = x.float() @ w.float().t() + b.float()
-    want = torch.relu(z) if act == 1 else torch.nn.functional.gelu(z)
+    want = torch.relu(z) if act == 1 else torch.nn.functional.leaky_relu(z, 0.1)
     got = gemm_nt(x, w, b, act=act)
     assert float((got.float() - want).abs().max()) <= 2 * EPS[dtype] * float(want.abs().max())
     res = _rand((B * T, N), dev, dtype, 7)
@@ -61,6 +61,41 @@ def test_gemm_nt_epilogues(dev, act):
     want = res.float() + mask.repeat_interleave(T)[:, None] * z
     assert float((got.float() - want).abs().max()) <= 2 * EPS[dtype] * float(want.abs().max())
     assert torch.equal(got[:T], res[:T])                       # dropped sample: the residual passes through exactly
+
+
+CONV_CASES = [  # B, H, W, C, N, k, stride, pad, dil
+    (2, 17, 23, 64, 64, 3, 1, 1, 1),        # VGG-style 3x3
+    (1, 33, 40, 8, 64, 7, 4, 3, 1),         # MiT patch_embed1 (RGB padded to 8 channels): K = 392 -> padded 448
+    (2, 20, 28, 64, 128, 3, 2, 1, 1),       # MiT patch_embed2..4
+    (1, 24, 24, 32, 128, 3, 1, 4, 4),       # refinement module, dilation 4 (C = 32: two taps per 16-byte... per k-step)
+    (1, 19, 27, 88, 128, 3, 1, 1, 1),       # flow decoder (84 channels padded to 88)
+    (2, 16, 30, 320, 320, 2, 2, 0, 1),      # spatial-reduction conv, kernel = stride
+    (1, 45, 60, 1024, 256, 3, 1, 1, 1),     # DAFormer bottleneck
+    (1, 30, 30, 256, 24, 1, 1, 0, 1),       # 1x1 to 19 classes (padded to 24)
+    (3, 9, 11, 16, 8, 3, 1, 2, 2),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,C,N,k,stride,pad,dil", CONV_CASES)
+def test_conv2d_implicit_gemm_matches_fp32_reference(dev, dtype, B, H, W, C, N, k, stride, pad, dil):
+    """Implicit-GEMM convolution on channels-last tensors against fp32 F.conv2d on the same 16-bit inputs: zero padding
+    at all four borders, strides, dilations, channel counts that are not multiples of the 64-wide k-step (a k-step spans
+    several taps, the last one is padded), bias + LeakyReLU epilogue, output written into a channel slice."""
+    from refign_amd.mfma import conv2d_nhwc, pack_conv_weight
+    import torch.nn.functional as F
+    x = _rand((B, C, H, W), dev, dtype, 30)
+    w = _rand((N, C, k, k), dev, dtype, 31, (C * k * k) ** -0.5)
+    b = _rand((N,), dev, dtype, 32)
+    want = F.leaky_relu(F.conv2d(x.float(), w.float(), b.float(), stride, pad, dil), 0.1).permute(0, 2, 3, 1)
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    wp = pack_conv_weight(w, dtype)
+    got = conv2d_nhwc(xh, wp, b, k, k, stride, pad, dil, act=3)
+    assert got is not None and got.shape == want.shape
+    assert float((got.float() - want).abs().max()) <= 2 * EPS[dtype] * float(want.abs().max()) + 1e-3
+    wide = torch.zeros(want.shape[:3] + (N + 16,), dtype=dtype, device=dev)
+    assert conv2d_nhwc(xh, wp, b, k, k, stride, pad, dil, act=3, out=wide[..., 8:8 + N]) is not None
+    assert torch.equal(wide[..., 8:8 + N], got) and float(wide[..., :8].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -77,6 +112,25 @@ def test_gemm_tn_matches_fp32_reference(dev, dtype, T, N, K, rows):
     want = g.double().t() @ x.double()
     got = part.double().sum(0)
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) * math.sqrt(T / 1000 + 1) + 1e-3
+
+
+@pytest.mark.parametrize("T,N,K", [(8160, 320, 320), (2040, 512, 2048), (4111, 128, 64)])
+def test_gemm_tn_accumulates_into_gradient_views(dev, T, N, K):
+    """accumulate mode: every slab is added into an existing fp32 (N, K) buffer with fp32 atomics, and the bias gradient
+    (column sums of g) into an existing (N,) buffer -- both on top of what is already there (three backward passes of a
+    Refign step accumulate into the same flat gradient buffer)."""
+    from refign_amd.mfma import gemm_tn
+    dtype = torch.bfloat16
+    g = _rand((T, N), dev, dtype, 20)
+    x = _rand((T, K), dev, dtype, 21)
+    gw0 = torch.randn(N, K, device=dev)
+    gb0 = torch.randn(N, device=dev)
+    gw, gb = gw0.clone(), gb0.clone()
+    assert gemm_tn(g, x, out=gw, bias_out=gb) is gw
+    want_w = gw0.double() + g.double().t() @ x.double()
+    want_b = gb0.double() + g.double().sum(0)
+    assert float((gw.double() - want_w).abs().max()) <= 2e-5 * float(want_w.abs().max()) * math.sqrt(T / 1000 + 1) + 1e-3
+    assert float((gb.double() - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max()) * math.sqrt(T / 1000 + 1) + 1e-3
 
 
 def _ref_attention(q, kv, heads, scale):

@@ -118,12 +118,46 @@ def test_hipgraph_replay_equals_eager(dev, use_hrda, monkeypatch):
             f_want = model._imnet_features(trg)
             for a, b in zip(f_got, f_want):
                 assert float((a.float() - b.float()).abs().max()) <= 2e-2 * max(1.0, float(b.float().abs().max()))
+    from refign_amd.graphs import GraphedNoGrad
     for name, graphed in model._graphs.items():
+        if not isinstance(graphed, GraphedNoGrad):
+            continue                                     # student passes: test_student_passes_graph_replay_equals_eager
         st = [s for s in graphed.states.values()]
         assert len(st) == 1 and st[0]["graph"] is not None and not st[0]["failed"], f"{name}: capture did not happen"
     # train()/eval() (folded-BN caches are re-made) drops the captures
     model.train()
     assert all(len(g_.states) == 0 for g_ in model._graphs.values())
+
+
+def test_student_passes_graph_replay_equals_eager(dev, monkeypatch):
+    """GraphedStep: the student's source pass (+ feature distance) and mixed pass -- forward, losses and every backward
+    kernel -- replayed from hipGraphs give the same training trajectory as the eager step: same three losses per step
+    and the same parameters after 5 optimiser steps (capture happens at step 3; the HRDA crop offsets, drawn on the host
+    from the reference's `random` stream, reach the replay as device data and differ from step to step)."""
+    from refign_amd.trainer import Trainer
+    H = W = 128
+    traj = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RFN_GRAPH_STUDENT", mode)
+        model = build(True, dev)
+        trainer = Trainer(model, fused_optimizer=False)
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        rows, boxes = [], []
+        for it in range(5):
+            batch = make_batch(2, H, W, 64, dev)
+            batch["image_src"] = batch["image_src"] + 0.1 * it
+            model.training_step(batch, it)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src",
+                                                          "train_loss_uda_trg")])
+            boxes.append(tuple(int(v) for v in model._crop_off["src"].tolist()) if mode == "1" else None)
+        traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), boxes)
+        if mode == "1":
+            for name in ("source_pass", "mixed_pass"):
+                st = list(model._graphs[name].states.values())
+                assert len(st) == 1 and st[0]["graph"] is not None and not st[0]["failed"], f"{name}: not captured"
+            assert len(set(boxes)) > 1, "the crop offsets never changed: the test would not see a frozen crop"
+    np.testing.assert_allclose(traj["1"][0], traj["0"][0], rtol=2e-3)
+    assert abs(traj["1"][1] - traj["0"][1]) < 1e-5 * traj["0"][1]
 
 
 def test_failed_graph_capture_falls_back_to_eager(dev, monkeypatch):
