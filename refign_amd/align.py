@@ -231,6 +231,16 @@ class VGG(nn.Module):
         i = lo
         while i < hi:
             m = self.features[i]
+            if isinstance(m, nn.Conv2d) and i + 1 < hi and isinstance(self.features[i + 1], nn.ReLU) and x.is_cuda \
+                    and not torch.is_grad_enabled():
+                # conv3x3 + bias + ReLU: one launch of the hand-written implicit-GEMM kernel (refign_amd/conv.py)
+                from .conv import conv2d_mfma
+                from .params import compute_dtype
+                y = conv2d_mfma(x, m.weight, m.bias, m.stride, m.padding, m.dilation, act='relu', dtype=compute_dtype(x))
+                if y is not None:
+                    x = y
+                    i += 2
+                    continue
             if fused and isinstance(m, nn.Conv2d) and i + 1 < hi and isinstance(self.features[i + 1], nn.ReLU):
                 x = torch.ops.aten.miopen_convolution_relu(x, m.weight, m.bias, m.stride, m.padding, m.dilation,
                                                            m.groups)

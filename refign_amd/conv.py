@@ -66,6 +66,10 @@ class Conv2d(nn.Conv2d):
         if torch.is_grad_enabled() and self.weight.requires_grad:
             return _Conv2dFn.apply(x, self.weight, self.bias, w_c, b_c, self.stride, self.padding, self.dilation,
                                    self.groups)
+        if self.groups == 1 and not torch.is_grad_enabled():
+            y = conv2d_mfma(x, self.weight, self.bias, self.stride, self.padding, self.dilation, dtype=cd)
+            if y is not None:
+                return y
         return F.conv2d(x, w_c, b_c, self.stride, self.padding, self.dilation, self.groups)
 
 
@@ -113,6 +117,10 @@ def _from_patches(gp, B, H, W, C, r, Hr, Wr):
     return g.reshape(B, H * W, C)
 
 
+def _krsc_view(p):
+    return p.permute(2, 3, 1, 0)
+
+
 class _PatchLinearFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
@@ -121,7 +129,8 @@ class _PatchLinearFn(torch.autograd.Function):
         ctx.save_for_backward(patches, w2)
         ctx.weight, ctx.bias = weight, bias
         ctx.geom = (x.shape, H, W, r, Hr, Wr)
-        return F.linear(patches, w2, b_c).view(x.shape[0], Hr * Wr, w2.shape[0])
+        y = _mfma.gemm_nt(patches, w2, b_c)
+        return (F.linear(patches, w2, b_c) if y is None else y).view(x.shape[0], Hr * Wr, w2.shape[0])
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -138,10 +147,18 @@ class _PatchLinearFn(torch.autograd.Function):
             g2 = g2.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _from_patches(torch.mm(g2, w2), B, H, W, C, r, Hr, Wr)
+            # (K, Co) = W^T of the patch Linear: dx = dy W on the NT kernel.  Cached as its (r, r, C, Co) view, the shape of
+            # weight.permute(2, 3, 1, 0), so that params.refresh() re-fills it in place (graph replays see live weights)
+            wT = derived(ctx.weight, (w2.dtype, "patch_linear_T"),
+                         lambda t: t.to(w2.dtype).permute(2, 3, 1, 0).contiguous(), _krsc_view).view(K, Co)
+            gp = _mfma.gemm_nt(g2, wT)
+            gx = _from_patches(torch.mm(g2, w2) if gp is None else gp, B, H, W, C, r, Hr, Wr)
         T = g2.shape[0]
         S = _split(T)
-        if S > 1:
+        part = _mfma.gemm_tn(g2, patches)                                               # fp32 slab partials (S, Co, K)
+        if part is not None:
+            part = part.view(part.shape[0], Co * K)
+        elif S > 1:
             part = torch.bmm(g2.view(S, T // S, Co).transpose(1, 2), patches.view(S, T // S, K)).view(S, Co * K)
         else:
             part = g2.t().mm(patches).view(1, Co * K)
@@ -178,4 +195,86 @@ def patch_conv_tokens(x, H, W, conv):
     if torch.is_grad_enabled() and conv.weight.requires_grad:
         return _PatchLinearFn.apply(x, conv.weight, conv.bias, w2, b_c, H, W, r)
     patches, Hr, Wr = _to_patches(x, H, W, r)
-    return F.linear(patches, w2, b_c).view(x.shape[0], Hr * Wr, Co)
+    y = _mfma.gemm_nt(patches, w2, b_c)
+    return (F.linear(patches, w2, b_c) if y is None else y).view(x.shape[0], Hr * Wr, Co)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Dense convolution on the hand-written implicit-GEMM MFMA kernel (csrc/mfma_gemm.hip: rfn_conv2d_nhwc), for the
+# gradient-free networks of the step: the frozen matcher (VGG-16, flow decoders, refinement, uncertainty tail --
+# vgg.py:108-120, modules.py:395-561) under its fp16 autocast and the EMA-teacher / ImageNet MiT patch embeddings.
+# Tensors keep their NCHW SHAPE and carry channels-last strides between layers, so consecutive layers hand each other
+# NHWC memory without a copy; bias, folded BatchNorm and ReLU / LeakyReLU ride in the epilogue.
+# ---------------------------------------------------------------------------------------------------------------------
+import os as _os
+
+from . import mfma as _mfma
+
+_ACT = {None: 0, 'relu': 1, 'leaky': 3}
+_CONV_MFMA = _os.environ.get("RFN_CONV_MFMA", "1") != "0"
+
+
+def _nhwc_view(p):
+    return p.permute(0, 2, 3, 1)
+
+
+def _packed(weight, bias, dtype):
+    """Cached ([N8, Kpad] tap-major 16-bit weight with the output channels padded to 8, bias padded likewise).  What is
+    cached per parameter is the (N, KH, KW, C) VIEW into the padded buffer -- the same shape as `weight.permute(0, 2, 3, 1)`
+    -- so that params.refresh() re-fills it IN PLACE after an optimizer / EMA update: a captured graph keeps pointing
+    at live weights (a re-made copy would leave the replay with stale ones)."""
+    def make(t):
+        N, C, KH, KW = t.shape
+        N8, Cp = -(-N // 8) * 8, -(-C // 8) * 8
+        Kp = -(-(KH * KW * Cp) // 64) * 64
+        base = torch.zeros((N8, Kp), dtype=dtype, device=t.device)
+        view = base[:N, :KH * KW * Cp].view(N, KH, KW, Cp)[..., :C]
+        view.copy_(t.permute(0, 2, 3, 1))
+        view._rfn_base = base
+        return view
+    wp = derived(weight, ("igemm", dtype), make, _nhwc_view)._rfn_base
+    bp = None
+    if bias is not None:
+        def makeb(t):
+            base = torch.zeros(-(-t.shape[0] // 8) * 8, dtype=dtype, device=t.device)
+            view = base[:t.shape[0]]
+            view.copy_(t)
+            view._rfn_base = base
+            return view
+        bp = derived(bias, ("igemm_bias", dtype), makeb, _identity)._rfn_base
+    return wp, bp
+
+
+def conv2d_mfma(x, weight, bias, stride=1, padding=0, dilation=1, act=None, dtype=None):
+    """F.conv2d(x, weight, bias, stride, padding, dilation) [+ ReLU / LeakyReLU(0.1)] for groups == 1 on the GPU, 16-bit
+    operands with fp32 accumulation.  x: (B, C, H, W) in any memory format (channels-last is used in place); returns a
+    (B, N, OH, OW) tensor with channels-last strides, or None when the call is outside the kernel's domain (caller falls
+    back to the library).  Gradient-free only."""
+    if not (_CONV_MFMA and _mfma.ENABLED and x.is_cuda and x.dim() == 4 and not torch.is_grad_enabled()):
+        return None
+    dtype = dtype or x.dtype
+    if dtype not in (torch.float16, torch.bfloat16):
+        return None
+    s, p, d = (v[0] if isinstance(v, (tuple, list)) else v for v in (stride, padding, dilation))
+    for v in (stride, padding, dilation):
+        if isinstance(v, (tuple, list)) and v[0] != v[1]:
+            return None
+    N, C, KH, KW = weight.shape
+    if x.shape[1] != C:
+        return None
+    wp, bp = _packed(weight, bias, dtype)
+    xh = x.permute(0, 2, 3, 1)
+    Cp = -(-C // 8) * 8
+    if xh.dtype != dtype or Cp != C or not xh.is_contiguous():
+        if Cp != C:
+            buf = torch.zeros(xh.shape[:3] + (Cp,), dtype=dtype, device=x.device)
+            buf[..., :C] = xh
+            xh = buf
+        else:
+            xh = xh.to(dtype).contiguous()
+    y = _mfma.conv2d_nhwc(xh, wp, bp, KH, KW, s, p, d, act=_ACT[act])
+    if y is None:
+        return None
+    if y.shape[-1] != N:
+        y = y[..., :N]
+    return y.permute(0, 3, 1, 2)

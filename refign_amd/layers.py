@@ -92,6 +92,16 @@ class ConvBNReLU(nn.Module):
         if self.depthwise_separable:
             return self.pointwise_conv(self.depthwise_conv(x))
         c = self.conv
+        if x.is_cuda and c.groups == 1 and not torch.is_grad_enabled() and (not self.use_norm or not self.training) \
+                and self.act_slope in (0.0, LEAKY_SLOPE):
+            # gradient-free, BatchNorm in eval mode (the frozen matcher): ONE launch of the hand-written implicit-GEMM
+            # kernel -- folded norm in the weights, bias and ReLU / LeakyReLU in its epilogue (refign_amd/conv.py)
+            from .conv import conv2d_mfma
+            from .params import compute_dtype
+            w, b = self.folded() if self.use_norm else (c.weight, c.bias)
+            y = conv2d_mfma(x, w, b, c.stride, c.padding, c.dilation, act=self.act, dtype=compute_dtype(x))
+            if y is not None:
+                return y
         if self.use_norm and not self.training and not torch.is_grad_enabled():
             x = self._conv2d(x, *self.folded())
         else:

@@ -160,6 +160,37 @@ def test_student_passes_graph_replay_equals_eager(dev, monkeypatch):
     assert abs(traj["1"][1] - traj["0"][1]) < 1e-5 * traj["0"][1]
 
 
+def test_graph_replays_see_live_weights_under_autocast(dev, monkeypatch):
+    """Every cached derived copy of a parameter (16-bit, transposed, tap-major, implicit-GEMM packed ...) that a captured
+    graph may point at must be re-filled IN PLACE after the optimiser / EMA update -- a copy that is dropped and re-made
+    would leave the replay computing with stale weights.  After 4 bf16 steps with all graphs on: every cache entry has
+    a refill view, is current, and sits at the address it had when the graphs were captured."""
+    from refign_amd.trainer import Trainer
+    monkeypatch.setenv("RFN_GRAPH_STUDENT", "1")
+    model = build(True, dev)
+    trainer = Trainer(model)
+    random.seed(9); np.random.seed(9); torch.manual_seed(9)
+    addr = {}
+    for it in range(4):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            model.training_step(make_batch(2, 128, 128, 64, dev), it)
+        if it == 2:                                   # captures happened in this step
+            for name, p in model.named_parameters():
+                for key, ent in p.__dict__.get("_rfn_derived", {}).items():
+                    addr[(name, key)] = ent[0].data_ptr()
+    assert any(s_["graph"] is not None for s_ in model._graphs["source_pass"].states.values())
+    checked = 0
+    for name, p in model.named_parameters():
+        for key, (t, _, _, refill) in p.__dict__.get("_rfn_derived", {}).items():
+            assert refill is not None, f"{name}: derived copy {key} cannot be refreshed in place"
+            want = refill(p.detach()).to(t.dtype)
+            assert torch.equal(t, want), f"{name}: derived copy {key} is stale"
+            if (name, key) in addr:
+                assert t.data_ptr() == addr[(name, key)], f"{name}: derived copy {key} moved after capture"
+            checked += 1
+    assert checked > 200
+
+
 def test_failed_graph_capture_falls_back_to_eager(dev, monkeypatch):
     """A region that cannot be captured (here: a host synchronisation inside it) must leave the process usable: warning,
     eager results from then on, later launches on the original stream work."""
