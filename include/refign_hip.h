@@ -271,20 +271,24 @@ int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, 
  * in place.
  *   rfn_attn_pack     rows of one tensor -> R-pack and/or T-pack (MFMA A-operand images, 4096 B per 32-row block and
  *                     (b, head); nblk blocks, zero padded).  Needed: K R+T, V R+T (forward uses K R, V T), Q R+T, dO R+T.
+ *                     A second tensor of the same geometry (src2 -> rpack2 / tpack2) rides in the same launch.  K and V
+ *                     of a kv tensor are packed in ONE call as 2 x heads "heads" (V's head h is pack head heads + h):
+ *                     the kernels take the pack pointers of K / V and kv_pack_heads = 2 x heads.
  *   rfn_attn_fwd      O and lse2[b*heads+h][nqpad] (base-2 log-sum-exp of the scaled scores), nkblk even.
  *   rfn_attn_bwd_dq   dQ, and delta[bh][nqpad] = rowsum(dO o O) for the dK/dV kernel.
  *   rfn_attn_bwd_dkv  dKV (B, Nkv, 2, heads, 64); accT: fp32 scratch of B*heads*2*64*nkpad floats; the query dimension is
  *                     split into chunks of `blocks_per_chunk` 32-row blocks per workgroup.
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_attn_pack(const void* src, long batch_stride, long row_stride, int B, int heads, int nrows, int nblk, void* rpack,
-                  void* tpack, rfn_stream_t stream);
+                  void* tpack, const void* src2, void* rpack2, void* tpack2, rfn_stream_t stream);
 int rfn_attn_fwd(const void* Q, long q_batch_stride, long q_row_stride, const void* k_rpack, const void* v_tpack, void* O,
                  long o_batch_stride, long o_row_stride, float* lse2, int B, int heads, int Nq, int Nkv, int nkblk,
-                 int nqpad, float scale, int dtype, rfn_stream_t stream);
+                 int nqpad, float scale, int kv_pack_heads, int dtype, rfn_stream_t stream);
 int rfn_attn_bwd_dq(const void* Q, long q_batch_stride, long q_row_stride, const void* dO, const void* O,
                     long o_batch_stride, long o_row_stride, const void* k_rpack, const void* v_rpack, const void* k_tpack,
                     const float* lse2, float* delta, void* dQ, long dq_batch_stride, long dq_row_stride, int B, int heads,
-                    int Nq, int Nkv, int nkblk, int nqpad, float scale, int dtype, rfn_stream_t stream);
+                    int Nq, int Nkv, int nkblk, int nqpad, float scale, int kv_pack_heads, int dtype,
+                    rfn_stream_t stream);
 int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv_row_stride, const void* q_rpack,
                      const void* q_tpack, const void* do_rpack, const void* do_tpack, const float* lse2,
                      const float* delta, float* accT, void* dKV, int B, int heads, int Nq, int Nkv, int nqblk, int nqpad,

@@ -56,11 +56,12 @@ SIGNATURES = {
     "rfn_conv2d_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int,
                                                                                        c_void_p]),
     "rfn_gemm_tn": (c_int, [c_void_p] * 3 + [ctypes.c_long] * 5 + [c_int, c_int, c_void_p, c_int, c_void_p]),
-    "rfn_attn_pack": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] + [c_int] * 4 + [c_void_p] * 3),
+    "rfn_attn_pack": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] + [c_int] * 4 + [c_void_p] * 6),
     "rfn_attn_fwd": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_void_p, ctypes.c_long,
-                             ctypes.c_long, c_void_p] + [c_int] * 6 + [c_float, c_int, c_void_p]),
+                             ctypes.c_long, c_void_p] + [c_int] * 6 + [c_float, c_int, c_int, c_void_p]),
     "rfn_attn_bwd_dq": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long]
-                        + [c_void_p] * 6 + [ctypes.c_long, ctypes.c_long] + [c_int] * 6 + [c_float, c_int, c_void_p]),
+                        + [c_void_p] * 6 + [ctypes.c_long, ctypes.c_long] + [c_int] * 6 + [c_float, c_int, c_int,
+                                                                                         c_void_p]),
     "rfn_attn_bwd_dkv": (c_int, [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long] + [c_void_p] * 8 + [c_int] * 8
                          + [c_float, c_int, c_void_p]),
     "rfn_uncertainty9_weights_len": (c_int, []),

@@ -33,10 +33,15 @@ constexpr float kLog2e = 1.4426950408889634f;
 // pack: rows [Nrows] x 64 of one (batch, head) -> R-pack and T-pack, zero padded to nblk blocks
 //   src element (b, row, head, d) at src + b * sb + row * sr + head * 64 + d
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_pack_kernel(const uint16_t* __restrict__ src, long sb, long sr, int heads,
-                                                        int nrows, int nblk, unsigned char* __restrict__ rpack,
-                                                        unsigned char* __restrict__ tpack) {
+__global__ __launch_bounds__(256) void attn_pack_kernel(const uint16_t* __restrict__ src0, const uint16_t* __restrict__ src1,
+                                                        long sb, long sr, int heads, int nrows, int nblk,
+                                                        unsigned char* __restrict__ rpack0, unsigned char* __restrict__ tpack0,
+                                                        unsigned char* __restrict__ rpack1, unsigned char* __restrict__ tpack1) {
   __shared__ unsigned tile[32][33];                    // [row][d pair], padded
+  // blockIdx.z picks one of two tensors of identical geometry (Q and dO of a backward pass go in one launch)
+  const uint16_t* src = blockIdx.z ? src1 : src0;
+  unsigned char* rpack = blockIdx.z ? rpack1 : rpack0;
+  unsigned char* tpack = blockIdx.z ? tpack1 : tpack0;
   const int blk = blockIdx.x, bh = blockIdx.y;
   const int b = bh / heads, hd = bh % heads;
   const int t = threadIdx.x, row = t >> 3, dc = t & 7;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
                                                        const unsigned char* __restrict__ Kr,
                                                        const unsigned char* __restrict__ Vt, uint16_t* __restrict__ O,
                                                        long osb, long osr, float* __restrict__ lse2, int heads, int Nq,
-                                                       int Nkv, int nblk, int nqpad, float scale) {
+                                                       int Nkv, int nblk, int nqpad, float scale, int pheads) {
   using E = Elem<DT>;
   using vec8 = typename E::vec8;
   constexpr int STAGE = 4 * kPackBlock;                 // 2 key blocks: K R-pack + V T-pack
@@ -130,8 +135,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   vec8 qf[4];
   load_row_frags<DT>(Q + (long)b * qsb + hd * 64, qsr, q, Nq, g, qf);
 
-  const unsigned char* kbase = Kr + (long)bh * nblk * kPackBlock;
-  const unsigned char* vbase = Vt + (long)bh * nblk * kPackBlock;
+  // K / V packs are indexed (b, pack head): K and V of one kv tensor are packed together as 2 x heads "heads"
+  const long pidx = (long)(b * pheads + hd) * nblk * kPackBlock;
+  const unsigned char* kbase = Kr + pidx;
+  const unsigned char* vbase = Vt + pidx;
   const int nst = nblk / 2;                              // nblk is even (host pads the packs)
   auto issue = [&](int st, int buf) {
     unsigned char* dst = smem + buf * STAGE;
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
                                                           const unsigned char* __restrict__ Kt,
                                                           const float* __restrict__ lse2, float* __restrict__ delta,
                                                           uint16_t* __restrict__ dQ, long dsb, long dsr, int heads, int Nq,
-                                                          int Nkv, int nblk, int nqpad, float scale) {
+                                                          int Nkv, int nblk, int nqpad, float scale, int pheads) {
   using E = Elem<DT>;
   using vec8 = typename E::vec8;
   constexpr int STAGE = 6 * kPackBlock;                 // 2 key blocks x (K R-pack, V R-pack, K T-pack)
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   const float ls = (q < nqpad) ? lse2[(long)bh * nqpad + q] : 0.f;
   if (g == 0 && q < nqpad) delta[(long)bh * nqpad + q] = ok ? dl : 0.f;
 
-  const long pbase = (long)bh * nblk * kPackBlock;
+  const long pbase = (long)(b * pheads + hd) * nblk * kPackBlock;
   const int nst = nblk / 2;
   auto issue = [&](int st, int buf) {
     unsigned char* dst = smem + buf * STAGE;
@@ -476,42 +483,46 @@ using namespace rfn;
 #define ATTN_DT_OK(dt) RFN_REQUIRE((dt) == 1 || (dt) == 2, "attention: dtype %d (1 = bf16, 2 = f16)", (dt))
 
 int rfn_attn_pack(const void* src, long batch_stride, long row_stride, int B, int heads, int nrows, int nblk, void* rpack,
-                  void* tpack, rfn_stream_t stream) {
+                  void* tpack, const void* src2, void* rpack2, void* tpack2, rfn_stream_t stream) {
   RFN_REQUIRE(src && (rpack || tpack), "attn_pack: null pointer");
+  RFN_REQUIRE(src2 == nullptr || rpack2 || tpack2, "attn_pack: second tensor without outputs");
   RFN_REQUIRE(B > 0 && heads > 0 && nrows > 0 && nblk * 32 >= nrows, "attn_pack: B=%d heads=%d rows=%d nblk=%d", B, heads,
               nrows, nblk);
   RFN_REQUIRE(row_stride % 8 == 0 && batch_stride % 8 == 0, "attn_pack: strides must be multiples of 8 elements");
-  dim3 grid(nblk, B * heads);
-  hipLaunchKernelGGL(attn_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, batch_stride,
-                     row_stride, heads, nrows, nblk, (unsigned char*)rpack, (unsigned char*)tpack);
+  dim3 grid(nblk, B * heads, src2 ? 2 : 1);
+  hipLaunchKernelGGL(attn_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src,
+                     (const uint16_t*)src2, batch_stride, row_stride, heads, nrows, nblk, (unsigned char*)rpack,
+                     (unsigned char*)tpack, (unsigned char*)rpack2, (unsigned char*)tpack2);
   return check_launch("attn_pack");
 }
 
 int rfn_attn_fwd(const void* Q, long q_batch_stride, long q_row_stride, const void* k_rpack, const void* v_tpack, void* O,
                  long o_batch_stride, long o_row_stride, float* lse2, int B, int heads, int Nq, int Nkv, int nkblk,
-                 int nqpad, float scale, int dtype, rfn_stream_t stream) {
+                 int nqpad, float scale, int kv_pack_heads, int dtype, rfn_stream_t stream) {
   ATTN_DT_OK(dtype);
   RFN_REQUIRE(Q && k_rpack && v_tpack && O && lse2, "attn_fwd: null pointer");
   RFN_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nkv > 0 && nkblk % 2 == 0 && nkblk * 32 >= Nkv && nqpad >= Nq,
               "attn_fwd: B=%d heads=%d Nq=%d Nkv=%d nkblk=%d nqpad=%d", B, heads, Nq, Nkv, nkblk, nqpad);
   RFN_REQUIRE(q_row_stride % 8 == 0 && o_row_stride % 8 == 0 && q_batch_stride % 8 == 0 && o_batch_stride % 8 == 0,
               "attn_fwd: strides must be multiples of 8 elements");
+  RFN_REQUIRE(kv_pack_heads >= heads, "attn_fwd: kv_pack_heads");
   dim3 grid(cdiv(Nq, 128), B * heads);
   if (dtype == 1)
     hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Q, q_batch_stride,
                        q_row_stride, (const unsigned char*)k_rpack, (const unsigned char*)v_tpack, (uint16_t*)O,
-                       o_batch_stride, o_row_stride, lse2, heads, Nq, Nkv, nkblk, nqpad, scale);
+                       o_batch_stride, o_row_stride, lse2, heads, Nq, Nkv, nkblk, nqpad, scale, kv_pack_heads);
   else
     hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Q, q_batch_stride,
                        q_row_stride, (const unsigned char*)k_rpack, (const unsigned char*)v_tpack, (uint16_t*)O,
-                       o_batch_stride, o_row_stride, lse2, heads, Nq, Nkv, nkblk, nqpad, scale);
+                       o_batch_stride, o_row_stride, lse2, heads, Nq, Nkv, nkblk, nqpad, scale, kv_pack_heads);
   return check_launch("attn_fwd");
 }
 
 int rfn_attn_bwd_dq(const void* Q, long q_batch_stride, long q_row_stride, const void* dO, const void* O,
                     long o_batch_stride, long o_row_stride, const void* k_rpack, const void* v_rpack, const void* k_tpack,
                     const float* lse2, float* delta, void* dQ, long dq_batch_stride, long dq_row_stride, int B, int heads,
-                    int Nq, int Nkv, int nkblk, int nqpad, float scale, int dtype, rfn_stream_t stream) {
+                    int Nq, int Nkv, int nkblk, int nqpad, float scale, int kv_pack_heads, int dtype,
+                    rfn_stream_t stream) {
   ATTN_DT_OK(dtype);
   RFN_REQUIRE(Q && dO && O && k_rpack && v_rpack && k_tpack && lse2 && delta && dQ, "attn_bwd_dq: null pointer");
   RFN_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nkv > 0 && nkblk % 2 == 0 && nkblk * 32 >= Nkv && nqpad >= Nq,
@@ -521,7 +532,8 @@ int rfn_attn_bwd_dq(const void* Q, long q_batch_stride, long q_row_stride, const
   hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Q, q_batch_stride, \
                      q_row_stride, (const uint16_t*)dO, (const uint16_t*)O, o_batch_stride, o_row_stride,               \
                      (const unsigned char*)k_rpack, (const unsigned char*)v_rpack, (const unsigned char*)k_tpack, lse2,  \
-                     delta, (uint16_t*)dQ, dq_batch_stride, dq_row_stride, heads, Nq, Nkv, nkblk, nqpad, scale)
+                     delta, (uint16_t*)dQ, dq_batch_stride, dq_row_stride, heads, Nq, Nkv, nkblk, nqpad, scale,          \
+                     kv_pack_heads)
   if (dtype == 1) RFN_DQ_LAUNCH(1); else RFN_DQ_LAUNCH(2);
 #undef RFN_DQ_LAUNCH
   return check_launch("attn_bwd_dq");

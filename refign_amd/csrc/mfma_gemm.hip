@@ -20,6 +20,7 @@
 #include <hip/hip_bf16.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -447,13 +448,16 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
     cg.zero = zero_page;
   }
   // tile: the widest n the problem fills; m 128, or 64 when the problem would not give every CU a tile otherwise
-  const int bn = (N % 128 == 0) ? 128 : 64;
-  const int bm = ((long)cdiv(M, 128) * cdiv(N, bn) >= 256) ? 128 : 64;
+  int bn = (N % 128 == 0) ? 128 : 64;
+  int bm = ((long)cdiv(M, 128) * cdiv(N, bn) >= 256) ? 128 : 64;
+  int ns = 2;
+  static const char* cfg_env = getenv("RFN_GEMM_CFG");          // "bm,bn,ns": tile sweep of tools/mfma_bench.py
+  if (cfg_env != nullptr) sscanf(cfg_env, "%d,%d,%d", &bm, &bn, &ns);
   const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
   const long total = (long)tiles_m * tiles_n;
-  // workgroups per CU by LDS (2-deep ring of (bm + bn) * 128 bytes; 160 KB per CU), at most 4
-  const int ring = 2 * (bm + bn) * 128;
-  const int per_cu = std::min(160 * 1024 / ring, 4);
+  // workgroups per CU by LDS (ns-deep ring of (bm + bn) * 128 bytes; 160 KB per CU), at most 4
+  const int ring = ns * (bm + bn) * 128;
+  const int per_cu = std::max(1, std::min(160 * 1024 / ring, 4));
   static const int persist_mode = getenv("RFN_GEMM_PERSIST") ? atoi(getenv("RFN_GEMM_PERSIST")) : -1;
   // persistent (one pipeline across tiles) pays when a tile has only a few K-steps: the next tile's loads hide under the
   // epilogue.  With many K-steps per tile the plain one-tile-per-workgroup launch measured faster (dispatcher refills a CU
@@ -461,14 +465,22 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   const bool persistent = persist_mode < 0 ? (K <= 256) : persist_mode != 0;
   const int slots = persistent ? 256 * per_cu : 0x7fffffff;
   dim3 grid((unsigned)std::min<long>(total, slots)), block(256);
-#define RFN_NT(BM_, BN_)                                                                                                \
-  hipLaunchKernelGGL((gemm_nt_kernel<DT, BM_, BN_, 64, 2, GATHER>), grid, block, 0, s, (const uint16_t*)X,               \
-                     (const uint16_t*)W,                                                                                 \
-                     (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tiles_n, (int)total, epi, cg)
-  if (bm == 128 && bn == 128) RFN_NT(128, 128);
-  else if (bm == 128) RFN_NT(128, 64);
-  else if (bn == 128) RFN_NT(64, 128);
-  else RFN_NT(64, 64);
+#define RFN_NT(BM_, BN_, NS_)                                                                                            \
+  hipLaunchKernelGGL((gemm_nt_kernel<DT, BM_, BN_, 64, NS_, GATHER>), grid, block, 0, s, (const uint16_t*)X,             \
+                     (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tiles_n, (int)total, epi,  \
+                     cg)
+  const int key = bm * 10000 + bn * 10 + ns;
+  switch (key) {
+    case 1281282: RFN_NT(128, 128, 2); break;
+    case 1280642: RFN_NT(128, 64, 2); break;
+    case 641282: RFN_NT(64, 128, 2); break;
+    case 640642: RFN_NT(64, 64, 2); break;
+    case 1281283: RFN_NT(128, 128, 3); break;
+    case 1280643: RFN_NT(128, 64, 3); break;
+    case 640644: RFN_NT(64, 64, 4); break;
+    case 640648: RFN_NT(64, 64, 8); break;
+    default: return fail(RFN_EINVAL, "gemm_nt: no kernel for tile %dx%d ring %d", bm, bn, ns);
+  }
 #undef RFN_NT
   return check_launch("gemm_nt");
 }

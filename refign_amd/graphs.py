@@ -114,16 +114,18 @@ class GraphedStep:
     The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
     throws leaves the pass eager for good, like GraphedNoGrad."""
 
-    _pool = None                # one memory pool for all student passes: they are never live at the same time
-
-    def __init__(self, fn, name, warmup=2):
+    def __init__(self, fn, name, warmup=2, shared=None):
+        """`shared`: a dict the passes of ONE model share -- they are never live at the same time, so their graphs
+        capture into one memory pool (held there; it dies with the model's graphs, never outlives them)."""
         self.fn, self.name, self.warmup = fn, name, warmup
+        self.shared = {} if shared is None else shared
         self.generation = 0
         self.states = {}
 
     def reset(self):
         self.generation += 1
         self.states.clear()
+        self.shared.pop("pool", None)
 
     @staticmethod
     def usable(t):
@@ -166,11 +168,10 @@ class GraphedStep:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g, pool=GraphedStep._pool, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=self.shared.get("pool"), capture_error_mode="thread_local"):
                 outputs = self.fn(*inputs)
         except BaseException:
             torch.cuda.set_stream(cur)
             raise
-        if GraphedStep._pool is None:
-            GraphedStep._pool = g.pool()
+        self.shared.setdefault("pool", g.pool())
         st["graph"], st["inputs"], st["outputs"] = g, inputs, outputs

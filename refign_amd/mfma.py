@@ -141,17 +141,19 @@ def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None):
 _PACK_BLOCK = 4096
 
 
-def _pack(src, batch_stride, row_stride, B, heads, nrows, nblk, want_r=True, want_t=True):
+def _pack(src, batch_stride, row_stride, B, heads, nrows, nblk, want_r=True, want_t=True, src2=None):
+    """R- / T-packs of `src` (and of `src2`, same geometry, in the same launch): ((r, t), (r2, t2))"""
     dev = src.device
     nbytes = B * heads * nblk * _PACK_BLOCK
-    r = torch.empty(nbytes, dtype=torch.uint8, device=dev) if want_r else None
-    t = torch.empty(nbytes, dtype=torch.uint8, device=dev) if want_t else None
+    new = lambda want: torch.empty(nbytes, dtype=torch.uint8, device=dev) if want else None  # noqa: E731
+    r, t = new(want_r), new(want_t)
+    r2, t2 = (new(want_r), new(want_t)) if src2 is not None else (None, None)
     lib = _lib.load_library()
     with on_device(dev):
-        rc = lib.rfn_attn_pack(ptr(src), batch_stride, row_stride, B, heads, nrows, nblk, ptr(r), ptr(t),
-                               current_stream(dev))
+        rc = lib.rfn_attn_pack(ptr(src), batch_stride, row_stride, B, heads, nrows, nblk, ptr(r), ptr(t), ptr(src2),
+                               ptr(r2), ptr(t2), current_stream(dev))
     _lib.check(rc, "attn_pack")
-    return r, t
+    return (r, t), (r2, t2)
 
 
 def _attn_ok(q, kv, heads):
@@ -174,18 +176,19 @@ def _dims(q, kv):
 def _fwd(q, kv, heads, scale, need_bwd):
     B, N, C, Nkv, nkblk, nqblk, nqpad = _dims(q, kv)
     dev = q.device
-    k_view, v_view = kv[:, :, :C], kv[:, :, C:]
-    kr, kt = _pack(k_view, kv.stride(0), kv.stride(1), B, heads, Nkv, nkblk, True, need_bwd)
-    vr, vt = _pack(v_view, kv.stride(0), kv.stride(1), B, heads, Nkv, nkblk, need_bwd, True)
+    # K and V in one launch: the kv tensor is (B, Nkv, 2 * heads, 64), i.e. 2 * heads "heads"; V's head h is pack head
+    # heads + h.  The forward needs K's R-pack and V's T-pack, the backward also V's R-pack and K's T-pack.
+    (kvr, kvt), _ = _pack(kv, kv.stride(0), kv.stride(1), B, 2 * heads, Nkv, nkblk)
+    voff = heads * nkblk * _PACK_BLOCK
     o = torch.empty_like(q)
     lse2 = torch.empty((B * heads, nqpad), dtype=torch.float32, device=dev)
     lib = _lib.load_library()
     with on_device(dev):
-        rc = lib.rfn_attn_fwd(ptr(q), q.stride(0), q.stride(1), ptr(kr), ptr(vt), ptr(o), o.stride(0), o.stride(1),
-                              ptr(lse2), B, heads, N, Nkv, nkblk, nqpad, float(scale), _DT16[q.dtype],
-                              current_stream(dev))
+        rc = lib.rfn_attn_fwd(ptr(q), q.stride(0), q.stride(1), kvr.data_ptr(), kvt.data_ptr() + voff, ptr(o),
+                              o.stride(0), o.stride(1), ptr(lse2), B, heads, N, Nkv, nkblk, nqpad, float(scale),
+                              2 * heads, _DT16[q.dtype], current_stream(dev))
     _lib.check(rc, "attn_fwd")
-    return o, lse2, (kr, kt, vr)
+    return o, lse2, (kvr, kvt)
 
 
 def _chunk_blocks(nqblk, Nkv, BH):
@@ -207,7 +210,7 @@ class _AttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do):
-        q, kv, o, lse2, kr, kt, vr = ctx.saved_tensors
+        q, kv, o, lse2, kvr, kvt = ctx.saved_tensors
         heads, scale = ctx.heads, ctx.scale
         B, N, C, Nkv, nkblk, nqblk, nqpad = _dims(q, kv)
         dev = q.device
@@ -219,14 +222,14 @@ class _AttnFn(torch.autograd.Function):
         lib = _lib.load_library()
         dq = torch.empty_like(q)
         delta = torch.empty_like(lse2)
+        voff = heads * nkblk * _PACK_BLOCK
         with on_device(dev):
             rc = lib.rfn_attn_bwd_dq(ptr(q), q.stride(0), q.stride(1), ptr(do), ptr(o), o.stride(0), o.stride(1),
-                                     ptr(kr), ptr(vr), ptr(kt), ptr(lse2), ptr(delta), ptr(dq), dq.stride(0),
-                                     dq.stride(1), B, heads, N, Nkv, nkblk, nqpad, float(scale), dt,
-                                     current_stream(dev))
+                                     kvr.data_ptr(), kvr.data_ptr() + voff, kvt.data_ptr(), ptr(lse2), ptr(delta),
+                                     ptr(dq), dq.stride(0), dq.stride(1), B, heads, N, Nkv, nkblk, nqpad, float(scale),
+                                     2 * heads, dt, current_stream(dev))
         _lib.check(rc, "attn_bwd_dq")
-        qr, qt = _pack(q, q.stride(0), q.stride(1), B, heads, N, nqblk)
-        gr, gt = _pack(do, do.stride(0), do.stride(1), B, heads, N, nqblk)
+        (qr, qt), (gr, gt) = _pack(q, q.stride(0), q.stride(1), B, heads, N, nqblk, src2=do)
         nkpad = -(-Nkv // 32) * 32
         accT = torch.empty(B * heads * 2 * 64 * nkpad, dtype=torch.float32, device=dev)
         dkv = torch.empty_like(kv)

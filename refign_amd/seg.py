@@ -303,7 +303,12 @@ class MixVisionTransformer(nn.Module):
                 x = blk(x, H, W, None if masks is None else masks[i:i + 2], None if masks32 is None else masks32[i:i + 2])
                 i += 2
             x = getattr(self, f"norm{s}")(x)
-            x = x.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+            # tokens (B, H*W, C) ARE the channels-last image of the (B, C, H, W) map: hand it on as that view on the GPU --
+            # the next patch embedding and the decode heads' token embeddings consume channels-last memory in place
+            # (the reference's reshape + permute + contiguous is two full copies per stage and pass)
+            x = x.view(B, H, W, -1).permute(0, 3, 1, 2)
+            if not x.is_cuda:
+                x = x.contiguous()
             outs.append(x)
         return outs
 

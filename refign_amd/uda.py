@@ -237,8 +237,9 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if self.enable_fdist:
             self._graphs["imnet_features"] = GraphedNoGrad(self._imnet_features, "ImageNet features")
         # forward + backward of the student passes (single process; eager under DDP: SyncBatchNorm collectives)
-        self._graphs["source_pass"] = GraphedStep(self._source_pass_device_crop, "student source pass")
-        self._graphs["mixed_pass"] = GraphedStep(self._mixed_pass_device_crop, "student mixed pass")
+        shared = {}
+        self._graphs["source_pass"] = GraphedStep(self._source_pass_device_crop, "student source pass", shared=shared)
+        self._graphs["mixed_pass"] = GraphedStep(self._mixed_pass_device_crop, "student mixed pass", shared=shared)
         self.load_weights(pretrained)
 
     # -- trainer hooks (what Lightning provides in the reference) ---------------------------------------------------
