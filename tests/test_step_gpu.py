@@ -215,3 +215,25 @@ def test_failed_graph_capture_falls_back_to_eager(dev, monkeypatch):
     torch.cuda.synchronize()
     assert float(z.sum()) == 8.0
     assert all(s["failed"] for s in g.states.values())
+
+
+def test_checkpoint_round_trip_on_gpu(dev, tmp_path):
+    """N3 on the device: a Lightning-format checkpoint saved from a GPU model (after one training step, so that BatchNorm
+    statistics, EMA weights and cached 16-bit copies have moved) loads strict into a fresh model that then computes the
+    identical inference output -- the cached derived copies of the old values must not survive load_state_dict."""
+    from refign_amd.trainer import Trainer
+    a = build(True, dev)
+    Trainer(a, fused_optimizer=False)
+    random.seed(3); np.random.seed(3); torch.manual_seed(3)
+    batch = make_batch(2, 128, 128, 64, dev)
+    a.training_step(batch, 0)
+    path = str(tmp_path / "step1.ckpt")
+    torch.save({"state_dict": a.state_dict()}, path)
+    b = build(True, dev)
+    b.load_weights(path)
+    a.eval(); b.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ya, yb = a(batch["image_trg"]), b(batch["image_trg"])
+        _ = a.align(ya.float(), batch["image_ref"], batch["image_trg"])
+    assert torch.equal(ya, yb)
+    assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
