@@ -68,20 +68,24 @@ template <int N> __device__ __forceinline__ void wait_dma_upto() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DT, int BM, int BN, int BK, int NS, bool GATHER>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+template <int DT, int BM, int BN, int BK, int NS, bool GATHER, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                       uint16_t* __restrict__ Y, int M, int N, int K, long ldx, long ldw,
                                                       long ldy, int tiles_n, int total_tiles, GemmEpi epi, ConvGeom cg) {
   using E = Elem<DT>;
   using vec8 = typename E::vec8;
   static_assert(BK == 32 || BK == 64, "K-step of 32 or 64");
-  constexpr int IB = BN / 64;              // 32-wide n blocks per wave (waves are 2 (m) x 2 (n))
+  // NW waves as 2 (m) x NW / 2 (n); 8 waves (a 256 x 256 tile, wave tile 128 x 64) halve the LDS-DMA instructions a wave
+  // issues per MFMA -- their issue cost, not the data volume, is what paces the 4-wave 128 x 128 tile (2 MFMAs per DMA)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  constexpr int WNW = NW / 2;              // waves along n
+  constexpr int IB = BN / (32 * WNW);      // 32-wide n blocks per wave
   constexpr int JB = BM / 64;              // 32-wide m blocks per wave
   constexpr int ROWB = BK * 2;             // bytes per LDS row
   constexpr int PPR = BK / 8;              // 16-byte pieces per row (4 or 8)
   constexpr int RPI = 64 / PPR;            // tile rows per DMA instruction (16 or 8)
   constexpr int XBYTES = BM * ROWB, WBYTES = BN * ROWB, STAGE = XBYTES + WBYTES;
-  constexpr int XI = BM / (4 * RPI), WI = BN / (4 * RPI);   // DMA instructions per wave and step (4 waves)
+  constexpr int XI = BM / (NW * RPI), WI = BN / (NW * RPI);   // DMA instructions per wave and step
   constexpr int IPS = XI + WI;
   // piece c of row r sits at c ^ swizzle(r): rows of 128 B: (r >> 1) & 7, rows of 64 B: (r >> 2) & 3 -- either way every
   // ds_read_b128 lane group covers 16 distinct 16-byte slots of the 256-byte bank row
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   // tiles wg, wg + G, wg + 2 G, ...: at any time the resident workgroups work on CONSECUTIVE tiles, i.e. the n tiles of
   // one X row panel run side by side on one XCD (xcd_remap) and share the panel in its L2.  (Contiguous per-workgroup
   // ranges re-read the panel tiles_n times from HBM: the chip-wide working set of panels is far beyond 8 x 4 MB of L2
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 #pragma unroll
     for (int q = 0; q < XI; ++q) {
-      const int m = min(m0 + RPI * (4 * q + wave) + drow, M - 1);
+      const int m = min(m0 + RPI * (NW * q + wave) + drow, M - 1);
       if constexpr (GATHER) {
         const int ohw = cg.OH * cg.OW;
         const int b = m / ohw, rem = m - b * ohw, oy = rem / cg.OW, ox = rem - oy * cg.OW;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
     }
 #pragma unroll
     for (int q = 0; q < WI; ++q) {
-      const int n = min(n0 + RPI * (4 * q + wave) + drow, N - 1);
+      const int n = min(n0 + RPI * (NW * q + wave) + drow, N - 1);
       wsrc[q] = (const unsigned char*)(W + (long)n * ldw) + 16 * dpiece;
     }
   };
@@ -144,14 +148,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
         const bool ok = tap_ok && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
         const unsigned char* src = ok ? xsrc[q] + ((long)(iy * cg.W + ix) * cg.C + c8 * 8) * 2
                                       : (const unsigned char*)cg.zero;
-        lds_dma16(src, xs + 1024 * (4 * q + wave));
+        lds_dma16(src, xs + 1024 * (NW * q + wave));
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < XI; ++q) lds_dma16(xsrc[q] + (long)kt * ROWB, xs + 1024 * (4 * q + wave));
+      for (int q = 0; q < XI; ++q) lds_dma16(xsrc[q] + (long)kt * ROWB, xs + 1024 * (NW * q + wave));
     }
 #pragma unroll
-    for (int q = 0; q < WI; ++q) lds_dma16(wsrc[q] + (long)kt * ROWB, ws + 1024 * (4 * q + wave));
+    for (int q = 0; q < WI; ++q) lds_dma16(wsrc[q] + (long)kt * ROWB, ws + 1024 * (NW * q + wave));
   };
 
   f32x16 acc[IB][JB];
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
   // fragment addresses: row (l & 31) of a 32-row block, piece (2 ks + g) ^ swizzle(row); block offsets are multiples
   // of 32 rows and do not change the swizzle
   const int g = lane >> 5, frow = lane & 31, swz = swizzle(frow);
-  const int xoff = (wm * (BM / 2) + frow) * ROWB, woff = XBYTES + (wn * (BN / 2) + frow) * ROWB;
+  const int xoff = (wm * (BM / 2) + frow) * ROWB, woff = XBYTES + (wn * (BN / WNW) + frow) * ROWB;
 
   // producer cursor: the next K-step to issue, over all tiles of this workgroup
   const long S = (long)ntiles * nk;
@@ -218,10 +222,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
       int tl = c_tile;
       asm volatile("" : "+s"(tl));
       const int m0 = (tl / tiles_n) * BM, n0 = (tl % tiles_n) * BN;
-      constexpr int WN = BN / 2;                       // columns of a wave's tile
+      constexpr int WN = BN / WNW;                     // columns of a wave's tile
       constexpr int PITCH = WN * 2 + 16;               // staging row pitch in bytes (16-byte aligned, 2-way at worst)
       constexpr int RPP = 64 / (WN / 8);               // rows per store instruction (8 pieces of 16 B per 64-column row)
-      static_assert(4 * 32 * PITCH <= STAGE, "staging block fits the consumed stage");
+      static_assert(NW * 32 * PITCH <= STAGE, "staging block fits the consumed stage");
       wg_barrier();                                    // every wave is done reading this stage's operands
       unsigned char* stg = const_cast<unsigned char*>(st) + wave * 32 * PITCH;
 #pragma unroll
@@ -451,6 +455,8 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   int bn = (N % 128 == 0) ? 128 : 64;
   int bm = ((long)cdiv(M, 128) * cdiv(N, bn) >= 256) ? 128 : 64;
   int ns = 2;
+  // big problems whose n extent fills 256-wide tiles: 8 waves on a 256 x 256 tile (1 workgroup per CU)
+  if (N % 256 == 0 && (long)cdiv(M, 256) * (N / 256) >= 256) bm = bn = 256;
   static const char* cfg_env = getenv("RFN_GEMM_CFG");          // "bm,bn,ns": tile sweep of tools/mfma_bench.py
   if (cfg_env != nullptr) sscanf(cfg_env, "%d,%d,%d", &bm, &bn, &ns);
   const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
@@ -479,6 +485,12 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
     case 1280643: RFN_NT(128, 64, 3); break;
     case 640644: RFN_NT(64, 64, 4); break;
     case 640648: RFN_NT(64, 64, 8); break;
+    case 2562562:
+      grid = dim3((unsigned)std::min<long>(total, persistent ? 256 : 0x7fffffff));
+      hipLaunchKernelGGL((gemm_nt_kernel<DT, 256, 256, 64, 2, GATHER, 8>), grid, dim3(512), 0, s, (const uint16_t*)X,
+                         (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tiles_n, (int)total,
+                         epi, cg);
+      break;
     default: return fail(RFN_EINVAL, "gemm_nt: no kernel for tile %dx%d ring %d", bm, bn, ns);
   }
 #undef RFN_NT

@@ -5,10 +5,10 @@ import os
 import subprocess
 import sys
 
-SHAPES = [(8160, 320, 320), (8160, 1280, 320), (8160, 320, 1280), (32640, 128, 128), (32640, 512, 128), (129600, 256, 64),
-          (2040, 512, 512), (2040, 2048, 512), (2040, 512, 2048), (81600, 320, 320), (81600, 1280, 320), (81600, 320, 1280),
-          (20400, 512, 2048), (326400, 512, 128)]
-CFGS = ["", "128,128,2", "128,64,2", "64,128,2", "64,64,2", "128,128,3", "128,64,3", "64,64,4", "64,64,8"]
+SHAPES = [(8160, 320, 320), (8160, 1280, 320), (8160, 320, 1280), (32640, 512, 128), (129600, 256, 64),
+          (2040, 2048, 512), (81600, 320, 320), (81600, 1280, 320), (81600, 320, 1280),
+          (20400, 512, 2048), (20400, 2048, 512), (326400, 512, 128), (1296000, 256, 64), (1296000, 256, 1024)]
+CFGS = ["", "128,128,2", "128,64,2", "64,64,2", "256,256,2"]
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
