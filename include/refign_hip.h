@@ -294,6 +294,21 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
                      const float* delta, float* accT, void* dKV, int B, int heads, int Nq, int Nkv, int nqblk, int nqpad,
                      int nkpad, int blocks_per_chunk, float scale, int dtype, rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm2d (+ ReLU) on channels-last 16-bit tensors viewed as (T = B*H*W, C): the norm + activation of
+ * the decode heads' ConvBNReLU blocks (models/modules.py:16-56), which use BATCH statistics in the student and in the EMA
+ * teacher.  dtype 1 = bf16, 2 = f16; statistics, affine parameters and running buffers fp32; C % 8 == 0.
+ *   rfn_bn_train_fwd  sums (2, C) <- (sum x, sum x^2) [zeroed inside]; y = relu?((x - mean) rstd gamma + beta);
+ *                     running_mean / running_var (may be NULL) <- (1 - momentum) old + momentum (mean, unbiased var).
+ *   rfn_bn_train_bwd  bwd_sums (2, C) <- (sum g', sum g' xhat) = (grad beta, grad gamma), g' = g masked by the ReLU;
+ *                     grad_x = gamma rstd (g' - (bwd_sums[0] + xhat bwd_sums[1]) / T).  fwd_sums = the forward's sums.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* sums, float* running_mean,
+                     float* running_var, long T, int C, float eps, float momentum, int relu, int dtype,
+                     rfn_stream_t stream);
+int rfn_bn_train_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
+                     void* grad_x, float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,8 @@ SIGNATURES = {
                                                                                          c_void_p]),
     "rfn_attn_bwd_dkv": (c_int, [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long] + [c_void_p] * 8 + [c_int] * 8
                          + [c_float, c_int, c_void_p]),
+    "rfn_bn_train_fwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_float, c_int, c_int, c_void_p]),
+    "rfn_bn_train_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
     "rfn_uncertainty9_weights_len": (c_int, []),
     "rfn_uncertainty9_frontend_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }

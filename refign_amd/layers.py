@@ -5,6 +5,8 @@ These hold parameters under the same state_dict keys as the reference (`conv.wei
 (conv -> BatchNorm with batch statistics -> activation) or, for frozen/eval networks under no_grad, a folded one
 (BatchNorm merged into the conv weights once, activation applied in place on the conv output).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -88,6 +90,30 @@ class ConvBNReLU(nn.Module):
             return y.permute(0, 3, 1, 2)                     # NCHW-shaped, channels_last strides
         return F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
 
+    def _conv_train(self, x, cd):
+        """The convolution of a training-mode block on the GPU in the 16-bit compute dtype `cd`.  1x1 (the ASPP / fusion
+        projections): a Linear over channels-last tokens on the MFMA GEMM kernels, forward and both gradients; depthwise
+        3x3: the HIP stencil; dense k x k without autograd (EMA teacher): the implicit-GEMM kernel; dense k x k under
+        autograd (the student's 3x3 bottleneck): the library convolution."""
+        c = self.conv
+        if c.groups == 1 and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0) and \
+                c.in_channels % 64 == 0 and c.out_channels % 8 == 0:
+            from .linear import linear_tokens
+            xh = x.permute(0, 2, 3, 1)
+            if xh.dtype != cd:
+                xh = xh.to(cd)
+            if not xh.is_contiguous():
+                xh = xh.contiguous()
+            B, H, W, C = xh.shape
+            y = linear_tokens(xh.reshape(B * H * W, C), c.weight, c.bias, cd)
+            return y.view(B, H, W, -1).permute(0, 3, 1, 2)
+        if c.groups == 1 and not torch.is_grad_enabled():
+            from .conv import conv2d_mfma
+            y = conv2d_mfma(x, c.weight, c.bias, c.stride, c.padding, c.dilation, dtype=cd)
+            if y is not None:
+                return y
+        return self._conv2d(x, c.weight, c.bias)
+
     def forward(self, x):
         if self.depthwise_separable:
             return self.pointwise_conv(self.depthwise_conv(x))
@@ -105,6 +131,15 @@ class ConvBNReLU(nn.Module):
         if self.use_norm and not self.training and not torch.is_grad_enabled():
             x = self._conv2d(x, *self.folded())
         else:
+            if x.is_cuda and self.use_norm and self.training and self.act in (None, 'relu') and \
+                    os.environ.get("RFN_BN_KERNEL", "1") != "0":
+                # decode heads (student and EMA teacher run BatchNorm with batch statistics): convolution on the
+                # hand-written kernels where they exist for the pass, then ONE fused BatchNorm(train) + ReLU (csrc/bn.hip)
+                from . import bn as bnk
+                from .params import compute_dtype
+                cd = compute_dtype(x)
+                if bnk.usable(x, self.bn, cd):
+                    return bnk.bn_act_train(self._conv_train(x, cd), self.bn, self.act == 'relu', cd)
             x = self._conv2d(x, c.weight, c.bias)
             if self.use_norm:
                 x = self.bn(x)

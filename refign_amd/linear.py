@@ -92,13 +92,26 @@ class _LinearFn(torch.autograd.Function):
             if sink_w is not None:
                 sum_rows(part, out=sink_w.view(-1), accumulate=True)
             else:
-                gw = sum_rows(part).view(N, K).to(ctx.weight.dtype)
+                gw = sum_rows(part).view(ctx.weight.shape).to(ctx.weight.dtype)
         if need_b:
             if sink_b is not None:
                 sum_rows(g2, out=sink_b, accumulate=True)
             else:
                 gb = sum_rows(g2).to(ctx.bias.dtype)
         return gx, gw, gb, None, None
+
+
+def linear_tokens(x2, weight, bias, cd):
+    """x2 (T, K) @ weight^T + bias for a weight parameter of shape (N, K) or (N, K, 1, 1) (a 1x1 convolution on
+    channels-last tokens), on the MFMA GEMM kernels: forward, input gradient and parameter gradients (accumulated into
+    the flat gradient buffer).  `cd`: 16-bit compute dtype."""
+    w_c = as_dtype(weight, cd)
+    w_c = w_c.view(w_c.shape[0], -1)
+    b_c = as_dtype(bias, cd)
+    if torch.is_grad_enabled() and (weight.requires_grad or x2.requires_grad):
+        return _LinearFn.apply(x2, weight, bias, w_c, b_c)
+    y = mfma.gemm_nt(x2, w_c, b_c)
+    return F.linear(x2, w_c, b_c) if y is None else y
 
 
 class Linear(nn.Linear):

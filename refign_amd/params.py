@@ -115,14 +115,14 @@ def as_dtype(p, dtype):
 
 
 def _t_view(t):
-    return t.t()
+    return t.reshape(t.shape[0], -1).t()              # (N, K) or (N, K, 1, 1) -> (K, N) view
 
 
 def transposed(p, dtype):
     """Contiguous transposed copy W^T (K, N) of a Linear weight (N, K) in the compute dtype: the B operand of the
     input-gradient GEMM dx = dy W run as an NT product (csrc/mfma_gemm.hip).  Cached like the plain 16-bit copy and
     re-filled in place after optimizer / EMA updates."""
-    return derived(p, ("T", dtype), lambda t: t.to(dtype).t().contiguous(), _t_view)
+    return derived(p, ("T", dtype), lambda t: t.reshape(t.shape[0], -1).to(dtype).t().contiguous(), _t_view)
 
 
 def compute_dtype(x):

@@ -208,3 +208,73 @@ def test_linear_module_uses_mfma_kernels(dev):
     assert float((x.grad - xr.grad).abs().max()) <= 0.02 * float(xr.grad.abs().max())
     assert float((lin.weight.grad - w.grad).abs().max()) <= 0.02 * float(w.grad.abs().max())
     assert float((lin.bias.grad - b.grad).abs().max()) <= 0.02 * float(b.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C,H,W,relu", [(2, 256, 17, 23, True), (4, 64, 9, 5, False), (1, 1024, 12, 20, True)])
+def test_batchnorm_relu_train_kernels(dev, dtype, B, C, H, W, relu):
+    """csrc/bn.hip against fp32 nn.BatchNorm2d(train) [+ ReLU] on the same 16-bit input: output, input gradient, affine
+    gradients, running statistics (unbiased variance, momentum 0.1) and num_batches_tracked."""
+    from refign_amd.bn import bn_act_train
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = torch.nn.BatchNorm2d(C).to(dev)
+    ref.load_state_dict(bn.state_dict())
+    x = (_rand((B, C, H, W), dev, dtype, 40, 2.0) + 0.7).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    g = _rand((B, C, H, W), dev, dtype, 41)
+    y = bn_act_train(x, bn, relu, dtype)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(g.float())
+    e = EPS[dtype]
+    assert float((y.float() - yr).abs().max()) <= 4 * e * float(yr.abs().max()) + 1e-3
+    assert float((x.grad.float() - xr.grad).abs().max()) <= 0.02 * float(xr.grad.abs().max()) + 1e-4
+    assert float((bn.weight.grad - ref.weight.grad).abs().max()) <= 0.02 * float(ref.weight.grad.abs().max()) + 1e-3
+    assert float((bn.bias.grad - ref.bias.grad).abs().max()) <= 0.02 * float(ref.bias.grad.abs().max()) + 1e-3
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-4)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_decode_heads_bf16_kernel_path_matches_fp32_path(dev, monkeypatch):
+    """DAFormerHead and SegFormerHead in TRAIN mode (batch-statistics BatchNorm) under bf16 autocast -- 1x1 convolutions
+    on the MFMA Linear kernels, depthwise stencils, fused BatchNorm + ReLU kernels -- against the same modules in fp32 on
+    the library path.  bf16 through eight normalised layers is noisy by itself, so the yardstick is the LIBRARY's bf16
+    path on the same modules: the kernels' deviation from fp32 (logits, input-feature gradients, parameter gradients)
+    may not exceed 1.5x the library-bf16 deviation (+ 1 % of range)."""
+    from fill import closed_form_fill
+    from refign_amd import mfma
+    from refign_amd.seg import DAFormerHead, SegFormerHead
+    dims = [64, 128, 320, 512]
+    feats = [_rand((2, c, 32 // s, 48 // s), dev, torch.float32, 50 + i) for i, (c, s) in enumerate(zip(dims, (1, 2, 4, 8)))]
+
+    def run(cls, mode):
+        m = closed_form_fill(cls(dims, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0)).to(dev).train()
+        f = [t.clone().requires_grad_(True) for t in feats]
+        monkeypatch.setenv("RFN_BN_KERNEL", "0" if mode == "lib16" else "1")
+        monkeypatch.setattr(mfma, "ENABLED", mode != "lib16")
+        if mode == "fp32":
+            y = m(f)
+        else:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(f)
+        go = _rand(tuple(y.shape), dev, torch.float32, 60)
+        y.float().backward(go)
+        out = {"logits": y.detach().float()}
+        out.update({f"dfeat{i}": t.grad for i, t in enumerate(f)})
+        out.update({"d" + n: p.grad for n, p in m.named_parameters()})
+        out.update({"buf/" + n: b.detach().float().clone() for n, b in m.named_buffers()})
+        return out
+
+    for cls in (DAFormerHead, SegFormerHead):
+        ref, lib, ker = run(cls, "fp32"), run(cls, "lib16"), run(cls, "kernels")
+        for k in ref:
+            rng = float(ref[k].abs().max()) + 1e-6
+            e_lib = float((lib[k].float() - ref[k]).abs().max()) / rng
+            e_ker = float((ker[k].float() - ref[k]).abs().max()) / rng
+            assert e_ker <= 1.5 * e_lib + 0.01, (cls.__name__, k, e_ker, e_lib)
