@@ -46,31 +46,7 @@ class _DWConv3x3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w_tap = ctx.saved_tensors
-        gy = gy.to(x.dtype).contiguous()
-        B, H, W, C = x.shape
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = _fwd(gy, w_tap, None, ctx.dilation, True)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            # straight into the parameters' views of the flat gradient buffer when the trainer provides one
-            sw, sb = grad_sink(ctx.weight), grad_sink(ctx.bias) if ctx.has_bias else None
-            direct = sw is not None and (sb is not None or not ctx.has_bias)
-            if direct:
-                dw, db = sw, sb
-            else:
-                dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
-                db = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            lib = _lib.load_library()
-            ws = workspace(_DW_WS_STRIPES * 10 * C * 4, x.device)   # == rfn_dwconv3x3_bwd_weight_workspace_bytes(C)
-            with on_device(x.device):
-                rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), ptr(ws), B, H, W, C,
-                                                       ctx.dilation, _DT[x.dtype], 3 if direct else 0,
-                                                       current_stream(x.device))
-            _lib.check(rc, "dwconv3x3_nhwc_bwd_weight")
-            if not direct:
-                gw = dw.t().reshape(ctx.wshape).to(ctx.wdtype)
-                gb = db
-        return gx, gw, gb, None
+        return _dwconv_backward(ctx, x, w_tap, gy.to(x.dtype).contiguous())
 
 
 class _DWConv3x3Gelu(torch.autograd.Function):
@@ -122,11 +98,20 @@ def _dwconv_backward(ctx, x, w_tap, gy):
             dw = torch.empty((9, C), dtype=torch.float32, device=x.device)
             db = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
         lib = _lib.load_library()
-        ws = workspace(_DW_WS_STRIPES * 10 * C * 4, x.device)
-        with on_device(x.device):
-            rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), ptr(ws), B, H, W, C, ctx.dilation,
-                                                   _DT[x.dtype], 3 if direct else 0, current_stream(x.device))
-        _lib.check(rc, "dwconv3x3_nhwc_bwd_weight")
+
+        def run():
+            ws = workspace(_DW_WS_STRIPES * 10 * C * 4, x.device)        # per stream: looked up on the stream it runs on
+            with on_device(x.device):
+                rc = lib.rfn_dwconv3x3_nhwc_bwd_weight(ptr(x), ptr(gy), ptr(dw), ptr(db), ptr(ws), B, H, W, C,
+                                                       ctx.dilation, _DT[x.dtype], 3 if direct else 0,
+                                                       current_stream(x.device))
+            _lib.check(rc, "dwconv3x3_nhwc_bwd_weight")
+
+        if direct:
+            from . import sidework                # parameter gradients: off the critical path (sidework.py)
+            sidework.fork(x.device, run, x, gy)
+        else:
+            run()
         if not direct:
             gw = dw.t().reshape(ctx.wshape).to(ctx.wdtype)
             gb = db
