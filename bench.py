@@ -418,6 +418,13 @@ def main():
                                       f"gradient all-reduce per step over RCCL"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        graphs = getattr(getattr(wl, "model", None), "_graphs", None)
+        if graphs:
+            # which regions of the step replay from hipGraphs (a failed capture falls back to eager launches: slower,
+            # same results -- visible here instead of only as a warning on stderr)
+            st = {k: [("replay" if s_["graph"] is not None else ("eager (capture failed)" if s_["failed"] else "eager"))
+                      for s_ in g.states.values()] for k, g in graphs.items()}
+            line["config"]["hipgraph_regions"] = {k: (v[0] if len(v) == 1 else v) for k, v in st.items() if v}
         print(json.dumps(line))
 
 

@@ -164,58 +164,73 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     if (st + 1 < nst) issue(st + 1, buf ^ 1);
     const unsigned char* ks = smem + buf * STAGE;
     const unsigned char* vs = ks + 2 * kPackBlock;
+    // one softmax step per STAGE (64 keys): both key blocks' S^T MFMAs are issued back to back, then the 32 scores of a
+    // lane go through max / exp / sum together (one running-max decision per stage), then both blocks' PV MFMAs -- the
+    // matrix pipe works on block 1 while the VALU starts on block 0, and the rescale test runs half as often
+    const int key0 = st * 64;
+    f32x16 sacc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      const int key0 = (st * 2 + kb) * 32;
-      if (key0 < Nkv) {                                  // wave-uniform
-        f32x16 s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const vec8 kf = *(const vec8*)(ks + kb * kPackBlock + ((2 * kk + g) * 32 + col) * 16);
-          s = E::mma(kf, qf[kk], s);
-        }
-        float p[16];
-        float mt = -1e30f;
-        const bool tail = key0 + 32 > Nkv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = s[r] * c;
-          if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * g >= Nkv) v = -1e30f;
-          p[r] = v;
-          mt = fmaxf(mt, v);
-        }
-        mt = half_max(mt);
-        const float mnew = fmaxf(mrun, mt);
-        if (__any(mnew > mrun)) {
-          const float alpha = exp2f(mrun - mnew);
-          lrun *= alpha;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            oacc[0][r] *= alpha;
-            oacc[1][r] *= alpha;
-          }
-          mrun = mnew;
-        }
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          p[r] = exp2f(p[r] - mrun);
-          ps += p[r];
-        }
-        lrun += ps;
-        vec8 pb[2];
-        to_operands<DT>(p, pb);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            const unsigned char* vq = vs + kb * kPackBlock + (db * 32 + col) * 8;
-            const vec8 vf = join8<DT>(*(const u32x2*)(vq + (4 * m + g) * 512), *(const u32x2*)(vq + (4 * m + 2 + g) * 512));
-            oacc[db] = E::mma(vf, pb[m], oacc[db]);
-          }
+      for (int kk = 0; kk < 4; ++kk) {
+        const vec8 kf = *(const vec8*)(ks + kb * kPackBlock + ((2 * kk + g) * 32 + col) * 16);
+        sacc[kb] = E::mma(kf, qf[kk], sacc[kb]);
       }
+    }
+    float p[2][16];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[kb][r] = sacc[kb][r];
+    if (key0 + 64 > Nkv) {                               // wave-uniform: only the last stage has padded keys
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g >= Nkv) p[kb][r] = -1e30f;
+    }
+    // running max in the scaled base-2 domain: c > 0, so max(c s) = c max(s); the scale itself rides in the fma of the
+    // exponent below (one v_fma + one v_exp per score)
+    float mt = p[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, p[kb][r]);
+    mt = half_max(mt) * c;
+    const float mnew = fmaxf(mrun, mt);
+    if (__any(mnew > mrun)) {
+      const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+      lrun *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        oacc[0][r] *= alpha;
+        oacc[1][r] *= alpha;
+      }
+      mrun = mnew;
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[kb][r], c, -mrun));   // raw v_exp_f32: arguments are <= 0
+        ps += p[kb][r];
+      }
+    lrun += ps;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      vec8 pb[2];
+      to_operands<DT>(p[kb], pb);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const unsigned char* vq = vs + kb * kPackBlock + (db * 32 + col) * 8;
+          const vec8 vf = join8<DT>(*(const u32x2*)(vq + (4 * m + g) * 512), *(const u32x2*)(vq + (4 * m + 2 + g) * 512));
+          oacc[db] = E::mma(vf, pb[m], oacc[db]);
+        }
     }
     wait_dma_all();
     wg_barrier();
@@ -291,41 +306,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     const int buf = st & 1;
     if (st + 1 < nst) issue(st + 1, buf ^ 1);
     const unsigned char* base = smem + buf * STAGE;
+    // both key blocks of the stage: 16 MFMAs (S^T and dP^T) back to back, the element-wise part on 32 values, 8 MFMAs
+    const int key0 = st * 64;
+    f32x16 sacc[2], dpacc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      const int key0 = (st * 2 + kb) * 32;
-      if (key0 < Nkv) {
-        const unsigned char* krs = base + kb * kPackBlock;
-        const unsigned char* vrs = base + (2 + kb) * kPackBlock;
-        const unsigned char* kts = base + (4 + kb) * kPackBlock;
-        f32x16 s, dp;
+      const unsigned char* krs = base + kb * kPackBlock;
+      const unsigned char* vrs = base + (2 + kb) * kPackBlock;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = dpacc[kb][r] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int off = ((2 * kk + g) * 32 + col) * 16;
-          s = E::mma(*(const vec8*)(krs + off), qf[kk], s);
-          dp = E::mma(*(const vec8*)(vrs + off), gf[kk], dp);
-        }
-        float ds[16];
-        const bool tail = key0 + 32 > Nkv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float pr = exp2f(s[r] * c - ls);
-          if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * g >= Nkv) pr = 0.f;
-          ds[r] = pr * (dp[r] - dl);
-        }
-        vec8 sb[2];
-        to_operands<DT>(ds, sb);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            const unsigned char* kq = kts + (db * 32 + col) * 8;
-            const vec8 kf = join8<DT>(*(const u32x2*)(kq + (4 * m + g) * 512), *(const u32x2*)(kq + (4 * m + 2 + g) * 512));
-            dq[db] = E::mma(kf, sb[m], dq[db]);
-          }
+      for (int kk = 0; kk < 4; ++kk) {
+        const int off = ((2 * kk + g) * 32 + col) * 16;
+        sacc[kb] = E::mma(*(const vec8*)(krs + off), qf[kk], sacc[kb]);
+        dpacc[kb] = E::mma(*(const vec8*)(vrs + off), gf[kk], dpacc[kb]);
       }
+    }
+    float ds[2][16];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ds[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], c, -ls)) * (dpacc[kb][r] - dl);
+    if (key0 + 64 > Nkv) {                               // wave-uniform: padded keys contribute nothing
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g >= Nkv) ds[kb][r] = 0.f;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const unsigned char* kts = base + (4 + kb) * kPackBlock;
+      vec8 sb[2];
+      to_operands<DT>(ds[kb], sb);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const unsigned char* kq = kts + (db * 32 + col) * 8;
+          const vec8 kf = join8<DT>(*(const u32x2*)(kq + (4 * m + g) * 512), *(const u32x2*)(kq + (4 * m + 2 + g) * 512));
+          dq[db] = E::mma(kf, sb[m], dq[db]);
+        }
     }
     wait_dma_all();
     wg_barrier();
@@ -416,7 +438,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __res
       float p[16], ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pr = exp2f(s[r] * c - l4[r >> 2][r & 3]);
+        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -l4[r >> 2][r & 3]));
         if (!kok) pr = 0.f;
         p[r] = pr;
         ds[r] = pr * (dp[r] - d4[r >> 2][r & 3]);

@@ -192,9 +192,12 @@ def _fwd(q, kv, heads, scale, need_bwd):
 
 
 def _chunk_blocks(nqblk, Nkv, BH):
-    """32-query blocks per dK/dV workgroup: ~768 workgroups over the chip, at least 4 blocks each."""
+    """32-query blocks per dK/dV workgroup: ~384 workgroups (512 threads each, one per CU at a time) over the chip, at
+    least 4 blocks each.  More, shorter chunks add fp32 atomics on the dK / dV image (every chunk adds its 256 x 64 x 2
+    partial) faster than they add parallelism: measured 199 / 189 / 159 / 260 us at 768 / 384 / 256 / 1536 target
+    workgroups on the stage-1 shape (B=4, 32 400 queries, 480 keys)."""
     kblocks = -(-Nkv // 256)
-    chunks = max(1, 768 // max(1, kblocks * BH))
+    chunks = max(1, int(os.environ.get("RFN_ATTN_DKV_WGS", "384")) // max(1, kblocks * BH))
     return max(4, -(-nqblk // chunks))
 
 

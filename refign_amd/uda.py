@@ -419,8 +419,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
             mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src,
                                                                    src_classes)
         off = self._crop_offsets(mixed_img, "mix")
-        (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.contiguous(), mixed_lbl.contiguous(),
-                                                   mixed_weight.contiguous(), off)
+        # one input signature for the replay: the blur of the DACS augmentation runs under autocast and hands back a
+        # 16-bit image on the steps where it fires (a second signature = a second capture with its own eager warm-up)
+        (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.to(images_src.dtype).contiguous(), mixed_lbl.contiguous(),
+                                                   mixed_weight.to(torch.float32).contiguous(), off)
         self.log("train_loss_uda_trg", mixed_loss)
         opt.step()
         sch.step()
