@@ -104,4 +104,23 @@ def g12():
          loss_noweight=loss2.item(), grad_noweight=lt2.grad.numpy())
 
 
-GROUPS = {"G9": g9, "G10": g10, "G11": g11, "G12": g12}
+def g9k3():
+    """MiT-B5 + DAFormer head on a K3/K4-SHAPED input: 136 x 240 keeps the odd geometry of the 540 x 960 views (stage maps
+    34x60 / 17x30 / 9x15 / 5x8: odd sizes, ceil-division strides, key counts 4x7=28 / 4x7 / 4x7 / 40 that are not
+    multiples of the 32-key attention block, ragged query tiles), batch 2.  Stored: every stage map strided + its abs
+    sum, and the full 19-class logits of the head."""
+    mt = R.ref_module("models.backbones.mix_transformer")
+    df = R.ref_module("models.heads.daformer")
+    dims = IN_CH["mit_b5"]
+    m = closed_form_fill(mt.MixVisionTransformer("mit_b5"), "backbone.").eval()
+    head = closed_form_fill(df.DAFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select'), "head.").eval()
+    x = img((2, 3, 136, 240), "g9/b5_k3")
+    outs = m(t(x))
+    logits = head(outs)
+    save("mit_b5_daformer_136x240",
+         **{f"c{i + 1}_sample": o.numpy()[:, ::4, ::2, ::2] for i, o in enumerate(outs)},
+         **{f"c{i + 1}_abs_sum": np.float64(np.abs(o.numpy().astype(np.float64)).sum()) for i, o in enumerate(outs)},
+         **{f"c{i + 1}_shape": np.array(o.shape) for i, o in enumerate(outs)}, logits=logits.numpy())
+
+
+GROUPS = {"G9": g9, "G9k3": g9k3, "G10": g10, "G11": g11, "G12": g12}

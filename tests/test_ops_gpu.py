@@ -219,3 +219,96 @@ def test_l2_normalize_channels(dev, B, C, H, W):
     want = torch.nn.functional.normalize(x, p=2, dim=1)
     assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), float((got - want).abs().max())
     assert float(got[0, :, 0, 0].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ full-size (K4) properties of the remaining kernels
+def test_warp_full_size_properties(dev):
+    """feature warp at the K4 level-1 size (2 x 128 x 270 x 480): integer flows are exact shifts with zero fill and the
+    strict-inequality mask of matching_utils.py:44-47, linearity in x, and agreement with grid_sample
+    (align_corners=True, zeros) on a smooth sub-pixel flow."""
+    from refign_amd.matching import warp_nocheck
+    g = torch.Generator(device="cpu").manual_seed(21)
+    B, C, H, W = 2, 128, 270, 480
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    x2 = torch.randn(B, C, H, W, generator=g).to(dev)
+    flo = torch.zeros(B, 2, H, W, device=dev)
+    flo[:, 0] = 3.0
+    flo[:, 1] = -2.0
+    out, mask = warp_nocheck(x, flo, return_mask=True)
+    want = torch.zeros_like(x)
+    want[:, :, 2:, :W - 3] = x[:, :, :H - 2, 3:]
+    # the sample position goes through the reference's normalise / un-normalise round trip in fp32 (matching_utils.py:
+    # 33-39), so an integer shift lands within ~1e-4 px of the pixel centre: exact up to that interpolation weight
+    assert torch.allclose(out, want, atol=2e-3)
+    m = mask.view(B, H, W).bool()
+    assert bool(m[:, 3:, 1:W - 4].all()) and not bool(m[:, :2].any()) and not bool(m[:, :, W - 3:].any())
+    coarse = 4.0 * torch.randn(B, 2, 9, 15, generator=g)
+    smooth = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=False).to(dev)
+    o1, o2 = warp_nocheck(x, smooth), warp_nocheck(x2, smooth)
+    assert torch.allclose(warp_nocheck(x + 2 * x2, smooth), o1 + 2 * o2, rtol=1e-4, atol=1e-4)
+    xx = torch.arange(W, device=dev).view(1, 1, 1, W).expand(B, 1, H, W) + smooth[:, :1]
+    yy = torch.arange(H, device=dev).view(1, 1, H, 1).expand(B, 1, H, W) + smooth[:, 1:]
+    grid = torch.cat((2 * xx / (W - 1) - 1, 2 * yy / (H - 1) - 1), 1).permute(0, 2, 3, 1)
+    ref = torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    assert torch.allclose(o1, ref, rtol=1e-3, atol=2e-3)
+
+
+def test_align_tail_full_size_properties(dev):
+    """align tail at 1080 x 1920 (x4 bilinear up-sampling of flow and log-variance, confidence, logits warp + mask in
+    one kernel): zero flow returns the logits and an all-valid mask; the confidence equals 1 - exp(-1 / (2 exp(lv))) of
+    the up-sampled log-variance; the fused result equals the unfused chain interpolate -> warp."""
+    from refign_amd.matching import align_tail, warp_nocheck
+    g = torch.Generator(device="cpu").manual_seed(22)
+    B, H, W = 2, 1080, 1920
+    logits = torch.randn(B, 19, H, W, generator=g).to(dev)
+    lv = (2 * torch.randn(B, 1, H // 4, W // 4, generator=g)).to(dev)
+    warped, mask, cert = align_tail(logits, torch.zeros(B, 2, H // 4, W // 4, device=dev), lv)
+    assert torch.allclose(warped[:, :, 1:-1, 1:-1], logits[:, :, 1:-1, 1:-1], atol=2e-3)   # same round trip as above
+    # borders: x = 0 / W-1 map to exactly -1 / +1 and are excluded by the strict inequalities of matching_utils.py:44-47
+    assert bool(mask[:, 1:-1, 1:-1].all())
+    up = torch.nn.functional.interpolate(lv, size=(H, W), mode="bilinear", align_corners=False)
+    assert torch.allclose(cert, 1 - torch.exp(-1 / (2 * torch.exp(up))), rtol=1e-4, atol=1e-5)
+    coarse = 6.0 * torch.randn(B, 2, 17, 30, generator=g)
+    fq = torch.nn.functional.interpolate(coarse, size=(H // 4, W // 4), mode="bilinear", align_corners=False).to(dev)
+    warped, mask, cert, fup = align_tail(logits, fq, lv, return_flow=True)
+    want_f = torch.nn.functional.interpolate(fq, size=(H, W), mode="bilinear", align_corners=False)
+    assert torch.allclose(fup, want_f, rtol=1e-5, atol=1e-4)
+    w2, m2 = warp_nocheck(logits, want_f.contiguous(), return_mask=True)
+    assert torch.allclose(warped, w2, rtol=1e-3, atol=2e-3)
+    assert float((mask.bool().view(-1) != m2.bool().view(-1)).float().mean()) < 1e-5
+
+
+@torch.no_grad()
+def test_uncertainty9_frontend_full_size_properties(dev):
+    """fused fp32-MFMA front end of UncertaintyModule at the K4 level-1 size (2 x 81 x 270 x 480): the output of a pixel
+    depends on that pixel's 81 values only -- permuting pixels permutes outputs, and a strided subset of pixels run on
+    its own gives the same numbers as inside the full map (covers every workgroup / tail position of the full launch)."""
+    from fill import closed_form_fill
+    from refign_amd import align as A
+    um = closed_form_fill(A.UncertaintyModule(1, search_size=9, feed_in_previous=True),
+                          "estimate_uncertainty_components1.").to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(23)
+    corr = (torch.rand(2, 81, 270, 480, generator=g) * 2 - 0.5).to(dev)
+    full = um.patch_statistics(corr)
+    assert full.shape == (2, 6, 270, 480) and bool(torch.isfinite(full).all())
+    sub = um.patch_statistics(corr[:, :, 3::7, 5::11].contiguous())
+    assert torch.allclose(sub, full[:, :, 3::7, 5::11], rtol=1e-5, atol=1e-6)
+    flipped = um.patch_statistics(corr.flip(3).contiguous())
+    assert torch.allclose(flipped, full.flip(3), rtol=1e-5, atol=1e-6)
+
+
+@torch.no_grad()
+def test_upsample_concat_full_size(dev):
+    """decode-head fusion front end at the student's K4 size (4 views, stage maps 135x240 / 68x120 / 34x60 / 17x30, 256
+    channels each, bf16): equals interpolate(bilinear, align_corners=False) + cat level by level."""
+    import torch.nn.functional as F
+    from refign_amd.upcat import upsample_concat
+    g = torch.Generator(device="cpu").manual_seed(24)
+    sizes = [(135, 240), (68, 120), (34, 60), (17, 30)]
+    toks = [torch.randn(4, h * w, 256, generator=g).to(dev).bfloat16() for h, w in sizes]
+    got = upsample_concat(toks, sizes, sizes[0])
+    assert got is not None and got.shape == (4, 1024, 135, 240)
+    for i, (t, (h, w)) in enumerate(zip(toks, sizes)):
+        m = t.float().transpose(1, 2).reshape(4, 256, h, w)
+        want = m if i == 0 else F.interpolate(m, size=sizes[0], mode="bilinear", align_corners=False)
+        assert torch.allclose(got[:, 256 * i:256 * (i + 1)].float(), want, rtol=2e-2, atol=2e-2), i

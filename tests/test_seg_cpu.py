@@ -52,6 +52,38 @@ def check_mit(dev, tol):
 
 
 @torch.no_grad()
+def check_mit_b5_k3(dev, tol, autocast=None):
+    """MiT-B5 + DAFormer head at the K3/K4-shaped 136 x 240 input (odd stage maps 34x60 / 17x30 / 9x15 / 5x8, key counts
+    28 / 28 / 28 / 40, batch 2) against the reference's outputs.  Returns the worst relative errors (stage maps, logits)."""
+    from refign_amd.seg import DAFormerHead, MixVisionTransformer
+    g = golden("mit_b5_daformer_136x240")
+    dims = [64, 128, 320, 512]
+    m = closed_form_fill(MixVisionTransformer("mit_b5"), "backbone.").to(dev).eval()
+    head = closed_form_fill(DAFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select'), "head.").to(dev).eval()
+    x = torch.from_numpy(img((2, 3, 136, 240), "g9/b5_k3")).to(dev)
+    if autocast is None:
+        outs = m(x)
+        logits = head(outs)
+    else:
+        with torch.autocast("cuda", dtype=autocast):
+            outs = m(x)
+            logits = head(outs)
+    worst = 0.0
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == tuple(g[f"c{i + 1}_shape"])
+        o = o.float().cpu().numpy()
+        want = g[f"c{i + 1}_sample"]
+        err = np.abs(o[:, ::4, ::2, ::2] - want).max() / np.abs(want).max()
+        worst = max(worst, err)
+        assert err < tol, (f"c{i + 1}", err)
+        assert abs(np.abs(o.astype(np.float64)).sum() - g[f"c{i + 1}_abs_sum"]) < max(tol, 1e-3) * g[f"c{i + 1}_abs_sum"]
+    lg = logits.float().cpu().numpy()
+    lerr = np.abs(lg - g["logits"]).max() / np.abs(g["logits"]).max()
+    assert lerr < tol, ("logits", lerr)
+    return worst, lerr, (lg.argmax(1) == g["logits"].argmax(1)).mean()
+
+
+@torch.no_grad()
 def check_heads(dev, tol):
     from refign_amd.seg import DAFormerHead, SegFormerHead
     f = feats("g10", 2, 64, 96, DIMS_B0, dev)
@@ -115,6 +147,10 @@ CPU = torch.device("cpu")
 
 def test_state_dicts_match_reference():
     check_state_dicts()
+
+
+def test_mit_b5_daformer_k3_shape_golden_cpu():
+    check_mit_b5_k3(torch.device("cpu"), 1e-3)
 
 
 def test_mit_golden_cpu():

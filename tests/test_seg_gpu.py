@@ -10,6 +10,20 @@ def test_mit_golden_gpu(dev):
     S.check_mit(dev, 1e-3)
 
 
+def test_mit_b5_daformer_k3_shape_golden_gpu(dev):
+    """fp32 on the GPU: 1e-3 of range on every MiT-B5 stage map and on the DAFormer logits at the 136 x 240 input."""
+    S.check_mit_b5_k3(dev, 1e-3)
+
+
+def test_mit_b5_daformer_k3_shape_bf16_kernels(dev):
+    """The bench-mode path (bf16 autocast: hand-written MFMA GEMM / attention / conv kernels, bf16 residual stream)
+    against the SAME fp32 reference outputs: bound written down -- 6 % of range on the stage maps and logits through
+    the 52 blocks of MiT-B5 (closed-form weights, no trained-weight contraction), argmax agreement >= 97 %."""
+    worst, lerr, agree = S.check_mit_b5_k3(dev, 6e-2, autocast=torch.bfloat16)
+    print(f"\nMiT-B5 136x240 bf16 kernels vs fp32 reference: stage maps {worst:.3e}, logits {lerr:.3e}, argmax {agree:.4f}")
+    assert agree >= 0.97
+
+
 def test_heads_golden_gpu(dev):
     S.check_heads(dev, 1e-3)
 
