@@ -45,6 +45,11 @@ const char* rfn_last_error(void);
  * The 12 ints are the same 12 ints, in the same order, as the reference's forward()/backward().
  * The one parameterisation the hot path uses (kernel 1, patch 9, stride 1, pad 0, dilation 1, dilation_patch 1:
  * modules.py:268-270) takes the LDS-tiled kernel; anything else takes a generic kernel.
+ * Patch offsets follow the CPU reference and both backward kernels: shift = (p - (patch - 1) / 2) * dilation_patch
+ * (correlation.cpp:28-30).  The reference's CUDA FORWARD computes p * dilation_patch - dilation_patch * (patch - 1) / 2
+ * (correlation_cuda_kernel.cu:50-56), which differs from its own CPU path for EVEN patch sizes with dilation_patch > 1
+ * (patch 2, dilation 2: {-1, 1} vs {0, 2}); the hot path (patch 9, dilation_patch 1) is not affected, and the oracle
+ * (oracle/corr_oracle.c) restates the CPU path.
  * f32 and f64 are provided (the CPU reference dispatches float/double: correlation.cpp:107).  The CUDA
  * reference additionally dispatches half (correlation_cuda_kernel.cu:267); the Python wrapper always casts to
  * float32 (correlation_function.py:51), so half is RFN_ENOTSUP here.

@@ -46,7 +46,13 @@ class ValEveryNSteps:
 
 
 class FlatGradBuffer:
-    """All trainable parameters' gradients as views into one contiguous fp32 tensor."""
+    """All trainable parameters' gradients as views into one contiguous fp32 tensor.
+
+    Limitation (vs. the reference, where a parameter that receives no gradient keeps `.grad = None` and is skipped by the
+    optimizer): every view is persistent and zero-filled, so a trainable parameter that is never touched in a step still
+    takes its AdamW weight-decay / moment update with a zero gradient.  No module of the hot path has such a parameter
+    (every trainable tensor of MiT / DAFormer / SegFormer heads is on all three backward passes); a custom head with an
+    unused branch should freeze it (`requires_grad_(False)`)."""
 
     ALIGN = 64          # elements: every view starts on a 256-byte boundary (16-byte vector stores in csrc/reduce.hip)
 
@@ -118,9 +124,29 @@ class Trainer:
             elif self._steps_done % self.gc_interval == 0:
                 gc.collect()
             self._steps_done += 1
-        self.model.training_step(batch, batch_idx)
+        try:
+            self.model.training_step(batch, batch_idx)
+        finally:
+            # a crop pre-drawn for a forward that did not happen (exception, mode mismatch) must not leak into the next
+            # unrelated extract_crop call
+            from . import seg
+            seg._PREDRAWN_CROPS.clear()
+            seg._DEVICE_CROPS.clear()
         return {k: (float(v) if torch.is_tensor(v) else v) for k, v in self.model.logged.items()} \
             if os.environ.get("RFN_LOG_LOSSES") else None
+
+
+    def close(self):
+        """Give the process its cyclic garbage collector back (step() runs with it disabled between its own collections)."""
+        if self.gc_interval and self._steps_done:
+            import gc
+            gc.enable()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _OptimizerProxy:

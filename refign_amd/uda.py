@@ -89,14 +89,18 @@ def one_mix(mask, data=None, target=None):
 
 
 def _color_jitter(img01, s):
-    """brightness / contrast / saturation / hue jitter of strength s on a [0,1] RGB batch, random order."""
-    ops = [0, 1, 2, 3]
-    random.shuffle(ops)
+    """brightness / contrast / saturation / hue jitter of strength s on a [0,1] RGB batch, random order.
+    The parameters are drawn from torch's CPU generator, like kornia's ColorJitter in the reference
+    (helpers/dacs_transforms.py:49-53) -- NOT from python's `random`, whose stream the reference consumes only for the
+    HRDA crop offsets, the adapt_to_ref coin and the DACS switches: a seeded run keeps making the reference's decisions
+    on the steps where the jitter fires.  Brightness is additive (kornia 0.5.8), the other three multiplicative."""
+    ops = torch.randperm(4).tolist()
     x = img01
     for op in ops:
-        f = random.uniform(max(0.0, 1 - s), 1 + s)
+        u = float(torch.rand(()))
+        f = max(0.0, 1 - s) + u * (1 + s - max(0.0, 1 - s))
         if op == 0:
-            x = x * f
+            x = x + (f - 1.0)
         elif op == 1:
             mean = x.mean(dim=(1, 2, 3), keepdim=True)
             x = (x - mean) * f + mean
@@ -104,7 +108,7 @@ def _color_jitter(img01, s):
             gray = (0.299 * x[:, 0:1] + 0.587 * x[:, 1:2] + 0.114 * x[:, 2:3])
             x = (x - gray) * f + gray
         else:
-            h = random.uniform(-s, s) * 2 * math.pi           # rotate chroma in YIQ space
+            h = (2.0 * float(torch.rand(())) - 1.0) * s * 2 * math.pi      # rotate chroma in YIQ space
             c, sn = math.cos(h), math.sin(h)
             yiq = np.array([[0.299, 0.587, 0.114], [0.596, -0.274, -0.322], [0.211, -0.523, 0.312]])
             rot = np.array([[1, 0, 0], [0, c, -sn], [0, sn, c]])
