@@ -51,6 +51,34 @@ _MIT_HEADS = [1, 2, 5, 8]
 _MIT_SR = [8, 4, 2, 1]
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# gradient-readiness marks (data-parallel all-reduce overlapped with the backward pass, refign_amd/trainer.py)
+# ---------------------------------------------------------------------------------------------------------------------
+_GRAD_READY_CB = None          # callable(tag) installed by the trainer for the LAST backward pass of a step
+
+
+class _GradMark(torch.autograd.Function):
+    """Identity whose backward tells the trainer that every parameter downstream of this point (later MiT stages, decode
+    heads) has its final gradient: their slice of the flat gradient buffer can go on the wire while the backward of the
+    earlier stages is still running."""
+
+    @staticmethod
+    def forward(ctx, x, tag):
+        ctx.tag = tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        cb = _GRAD_READY_CB
+        if cb is not None:
+            cb(ctx.tag)
+        return g, None
+
+
+def grad_mark(x, tag):
+    return _GradMark.apply(x, tag) if (torch.is_grad_enabled() and x.requires_grad) else x
+
+
 class DWConv(nn.Module):
     """3x3 depthwise conv on tokens (mix_transformer.py:556-568); parameter path `dwconv.weight`."""
 
@@ -298,6 +326,8 @@ class MixVisionTransformer(nn.Module):
         mm, i = self._drop_path_masks(x), 0
         masks, masks32 = (None, None) if mm is None else mm
         for s in range(1, 5):
+            if s > 1:
+                x = grad_mark(x, f"stage{s}")        # backward passing here: stages s.. and everything after are done
             x, H, W = getattr(self, f"patch_embed{s}")(x)
             for blk in getattr(self, f"block{s}"):
                 x = blk(x, H, W, None if masks is None else masks[i:i + 2], None if masks32 is None else masks32[i:i + 2])

@@ -5,8 +5,10 @@ Data parallelism: image pairs are independent, so ranks shard the 
 gradient-free replicas with ZERO communication.  The student's gradients of the three backward passes of a step are
 accumulated into one flat fp32 buffer (every `p.grad` is a view into it) and all-reduced ONCE per step with RCCL,
 averaged over ranks -- the reference's DDP does the same reduction three times per step (once per manual_backward).
-On xGMI (7 point-to-point links per GPU) one 342 MB all-reduce is bandwidth-bound; the flat buffer is reduced in
-`bucket_mb` chunks issued back to back on the RCCL stream so the first chunks overlap the tail of the backward pass.
+On xGMI (7 point-to-point links per GPU) one 342 MB all-reduce is bandwidth-bound; the flat buffer is laid out in
+gradient-readiness order (decode heads + MiT stage 4, stage 3, stage 2, stage 1) and, during the LAST backward pass of
+the step, each finished range is put on the RCCL stream in `bucket_mb` pieces while the backward of the earlier stages
+is still running (marks in seg.MixVisionTransformer.forward_features); the remainder follows when the pass ends.
 BatchNorm layers become SyncBatchNorm when the config says `sync_batchnorm: True` (student AND teacher, D9).
 """
 import os
@@ -52,34 +54,80 @@ class FlatGradBuffer:
     optimizer): every view is persistent and zero-filled, so a trainable parameter that is never touched in a step still
     takes its AdamW weight-decay / moment update with a zero gradient.  No module of the hot path has such a parameter
     (every trainable tensor of MiT / DAFormer / SegFormer heads is on all three backward passes); a custom head with an
-    unused branch should freeze it (`requires_grad_(False)`)."""
+    unused branch should freeze it (`requires_grad_(False)`).
+
+    `groups`: [(tag, [params])] in the order the gradients become FINAL during a backward pass
+    (uda.grad_ready_groups): the buffer is laid out in that order, so `on_ready(tag)` -- called from the backward pass
+    itself through seg._GradMark -- can put the range of a finished group on the wire (async all-reduce in `bucket_mb`
+    pieces on the RCCL stream) while the backward of the earlier MiT stages is still running.  `all_reduce_mean()`
+    reduces whatever has not been released, waits for everything and divides by the world size."""
 
     ALIGN = 64          # elements: every view starts on a 256-byte boundary (16-byte vector stores in csrc/reduce.hip)
 
-    def __init__(self, params):
+    def __init__(self, params, groups=None, bucket_mb=64):
         self.params = [p for p in params if p.requires_grad]
+        order, self.ranges = [], {}
+        known = {id(p) for p in self.params}
         pad = lambda k: (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN  # noqa: E731
-        n = sum(pad(p.numel()) for p in self.params)
+        off, placed = 0, set()
+        for tag, ps in (groups or []):
+            start = off
+            for p in ps:
+                if id(p) in known and id(p) not in placed:
+                    order.append(p)
+                    placed.add(id(p))
+                    off += pad(p.numel())
+            if off > start:
+                self.ranges[tag] = (start, off)
+        rest = [p for p in self.params if id(p) not in placed]
+        order += rest
+        n = off + sum(pad(p.numel()) for p in rest)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
-        for p in self.params:
+        for p in order:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             mark_grad_sink(p)                       # backward kernels may accumulate into this view directly
             off += pad(p.numel())
+        self.bucket_mb = bucket_mb
+        self._works, self._released = [], []
 
     def zero(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self, bucket_mb=64):
+    def _reduce_range(self, a, b):
+        step = max(1, int(self.bucket_mb * 1024 * 1024 // 4))
+        for i in range(a, b, step):
+            self._works.append(dist.all_reduce(self.flat[i:min(i + step, b)], op=dist.ReduceOp.SUM, async_op=True))
+
+    def on_ready(self, tag):
+        """A group's gradients are final (called from inside the last backward pass of the step)."""
+        r = self.ranges.get(tag)
+        if r is None or r in self._released or not (dist.is_available() and dist.is_initialized()):
+            return
+        # (torch's NCCL process group orders an async collective after the work queued so far on the CURRENT stream --
+        # inside the autograd engine that is the stream of the backward kernels that produced these gradients)
+        self._released.append(r)
+        self._reduce_range(*r)
+
+    def all_reduce_mean(self, bucket_mb=None):
         if not (dist.is_available() and dist.is_initialized()):
             return
+        if bucket_mb is not None:
+            self.bucket_mb = bucket_mb
         world = dist.get_world_size()
-        step = max(1, int(bucket_mb * 1024 * 1024 // 4))
-        works = [dist.all_reduce(self.flat[i:i + step], op=dist.ReduceOp.SUM, async_op=True)
-                 for i in range(0, self.flat.numel(), step)]
-        for w in works:
+        # what the backward pass has not released: the gaps between the released ranges
+        pos = 0
+        for a, b in sorted(self._released):
+            if a > pos:
+                self._reduce_range(pos, a)
+            pos = max(pos, b)
+        if pos < self.flat.numel():
+            self._reduce_range(pos, self.flat.numel())
+        for w in self._works:
             w.wait()
+        self.overlapped_elements = sum(b - a for a, b in self._released)     # diagnostics / tests
+        self._works, self._released = [], []
         self.flat.div_(world)
 
 
@@ -101,12 +149,25 @@ class Trainer:
                                     "init_args": {**model.optimizer_init["init_args"], "fused": True}}
         (opt,), (sch,) = model.configure_optimizers()
         self.optimizer, self.scheduler = opt, sch
-        self.grads = FlatGradBuffer([p for g in opt.param_groups for p in g["params"]])
+        groups = model.grad_ready_groups() if hasattr(model, "grad_ready_groups") else None
+        self.grads = FlatGradBuffer([p for g in opt.param_groups for p in g["params"]], groups, bucket_mb)
         self.bucket_mb = bucket_mb
         model._optimizer = _OptimizerProxy(self)
         model._scheduler = sch
+        model._backward = self._backward
         if dist.is_available() and dist.is_initialized():
             self.broadcast_parameters()
+
+    def _backward(self, loss, retain_graph=False, last=False):
+        """What Lightning's manual_backward does, plus: during the LAST backward pass of a step under data parallelism
+        the readiness marks of the MiT stages release finished ranges of the flat gradient buffer to the all-reduce."""
+        from . import seg
+        overlap = last and self.world > 1 and os.environ.get("RFN_DDP_OVERLAP", "1") != "0"
+        seg._GRAD_READY_CB = self.grads.on_ready if overlap else None
+        try:
+            loss.backward(retain_graph=retain_graph)
+        finally:
+            seg._GRAD_READY_CB = None
 
     def broadcast_parameters(self):
         for t in list(self.model.parameters()) + list(self.model.buffers()):

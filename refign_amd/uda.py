@@ -258,9 +258,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def lr_schedulers(self):
         return self._scheduler
 
-    def manual_backward(self, loss, retain_graph=False):
+    def manual_backward(self, loss, retain_graph=False, last=False):
+        """`last`: the final backward pass of the step -- the trainer may start reducing gradients that are complete
+        while it is still running (refign_amd/trainer.py)."""
         if self._backward is not None:
-            self._backward(loss, retain_graph)
+            self._backward(loss, retain_graph, last)
         else:
             loss.backward(retain_graph=retain_graph)
         sidework.join()          # parameter-gradient kernels forked to the side stream are complete from here on
@@ -346,7 +348,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
             mixed_pred = F.interpolate(mixed_pred, mixed_img.shape[-2:], mode='bilinear', align_corners=False)
             mixed_loss = self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight)
         self.log("train_loss_uda_trg", mixed_loss)
-        self.manual_backward(mixed_loss)
+        self.manual_backward(mixed_loss, last=True)
         del mixed_loss, mixed_pred
 
         opt.step()
@@ -691,6 +693,26 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return out
 
     # -- EMA (:670-689) --------------------------------------------------------------------------------------------
+    def grad_ready_groups(self):
+        """Trainable parameters in the order their gradients become final during a backward pass: decode heads + MiT
+        stage 4 first (mark `stage4`), then stage 3, stage 2, and stage 1 last -- the order of the flat gradient buffer,
+        so that each mark releases one contiguous range."""
+        seen, groups = set(), []
+
+        def take(tag, mods):
+            ps = [p for m in mods if m is not None for p in m.parameters() if p.requires_grad and id(p) not in seen]
+            seen.update(id(p) for p in ps)
+            groups.append((tag, ps))
+
+        bb = self.backbone
+        stage = lambda s: [getattr(bb, f"patch_embed{s}", None), getattr(bb, f"block{s}", None), getattr(bb, f"norm{s}", None)]  # noqa: E731
+        if hasattr(bb, "patch_embed4"):
+            take("stage4", [self.head, self.hrda_scale_attention] + stage(4))
+            take("stage3", stage(3))
+            take("stage2", stage(2))
+        take("rest", [self])
+        return groups
+
     def ema_parameters(self):
         for m in filter(None, [self.m_backbone, self.m_head, self.m_hrda_scale_attention]):
             yield from m.parameters()

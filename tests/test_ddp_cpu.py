@@ -139,8 +139,9 @@ def _step_worker(rank, world, port, out):
     dist.all_gather(gathered, live)
     gathered_ema = [torch.zeros_like(ema) for _ in range(world)]
     dist.all_gather(gathered_ema, ema)
+    overlapped = trainer.grads.overlapped_elements / trainer.grads.flat.numel()
     if rank == 0:
-        torch.save({"same_live": bool(torch.equal(gathered[0], gathered[1])),
+        torch.save({"overlapped": overlapped, "live": live.clone(), "same_live": bool(torch.equal(gathered[0], gathered[1])),
                     "same_ema": bool(torch.equal(gathered_ema[0], gathered_ema[1])),
                     "finite": bool(torch.isfinite(live).all()), "step": model.global_step,
                     "lr": trainer.optimizer.param_groups[0]["lr"]}, out)
@@ -152,4 +153,15 @@ def test_two_rank_training_step_keeps_replicas_identical(tmp_path):
     mp.spawn(_step_worker, args=(2, port, out), nprocs=2, join=True)
     r = torch.load(out)
     assert r["same_live"] and r["same_ema"] and r["finite"] and r["step"] == 2
+    # the ranges of the decode head and MiT stages 4..2 went on the wire from inside the last backward pass
+    assert r["overlapped"] > 0.8, r["overlapped"]
+    # ... and releasing them early changes nothing: the same run with the whole buffer reduced after the backward pass
+    os.environ["RFN_DDP_OVERLAP"] = "0"
+    try:
+        port2, out2 = _free_port(), str(tmp_path / "step_noovl.pt")
+        mp.spawn(_step_worker, args=(2, port2, out2), nprocs=2, join=True)
+    finally:
+        del os.environ["RFN_DDP_OVERLAP"]
+    r2 = torch.load(out2)
+    assert r2["overlapped"] == 0.0 and torch.equal(r["live"], r2["live"])
     assert abs(r["lr"] - 1e-3) < 1e-9       # warm-up of 2 iterations finished (LinearWarmupPolynomialLR)
