@@ -231,11 +231,31 @@ class RefignStep:
             self._kern = AlignRefineKernels(self.batch["image_src"].device, self.b, 4321)
         return self._kern
 
+    def _level1_features(self):
+        """The level-1 operands the step itself feeds the kernel: VGG-16 pool-2 features (128 channels, 1/4 resolution) of
+        this workload's (reference, target) images, L2-normalised over channels, as UAWarpCHead.forward does
+        (uawarpc.py:96-108) -- the SAME data the in-step launches see, so the HIP-event figure of the bench line and the
+        in-step rocprofv3 kernel-trace average (profiles/) measure one thing."""
+        if getattr(self, "_l1", None) is None:
+            from refign_amd import align as A
+            from refign_amd.matching import l2_normalize_channels
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.precision == "bf16"):
+                dt = A.align_compute_dtype()
+                with torch.autocast("cuda", enabled=dt != torch.float32, dtype=dt if dt != torch.float32 else None):
+                    pt, pr, _, _ = A.extract_pyramids(self.model.alignment_backbone, self.batch["image_ref"].float(),
+                                                      self.batch["image_trg"].float())
+                self._l1 = (l2_normalize_channels(pr[0].float().contiguous()),
+                            l2_normalize_channels(pt[0].float().contiguous()))
+        return self._l1
+
     def roofline_launch(self):
-        return self._kernels().roofline_launch()
+        from refign_amd.correlation import local_correlation_layer
+        src, trg = self._level1_features()
+        return local_correlation_layer(src, trg)
 
     def roofline_bytes(self):
-        return self._kernels().roofline_bytes()
+        b, c, h, w = self._level1_features()[0].shape
+        return 4 * b * h * w * (2 * c + 81)          # SURVEY 8(d): 4*B*H*W*(2C+81)
 
     def cpu_step(self, kind, corr_fn):
         return self._kernels().cpu_step(kind, corr_fn)
