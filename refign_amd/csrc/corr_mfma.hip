@@ -298,6 +298,199 @@ __global__ __launch_bounds__(64 * (kTH / (2 * P)) * kTilesPerWg) void corr9_mfma
   }
 }
 
+// ---- wave-private variant: no workgroup barrier anywhere in the channel loop ------------------------------------------
+// Each wave stages ITS OWN 12 source rows x 40 pixels + 4 target rows x 32 pixels of a channel (16 LDS rows of 48 floats
+// = exactly 3 DMA instructions) into its own D-deep ring, so the hand-off of a channel is a counted `s_waitcnt vmcnt`
+// of the wave itself.  What that buys: with tiles shared by the workgroup (kernel above) every chunk ends in an
+// s_barrier at which all 8 waves stop, the matrix pipe drains, and all of them then issue their DMAs at once -- measured
+// 46 % pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES) and 40 % of the wave cycles in waits; without barriers the waves
+// drift apart and a SIMD always has a wave with MFMAs to issue.  What it costs: the source rows that neighbouring waves
+// share are fetched (from L2) and held in LDS once per wave -- 3 KB instead of 1.9 KB per wave and channel.
+// Every wave issues exactly 3 DMA instructions per channel, also past the last channel (all lanes then read the zero
+// slot), so the channel loop has no branch and one wait count.
+template <bool FUSE, int D>
+__global__ __launch_bounds__(512) void corr9_mfma_wave_kernel(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
+    int tilesX, int tilesY, int ntiles, int ablate, long long* __restrict__ trace) {
+  constexpr int P = 2, NX = P + 8, LA = 4;
+  constexpr int PITCH = 48, V = PITCH / 4;
+  constexpr int NSRC = 2 * P + 8, NTGT = 2 * P;       // source / target rows of a wave (12 / 4)
+  constexpr int CH = (NSRC + NTGT) * PITCH;           // floats per channel and wave: 768 = 3 DMA instructions
+  static_assert(CH == 3 * 256 && NX % (LA + 1) == 0, "3 DMA instructions per channel; operand ring keeps its phase");
+  __shared__ __attribute__((aligned(16))) float ring[8 * D * CH];
+
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave of the workgroup, 0..7
+  const int half = wv >> 2, wave = wv & 3, lane = threadIdx.x & 63;
+  float* const wring = ring + wv * (D * CH);
+
+  const int tile = blockIdx.x * kTilesPerWg + half;
+  const bool live = tile < ntiles;
+  int bid = live ? tile : 0;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY;
+  const int n = bid / tilesY;
+  const int h0 = ty * kTH, w0 = tx * kTW;
+  const int r0 = wave * 2 * P;                       // my target rows r0 .. r0 + 3 of the tile
+  const size_t plane = (size_t)H * W;
+  const float* base1 = in1 + (size_t)n * C * plane;  // target features of this image
+  const float* base2 = in2 + (size_t)n * C * plane;  // source features
+
+  const float* gsrc[3];
+  unsigned gvalid = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int slot = k * 64 + lane;
+    const int v = slot % V, row = slot / V;
+    bool ok = live;
+    const float* src = g_zero_slot;
+    if (row < NSRC) {
+      const int gy = h0 + r0 - kHalo + row, gx = w0 - kHalo + 4 * v;
+      ok = ok && v < (kTW + 2 * kHalo) / 4 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+      if (ok) src = base2 + (long)gy * W + gx;
+    } else {
+      const int gy = h0 + r0 + row - NSRC, gx = w0 + 4 * v;
+      ok = ok && v < kTW / 4 && gy < H && gx + 3 < W;
+      if (ok) src = base1 + (long)gy * W + gx;
+    }
+    gsrc[k] = src;
+    gvalid |= ok ? (1u << k) : 0u;
+  }
+
+  // one DMA instruction (k-th of a channel) into `stage`; `real` = the channel exists
+  auto issue_one = [&](int k, float* stage, bool real) {
+    lds_dma16_v(real ? gsrc[k] : (const float*)g_zero_slot, stage + k * 256);
+    gsrc[k] += (gvalid & (1u << k)) ? plane : 0;
+  };
+
+  f32x4 acc[P][9][3];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int d = 0; d < 9; ++d)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[p][d][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int lane_off = P * hh * PITCH + l31;          // lanes 0-31: target rows 0, 1; lanes 32-63: target rows 2, 3
+
+  const bool tracing = trace != nullptr && threadIdx.x == 0;
+  long long t_start = 0, t_loop = 0, c_start = 0;
+  if (trace) { t_start = wall_clock64(); c_start = clock64(); }
+
+  float aq[LA + 1][3];
+  float bc[P], bn[P];
+  auto load_row = [&](const float* sb, int x, float (&a)[3]) {
+    const float* q = sb + x * PITCH;
+    a[0] = q[0]; a[1] = q[4]; a[2] = q[8];
+  };
+
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) issue_one(k, wring + s * CH, s < C);
+  wait_vmcnt<(D - 2) * 3>();                           // channel 0 has landed
+#pragma unroll
+  for (int p = 0; p < P; ++p) bc[p] = wring[lane_off + (NSRC + p) * PITCH];
+#pragma unroll
+  for (int x = 0; x < LA; ++x) load_row(wring + lane_off, x, aq[x]);
+
+  int st = 0;
+  for (int c = 0; c < C; ++c) {
+    const int nst = st + 1 == D ? 0 : st + 1;
+    const int pst = st == 0 ? D - 1 : st - 1;          // stage of channel c - 1 == stage of channel c + D - 1
+    const float* sb = wring + st * CH + lane_off;
+    const float* sbn = wring + nst * CH + lane_off;
+    float* const ist = wring + pst * CH;
+    const bool more = c + D - 1 < C;
+#pragma unroll
+    for (int x = 0; x < NX; ++x) {
+      if (x >= 1 && x <= 3) issue_one(x - 1, ist, more);
+      if (x == NX - LA) wait_vmcnt<(D - 2) * 3>();     // channel c + 1 has landed (look-ahead reads it from here on)
+      if (x + LA < NX) load_row(sb, x + LA, aq[(x + LA) % (LA + 1)]);
+      else load_row(sbn, x + LA - NX, aq[(x + LA) % (LA + 1)]);
+      if (x == NX - 3) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) bn[p] = sbn[(NSRC + p) * PITCH];
+      }
+      const float(&a)[3] = aq[x % (LA + 1)];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int d = x - p;
+        if (d >= 0 && d <= 8) {
+          acc[p][d][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], bc[p], acc[p][d][0], 0, 0, 0);
+          acc[p][d][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], bc[p], acc[p][d][1], 0, 0, 0);
+          acc[p][d][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], bc[p], acc[p][d][2], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) bc[p] = bn[p];
+    st = nst;
+  }
+  wait_vmcnt<0>();                                     // the trailing zero-slot DMAs
+  long long c_loop = 0;
+  if (trace) { t_loop = wall_clock64(); c_loop = clock64() - c_start; }
+
+  // ---- epilogue (as above): rotate each accumulator group by j, pick the 9 planes, (ReLU + L2 norm), store ----
+  const int j = lane & 3;
+  const bool j1 = (j & 1) != 0, j2 = (j & 2) != 0;
+  const int wx = w0 + l31;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    float o[9][9];
+    float ss = 0.f;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) {
+      float R[3][4];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const f32x4 A = acc[p][d][g];
+        const float t0 = j1 ? A[1] : A[0], t1 = j1 ? A[2] : A[1], t2 = j1 ? A[3] : A[2], t3 = j1 ? A[0] : A[3];
+        R[g][0] = j2 ? t2 : t0; R[g][1] = j2 ? t3 : t1; R[g][2] = j2 ? t0 : t2; R[g][3] = j2 ? t1 : t3;
+      }
+      float* q = o[d];
+      q[0] = R[0][0];
+      q[1] = j < 3 ? R[0][1] : R[1][1];
+      q[2] = j < 2 ? R[0][2] : R[1][2];
+      q[3] = j < 1 ? R[0][3] : R[1][3];
+      q[4] = R[1][0];
+      q[5] = j < 3 ? R[1][1] : R[2][1];
+      q[6] = j < 2 ? R[1][2] : R[2][2];
+      q[7] = j < 1 ? R[1][3] : R[2][3];
+      q[8] = R[2][0];
+      if constexpr (FUSE) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+          q[e] = fmaxf(q[e], 0.f);
+          ss = fmaf(q[e], q[e], ss);
+        }
+      }
+    }
+    float sc = 1.f;
+    if constexpr (FUSE) sc = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    const int h = h0 + r0 + p + P * hh;
+    if (live && wx < W && h < H && !(ablate & 4)) {
+      float* ob = out + (size_t)n * 81 * plane + (size_t)h * W + wx;
+#pragma unroll
+      for (int d = 0; d < 9; ++d)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) ob[(size_t)(d * 9 + e) * plane] = o[d][e] * sc;
+    }
+  }
+  if (trace) {
+    const long long t_alu = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores have been acknowledged
+    const long long t_end = wall_clock64();
+    if (tracing) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
+      long long* r = trace + (size_t)blockIdx.x * 8;
+      r[0] = t_start; r[1] = 0; r[2] = t_loop; r[3] = t_alu; r[4] = t_end; r[5] = hw; r[6] = __smid(); r[7] = c_loop;
+    }
+  }
+}
+
 }  // namespace
 
 // Launcher used by corr.hip's dispatch.  Returns RFN_OK, or a positive value when the shape is outside what this kernel
@@ -316,7 +509,12 @@ int launch_corr9_mfma(const float* in1, const float* in2, float* out, int B, int
   if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");
   const dim3 grid((unsigned)blocks);
   if (trace_path && !trace_buf && hipMalloc(&trace_buf, sizeof(long long) * 8 * 65536) != hipSuccess) trace_buf = nullptr;
-  long long* tr = (trace_path && blocks <= 65536) ? trace_buf : nullptr;
+  // RFN_CORR_TRACE_EVERY=N: trace (and synchronise) only every N-th launch, so that the traced launch runs in the
+  // sustained conditions of N - 1 back-to-back launches before it
+  static const int trace_every = getenv("RFN_CORR_TRACE_EVERY") ? atoi(getenv("RFN_CORR_TRACE_EVERY")) : 1;
+  static long launch_no = 0;
+  ++launch_no;
+  long long* tr = (trace_path && blocks <= 65536 && launch_no % trace_every == 0) ? trace_buf : nullptr;
   static const int cfg = getenv("RFN_CORR_MFMA_CFG") ? atoi(getenv("RFN_CORR_MFMA_CFG")) : 0;   // tuning knob
 #define RFN_LAUNCH(CC_, D_, P_)                                                                                   \
   {                                                                                                               \
@@ -328,11 +526,22 @@ int launch_corr9_mfma(const float* in1, const float* in2, float* out, int B, int
       hipLaunchKernelGGL((corr9_mfma_kernel<false, CC_, D_, P_>), grid, block, 0, st, in1, in2, out, C, H, W,      \
                          tilesX, tilesY, (int)ntiles, ablate, tr);                                                \
   }
+#define RFN_LAUNCH_WAVE(D_)                                                                                       \
+  {                                                                                                               \
+    if (fuse)                                                                                                     \
+      hipLaunchKernelGGL((corr9_mfma_wave_kernel<true, D_>), grid, dim3(512), 0, st, in1, in2, out, C, H, W,       \
+                         tilesX, tilesY, (int)ntiles, ablate, tr);                                                \
+    else                                                                                                          \
+      hipLaunchKernelGGL((corr9_mfma_wave_kernel<false, D_>), grid, dim3(512), 0, st, in1, in2, out, C, H, W,      \
+                         tilesX, tilesY, (int)ntiles, ablate, tr);                                                \
+  }
   switch (cfg) {
     case 1: RFN_LAUNCH(2, 3, 2) break;
-    case 2: RFN_LAUNCH(2, 4, 2) break;
-    default: RFN_LAUNCH(2, 5, 2) break;
+    case 2: RFN_LAUNCH(2, 5, 2) break;
+    case 3: RFN_LAUNCH_WAVE(4) break;
+    default: RFN_LAUNCH_WAVE(6) break;
   }
+#undef RFN_LAUNCH_WAVE
 #undef RFN_LAUNCH
   const int rc = check_launch("corr9_mfma_kernel");
   if (tr && rc == RFN_OK) {

@@ -1,5 +1,7 @@
 """GPU parity: the HIP kernels (through the C ABI) against the golden vectors captured from the reference and against
 the CPU oracle on fresh seeded inputs, plus size-independent properties at the benchmark's full sizes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -312,3 +314,19 @@ def test_upsample_concat_full_size(dev):
         m = t.float().transpose(1, 2).reshape(4, 256, h, w)
         want = m if i == 0 else F.interpolate(m, size=sizes[0], mode="bilinear", align_corners=False)
         assert torch.allclose(got[:, 256 * i:256 * (i + 1)].float(), want, rtol=2e-2, atol=2e-2), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["0", "2"])
+def test_corr9_matrix_pipe_variants_match_fp64_formulation(cfg):
+    """The opt-in fp32-MFMA correlation kernels (corr_mfma.hip: wave-private rings = cfg 0, workgroup-shared tiles =
+    cfg 2) against a plain fp64 torch formulation on ragged / tiny / multi-tile shapes, raw and with the fused ReLU +
+    L2 norm (1e-5 relative; the kernel is selected once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RFN_CORR_VARIANT="30", RFN_CORR_MFMA_CFG=cfg, RFN_CORR_CHECK_ONLY="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "corr_variant_check.py")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "worst" in r.stdout and " OK" in r.stdout, r.stdout + r.stderr

@@ -20,7 +20,7 @@ C, H, W = 128, 270, 480
 f1 = F.normalize(torch.randn(2, C, H, W, generator=g), dim=1).to(dev)
 f2 = F.normalize(torch.randn(2, C, H, W, generator=g), dim=1).to(dev)
 for fused in (False, True):
-    for _ in range(3):
+    for _ in range(int(os.environ.get("RFN_CORR_TRACE_EVERY", "1")) * 3):
         (correlation.local_correlation_layer(f2, f1) if fused else correlation.forward(f1, f2, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1))
     torch.cuda.synchronize()
     r = np.fromfile(path, dtype=np.int64).reshape(-1, 8).astype(np.float64)
