@@ -303,11 +303,24 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
  * Training-mode BatchNorm2d (+ ReLU) on channels-last 16-bit tensors viewed as (T = B*H*W, C): the norm + activation of
  * the decode heads' ConvBNReLU blocks (models/modules.py:16-56), which use BATCH statistics in the student and in the EMA
  * teacher.  dtype 1 = bf16, 2 = f16; statistics, affine parameters and running buffers fp32; C % 8 == 0.
- *   rfn_bn_train_fwd  sums (2, C) <- (sum x, sum x^2) [zeroed inside]; y = relu?((x - mean) rstd gamma + beta);
- *                     running_mean / running_var (may be NULL) <- (1 - momentum) old + momentum (mean, unbiased var).
- *   rfn_bn_train_bwd  bwd_sums (2, C) <- (sum g', sum g' xhat) = (grad beta, grad gamma), g' = g masked by the ReLU;
- *                     grad_x = gamma rstd (g' - (bwd_sums[0] + xhat bwd_sums[1]) / T).  fwd_sums = the forward's sums.
+ * Statistics buffer `sums`: 2 C + 1 floats = (sum x, sum x^2, number of rows); the apply passes normalise with the row
+ * count they find THERE, so a SUM all-reduce of the buffer between a stats pass and an apply pass turns batch statistics
+ * into cross-replica ones -- SyncBatchNorm (torch/nn/modules/_functions.py:SyncBatchNorm; the reference trains with
+ * `sync_batchnorm: True`).  `bwd_sums`: 2 C floats.
+ *   rfn_bn_stats_fwd  sums <- (sum_t x, sum_t x^2, T)  [zeroed inside]
+ *   rfn_bn_apply_fwd  y = relu?((x - mean) rstd gamma + beta); running_mean / running_var (may be NULL) <-
+ *                     (1 - momentum) old + momentum (mean, unbiased var)
+ *   rfn_bn_stats_bwd  bwd_sums <- (sum g', sum g' xhat) = the LOCAL (grad beta, grad gamma), g' = g masked by the ReLU
+ *   rfn_bn_apply_bwd  grad_x = gamma rstd (g' - (bwd_sums[0] + xhat bwd_sums[1]) / rows)
+ *   rfn_bn_train_fwd / _bwd   one replica: the two passes back to back
  * ---------------------------------------------------------------------------------------------------------- */
+int rfn_bn_stats_fwd(const void* x, float* sums, long T, int C, int dtype, rfn_stream_t stream);
+int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* running_mean,
+                     float* running_var, long T, int C, float eps, float momentum, int relu, int dtype, rfn_stream_t stream);
+int rfn_bn_stats_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
+                     float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
+int rfn_bn_apply_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* bwd_sums, const float* gamma,
+                     const float* beta, void* grad_x, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
 int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* sums, float* running_mean,
                      float* running_var, long T, int C, float eps, float momentum, int relu, int dtype,
                      rfn_stream_t stream);

@@ -64,6 +64,10 @@ SIGNATURES = {
                                                                                          c_void_p]),
     "rfn_attn_bwd_dkv": (c_int, [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long] + [c_void_p] * 8 + [c_int] * 8
                          + [c_float, c_int, c_void_p]),
+    "rfn_bn_stats_fwd": (c_int, [c_void_p] * 2 + [ctypes.c_long, c_int, c_int, c_void_p]),
+    "rfn_bn_apply_fwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_float, c_int, c_int, c_void_p]),
+    "rfn_bn_stats_bwd": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
+    "rfn_bn_apply_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
     "rfn_bn_train_fwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_float, c_int, c_int, c_void_p]),
     "rfn_bn_train_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
     "rfn_uncertainty9_weights_len": (c_int, []),

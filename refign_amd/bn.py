@@ -1,12 +1,19 @@
 """Training-mode BatchNorm2d (+ ReLU) of the decode heads on the hand-written kernels of csrc/bn.hip.
 
 `bn_act_train(x, bn, relu)`: x is an NCHW-SHAPED tensor with channels-last memory (what the convolution kernels hand
-over), bn a plain nn.BatchNorm2d in training mode; returns relu?(bn(x)) in the same layout, updates bn's running
-statistics and num_batches_tracked like the module would, and routes the affine parameters' gradients into the flat
-gradient buffer when the trainer provides one.  SyncBatchNorm modules are NOT taken here (the caller keeps torch's
-implementation for them): their cross-rank statistics exchange is untested on this one-GPU development setup.
+over), bn an nn.BatchNorm2d or nn.SyncBatchNorm in training mode; returns relu?(bn(x)) in the same layout, updates bn's
+running statistics and num_batches_tracked like the module would, and routes the affine parameters' gradients into the
+flat gradient buffer when the trainer provides one.
+
+Data parallelism (the reference trains with `sync_batchnorm: True`; torch/nn/modules/_functions.py:SyncBatchNorm): a
+SyncBatchNorm module in an initialised process group of more than one rank gets ONE all-reduce (SUM) of the
+(sum x, sum x^2, rows) buffer between the statistics pass and the apply pass, and one of (sum g, sum g xhat) in the
+backward; the affine gradients are the local sums, averaged over the ranks with all other gradients by the trainer.  The
+collectives are ordinary torch.distributed calls on the module's process group: RCCL calls are capturable, so the passes
+stay replayable from hipGraphs (tools/micro/rccl_capture.py).
 """
 import torch
+import torch.distributed as dist
 
 from . import _lib
 from ._tensor import current_stream, on_device, ptr
@@ -15,61 +22,102 @@ from .params import grad_sink
 _DT16 = {torch.bfloat16: 1, torch.float16: 2}
 
 
+def sync_group(bn):
+    """The process group a module's statistics are exchanged over: None for plain BatchNorm2d and for a world of one
+    (torch's SyncBatchNorm also normalises locally then), else the module's group (default: the world)."""
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
+
+
 def usable(x, bn, dtype):
-    return (x.is_cuda and dtype in _DT16 and type(bn) is torch.nn.BatchNorm2d and bn.training and bn.affine
-            and bn.track_running_stats and bn.momentum is not None and x.shape[1] % 8 == 0
+    return (x.is_cuda and dtype in _DT16 and type(bn) in (torch.nn.BatchNorm2d, torch.nn.SyncBatchNorm) and bn.training
+            and bn.affine and bn.track_running_stats and bn.momentum is not None and x.shape[1] % 8 == 0
             and x.shape[0] * x.shape[2] * x.shape[3] > 1)
+
+
+# The four kernel passes (csrc/bn.hip) on (B, H, W, C) 16-bit tensors; module-level so that tests/test_ddp_cpu.py can put
+# CPU restatements in their place and drive the exchange logic below over gloo.
+def _stats_fwd(xh, sums):
+    T, C = xh.numel() // xh.shape[-1], xh.shape[-1]
+    with on_device(xh.device):
+        _lib.check(_lib.load_library().rfn_bn_stats_fwd(ptr(xh), ptr(sums), T, C, _DT16[xh.dtype], current_stream(xh.device)),
+                   "bn_stats_fwd")
+
+
+def _apply_fwd(xh, weight, bias, y, sums, bn, relu):
+    T, C = xh.numel() // xh.shape[-1], xh.shape[-1]
+    with on_device(xh.device):
+        _lib.check(_lib.load_library().rfn_bn_apply_fwd(ptr(xh), ptr(weight), ptr(bias), ptr(y), ptr(sums),
+                                                        ptr(bn.running_mean), ptr(bn.running_var), T, C, float(bn.eps),
+                                                        float(bn.momentum), 1 if relu else 0, _DT16[xh.dtype],
+                                                        current_stream(xh.device)), "bn_apply_fwd")
+
+
+def _stats_bwd(xh, gy, sums, weight, bias, bsums, eps, relu):
+    T, C = xh.numel() // xh.shape[-1], xh.shape[-1]
+    with on_device(xh.device):
+        _lib.check(_lib.load_library().rfn_bn_stats_bwd(ptr(xh), ptr(gy), ptr(sums), ptr(weight), ptr(bias), ptr(bsums), T, C,
+                                                        eps, 1 if relu else 0, _DT16[xh.dtype], current_stream(xh.device)),
+                   "bn_stats_bwd")
+
+
+def _apply_bwd(xh, gy, sums, bsums, weight, bias, gx, eps, relu):
+    T, C = xh.numel() // xh.shape[-1], xh.shape[-1]
+    with on_device(xh.device):
+        _lib.check(_lib.load_library().rfn_bn_apply_bwd(ptr(xh), ptr(gy), ptr(sums), ptr(bsums), ptr(weight), ptr(bias),
+                                                        ptr(gx), T, C, eps, 1 if relu else 0, _DT16[xh.dtype],
+                                                        current_stream(xh.device)), "bn_apply_bwd")
 
 
 class _BNActTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xh, weight, bias, bn, relu):
+    def forward(ctx, xh, weight, bias, bn, relu, group):
         # xh: (B, H, W, C) contiguous, 16-bit
-        B, H, W, C = xh.shape
-        T = B * H * W
+        C = xh.shape[-1]
         y = torch.empty_like(xh)
-        sums = torch.empty((2, C), dtype=torch.float32, device=xh.device)
-        lib = _lib.load_library()
-        with on_device(xh.device):
-            rc = lib.rfn_bn_train_fwd(ptr(xh), ptr(weight), ptr(bias), ptr(y), ptr(sums), ptr(bn.running_mean),
-                                      ptr(bn.running_var), T, C, float(bn.eps), float(bn.momentum), 1 if relu else 0,
-                                      _DT16[xh.dtype], current_stream(xh.device))
-        _lib.check(rc, "bn_train_fwd")
+        sums = torch.empty(2 * C + 1, dtype=torch.float32, device=xh.device)
+        _stats_fwd(xh, sums)
+        if group is not None:
+            dist.all_reduce(sums, group=group)
+        _apply_fwd(xh, weight, bias, y, sums, bn, relu)
         bn.num_batches_tracked.add_(1)
         if any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(xh, sums, weight, bias)
-            ctx.eps, ctx.relu = float(bn.eps), relu
+            ctx.eps, ctx.relu, ctx.group = float(bn.eps), relu, group
         return y
 
     @staticmethod
     def backward(ctx, gy):
         xh, sums, weight, bias = ctx.saved_tensors
-        B, H, W, C = xh.shape
+        C = xh.shape[-1]
         if gy.dtype != xh.dtype:
             gy = gy.to(xh.dtype)
         if not gy.is_contiguous():
             gy = gy.contiguous()
         gx = torch.empty_like(xh)
         bsums = torch.empty((2, C), dtype=torch.float32, device=xh.device)
-        lib = _lib.load_library()
-        with on_device(xh.device):
-            rc = lib.rfn_bn_train_bwd(ptr(xh), ptr(gy), ptr(sums), ptr(weight), ptr(bias), ptr(gx), ptr(bsums), B * H * W, C,
-                                      ctx.eps, 1 if ctx.relu else 0, _DT16[xh.dtype], current_stream(xh.device))
-        _lib.check(rc, "bn_train_bwd")
+        _stats_bwd(xh, gy, sums, weight, bias, bsums, ctx.eps, ctx.relu)
+        local = bsums
+        if ctx.group is not None:                           # parameter gradients: this replica's sums
+            local = bsums.clone()
+            dist.all_reduce(bsums, group=ctx.group)
+        _apply_bwd(xh, gy, sums, bsums, weight, bias, gx, ctx.eps, ctx.relu)
         gw = gb = None
         if ctx.needs_input_grad[1]:
             sink = grad_sink(weight)
             if sink is not None:
-                sink.add_(bsums[1])
+                sink.add_(local[1])
             else:
-                gw = bsums[1].to(weight.dtype)
+                gw = local[1].to(weight.dtype)
         if ctx.needs_input_grad[2]:
             sink = grad_sink(bias)
             if sink is not None:
-                sink.add_(bsums[0])
+                sink.add_(local[0])
             else:
-                gb = bsums[0].to(bias.dtype)
-        return (gx if ctx.needs_input_grad[0] else None), gw, gb, None, None
+                gb = local[0].to(bias.dtype)
+        return (gx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None
 
 
 def bn_act_train(x, bn, relu, dtype):
@@ -82,4 +130,4 @@ def bn_act_train(x, bn, relu, dtype):
         xh = xh.contiguous()
     w = bn.weight if bn.weight.dtype == torch.float32 else bn.weight.float()
     b = bn.bias if bn.bias.dtype == torch.float32 else bn.bias.float()
-    return _BNActTrain.apply(xh, w, b, bn, relu).permute(0, 3, 1, 2)
+    return _BNActTrain.apply(xh, w, b, bn, relu, sync_group(bn)).permute(0, 3, 1, 2)

@@ -8,8 +8,14 @@
 //             apply pass : dx = gamma * rstd * ( g' - (sums[0] + xhat * sums[1]) / T )
 // The two-pass split is the data dependence of BatchNorm itself (3 tensor passes forward, 5 backward -- what any
 // implementation moves); what is fused away are the separate ReLU / ReLU-backward passes and the per-call
-// normalisation-constant kernels.  The sums are exactly what a data-parallel SyncBatchNorm all-reduces (one (2, C)
-// vector per pass), should the host choose to.  Lanes run along channels (16-byte vectors), rows are strided over lanes.
+// normalisation-constant kernels.  Lanes run along channels (16-byte vectors), rows are strided over lanes.
+//
+// Data parallelism (SyncBatchNorm, torch/nn/modules/_functions.py: the reference trains with `sync_batchnorm: True`): the
+// statistics buffer is 2 C + 1 floats, the last one the number of rows the sums were taken over -- the stats pass adds
+// its own T there -- so that ONE all-reduce (SUM) of the buffer between the stats pass and the apply pass turns local
+// statistics into global ones; the apply passes normalise with the count they find in the buffer, never with T.  The
+// four phases are separate entry points for that (rfn_bn_stats_fwd / _apply_fwd / _stats_bwd / _apply_bwd); the
+// parameter gradients are the LOCAL backward sums (read before the exchange), as in SyncBatchNorm.
 #include <hip/hip_bf16.h>
 
 #include "common.h"
@@ -35,6 +41,7 @@ template <int DT> __device__ __forceinline__ void store8(uint16_t* p, const floa
 
 // per-channel constants from the forward sums
 __device__ __forceinline__ void norm_consts(const float* sums, int C, int c, float invT, float eps, float& mean, float& rstd) {
+  // invT = 1 / sums[2 C]: the (global) number of rows behind the sums
   mean = sums[c] * invT;
   const float var = fmaxf(sums[C + c] * invT - mean * mean, 0.f);
   rstd = rsqrtf(var + eps);
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float r;
-        norm_consts(fwd_sums, C, c0 + i, 1.f / (float)T, eps, mean[i], r);
+        norm_consts(fwd_sums, C, c0 + i, 1.f / fwd_sums[2 * C], eps, mean[i], r);
         a[i] = r;                                                       // xhat = (x - mean) * rstd
         b[i] = (gamma ? gamma[c0 + i] : 1.f);
       }
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
     for (int r = 0; r < pl; ++r) sum += red[which][r * cvb + v][e];
     atomicAdd(sums + which * C + cvg * 8 + e, sum);
   }
+  if (!BWD && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(sums + 2 * C, (float)T);
 }
 
 template <int DT, bool BWD>
@@ -111,7 +119,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
                                                        float momentum, int relu) {
   const int CV = C / 8, pl = 256 / cvb;
   const int cv = blockIdx.x * cvb + threadIdx.x % cvb, rl = threadIdx.x / cvb;
-  const float invT = 1.f / (float)T;
+  const float cnt = fwd_sums[2 * C];                   // rows behind the statistics (all ranks')
+  const float invT = 1.f / cnt;
   if (!BWD && running_mean != nullptr && blockIdx.y == 0 && rl == 0 && cv < CV) {
     // running statistics: mean and UNBIASED variance of this batch, as nn.BatchNorm2d
 #pragma unroll
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
       const float mean = fwd_sums[c] * invT;
       const float var = fmaxf(fwd_sums[C + c] * invT - mean * mean, 0.f);
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)T / fmaxf((float)T - 1.f, 1.f));
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (cnt / fmaxf(cnt - 1.f, 1.f));
     }
   }
   if (cv >= CV) return;
@@ -192,33 +201,60 @@ static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const f
 extern "C" {
 using namespace rfn;
 
+#define RFN_BN_DISPATCH(...) (dtype == 1 ? bn_launch<1>(__VA_ARGS__) : bn_launch<2>(__VA_ARGS__))
+
+static int bn_check(const char* what, long T, int C, int dtype) {
+  RFN_REQUIRE(T >= 1 && C > 0 && C % 8 == 0, "%s: T=%ld C=%d (C %% 8)", what, T, C);
+  RFN_REQUIRE(dtype == 1 || dtype == 2, "%s: dtype %d (1 = bf16, 2 = f16)", what, dtype);
+  return RFN_OK;
+}
+
+int rfn_bn_stats_fwd(const void* x, float* sums, long T, int C, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && sums, "bn_stats_fwd: null pointer");
+  if (int rc = bn_check("bn_stats_fwd", T, C, dtype)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, (2 * (size_t)C + 1) * sizeof(float), s) != hipSuccess) return fail(RFN_ELAUNCH, "bn_stats_fwd: memset");
+  return RFN_BN_DISPATCH(false, false, x, nullptr, nullptr, sums, nullptr, nullptr, nullptr, nullptr, nullptr, T, C, 0.f, 0.f, 0, s);
+}
+
+int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* running_mean,
+                     float* running_var, long T, int C, float eps, float momentum, int relu, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && y && sums, "bn_apply_fwd: null pointer");
+  if (int rc = bn_check("bn_apply_fwd", T, C, dtype)) return rc;
+  return RFN_BN_DISPATCH(false, true, x, nullptr, sums, nullptr, gamma, beta, y, running_mean, running_var, T, C, eps, momentum, relu,
+                         (hipStream_t)stream);
+}
+
+int rfn_bn_stats_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
+                     float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && grad_y && fwd_sums && bwd_sums, "bn_stats_bwd: null pointer");
+  if (int rc = bn_check("bn_stats_bwd", T, C, dtype)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(bwd_sums, 0, 2 * (size_t)C * sizeof(float), s) != hipSuccess) return fail(RFN_ELAUNCH, "bn_stats_bwd: memset");
+  return RFN_BN_DISPATCH(true, false, x, grad_y, fwd_sums, bwd_sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, 0.f, relu, s);
+}
+
+int rfn_bn_apply_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* bwd_sums, const float* gamma,
+                     const float* beta, void* grad_x, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && grad_y && fwd_sums && bwd_sums && grad_x, "bn_apply_bwd: null pointer");
+  if (int rc = bn_check("bn_apply_bwd", T, C, dtype)) return rc;
+  return RFN_BN_DISPATCH(true, true, x, grad_y, fwd_sums, const_cast<float*>(bwd_sums), gamma, beta, grad_x, nullptr, nullptr, T, C, eps,
+                         0.f, relu, (hipStream_t)stream);
+}
+
+// one rank: stats + apply back to back (`sums`: 2 C + 1 floats)
 int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* sums, float* running_mean,
                      float* running_var, long T, int C, float eps, float momentum, int relu, int dtype,
                      rfn_stream_t stream) {
-  RFN_REQUIRE(x && y && sums, "bn_train_fwd: null pointer");
-  RFN_REQUIRE(T > 1 && C > 0 && C % 8 == 0, "bn_train_fwd: T=%ld C=%d (C %% 8)", T, C);
-  RFN_REQUIRE(dtype == 1 || dtype == 2, "bn_train_fwd: dtype %d (1 = bf16, 2 = f16)", dtype);
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(float), s) != hipSuccess) return fail(RFN_ELAUNCH, "bn_train_fwd: memset");
-  int rc = dtype == 1 ? bn_launch<1>(false, false, x, nullptr, nullptr, sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, momentum, relu, s)
-                      : bn_launch<2>(false, false, x, nullptr, nullptr, sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, momentum, relu, s);
-  if (rc != RFN_OK) return rc;
-  return dtype == 1 ? bn_launch<1>(false, true, x, nullptr, sums, nullptr, gamma, beta, y, running_mean, running_var, T, C, eps, momentum, relu, s)
-                    : bn_launch<2>(false, true, x, nullptr, sums, nullptr, gamma, beta, y, running_mean, running_var, T, C, eps, momentum, relu, s);
+  RFN_REQUIRE(T > 1, "bn_train_fwd: T=%ld", T);
+  if (int rc = rfn_bn_stats_fwd(x, sums, T, C, dtype, stream)) return rc;
+  return rfn_bn_apply_fwd(x, gamma, beta, y, sums, running_mean, running_var, T, C, eps, momentum, relu, dtype, stream);
 }
 
 int rfn_bn_train_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
                      void* grad_x, float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream) {
-  RFN_REQUIRE(x && grad_y && fwd_sums && grad_x && bwd_sums, "bn_train_bwd: null pointer");
-  RFN_REQUIRE(T > 1 && C > 0 && C % 8 == 0, "bn_train_bwd: T=%ld C=%d (C %% 8)", T, C);
-  RFN_REQUIRE(dtype == 1 || dtype == 2, "bn_train_bwd: dtype %d (1 = bf16, 2 = f16)", dtype);
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(bwd_sums, 0, 2 * (size_t)C * sizeof(float), s) != hipSuccess) return fail(RFN_ELAUNCH, "bn_train_bwd: memset");
-  int rc = dtype == 1 ? bn_launch<1>(true, false, x, grad_y, fwd_sums, bwd_sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, 0.f, relu, s)
-                      : bn_launch<2>(true, false, x, grad_y, fwd_sums, bwd_sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, 0.f, relu, s);
-  if (rc != RFN_OK) return rc;
-  return dtype == 1 ? bn_launch<1>(true, true, x, grad_y, fwd_sums, bwd_sums, gamma, beta, grad_x, nullptr, nullptr, T, C, eps, 0.f, relu, s)
-                    : bn_launch<2>(true, true, x, grad_y, fwd_sums, bwd_sums, gamma, beta, grad_x, nullptr, nullptr, T, C, eps, 0.f, relu, s);
+  if (int rc = rfn_bn_stats_bwd(x, grad_y, fwd_sums, gamma, beta, bwd_sums, T, C, eps, relu, dtype, stream)) return rc;
+  return rfn_bn_apply_bwd(x, grad_y, fwd_sums, bwd_sums, gamma, beta, grad_x, T, C, eps, relu, dtype, stream);
 }
 
 }  // extern "C"

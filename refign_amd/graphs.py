@@ -110,7 +110,10 @@ class GraphedStep:
     offsets, seg.DeviceBox; stochastic depth / dropout masks come from the device generator, which torch re-seeds per
     replay); parameter gradients accumulate IN PLACE into the flat gradient buffer (trainer.FlatGradBuffer) and
     parameters / cached 16-bit copies are only updated in place between replays; BatchNorm statistics are in-place
-    buffer updates.  Not captured while a process group is active (SyncBatchNorm collectives of the decode heads).
+    buffer updates.  Under data parallelism the pass contains the SyncBatchNorm statistics exchanges of the decode heads
+    (refign_amd/bn.py: RCCL all-reduces, which are capturable -- tools/micro/rccl_capture.py); replaying them has only been
+    run with a 1-rank group (one-GPU development boxes), so for more than one rank the capture is OPT-IN
+    (RFN_GRAPH_DDP=1) and the default is the eager pass.
     The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
     throws leaves the pass eager for good, like GraphedNoGrad."""
 
@@ -132,7 +135,9 @@ class GraphedStep:
         if not (t.is_cuda and enabled() and os.environ.get("RFN_GRAPH_STUDENT", "1") != "0"):
             return False
         import torch.distributed as dist
-        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return os.environ.get("RFN_GRAPH_DDP", "0") == "1" and dist.get_backend() == "nccl"
+        return True
 
     def __call__(self, *tensors):
         if not self.usable(tensors[0]):

@@ -143,6 +143,15 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if sync_batchnorm and dist.is_available() and dist.is_initialized():
             nn.SyncBatchNorm.convert_sync_batchnorm(model)   # student AND teacher BNs (reference: sync_batchnorm: True)
+            # The EMA teacher runs on a side stream next to the student (and next to hipGraph replays that contain the
+            # student's statistics exchanges): its BatchNorm collectives get a communicator of their own, so that the
+            # two streams never interleave collectives of ONE communicator in a rank-dependent order.
+            teacher = [m for n, mod in model.named_children() if n.startswith("m_") for m in mod.modules()
+                       if isinstance(m, nn.SyncBatchNorm)]
+            if teacher and self.world > 1:
+                group = dist.new_group()
+                for m in teacher:
+                    m.process_group = group
         if fused_optimizer and model.optimizer_init["class_path"].endswith("AdamW") and \
                 next(model.parameters()).is_cuda:
             model.optimizer_init = {**model.optimizer_init,
@@ -162,7 +171,9 @@ class Trainer:
         """What Lightning's manual_backward does, plus: during the LAST backward pass of a step under data parallelism
         the readiness marks of the MiT stages release finished ranges of the flat gradient buffer to the all-reduce."""
         from . import seg
-        overlap = last and self.world > 1 and os.environ.get("RFN_DDP_OVERLAP", "1") != "0"
+        # (not inside a hipGraph capture of the pass: the replayed pass is followed by one reduce of the whole buffer)
+        overlap = last and self.world > 1 and os.environ.get("RFN_DDP_OVERLAP", "1") != "0" and \
+            not (loss.is_cuda and torch.cuda.is_current_stream_capturing())
         seg._GRAD_READY_CB = self.grads.on_ready if overlap else None
         try:
             loss.backward(retain_graph=retain_graph)

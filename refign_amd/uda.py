@@ -287,13 +287,12 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # in this step, only on the EMA update above: start it NOW on a side stream so that its kernels fill the gaps
         # of the launch-bound student forward/backward (many small kernels, each well below 256 workgroups).
         early = early_imnet = None
-        graphed = self._student_graphs(images_src)
+        if self._student_graphs(images_src):
+            return self._training_step_graphed(batch, images_src, gt_src, src_classes, opt, sch)
         if self._overlap_teacher(images_src):
-            if self.enable_fdist and not graphed:                        # needed first (after the source backward)
+            if self.enable_fdist:                                        # needed first (after the source backward)
                 early_imnet = self._start_imnet_features(images_src)
             early = self._start_target_branch(batch, images_src)
-        if graphed:
-            return self._training_step_graphed(batch, images_src, gt_src, src_classes, early, opt, sch)
 
         # SOURCE (:156-179)
         feats_src = self.backbone(images_src)
@@ -405,12 +404,18 @@ class DomainAdaptationSegmentationModel(nn.Module):
         self.manual_backward(mixed_loss)
         return (mixed_loss.detach(),)
 
-    def _training_step_graphed(self, batch, images_src, gt_src, src_classes, early, opt, sch):
+    def _training_step_graphed(self, batch, images_src, gt_src, src_classes, opt, sch):
         """training_step with the two student passes replayed from hipGraphs.  Same order of host random draws as the
-        eager path: source crop (pre-drawn when the teacher branch started early), adapt_to_ref coin, DACS parameters,
-        mixed crop."""
+        reference: source crop, adapt_to_ref coin, DACS parameters, mixed crop.
+        The source pass is ONE host call, the teacher branch tens of milliseconds of host work (its decode head and the
+        glue between its graphs are eager): the replay goes out FIRST, then the teacher branch is enqueued on the side
+        stream behind an event taken before the replay (it depends on the EMA update only) -- so the device runs both
+        from the start of the step instead of idling on the main stream while the host enqueues the teacher
+        (measured in round 2: 65 ms of every 236 ms step had only the side stream busy)."""
+        ready = torch.cuda.current_stream().record_event() if self._overlap_teacher(images_src) else None
         off = self._crop_offsets(images_src, "src")
         losses = self._graphs["source_pass"](images_src, gt_src, off)
+        early = None if ready is None else self._start_target_branch(batch, images_src, after=ready)
         self.log("train_loss_src", losses[0])
         if self.enable_fdist:
             self.log("train_loss_featdist_src", losses[1])
@@ -452,16 +457,20 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def _overlap_teacher(self, x):
         return x.is_cuda and os.environ.get("RFN_OVERLAP_TEACHER", "1") != "0"
 
-    def _start_target_branch(self, batch, images_src):
+    def _start_target_branch(self, batch, images_src, after=None):
         """_target_branch on the side stream.  The adapt_to_ref coin is the THIRD draw of the python `random` stream
         in a step (after the two HRDA crop offsets of the source forward): those two are drawn here, in order, and
-        handed to the source forward (seg.predraw_crop), so a seeded run makes the same decisions as the reference."""
-        if self.adapt_to_ref and self.use_hrda and self.training:
-            H, W = images_src.shape[-2:]
-            predraw_crop(H, W, (int(H * 0.5), int(W * 0.5)), self.hrda_output_stride * 2.0)
-        cur = torch.cuda.current_stream()
+        handed to the source forward (seg.predraw_crop), so a seeded run makes the same decisions as the reference.
+        `after`: an event on the main stream the branch waits for instead of everything queued there so far (the
+        caller has already drawn the crop and queued the source pass)."""
         self._ensure_side_stream(images_src.device)
-        self._side_stream.wait_stream(cur)                       # EMA update (and the batch) are ready
+        if after is not None:
+            self._side_stream.wait_event(after)
+        else:
+            if self.adapt_to_ref and self.use_hrda and self.training:
+                H, W = images_src.shape[-2:]
+                predraw_crop(H, W, (int(H * 0.5), int(W * 0.5)), self.hrda_output_stride * 2.0)
+            self._side_stream.wait_stream(torch.cuda.current_stream())   # EMA update (and the batch) are ready
         with torch.cuda.stream(self._side_stream):
             return self._target_branch(batch)
 

@@ -165,3 +165,70 @@ def test_two_rank_training_step_keeps_replicas_identical(tmp_path):
     r2 = torch.load(out2)
     assert r2["overlapped"] == 0.0 and torch.equal(r["live"], r2["live"])
     assert abs(r["lr"] - 1e-3) < 1e-9       # warm-up of 2 iterations finished (LinearWarmupPolynomialLR)
+
+
+# ---- SyncBatchNorm semantics of refign_amd/bn.py (statistics exchange between the kernel passes) ------------------------
+def _syncbn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bn_standin
+    from refign_amd import bn as bnk
+    bn_standin.install(bnk)                         # CPU restatements of the four kernel passes (tests/bn_standin.py)
+    torch.manual_seed(7)
+    C, per = 16, 3
+    full = torch.randn(world * per, C, 5, 6, dtype=torch.float64) * 2 + 0.5
+    gfull = torch.randn(world * per, C, 5, 6, dtype=torch.float64)
+    results = {}
+    for relu in (False, True):
+        for teacher in (False, True):               # teacher: train-mode statistics under no_grad
+            ref = nn.BatchNorm2d(C).double().train()
+            with torch.no_grad():
+                ref.weight.copy_(torch.linspace(0.5, 1.5, C))
+                ref.bias.copy_(torch.linspace(-0.3, 0.3, C))
+            mod = nn.SyncBatchNorm(C).double().train()
+            mod.load_state_dict(ref.state_dict())
+            group = dist.new_group() if teacher else None
+            mod.process_group = group
+            assert bnk.sync_group(mod) is not None
+            x = full[rank * per:(rank + 1) * per].clone().requires_grad_(not teacher)
+            xr = full.clone().requires_grad_(not teacher)
+            with torch.set_grad_enabled(not teacher):
+                y = bnk._BNActTrain.apply(x.permute(0, 2, 3, 1).contiguous(), mod.weight, mod.bias, mod, relu,
+                                          bnk.sync_group(mod)).permute(0, 3, 1, 2)
+                yr = ref(xr)
+                yr = torch.relu(yr) if relu else yr
+            err = {"y": (y - yr[rank * per:(rank + 1) * per]).abs().max().item(),
+                   "rm": (mod.running_mean - ref.running_mean).abs().max().item(),
+                   "rv": (mod.running_var - ref.running_var).abs().max().item(),
+                   "nbt": int(mod.num_batches_tracked)}
+            if not teacher:
+                y.backward(gfull[rank * per:(rank + 1) * per])
+                yr.backward(gfull)
+                err["gx"] = (x.grad - xr.grad[rank * per:(rank + 1) * per]).abs().max().item()
+                # affine gradients are LOCAL sums; their sum over ranks is the full-batch gradient
+                gw, gb = mod.weight.grad.clone(), mod.bias.grad.clone()
+                dist.all_reduce(gw)
+                dist.all_reduce(gb)
+                err["gw"] = (gw - ref.weight.grad).abs().max().item()
+                err["gb"] = (gb - ref.bias.grad).abs().max().item()
+            results[(relu, teacher)] = err
+    torch.save(results, f"{out}/syncbn_{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_statistics_exchange_equals_full_batch(tmp_path):
+    """2 ranks over gloo, each with its part of a batch: the SyncBatchNorm path of refign_amd/bn.py (one all-reduce of
+    (sum, sum^2, rows) between the statistics and the apply pass, one of the backward sums; kernel passes replaced by
+    the torch restatements of tests/bn_standin.py) == nn.BatchNorm2d on the whole batch: outputs, running statistics
+    (unbiased variance over ALL rows), input gradients, and affine gradients summed over the ranks -- for the student
+    (autograd) and for the EMA teacher's train-mode BatchNorms under no_grad on a process group of their own."""
+    port, out = _free_port(), str(tmp_path)
+    mp.spawn(_syncbn_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in range(2):
+        res = torch.load(f"{out}/syncbn_{rank}.pt")
+        for key, err in res.items():
+            assert err.pop("nbt") == 1
+            for k, v in err.items():
+                assert v < 2e-5, (rank, key, k, v)          # the exchanged statistics are fp32, as in the kernels

@@ -1,0 +1,179 @@
+"""GPU: the data-parallel (SyncBatchNorm) path of refign_amd/bn.py + csrc/bn.hip.
+  * the split-phase kernels through the C ABI on two halves of a batch with the buffers ADDED between the passes (what
+    an all-reduce does) == nn.BatchNorm2d(train) on the whole batch;
+  * the same with two real processes sharing the one GPU of the box, exchanging over gloo (RCCL refuses two ranks on
+    one device: "Duplicate GPU detected");
+  * a 1-rank RCCL group: the student passes WITH the statistics exchanges inside are captured into hipGraphs and replay
+    to the eager trajectory (what N > 1 runs with RFN_GRAPH_DDP=1; exchanges forced on for the 1-rank group)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _reference(full, gfull, weight, bias, relu):
+    ref = torch.nn.BatchNorm2d(full.shape[1]).to(full.device)
+    with torch.no_grad():
+        ref.weight.copy_(weight)
+        ref.bias.copy_(bias)
+    xr = full.float().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(gfull.float())
+    return ref, xr, yr
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("relu", [True, False])
+def test_split_phase_kernels_with_added_buffers_equal_full_batch(dev, dtype, relu):
+    from refign_amd import bn as bnk
+    torch.manual_seed(3)
+    C, parts = 64, [(0, 3), (3, 4)]                  # unequal replica batches: the row counts travel in the buffer
+    full = (torch.randn(4, 13, 11, C, device=dev) * 2 + 0.7).to(dtype)
+    gfull = torch.randn(4, 13, 11, C, device=dev).to(dtype)
+    weight = torch.linspace(0.5, 1.5, C, device=dev)
+    bias = torch.linspace(-0.4, 0.4, C, device=dev)
+    mods = [torch.nn.BatchNorm2d(C).to(dev) for _ in parts]
+    xs = [full[a:b].contiguous() for a, b in parts]
+    gs = [gfull[a:b].contiguous() for a, b in parts]
+    sums = [torch.empty(2 * C + 1, device=dev) for _ in parts]
+    for x, s in zip(xs, sums):
+        bnk._stats_fwd(x, s)
+    tot = sums[0] + sums[1]
+    assert float(tot[2 * C]) == 4 * 13 * 11
+    ys = [torch.empty_like(x) for x in xs]
+    for x, y, m in zip(xs, ys, mods):
+        bnk._apply_fwd(x, weight, bias, y, tot, m, relu)
+    bs = [torch.empty(2, C, device=dev) for _ in parts]
+    for x, g, b in zip(xs, gs, bs):
+        bnk._stats_bwd(x, g, tot, weight, bias, b, 1e-5, relu)
+    btot = bs[0] + bs[1]
+    gxs = [torch.empty_like(x) for x in xs]
+    for x, g, gx in zip(xs, gs, gxs):
+        bnk._apply_bwd(x, g, tot, btot, weight, bias, gx, 1e-5, relu)
+    ref, xr, yr = _reference(full.permute(0, 3, 1, 2), gfull.permute(0, 3, 1, 2), weight, bias, relu)
+    y = torch.cat(ys).permute(0, 3, 1, 2).float()
+    gx = torch.cat(gxs).permute(0, 3, 1, 2).float()
+    e = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert float((y - yr).abs().max()) <= 4 * e * float(yr.abs().max()) + 1e-3
+    assert float((gx - xr.grad).abs().max()) <= 0.02 * float(xr.grad.abs().max()) + 1e-4
+    assert float((btot[1] - ref.weight.grad).abs().max()) <= 0.02 * float(ref.weight.grad.abs().max()) + 1e-3
+    assert float((btot[0] - ref.bias.grad).abs().max()) <= 0.02 * float(ref.bias.grad.abs().max()) + 1e-3
+    for m in mods:                                   # every replica tracks the statistics of the WHOLE batch
+        assert torch.allclose(m.running_mean, ref.running_mean, atol=1e-4)
+        assert torch.allclose(m.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+
+
+def _two_rank_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    from refign_amd import bn as bnk
+    torch.manual_seed(11)
+    C, per = 256, 2
+    full = (torch.randn(world * per, C, 9, 14, device=dev) * 1.5 + 0.3).to(torch.bfloat16)
+    gfull = torch.randn(world * per, C, 9, 14, device=dev).to(torch.bfloat16)
+    weight = torch.linspace(0.5, 1.5, C, device=dev)
+    bias = torch.linspace(-0.4, 0.4, C, device=dev)
+    mod = torch.nn.SyncBatchNorm(C).to(dev).train()
+    with torch.no_grad():
+        mod.weight.copy_(weight)
+        mod.bias.copy_(bias)
+    assert bnk.usable(full, mod, torch.bfloat16) and bnk.sync_group(mod) is not None
+    x = full[rank * per:(rank + 1) * per].contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = bnk.bn_act_train(x, mod, True, torch.bfloat16)
+    y.backward(gfull[rank * per:(rank + 1) * per])
+    ref, xr, yr = _reference(full, gfull, weight, bias, True)
+    gw, gb = mod.weight.grad.clone(), mod.bias.grad.clone()
+    dist.all_reduce(gw)
+    dist.all_reduce(gb)
+    sl = slice(rank * per, (rank + 1) * per)
+    res = {"y": float((y.float() - yr[sl]).abs().max() / yr.abs().max()),
+           "gx": float((x.grad.float() - xr.grad[sl]).abs().max() / xr.grad.abs().max()),
+           "gw": float((gw - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()),
+           "gb": float((gb - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()),
+           "rm": float((mod.running_mean - ref.running_mean).abs().max()),
+           "rv": float((mod.running_var - ref.running_var).abs().max())}
+    torch.save(res, f"{out}/r{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_exchange_statistics(dev, tmp_path):
+    port, out = _free_port(), str(tmp_path)
+    mp.spawn(_two_rank_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in range(2):
+        r = torch.load(f"{out}/r{rank}.pt")
+        assert r["y"] < 0.02 and r["gx"] < 0.02 and r["gw"] < 0.02 and r["gb"] < 0.02, r
+        assert r["rm"] < 1e-4 and r["rv"] < 1e-4, r
+
+
+def _rccl_step_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RFN_GRAPH_DDP="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import random
+    import test_step_gpu as T
+    from refign_amd import bn as bnk, graphs
+    from refign_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    world_group = dist.group.WORLD
+    # a 1-rank group: force the exchanges (and the capture policy of N > 1) on, so that the RCCL calls are really made
+    bnk.sync_group = lambda bn: world_group if isinstance(bn, torch.nn.SyncBatchNorm) else None
+    real_usable = graphs.GraphedStep.usable
+    graphs.GraphedStep.usable = staticmethod(
+        lambda t: t.is_cuda and graphs.enabled() and os.environ.get("RFN_GRAPH_STUDENT", "1") != "0")
+    traj = {}
+    for mode in ("1", "0"):
+        os.environ["RFN_GRAPH_STUDENT"] = mode
+        model = T.build(True, dev)
+        trainer = Trainer(model, sync_batchnorm=True, fused_optimizer=False)
+        n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        rows = []
+        for it in range(5):
+            batch = T.make_batch(2, 128, 128, 64, dev)
+            batch["image_src"] = batch["image_src"] + 0.1 * it
+            with torch.autocast("cuda", dtype=torch.bfloat16):   # the BatchNorm kernels are the 16-bit path
+                trainer.step(batch, it)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src",
+                                                          "train_loss_uda_trg")])
+        captured = all(len(model._graphs[n].states) == 1 and list(model._graphs[n].states.values())[0]["graph"] is not None
+                       for n in ("source_pass", "mixed_pass")) if mode == "1" else None
+        traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), captured, n_sync)
+    graphs.GraphedStep.usable = real_usable
+    torch.save(traj, f"{out}/traj.pt")
+    dist.destroy_process_group()
+
+
+def test_student_graphs_with_rccl_statistics_exchange_inside(dev, tmp_path):
+    port, out = _free_port(), str(tmp_path)
+    mp.spawn(_rccl_step_worker, args=(1, port, out), nprocs=1, join=True)
+    traj = torch.load(f"{out}/traj.pt", weights_only=False)
+    assert traj["1"][3] > 0, "no SyncBatchNorm module in the model: nothing was exchanged"
+    assert traj["1"][2], "student passes were not captured"
+    # bf16 passes with atomics in the weight-gradient kernels: the two trajectories agree to rounding, not to the bit
+    np.testing.assert_allclose(traj["1"][0], traj["0"][0], rtol=3e-2)
+    assert abs(traj["1"][1] - traj["0"][1]) < 1e-4 * traj["0"][1]

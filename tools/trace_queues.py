@@ -75,3 +75,43 @@ for q, rs in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e, _, _ in kv[
         agg[k][1] += 1
     for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:22]:
         print(f"      {t / 1e6 / periods:8.2f} ms  n={n / periods:7.1f}  avg {t / n / 1e3:8.1f} us  {k[:110]}")
+
+# ---- timeline of the last step: how busy is each queue in 5 ms buckets, and where does the busiest queue idle ----
+ts = marks[-2], marks[-1]
+last = [r for r in rows if ts[0] <= r[0] < ts[1]]
+qs = sorted(byq, key=lambda q: -sum(e - s for s, e, _, _ in byq[q]))[:2]
+B = 5e6
+nb = int((ts[1] - ts[0]) / B) + 1
+print(f"\nlast step ({(ts[1] - ts[0]) / 1e6:.1f} ms): busy fraction per 5 ms bucket, queues {qs}")
+for q in qs:
+    occ = [0.0] * nb
+    for s, e, _, qq in last:
+        if qq != q:
+            continue
+        b0 = int((s - ts[0]) / B)
+        while s < e and b0 < nb:
+            be = ts[0] + (b0 + 1) * B
+            occ[b0] += min(e, be) - s
+            s = min(e, be)
+            b0 += 1
+    print(f"  {str(q):12s} " + " ".join(f"{int(round(100 * o / B)):3d}" for o in occ))
+main = sorted([r for r in last if r[3] == qs[0]])
+gaps = []
+for a, b in zip(main, main[1:]):
+    if b[0] - a[1] > 150e3:
+        gaps.append((b[0] - a[1], a, b))
+print(f"idle gaps > 150 us on {qs[0]}: {len(gaps)}, total {sum(g[0] for g in gaps) / 1e6:.1f} ms")
+for g, a, b in sorted(gaps, key=lambda x: -x[0])[:12]:
+    print(f"  {g / 1e3:8.0f} us at +{(a[1] - ts[0]) / 1e6:6.1f} ms   after {a[2][:60]}   before {b[2][:60]}")
+print("\ndominant kernel per 10 ms bucket of the last step:")
+for q in qs:
+    print(f" queue {q}")
+    nb2 = int((ts[1] - ts[0]) / 1e7) + 1
+    for b in range(nb2):
+        agg2 = defaultdict(int)
+        for s, e, k, qq in last:
+            if qq == q and int((s - ts[0]) / 1e7) == b:
+                agg2[k] += e - s
+        if agg2:
+            top = sorted(agg2.items(), key=lambda kv: -kv[1])[:2]
+            print(f"   +{b * 10:4d} ms  busy {sum(agg2.values()) / 1e6:5.1f}  " + " | ".join(f"{t / 1e6:4.1f} {k[:70]}" for k, t in top))
