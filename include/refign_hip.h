@@ -95,6 +95,12 @@ int rfn_global_corr_layer_f32(const float* feature_source, const float* feature_
  * last row/column where the mask differs (handled by the host wrapper, refign_amd/matching.py). */
 int rfn_warp_f32(const float* x, const float* flow, float* out, unsigned char* mask, int B, int C, int H,
                  int W, rfn_stream_t stream);
+/* Backward of rfn_warp_f32 (grid_sample backward composed with the flow -> grid map): grad_x (B,C,H,W) and / or
+ * grad_flow (B,2,H,W), either may be NULL; both are zeroed inside (scatter / cross-channel sums use float atomics).
+ * Used by matcher training (models/alignment_model.py:81-146: the head warps source features and the W-bipath loss
+ * warps flows with differentiable flows). */
+int rfn_warp_bwd_f32(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow, int B,
+                     int C, int H, int W, rfn_stream_t stream);
 
 /* F.interpolate(x, size=(OH,OW), mode='area') of align() (segmentation_model.py:498-501): adaptive average pooling
  * with ATen's window rule [floor(o*I/O), ceil((o+1)*I/O)).  x: (planes,H,W) -> out: (planes,OH,OW). */

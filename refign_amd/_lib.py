@@ -29,6 +29,7 @@ SIGNATURES = {
     "rfn_local_corr_layer_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "rfn_global_corr_layer_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     "rfn_warp_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "rfn_warp_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "rfn_l2norm_channels_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "rfn_area_resize_f32": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "rfn_refine_workspace_bytes": (ctypes.c_ulong, [c_int]),

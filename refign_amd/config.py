@@ -20,14 +20,16 @@ ALIASES = {
     "models.heads.SegFormerHead": "refign_amd.seg.SegFormerHead",
     "models.heads.UAWarpCHead": "refign_amd.align.UAWarpCHead",
     "models.losses.PixelWeightedCrossEntropyLoss": "refign_amd.seg.PixelWeightedCrossEntropyLoss",
+    "models.losses.HuberLoss": "refign_amd.losses.HuberLoss",
+    "models.losses.MultiScaleFlowLoss": "refign_amd.losses.MultiScaleFlowLoss",
+    "models.losses.WBipathLoss": "refign_amd.losses.WBipathLoss",
     "helpers.lr_scheduler.LinearWarmupPolynomialLR": "refign_amd.trainer.LinearWarmupPolynomialLR",
     "helpers.callbacks.ValEveryNSteps": "refign_amd.trainer.ValEveryNSteps",
 }
 # subsystems that are out of scope here (host I/O, logging, evaluation): accepted in a config, not instantiated
 IGNORED_PREFIXES = ("pytorch_lightning.", "data_modules.", "helpers.metrics.")
-# matcher-training losses (SURVEY.md section 8f, row N1 -- "next"): a megadepth config carries them; AlignmentModel
-# keeps the spec and its training_step says so, forward / evaluation do not need them
-DEFERRED = ("models.losses.MultiScaleFlowLoss", "models.losses.WBipathLoss")
+# class paths accepted in a config but kept as specs (none at present: the matcher-training losses of row N1 are built)
+DEFERRED = ()
 
 
 # reference packages whose classes are routed through ALIASES; anything of theirs that has no alias is a component

@@ -71,6 +71,66 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
   for (int c = 0; c < cend; ++c) dst[(size_t)c * HW] = tap_sample(src + (size_t)c * HW, t);
 }
 
+// Backward of warp() = backward of grid_sample(bilinear, align_corners=True, zeros) composed with the flow -> grid map
+// (ATen grid_sampler_2d_backward: gix = sum_c g [ (ne - nw) (1 - ty) + (se - sw) ty ], giy likewise; taps outside the
+// image contribute zero).  d ix / d flow_x = ((W - 1) / 2) (2 / max(W - 1, 1)): 1 for W > 1, 0 for a one-pixel axis.
+// One thread per pixel and channel group: grad_x is a scatter (float atomics, pre-zeroed), grad_flow the sum over the
+// channel groups (atomics on 2 floats per pixel, pre-zeroed).
+// grid: (ceil(HW/256), channel groups, B)
+template <int CG>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                       const float* __restrict__ gout, float* __restrict__ gx_out,
+                                                       float* __restrict__ gflow, int C, int H, int W) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (pix >= HW) return;
+  const int n = blockIdx.z, c0 = blockIdx.y * CG;
+  const int gy = pix / W, gx = pix - gy * W;
+  const float* fl = flow + (size_t)n * 2 * HW;
+  const Tap t = bilinear_tap((float)gx, (float)gy, fl[pix], fl[HW + pix], H, W);
+  // fractional parts and tap validity, recovered from the weights' construction
+  const float fxv = fl[pix], fyv = fl[HW + pix];
+  const float wm = (float)max(W - 1, 1), hm = (float)max(H - 1, 1);
+  float ix, iy;
+  {
+#pragma clang fp contract(off)
+    const float vx = 2.0f * ((float)gx + fxv) / wm - 1.0f, vy = 2.0f * ((float)gy + fyv) / hm - 1.0f;
+    ix = ((vx + 1.0f) / 2.0f) * (float)(W - 1);
+    iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
+  }
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float tx = ix - x0f, ty = iy - y0f, ax = 1.0f - tx, ay = 1.0f - ty;
+  const bool finite = (ix == ix) && (iy == iy) && fabsf(ix) < 1e9f && fabsf(iy) < 1e9f;
+  const int x0 = finite ? (int)x0f : -2, y0 = finite ? (int)y0f : -2;
+  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+  const bool v00 = vx0 && vy0, v01 = vx1 && vy0, v10 = vx0 && vy1, v11 = vx1 && vy1;
+  const float* src = x + ((size_t)n * C + c0) * HW;
+  const float* go = gout + ((size_t)n * C + c0) * HW + pix;
+  float* gxp = gx_out ? gx_out + ((size_t)n * C + c0) * HW : nullptr;
+  const int cend = min(CG, C - c0);
+  float gix = 0.f, giy = 0.f;
+  for (int c = 0; c < cend; ++c) {
+    const float g = go[(size_t)c * HW];
+    const float* s = src + (size_t)c * HW;
+    const float nw = v00 ? s[t.o00] : 0.f, ne = v01 ? s[t.o01] : 0.f, sw = v10 ? s[t.o10] : 0.f, se = v11 ? s[t.o11] : 0.f;
+    gix += g * ((ne - nw) * ay + (se - sw) * ty);
+    giy += g * ((sw - nw) * ax + (se - ne) * tx);
+    if (gxp) {
+      float* d = gxp + (size_t)c * HW;
+      if (v00) atomicAdd(d + t.o00, g * t.w00);
+      if (v01) atomicAdd(d + t.o01, g * t.w01);
+      if (v10) atomicAdd(d + t.o10, g * t.w10);
+      if (v11) atomicAdd(d + t.o11, g * t.w11);
+    }
+  }
+  if (gflow) {
+    float* gf = gflow + (size_t)n * 2 * HW;
+    if (W > 1 && finite) atomicAdd(gf + pix, gix);
+    if (H > 1 && finite) atomicAdd(gf + HW + pix, giy);
+  }
+}
+
 // ATen upsample_bilinear2d source index, align_corners=False: max(scale*(dst+0.5)-0.5, 0)
 __device__ __forceinline__ void up_index(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
 #pragma clang fp contract(off)
@@ -210,6 +270,23 @@ int rfn_warp_f32(const float* x, const float* flow, float* out, unsigned char* m
   dim3 grid(cdiv((long)H * W, 256), cdiv(C, CG), B);
   hipLaunchKernelGGL((warp_kernel<CG>), grid, dim3(256), 0, (hipStream_t)stream, x, flow, out, mask, C, H, W);
   return check_launch("warp_kernel");
+}
+
+int rfn_warp_bwd_f32(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow, int B,
+                     int C, int H, int W, rfn_stream_t stream) {
+  RFN_REQUIRE(x && flow && grad_out && (grad_x || grad_flow), "rfn_warp_bwd_f32: null pointer");
+  RFN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "rfn_warp_bwd_f32: non-positive size");
+  RFN_REQUIRE((long)H * W < 0x7fffffffL && B <= 65535, "rfn_warp_bwd_f32: tensor too large");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t HW = (size_t)H * W;
+  if (grad_x && hipMemsetAsync(grad_x, 0, (size_t)B * C * HW * sizeof(float), s) != hipSuccess)
+    return fail(RFN_ELAUNCH, "rfn_warp_bwd_f32: memset");
+  if (grad_flow && hipMemsetAsync(grad_flow, 0, (size_t)B * 2 * HW * sizeof(float), s) != hipSuccess)
+    return fail(RFN_ELAUNCH, "rfn_warp_bwd_f32: memset");
+  constexpr int CG = 32;
+  dim3 grid(cdiv((long)HW, 256), cdiv(C, CG), B);
+  hipLaunchKernelGGL((warp_bwd_kernel<CG>), grid, dim3(256), 0, s, x, flow, grad_out, grad_x, grad_flow, C, H, W);
+  return check_launch("warp_bwd_kernel");
 }
 
 int rfn_align_tail_f32(const float* logits_ref, const float* flow_q, const float* logvar_q, float* warped,

@@ -25,7 +25,33 @@ def warp(x, flo, padding_mode='zeros', return_mask=False):
         if return_mask:
             return x, torch.ones((B, H, W), dtype=torch.bool, device=dev)
         return x
+    if torch.is_grad_enabled() and (x.requires_grad or flo.requires_grad):
+        # matcher training (alignment_model.py:81-146): differentiable in the features AND in the flow, like grid_sample
+        out = _WarpFn.apply(x, flo)
+        if return_mask:
+            return out, warp_nocheck(x.detach(), flo.detach(), True)[1]
+        return out
     return warp_nocheck(x, flo, return_mask)
+
+
+class _WarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flo):
+        ctx.save_for_backward(x, flo)
+        return warp_nocheck(x, flo)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, flo = ctx.saved_tensors
+        g = g.float().contiguous()
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gf = torch.empty_like(flo) if ctx.needs_input_grad[1] else None
+        lib = _lib.load_library()
+        with on_device(x.device):
+            rc = lib.rfn_warp_bwd_f32(ptr(x), ptr(flo), ptr(g), ptr(gx), ptr(gf), B, C, H, W, current_stream(x.device))
+        _lib.check(rc, "warp backward")
+        return gx, gf
 
 
 def warp_nocheck(x, flo, return_mask=False):
@@ -103,6 +129,26 @@ def unnormalise_and_convert_mapping_to_flow(map, output_channel_first=True):
     if not output_channel_first:
         flow = flow.permute(0, 2, 3, 1)
     return flow
+
+
+def convert_flow_to_mapping(flow, output_channel_first=True):
+    """matching_utils.py (4-D case): flow in pixels -> absolute sampling position (x, y) of every pixel."""
+    if flow.dim() != 4:
+        raise RuntimeError("convert_flow_to_mapping: expects (B,2,H,W)")
+    if flow.shape[1] != 2:
+        flow = flow.permute(0, 3, 1, 2)
+    B, C, H, W = flow.shape
+    xx = torch.arange(0, W, dtype=flow.dtype, device=flow.device).view(1, 1, W)
+    yy = torch.arange(0, H, dtype=flow.dtype, device=flow.device).view(1, H, 1)
+    mapping = torch.stack((flow[:, 0] + xx, flow[:, 1] + yy), dim=1)
+    return mapping if output_channel_first else mapping.permute(0, 2, 3, 1)
+
+
+def get_gt_correspondence_mask(flow):
+    """matching_utils.py:60-74: True where the flow points inside the image (borders included)."""
+    m = convert_flow_to_mapping(flow)
+    h, w = m.shape[-2:]
+    return (m[:, 0] >= 0) & (m[:, 0] <= w - 1) & (m[:, 1] >= 0) & (m[:, 1] <= h - 1)
 
 
 def estimate_probability_of_confidence_interval_of_mixture_density(uncert_output, R=1.0):

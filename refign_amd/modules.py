@@ -19,7 +19,8 @@ class LocalFeatureCorrelationLayer(nn.Module):
         self.patch_size = patch_size
 
     def forward(self, feature_source, feature_target, flow=None):
-        needs_grad = torch.is_grad_enabled() and (feature_source.requires_grad or feature_target.requires_grad)
+        needs_grad = torch.is_grad_enabled() and (feature_source.requires_grad or feature_target.requires_grad
+                                                  or (flow is not None and flow.requires_grad))
         if self.patch_size == 9 and not needs_grad:
             return local_correlation_layer(feature_source.float().contiguous(), feature_target.float().contiguous(),
                                            None if flow is None else flow.float().contiguous())

@@ -1,0 +1,176 @@
+"""GPU: matcher training -- the differentiable warp (csrc/warp.hip forward + backward), the
+W-bipath loss and one whole `AlignmentModel.training_step` against golden vectors captured from the reference
+(tests/golden/make_golden_matcher.py: models/alignment_model.py:81-146, models/losses.py:37-328)."""
+import numpy as np
+import pytest
+import torch
+from conftest import golden
+from fill import closed_form_fill, hashed_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def T(a, dev, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev).requires_grad_(grad)
+
+
+def _grid_sample_warp(x, flo):
+    """helpers/matching_utils.py:11-49 with torch's own autograd (the reference's formulation)."""
+    B, C, H, W = x.shape
+    xx = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, 1, W).expand(B, 1, H, W)
+    yy = torch.arange(H, device=x.device, dtype=x.dtype).view(1, 1, H, 1).expand(B, 1, H, W)
+    v = torch.cat((xx, yy), 1) + flo
+    vx = 2.0 * v[:, 0] / max(W - 1, 1) - 1.0
+    vy = 2.0 * v[:, 1] / max(H - 1, 1) - 1.0
+    return torch.nn.functional.grid_sample(x, torch.stack((vx, vy), 3), align_corners=True, padding_mode="zeros")
+
+
+@pytest.mark.parametrize("B,C,H,W,amp", [(2, 5, 17, 23, 3.0), (1, 33, 32, 40, 12.0), (2, 2, 9, 1, 2.0), (1, 64, 8, 8, 30.0)])
+def test_warp_backward_matches_grid_sample_autograd(dev, B, C, H, W, amp):
+    """Gradients of warp() with respect to the features AND the flow, flows reaching far outside the image included,
+    against torch's grid_sample backward (fp32; the scatter uses float atomics: 1e-5 relative)."""
+    from refign_amd.matching import warp
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    flo = (torch.randn(B, 2, H, W, generator=g) * amp).to(dev)
+    go = torch.randn(B, C, H, W, generator=g).to(dev)
+    x1, f1 = x.clone().requires_grad_(True), flo.clone().requires_grad_(True)
+    x2, f2 = x.clone().requires_grad_(True), flo.clone().requires_grad_(True)
+    y1 = warp(x1, f1)
+    y2 = _grid_sample_warp(x2, f2)
+    assert float((y1 - y2).abs().max()) <= 1e-5 * max(float(y2.abs().max()), 1.0)
+    y1.backward(go)
+    y2.backward(go)
+    for a, b, name in ((x1.grad, x2.grad, "grad x"), (f1.grad, f2.grad, "grad flow")):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1.0), name
+    # flow-only and feature-only gradients (the other output of the kernel is NULL then)
+    f3 = flo.clone().requires_grad_(True)
+    warp(x, f3).backward(go)
+    assert float((f3.grad - f2.grad).abs().max()) <= 2e-5 * max(float(f2.grad.abs().max()), 1.0)
+    x4 = x.clone().requires_grad_(True)
+    warp(x4, flo).backward(go)
+    assert float((x4.grad - x2.grad).abs().max()) <= 2e-5 * max(float(x2.grad.abs().max()), 1.0)
+
+
+def test_wbipath_loss_matches_reference(dev):
+    """W-bipath loss on four near-consistent levels with log-variances: value, per-level validity and visibility masks,
+    composed flows, and gradients with respect to all sixteen inputs; and the deterministic L1 variant with the
+    gradient flowing THROUGH the warping flow (detach_flow_for_warping=False)."""
+    from refign_amd.losses import MultiScaleFlowLoss, WBipathLoss
+    z = golden("matcher_losses_128x160")
+    first = [(T(z[f"in/f{i}"], dev, True), T(z[f"in/uf{i}"], dev, True)) for i in range(4)]
+    second = [(T(z[f"in/s{i}"], dev, True), T(z[f"in/us{i}"], dev, True)) for i in range(4)]
+    flow, mask = T(z["flow_prime"], dev), T(z["mask_prime"], dev)
+    ss = MultiScaleFlowLoss(loss_type='HuberLoss', level_weights=[0.32, 0.08, 0.02, 0.01])
+    us = WBipathLoss(objective='multi_scale_flow_loss', loss_type='HuberLoss', visibility_mask=True)
+    l_ss = ss(first, flow, mask=mask)
+    l_us, masks, cyc, comp = us(first, second, flow, mask_used=mask, return_masks=True)
+    assert abs(float(l_ss) - float(z["ss_loss"])) <= 1e-5 * float(z["ss_loss"])
+    assert abs(float(l_us) - float(z["us_loss"])) <= 1e-5 * float(z["us_loss"])
+    (l_ss + l_us).backward()
+    for i in range(4):
+        # masks are thresholds on fp32 quantities: allow a handful of pixels on the decision boundary
+        assert (masks[i].cpu().numpy() != z[f"mask{i}"]).sum() <= 2
+        assert (cyc[i].cpu().numpy() != z[f"cyclic{i}"]).sum() <= 2
+        assert np.abs(comp[i][0].detach().cpu().numpy() - z[f"composed{i}"]).max() <= 1e-4
+        for nm, x in (("f", first[i][0]), ("uf", first[i][1]), ("s", second[i][0]), ("us", second[i][1])):
+            want = z[f"grad/{nm}{i}"]
+            assert np.abs(x.grad.cpu().numpy() - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6), (nm, i)
+            x.grad = None
+    us2 = WBipathLoss(objective='multi_scale_flow_loss', loss_type='L1Loss', visibility_mask=False,
+                      detach_flow_for_warping=False)
+    l2 = us2([f for f, _ in first], [f for f, _ in second], flow, mask_used=mask)
+    assert abs(float(l2) - float(z["us_l1_nodetach_loss"])) <= 1e-5 * float(z["us_l1_nodetach_loss"])
+    l2.backward()
+    for i in range(4):
+        for nm, x in (("f", first[i][0]), ("s", second[i][0])):
+            want = z[f"grad_l1/{nm}{i}"]
+            assert np.abs(x.grad.cpu().numpy() - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6), (nm, i)
+
+
+def build_matcher(dev):
+    from refign_amd.align import VGG, UAWarpCHead
+    from refign_amd.alignment_model import AlignmentModel
+    from refign_amd.losses import MultiScaleFlowLoss, WBipathLoss
+    model = AlignmentModel(
+        optimizer_init={"class_path": "torch.optim.AdamW", "init_args": {"lr": 1e-4, "weight_decay": 4e-4}},
+        lr_scheduler_init={"class_path": "torch.optim.lr_scheduler.StepLR", "init_args": {"step_size": 100}},
+        alignment_backbone=closed_form_fill(VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone."),
+        alignment_head=closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select',
+                                                    estimate_uncertainty=True)),
+        selfsupervised_loss=MultiScaleFlowLoss(loss_type='HuberLoss'),
+        unsupervised_loss=WBipathLoss(objective='multi_scale_flow_loss', loss_type='HuberLoss', visibility_mask=False))
+    return model.to(dev).train()
+
+
+def matcher_batch(z, dev):
+    b, (H, W) = 2, [int(v) for v in z["size"]]
+    trg = (hashed_uniform((b, 3, H, W), "g14/trg") * 4 - 2).astype(np.float32)
+    ref = (0.8 * np.roll(trg, (2, -3), (2, 3)) + 0.2 * (hashed_uniform((b, 3, H, W), "g14/ref") * 4 - 2)).astype(np.float32)
+    return {"image_ref": T(ref, dev), "image_trg": T(trg, dev), "image_prime": T(z["image_prime"], dev),
+            "flow_prime": T(z["flow_prime"], dev), "mask_prime": T(z["mask_prime"], dev),
+            "prime_trg_idx": [int(v) for v in z["prime_trg_idx"]]}
+
+
+def test_matcher_training_step_matches_reference(dev):
+    """One AlignmentModel.training_step (three head passes in train mode on the frozen VGG-16 pyramid, warp-supervision
+    + W-bipath losses, the reference's loss balancing) and its backward: the two losses to 2e-4 relative, the total, the
+    gradient norm of every sub-module of the head to 2e-3, sampled entries of the first decoder layer's weight gradient
+    to 1 % of their largest entry, and the head outputs of all three passes at all four levels (flow 2e-3 px, log-variance 2e-3)."""
+    z = golden("matcher_step_128x160")
+    model = build_matcher(dev)
+    assert not any(p.requires_grad for p in model.alignment_backbone.parameters())
+    batch = matcher_batch(z, dev)
+    passes = []
+    head_forward = model.alignment_head.forward
+    model.alignment_head.forward = lambda *a: (passes.append(head_forward(*a)), passes[-1])[1]
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    for pi, out in enumerate(passes):
+        for li, (fl, un) in enumerate(out):
+            assert np.abs(fl.detach().cpu().numpy() - z[f"pass{pi}/flow{li}"]).max() <= 2e-3, (pi, li)
+            assert np.abs(un.detach().cpu().numpy() - z[f"pass{pi}/uncert{li}"]).max() <= 2e-3, (pi, li)
+    assert abs(float(model.logged["train_ss_loss"]) - float(z["ss_loss"])) <= 2e-4 * float(z["ss_loss"])
+    assert abs(float(model.logged["train_us_loss"]) - float(z["us_loss"])) <= 2e-4 * float(z["us_loss"])
+    assert abs(float(loss) - float(z["loss"])) <= 2e-4 * float(z["loss"])
+    head = model.alignment_head
+    for name, mod in head.named_children():
+        key = "gradnorm/" + name
+        if key in z:
+            g = [p.grad for p in mod.parameters() if p.grad is not None]
+            norm = float(torch.sqrt(sum((x.double() ** 2).sum() for x in g)))
+            assert abs(norm - float(z[key])) <= 2e-3 * float(z[key]), (name, norm, float(z[key]))
+    params = dict(head.named_parameters())
+    checked = 0
+    for key in z:
+        if key.startswith("grad/"):
+            got = params[key[5:]].grad.detach().cpu().numpy().reshape(-1)[::7]
+            assert np.abs(got - z[key]).max() <= 1e-2 * np.abs(z[key]).max(), key
+            checked += 1
+    assert checked >= 1
+
+
+def test_matcher_trains(dev):
+    """Five optimiser steps on one batch: finite, and the objective the step minimises goes down."""
+    z = golden("matcher_step_128x160")
+    model = build_matcher(dev)
+    (opt,), _ = model.configure_optimizers()
+    assert sum(p.numel() for g in opt.param_groups for p in g["params"]) == \
+        sum(p.numel() for p in model.alignment_head.parameters())
+    batch = matcher_batch(z, dev)
+    vals = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        vals.append(float(model.logged["train_ss_loss"]))
+        assert np.isfinite(vals[-1])
+    assert vals[-1] < vals[0]
