@@ -148,6 +148,8 @@ class UncertaintyModule(nn.Module):
                 and self.conv_0.use_norm and corr.dtype == torch.float32
                 and os.environ.get("RFN_UNCERT_FUSED", "1") != "0"):
             return matching.uncertainty9_frontend(corr, self.packed_frontend_weights())
+        if s == 9 and (self.training or torch.is_grad_enabled()):
+            return self._patch_statistics_tiled(corr)
         x = corr.permute(0, 2, 3, 1).reshape(b * h * w, 1, s, s)
         outs = []
         for i in range(0, x.shape[0], self.MICRO_BATCH):
@@ -158,6 +160,30 @@ class UncertaintyModule(nn.Module):
             outs.append(y.flatten(1))
         y = outs[0] if len(outs) == 1 else torch.cat(outs)
         return y.view(b, h, w, 6).permute(0, 3, 1, 2)
+
+    def _patch_statistics_tiled(self, corr):
+        """The micro-image chain under autograd (matcher training) as FOUR convolutions on
+        ordinary images instead of one convolution per 100 000 9x9 micro-images (which the library runs as one
+        im2col + GEMM pair per micro-image: 35 000 launches per call, measured): the micro-image of pixel (y, x) is tile
+        (y, x) of a (9 h, 9 w) image; a valid 3x3 convolution of the tiled image contains every micro-image's 7x7
+        result (plus windows that straddle tiles, dropped); the 7x7 results are re-tiled into a (7 h, 7 w) image, and so
+        on 9 -> 7 -> 5 -> 3 -> 1.  BatchNorm over the re-tiled image sees exactly the N x 49 (25, 9) values per
+        channel it sees in the micro-image batch, so batch statistics and running buffers are the reference's."""
+        b, _, h, w = corr.shape
+
+        def retile(y, k):                                # (b, C, k h + 2 - 2.., ..): valid part of every (k+2)-tile
+            y = F.pad(y, (0, 2, 0, 2))
+            c = y.shape[1]
+            return y.view(b, c, h, k + 2, w, k + 2)[:, :, :, :k, :, :k].reshape(b, c, k * h, k * w)
+
+        x = corr.view(b, 9, 9, h, w).permute(0, 3, 1, 4, 2).reshape(b, 1, 9 * h, 9 * w)
+        for m, k in ((self.conv_0, 7), (self.conv_1, 5), (self.conv_2, 3)):
+            x = retile(F.conv2d(x, m.conv.weight, m.conv.bias), k)
+            if m.use_norm:
+                x = m.bn(x)
+            x = F.leaky_relu(x, m.act_slope, inplace=True) if m.act == 'leaky' else F.relu(x, inplace=True)
+        y = F.conv2d(x, self.predict_uncertainty.weight, self.predict_uncertainty.bias)   # (b, 6, 3 h - 2, 3 w - 2)
+        return F.pad(y, (0, 2, 0, 2)).view(b, 6, h, 3, w, 3)[:, :, :, 0, :, 0]
 
     def forward(self, corr, feat, up_previous_uncertainty=None, up_previous_flow=None):
         parts = [self.patch_statistics(corr), feat]
