@@ -206,6 +206,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
             self.imnet_backbone.requires_grad_(False)
         self.loss = loss
         self.metrics_cfg = metrics
+        from .metrics import build_collections
+        self.valid_metrics, self.test_metrics = build_collections(metrics, instantiate_class)
         self.optimizer_init, self.lr_scheduler_init = optimizer_init, lr_scheduler_init
         self.backbone_lr_factor = backbone_lr_factor
         self.use_refign, self.use_align, self.gamma = use_refign, use_align, gamma
@@ -519,6 +521,37 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def load_state_dict(self, *a, **k):
         self._reset_graphs()
         return super().load_state_dict(*a, **k)
+
+    # -- evaluation (:255-281) ---------------------------------------------------------------
+    @torch.no_grad()
+    def _eval_step(self, metrics, batch, src_name):
+        """validation_step / test_step: logits at the label size, every metric of this dataset accumulates.  `src_name`
+        is what the reference reads from trainer.datamodule.idx_to_name[split][dataloader_idx]."""
+        x, y = batch['image'], batch['semantic']
+        y_hat = self.forward(x, out_size=y.shape[-2:])
+        for k, m in metrics.items():
+            if src_name in k:
+                m(y_hat, y)
+        return y_hat
+
+    def validation_step(self, batch, batch_idx=0, dataloader_idx=0, src_name=""):
+        return self._eval_step(self.valid_metrics, batch, src_name)
+
+    def test_step(self, batch, batch_idx=0, dataloader_idx=0, src_name=""):
+        return self._eval_step(self.test_metrics, batch, src_name)
+
+    def _epoch_end(self, metrics):
+        out = metrics.compute()
+        metrics.reset()
+        for k, v in out.items():
+            self.log(k, v)
+        return out
+
+    def validation_epoch_end(self, outs=None):
+        return self._epoch_end(self.valid_metrics)
+
+    def test_epoch_end(self, outs=None):
+        return self._epoch_end(self.test_metrics)
 
     # -- inference (:304-382) ------------------------------------------------------------------------------------
     def forward(self, x, out_size=None):
