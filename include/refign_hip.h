@@ -246,12 +246,12 @@ int rfn_patchify_tokens(const void* src, void* dst, int B, int H, int W, int C, 
  * of MiT (mix_transformer.py:96-103,137-164) and the MLP embeds of the decode heads (daformer.py:129-149).
  * dtype 1 = bfloat16, 2 = float16 operands and result, fp32 accumulation.  Row-major, leading dimensions in elements.
  *
- * rfn_gemm_nt:  Y[M,N] = res + rowscale[m / rows_per_sample] * act( X[M,K] . W[N,K]^T + bias[N] )
+ * rfn_gemm_nt:  Y[M,N] = res + rowscale[m / rows_per_sample] * act( X[M,K] . W[N,K]^T + bias[N] )   (res, rowscale, bias: NULL = absent)
  *   forward: X = tokens, W = weight.  dgrad: X = grad_y [T,N], W = weight^T [K,N] (host keeps the transposed copy).
  *   bias / res / rowscale may be NULL (res NULL: Y = act(...); rowscale needs res: the stochastic-depth residual
  *   `x + drop_path(branch)` of mix_transformer.py:203-207 with per-sample keep masks).  act: 0 none, 1 ReLU, 3 LeakyReLU(0.1).
  *   K % 64 == 0, N % 8 == 0, ldx / ldw / ldy % 8 == 0.
- * rfn_gemm_tn:  sum over rows t of slab s of G[t,n] * X[t,k], S = ceil(T / rows_per_slab) slabs computed by separate
+ * rfn_gemm_tn:  sum over rows t of slab s of rowscale[t / rows_per_sample] * G[t,n] * X[t,k] (rowscale may be NULL), S = ceil(T / rows_per_slab) slabs computed by separate
  *   workgroups (the reduction of a weight gradient is the TOKEN dimension: 8 160 ... 259 200 rows for a <= 2048 x 2048
  *   result).  wgrad: G = grad_y [T,N], X = tokens [T,K].
  *     accumulate = 0: P[s][N,K] = fp32 partial of slab s (deterministic; caller reduces);
@@ -272,7 +272,8 @@ int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* 
                     int Wd, int C, int N, int KH, int KW, int stride, int pad, int dil, long ldw, long ldy, int dtype,
                     rfn_stream_t stream);
 int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int rows_per_slab,
-                int accumulate, float* grad_bias, int dtype, rfn_stream_t stream);
+                int accumulate, float* grad_bias, const float* rowscale, int rows_per_sample, int dtype,
+                rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hand-written matrix-core attention for MiT's efficient self-attention (mix_transformer.py:137-164):

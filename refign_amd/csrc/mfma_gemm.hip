@@ -259,9 +259,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
           const int m = m0 + wm * (BM / 2) + j * 32 + row, n = n0 + wn * WN + piece * 8;
           u32x4 o = *(const u32x4*)(stg + row * PITCH + piece * 16);
           if (m < M && n < N) {
-            if (epi.res != nullptr) {
+            if (epi.res != nullptr || epi.rowscale != nullptr) {
               const float rs = epi.rowscale != nullptr ? epi.rowscale[m / epi.rows_per_sample] : 1.f;
-              const u32x4 rr = *(const u32x4*)(epi.res + (long)m * ldy + n);
+              const u32x4 rr = epi.res != nullptr ? *(const u32x4*)(epi.res + (long)m * ldy + n) : u32x4{0u, 0u, 0u, 0u};
               float a[4], b[4], c[4], d[4];
               unpack4<DT>(u32x2{o[0], o[1]}, a);
               unpack4<DT>(u32x2{o[2], o[3]}, b);
@@ -294,7 +294,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
 template <int DT, int BN, int BK>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
                                                       float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
-                                                      int R, int tiles_k, int accumulate, float* __restrict__ gbias) {
+                                                      int R, int tiles_k, int accumulate, float* __restrict__ gbias,
+                                                      const float* __restrict__ rowscale, int rows_per_sample) {
   using E = Elem<DT>;
   constexpr int BT = 32;                   // rows of the reduction per stage (two 16-slot k-steps)
   constexpr int IB = BN / 64, JB = BK / 64;
@@ -328,6 +329,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         greg[u][r] = (tb + 4 * q + r < T) ? *(const unsigned*)(G + (tb + 4 * q + r) * ldg + n0 + 2 * cp) : 0u;
+      if (rowscale != nullptr) {
+        // G <- diag(rowscale[row / rows_per_sample]) G (the stochastic-depth scale of the branch this gradient belongs
+        // to): the two 16-bit values of each row dword, scaled in fp32 and rounded back like the eager g * mask
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long row = tb + 4 * q + r;
+          const float sc = row < T ? rowscale[row / rows_per_sample] : 0.f;
+          float f[4];
+          unpack4<DT>(u32x2{greg[u][r], 0u}, f);
+          greg[u][r] = pack4<DT>(f[0] * sc, f[1] * sc, 0.f, 0.f)[0];
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < XPT; ++u) {
@@ -499,17 +512,17 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
 
 template <int DT>
 static int launch_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int R,
-                     int accumulate, float* gbias, hipStream_t s) {
+                     int accumulate, float* gbias, const float* rowscale, int rps, hipStream_t s) {
   const int S = cdiv(T, R);
   dim3 block(256);
   if (N % 128 == 0 && K % 128 == 0) {
     dim3 grid((unsigned)((N / 128) * (K / 128) * S));
     hipLaunchKernelGGL((gemm_tn_kernel<DT, 128, 128>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias);
+                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps);
   } else {
     dim3 grid((unsigned)((N / 64) * (K / 64) * S));
     hipLaunchKernelGGL((gemm_tn_kernel<DT, 64, 64>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias);
+                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps);
   }
   return check_launch("gemm_tn");
 }
@@ -528,7 +541,7 @@ int rfn_gemm_nt(const void* X, const void* W, const void* bias, const void* res,
   RFN_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldx >= K && ldw >= K && ldy >= N,
               "gemm_nt: leading dimensions must be multiples of 8 elements");
   RFN_REQUIRE(M < (1L << 31) && N < (1L << 31), "gemm_nt: extent");
-  RFN_REQUIRE(rowscale == nullptr || (res != nullptr && rows_per_sample > 0), "gemm_nt: rowscale needs res");
+  RFN_REQUIRE(rowscale == nullptr || rows_per_sample > 0, "gemm_nt: rowscale needs rows_per_sample");
   RFN_REQUIRE(act == 0 || act == 1 || act == 3, "gemm_nt: act (0 none, 1 ReLU, 3 LeakyReLU 0.1)");
   GemmEpi epi{(const uint16_t*)bias, (const uint16_t*)res, rowscale, rows_per_sample > 0 ? rows_per_sample : 1, act};
   hipStream_t s = (hipStream_t)stream;
@@ -563,16 +576,18 @@ int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* 
 }
 
 int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int rows_per_slab,
-                int accumulate, float* grad_bias, int dtype, rfn_stream_t stream) {
+                int accumulate, float* grad_bias, const float* rowscale, int rows_per_sample, int dtype,
+                rfn_stream_t stream) {
   using namespace rfn;
   RFN_REQUIRE(G && X && P, "gemm_tn: null operand");
+  RFN_REQUIRE(rowscale == nullptr || rows_per_sample > 0, "gemm_tn: rowscale needs rows_per_sample");
   RFN_REQUIRE(dtype == 1 || dtype == 2, "gemm_tn: dtype %d", dtype);
   RFN_REQUIRE(T > 0 && T < (1L << 31) && rows_per_slab > 0 && rows_per_slab % 32 == 0,
               "gemm_tn: T=%ld rows_per_slab=%d (%% 32)", T, rows_per_slab);
   RFN_REQUIRE(N % 64 == 0 && K % 64 == 0 && ldg % 2 == 0 && ldx % 2 == 0, "gemm_tn: N=%ld K=%ld (%% 64)", N, K);
   hipStream_t s = (hipStream_t)stream;
-  return dtype == 1 ? launch_tn<1>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, accumulate, grad_bias, s)
-                    : launch_tn<2>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, accumulate, grad_bias, s);
+  return dtype == 1 ? launch_tn<1>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, accumulate, grad_bias, rowscale, rows_per_sample, s)
+                    : launch_tn<2>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, accumulate, grad_bias, rowscale, rows_per_sample, s);
 }
 
 }  // extern "C"

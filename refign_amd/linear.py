@@ -21,6 +21,11 @@ from .params import as_dtype, compute_dtype, grad_sink, linear_gemm, linear_para
 
 
 _FUSED_GRADS = os.environ.get("RFN_LINEAR_FUSED_GRADS", "1") != "0"      # A/B switch (tools)
+# residual + stochastic depth in the proj / fc2 GEMMs under autograd (the gradient-free passes always fuse).  OFF by default:
+# measured on the bench step it is neutral to slightly slower (239.0 / 241.5 vs 237.5 / 240.1 ms per step, same box) --
+# the 410 element-wise launches it removes per step cost what the scaled operand staging of the weight-gradient kernel
+# and the extra epilogue read add to 620 latency-bound GEMM launches.
+_FUSED_RESIDUAL = os.environ.get("RFN_FUSED_RESIDUAL", "0") == "1"
 
 
 def _split(T):
@@ -35,11 +40,23 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, w_c, b_c):
-        ctx.save_for_backward(x, w_c)
+    def forward(ctx, x, weight, bias, w_c, b_c, res=None, rowscale=None):
+        """With `res` (same shape as the output, compute dtype) and optionally `rowscale` ((B,) fp32, one value per
+        leading-dimension sample): y = res + rowscale[b] * (x W^T + b) in the GEMM epilogue -- the stochastic-depth
+        residual of mix_transformer.py:203-207 under autograd.  Backward: the residual's gradient is the incoming one;
+        the branch's gradient diag(rowscale) g is never materialised: the scale rides in the epilogue of the input-
+        gradient GEMM and in the operand staging of the weight-gradient kernel."""
         ctx.weight, ctx.bias = weight, bias
         N, K = w_c.shape
         x2 = x.reshape(-1, K)
+        ctx.rps = x2.shape[0] // x.shape[0] if rowscale is not None else 0
+        if res is not None:
+            ctx.save_for_backward(x, w_c, rowscale)
+            y = mfma.gemm_nt(x2, w_c, b_c, res=res.reshape(-1, N), rowscale=rowscale, rows_per_sample=ctx.rps)
+            if y is None:
+                raise RuntimeError("fused residual Linear: operands outside the MFMA kernel's domain")
+            return y.view(x.shape[:-1] + (N,))
+        ctx.save_for_backward(x, w_c, None)
         y = mfma.gemm_nt(x2, w_c, b_c)                       # hand-written MFMA kernel (16-bit operands)
         if y is None:
             y = linear_gemm(0, w_c, x2, (x2.shape[0], N), b_c, x2.shape[0], N, K) if x2.is_contiguous() else None
@@ -48,9 +65,15 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
-        x, w_c = ctx.saved_tensors
+        x, w_c, rowscale = ctx.saved_tensors
         N, K = w_c.shape
         gx = gw = gb = None
+        g_res = gy if ctx.needs_input_grad[5] else None
+        if rowscale is not None:
+            out = _LinearFn._backward_scaled(ctx, gy, x, w_c, rowscale)
+            if out is not None:
+                return out + (g_res, None)
+            gy = gy * rowscale.to(gy.dtype).view((-1,) + (1,) * (gy.dim() - 1))
         if gy.dtype != w_c.dtype:
             gy = gy.to(w_c.dtype)
         g2 = gy.reshape(-1, N)
@@ -72,7 +95,7 @@ class _LinearFn(torch.autograd.Function):
             x2 = x.reshape(-1, K)
             if sidework.fork(g2.device, lambda: mfma.gemm_tn(g2, x2, out=sink_w, bias_out=sink_b if need_b else None),
                              g2, x2) is not None:
-                return gx, None, None, None, None
+                return gx, None, None, None, None, g_res, None
         if need_w:
             x2 = x.reshape(-1, K)
             T = x2.shape[0]
@@ -90,7 +113,7 @@ class _LinearFn(torch.autograd.Function):
         # both gradients straight into the flat gradient buffer in two launches
         if need_w and need_b and sink_w is not None and sink_b is not None and _FUSED_GRADS and \
                 part.dtype == g2.dtype and linear_param_grads(g2, part, sink_b, sink_w.view(-1)):
-            return gx, None, None, None, None
+            return gx, None, None, None, None, g_res, None
         if need_w:
             if sink_w is not None:
                 sum_rows(part, out=sink_w.view(-1), accumulate=True)
@@ -101,7 +124,37 @@ class _LinearFn(torch.autograd.Function):
                 sum_rows(g2, out=sink_b, accumulate=True)
             else:
                 gb = sum_rows(g2).to(ctx.bias.dtype)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, g_res, None
+
+    @staticmethod
+    def _backward_scaled(ctx, gy, x, w_c, rowscale):
+        """Backward of the branch y = res + diag(rowscale) (x W^T + b) on the kernels that take the scale as an argument;
+        None if one of them declines (the caller then scales the gradient and takes the general path)."""
+        N, K = w_c.shape
+        if not (mfma.ENABLED and w_c.dtype != torch.float32):
+            return None
+        if gy.dtype != w_c.dtype:
+            gy = gy.to(w_c.dtype)
+        g2 = gy.reshape(-1, N)
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        need_w, need_b = ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]
+        sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
+        if (need_w and sink_w is None) or (need_b and sink_b is None) or (need_b and not need_w):
+            return None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype), rowscale=rowscale, rows_per_sample=ctx.rps)
+            if gx is None:
+                return None
+            gx = gx.view(x.shape)
+        if need_w:
+            if mfma.gemm_tn(g2, x.reshape(-1, K), out=sink_w, bias_out=sink_b if need_b else None, rowscale=rowscale,
+                            rows_per_sample=ctx.rps) is None:
+                if gx is not None:
+                    return None                          # (nothing accumulated yet: gemm_tn declined before launching)
+                return None
+        return gx, None, None, None, None
 
 
 def linear_tokens(x2, weight, bias, cd):
@@ -112,7 +165,7 @@ def linear_tokens(x2, weight, bias, cd):
     w_c = w_c.view(w_c.shape[0], -1)
     b_c = as_dtype(bias, cd)
     if torch.is_grad_enabled() and (weight.requires_grad or x2.requires_grad):
-        return _LinearFn.apply(x2, weight, bias, w_c, b_c)
+        return _LinearFn.apply(x2, weight, bias, w_c, b_c, None, None)
     y = mfma.gemm_nt(x2, w_c, b_c)
     return F.linear(x2, w_c, b_c) if y is None else y
 
@@ -130,7 +183,11 @@ class Linear(nn.Linear):
         if x.dtype != cd:
             x = x.to(cd)
         if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
-            y = _LinearFn.apply(x, self.weight, self.bias, w_c, b_c)
+            if res is not None and _FUSED_RESIDUAL and mfma.ENABLED and cd != torch.float32 and res.dtype == cd and \
+                    res.is_contiguous() and x.is_contiguous() and w_c.shape[1] % 64 == 0 and w_c.shape[0] % 64 == 0 and \
+                    grad_sink(self.weight) is not None and (self.bias is None or grad_sink(self.bias) is not None):
+                return _LinearFn.apply(x, self.weight, self.bias, w_c, b_c, res, rowscale)
+            y = _LinearFn.apply(x, self.weight, self.bias, w_c, b_c, None, None)
             return y if res is None else _residual(res, y, rowscale)
         N, K = w_c.shape
         x2 = x.reshape(-1, K)

@@ -37,7 +37,7 @@ def gemm_nt(x, w, bias=None, res=None, rowscale=None, rows_per_sample=0, act=0, 
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     if res is not None and not (res.dtype == x.dtype and res.shape == out.shape and res.stride() == out.stride()):
         return None
-    if rowscale is not None and (res is None or rowscale.dtype != torch.float32 or not rowscale.is_contiguous()):
+    if rowscale is not None and (rows_per_sample <= 0 or rowscale.dtype != torch.float32 or not rowscale.is_contiguous()):
         return None
     lib = _lib.load_library()
     with on_device(x.device):
@@ -101,8 +101,9 @@ def slab_rows(T, tiles):
     return rows
 
 
-def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None):
-    """g[T,N]^T @ x[T,K] with the token dimension split into slabs.  `out` None: returns the fp32 partials (S, N, K)
+def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None, rowscale=None, rows_per_sample=0):
+    """(diag(rowscale) g[T,N])^T @ x[T,K] with the token dimension split into slabs (`rowscale`: fp32, one value per
+    `rows_per_sample` consecutive rows -- the stochastic-depth scale of the branch the gradient g belongs to).  `out` None: returns the fp32 partials (S, N, K)
     (deterministic; sum over S is the result).  `out` (N, K) fp32: every slab is ADDED into it with fp32 atomics (the
     parameter's view of the flat gradient buffer) and `bias_out` (N,) fp32, if given, += the column sums of g.
     None if outside the kernel's domain."""
@@ -113,6 +114,9 @@ def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None):
     T, N = g.shape
     K = x.shape[1]
     if x.shape[0] != T or N % 64 != 0 or K % 64 != 0 or T == 0:
+        return None
+    if rowscale is not None and not (rowscale.dtype == torch.float32 and rowscale.is_contiguous() and rows_per_sample > 0
+                                     and rowscale.numel() * rows_per_sample >= T):
         return None
     if rows_per_slab is None:
         tile = 128 if (N % 128 == 0 and K % 128 == 0) else 64
@@ -129,8 +133,8 @@ def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None):
     lib = _lib.load_library()
     with on_device(g.device):
         rc = lib.rfn_gemm_tn(ptr(g), ptr(x), ptr(part), T, N, K, g.stride(0), x.stride(0), int(rows_per_slab),
-                             0 if out is None else 1, ptr(bias_out) if out is not None else None, _DT16[g.dtype],
-                             current_stream(g.device))
+                             0 if out is None else 1, ptr(bias_out) if out is not None else None, ptr(rowscale),
+                             int(rows_per_sample), _DT16[g.dtype], current_stream(g.device))
     _lib.check(rc, "gemm_tn")
     return part
 

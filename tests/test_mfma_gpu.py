@@ -278,3 +278,40 @@ def test_decode_heads_bf16_kernel_path_matches_fp32_path(dev, monkeypatch):
             e_lib = float((lib[k].float() - ref[k]).abs().max()) / rng
             e_ker = float((ker[k].float() - ref[k]).abs().max()) / rng
             assert e_ker <= 2.0 * e_lib + 0.02, (cls.__name__, k, e_ker, e_lib)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,K,N,scaled", [(4, 300, 64, 256, True), (3, 77, 320, 320, True), (2, 510, 128, 64, False)])
+def test_linear_fused_residual_and_drop_path_under_autograd(dev, dtype, B, T, K, N, scaled, monkeypatch):
+    """linear.Linear(x, res=, rowscale=) WITH gradients: y = res + rowscale[b] (x W^T + b) in the GEMM epilogue; backward
+    through the kernels that take the scale as an argument (input-gradient GEMM epilogue, weight-gradient operand
+    staging, bias gradient) against the fp32 composition: output, d/dx, d/dres, dW, db (16-bit rounding tolerances)."""
+    from refign_amd import linear
+    from refign_amd.linear import Linear
+    from refign_amd.trainer import FlatGradBuffer
+    monkeypatch.setattr(linear, "_FUSED_RESIDUAL", True)              # opt-in path (RFN_FUSED_RESIDUAL=1)
+    torch.manual_seed(1)
+    lin = Linear(K, N).to(dev)
+    buf = FlatGradBuffer(list(lin.parameters()))                      # gradient sinks, as in the trainer
+    x = _rand((B, T, K), dev, dtype, 50).requires_grad_(True)
+    res = _rand((B, T, N), dev, dtype, 51).requires_grad_(True)
+    rs = torch.tensor([0.0, 1.25, 1.25, 0.0][:B], device=dev) if scaled else None
+    gy = _rand((B, T, N), dev, dtype, 52)
+    with torch.autocast("cuda", dtype=dtype):
+        y = lin(x, res=res, rowscale=rs)
+    assert y.dtype == dtype
+    y.backward(gy)
+    xr, rr = x.detach().float().requires_grad_(True), res.detach().float().requires_grad_(True)
+    w, b = lin.weight.detach().clone().requires_grad_(True), lin.bias.detach().clone().requires_grad_(True)
+    br = torch.nn.functional.linear(xr, w, b)
+    yr = rr + (br if rs is None else br * rs.view(-1, 1, 1))
+    yr.backward(gy.float())
+    tol = 0.02
+    assert float((y.float() - yr).abs().max()) <= tol * float(yr.abs().max())
+    assert float((x.grad.float() - xr.grad).abs().max()) <= tol * float(xr.grad.abs().max()) + 1e-6
+    assert float((res.grad.float() - rr.grad).abs().max()) <= tol * float(rr.grad.abs().max())
+    assert float((lin.weight.grad - w.grad).abs().max()) <= tol * float(w.grad.abs().max()) + 1e-6
+    assert float((lin.bias.grad - b.grad).abs().max()) <= tol * float(b.grad.abs().max()) + 1e-6
+    if scaled:                                                        # dropped samples contribute nothing at all
+        assert float(x.grad[0].abs().max()) == 0.0
+    del buf
