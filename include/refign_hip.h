@@ -209,6 +209,11 @@ int rfn_linear_param_grads(const void* grad_y, float* grad_bias, void* workspace
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_multi_cast_chunk_elems(void);
 int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream);
+/* EMA-teacher update of a whole parameter set in ONE launch (models/segmentation_model.py:676-689):
+ * ema <- momentum * ema + (1 - momentum) * live, fp32 in place; table = nchunks x {float* ema, const float* live,
+ * bf16* copy_or_NULL, long n} in device memory (chunks of at most rfn_multi_cast_chunk_elems() elements); where a chunk
+ * has a bf16 copy pointer, the rounded new value is written there in the same pass (the teacher's cached 16-bit weight). */
+int rfn_multi_ema_f32(const void* table, int nchunks, float momentum, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * The three GEMMs of a token-wise nn.Linear (mix_transformer.py: q / kv / proj / fc1 / fc2) on the ROCm library

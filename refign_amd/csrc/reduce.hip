@@ -287,9 +287,51 @@ __global__ __launch_bounds__(256) void multi_cast_f32_bf16_kernel(const CastChun
     c.dst[j] = (unsigned short)f32_to_bf16_bits(c.src[j]);
 }
 
+// EMA of a whole parameter set in one launch (models/segmentation_model.py:676-689: teacher <- m teacher + (1 - m) student)
+// with the bf16 copy of the updated teacher weight written in the same pass where the chunk has one (dst16 != null).
+struct EmaChunk {
+  float* ema;
+  const float* live;
+  unsigned short* dst16;
+  long n;
+};
+
+__global__ __launch_bounds__(256) void multi_ema_kernel(const EmaChunk* __restrict__ table, float m, float one_minus_m) {
+  const EmaChunk c = table[blockIdx.x];
+  const bool aligned = (((size_t)c.ema & 15) == 0) && (((size_t)c.live & 15) == 0) && (((size_t)c.dst16 & 7) == 0);
+  long i = (long)threadIdx.x * 4;
+  if (aligned) {
+    for (; i + 3 < c.n; i += 256 * 4) {
+      float4 e = *reinterpret_cast<const float4*>(c.ema + i);
+      const float4 l = *reinterpret_cast<const float4*>(c.live + i);
+      e.x = e.x * m + l.x * one_minus_m; e.y = e.y * m + l.y * one_minus_m;
+      e.z = e.z * m + l.z * one_minus_m; e.w = e.w * m + l.w * one_minus_m;
+      *reinterpret_cast<float4*>(c.ema + i) = e;
+      if (c.dst16 != nullptr) {
+        uint2 o;
+        o.x = f32_to_bf16_bits(e.x) | (f32_to_bf16_bits(e.y) << 16);
+        o.y = f32_to_bf16_bits(e.z) | (f32_to_bf16_bits(e.w) << 16);
+        *reinterpret_cast<uint2*>(c.dst16 + i) = o;
+      }
+    }
+  }
+  for (long j = aligned ? (c.n & ~3L) + threadIdx.x : threadIdx.x; j < c.n; j += 256) {
+    const float e = c.ema[j] * m + c.live[j] * one_minus_m;
+    c.ema[j] = e;
+    if (c.dst16 != nullptr) c.dst16[j] = (unsigned short)f32_to_bf16_bits(e);
+  }
+}
+
 }  // namespace rfn
 
 extern "C" {
+
+int rfn_multi_ema_f32(const void* table, int nchunks, float momentum, rfn_stream_t stream) {
+  RFN_REQUIRE(table && nchunks > 0, "rfn_multi_ema_f32: empty table");
+  hipLaunchKernelGGL(rfn::multi_ema_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                     (const rfn::EmaChunk*)table, momentum, 1.0f - momentum);
+  return rfn::check_launch("multi_ema_kernel");
+}
 
 int rfn_multi_cast_chunk_elems(void) { return 16384; }
 

@@ -29,19 +29,23 @@ def derived(p, key, fn, refill=None):
         with torch.no_grad():
             t = fn(p.detach())
         cache[key] = ent = (t, p._version, p.data_ptr(), refill)
+        _GENERATION[0] += 1                            # cached refresh plans are stale
     return ent[0]
+
+
+_GENERATION = [0]        # bumped whenever a derived entry is created, replaced or dropped
+_PLANS = {}              # plan key -> what refresh() does for one fixed parameter set (see refresh)
 
 
 def _identity(t):
     return t
 
 
-def refresh(params):
-    """Bring the cached copies of `params` up to date after the parameters were updated in place by something that
-    does not bump their version counters (fused / foreach optimizers, EMA updates through `.data`): copies with a
-    refill view are re-filled with ONE multi-tensor copy, every other derived tensor is dropped and re-made on next
-    use.  Called by an optimizer-step post hook (every torch optimizer) and by update_momentum_encoder."""
-    dst, src = [], []
+def _build_plan(params):
+    """One pass over the parameters' caches: which cached tensors are re-filled from which views of their parameter.
+    The views alias the parameters' storage, so the same (dst, src) lists serve every later refresh of this parameter
+    set for as long as no cache entry is created or dropped and no parameter is re-allocated."""
+    entries, dst, src = [], [], []
     for p in params:
         cache = p.__dict__.get("_rfn_derived")
         if not cache:
@@ -54,57 +58,124 @@ def refresh(params):
                     dst.append(t)
                     src.append(v)
                     cache[key] = (t, p._version, dptr, refill)
+                    entries.append((cache, key, p))
                     continue
             del cache[key]
-    if not dst:
-        return
+            _GENERATION[0] += 1
     # plain fp32 -> bf16 casts of contiguous tensors: ONE launch of the multi-tensor cast kernel (csrc/reduce.hip);
     # torch._foreach_copy_ with a dtype change is one tiny kernel per tensor.  Layout-changing copies stay per tensor.
     fast = [i for i, (d, s_) in enumerate(zip(dst, src))
             if d.is_cuda and d.dtype == torch.bfloat16 and s_.dtype == torch.float32 and d.is_contiguous()
             and s_.is_contiguous() and d.numel() == s_.numel() and d.numel() > 0]
-    with torch.no_grad():
-        if len(fast) >= 4:
-            by_dev = {}
-            for i in fast:
-                by_dev.setdefault(dst[i].device, []).append(i)
-            for dev, idx in by_dev.items():
-                _multi_cast([dst[i] for i in idx], [src[i] for i in idx], dev)
-            skip = set(fast)
-            dst = [d for i, d in enumerate(dst) if i not in skip]
-            src = [s_ for i, s_ in enumerate(src) if i not in skip]
-        if dst:
-            torch._foreach_copy_(dst, src)
+    casts = {}
+    if len(fast) >= 4:
+        for i in fast:
+            casts.setdefault(dst[i].device, []).append(i)
+        skip = set(fast)
+    else:
+        skip = set()
+    return {"entries": entries,
+            # (the tensors are kept next to the table: they own the memory the table points into)
+            "casts": [_cast_table([dst[i] for i in idx], [src[i] for i in idx], dev) + (dev, [dst[i] for i in idx],
+                                                                                         [src[i] for i in idx])
+                      for dev, idx in casts.items()],
+            "rest": ([d for i, d in enumerate(dst) if i not in skip], [s_ for i, s_ in enumerate(src) if i not in skip]),
+            "gen": _GENERATION[0]}
 
 
-_CAST_TABLES = {}
+def _cast_table(dst, src, dev):
+    """Chunk table of the multi-tensor fp32 -> bf16 cast kernel: {src*, dst*, n}, 24 bytes per chunk, built once."""
+    import numpy as np
+    chunk = _lib.load_library().rfn_multi_cast_chunk_elems()
+    rows = []
+    for s_, d in zip(src, dst):
+        n, sp, dp = s_.numel(), s_.data_ptr(), d.data_ptr()
+        rows += [(sp + 4 * off, dp + 2 * off, min(chunk, n - off)) for off in range(0, n, chunk)]
+    return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows)
 
 
-def _multi_cast(dst, src, dev):
-    key = (tuple(t.data_ptr() for t in src), tuple(t.data_ptr() for t in dst), tuple(t.numel() for t in src))
-    ent = _CAST_TABLES.get(key)
-    lib = _lib.load_library()
-    if ent is None:
-        import numpy as np
-        chunk = lib.rfn_multi_cast_chunk_elems()
-        rows = []
-        for s_, d in zip(src, dst):
-            n, sp, dp = s_.numel(), s_.data_ptr(), d.data_ptr()
-            rows += [(sp + 4 * off, dp + 2 * off, min(chunk, n - off)) for off in range(0, n, chunk)]
-        table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)       # {src*, dst*, n}: 24 bytes per chunk
-        if len(_CAST_TABLES) >= 16:
-            _CAST_TABLES.clear()
-        ent = _CAST_TABLES[key] = (table, len(rows))
+def _multi_cast(table, nrows, dev):
     with on_device(dev):
-        rc = lib.rfn_multi_cast_f32_bf16(ptr(ent[0]), ent[1], current_stream(dev))
+        rc = _lib.load_library().rfn_multi_cast_f32_bf16(ptr(table), nrows, current_stream(dev))
     _lib.check(rc, "multi_cast_f32_bf16")
 
 
 def _optimizer_step_post_hook(optimizer, args, kwargs):
-    refresh(p for g in optimizer.param_groups for p in g["params"])
+    refresh((p for g in optimizer.param_groups for p in g["params"]), plan_key=("optimizer", id(optimizer)))
 
 
 register_optimizer_step_post_hook(_optimizer_step_post_hook)
+
+
+def refresh(params, plan_key=None):
+    """Bring the cached copies of `params` up to date after the parameters were updated in place by something that
+    does not bump their version counters (fused / foreach optimizers, EMA updates through `.data`): copies with a
+    refill view are re-filled with ONE multi-tensor cast launch + one multi-tensor copy, every other derived tensor is
+    dropped and re-made on next use.  Called by an optimizer-step post hook (every torch optimizer) and by the EMA
+    update.  `plan_key`: callers that refresh the SAME parameter set every step name it; the (dst, src) lists are then
+    built once (walking 1 000 parameters and building their views costs ~3 ms of host time per call) and reused until
+    a cache entry is created / dropped or a parameter moves."""
+    plan = _PLANS.get(plan_key) if plan_key is not None else None
+    if plan is not None and plan["gen"] == _GENERATION[0]:
+        ents = plan["entries"]
+        # the parameters of a set are updated (and moved) together: the first and the last entry tell whether the
+        # version stamps need a pass and whether the storage is still where the plan's views point
+        probe = [(c.get(k), p) for c, k, p in ((ents[0], ents[-1]) if ents else ())]
+        if any(e is None or e[2] != p.data_ptr() for e, p in probe):
+            plan = None                                # parameter re-allocated or entry gone: rebuild
+        elif any(e[1] != p._version for e, p in probe):
+            for cache, key, p in ents:
+                ent = cache.get(key)
+                if ent is not None and ent[1] != p._version:
+                    cache[key] = (ent[0], p._version, ent[2], ent[3])
+    else:
+        plan = None
+    if plan is None:
+        plan = _build_plan(list(params))
+        if plan_key is not None:
+            if len(_PLANS) >= 8:
+                _PLANS.clear()
+            _PLANS[plan_key] = plan
+    with torch.no_grad():
+        for table, nrows, dev, _, _ in plan["casts"]:
+            _multi_cast(table, nrows, dev)
+        if plan["rest"][0]:
+            torch._foreach_copy_(*plan["rest"])
+
+
+_EMA_TABLES = {}
+
+
+def ema_update(ema_params, live_params, momentum, plan_key):
+    """ema <- momentum * ema + (1 - momentum) * live over two aligned parameter lists (segmentation_model.py:676-689) as
+    ONE kernel launch (csrc/reduce.hip: rfn_multi_ema_f32) from a chunk table that is built once per parameter set,
+    then refresh() of the teacher's cached copies.  Falls back to two multi-tensor torch ops off the GPU."""
+    ema_params, live_params = list(ema_params), list(live_params)
+    if not ema_params:
+        return
+    dev = ema_params[0].device
+    if dev.type == "cuda" and all(p.dtype == torch.float32 and p.is_contiguous() for p in ema_params + live_params):
+        sig = (len(ema_params), ema_params[0].data_ptr(), ema_params[-1].data_ptr(), live_params[0].data_ptr(),
+               live_params[-1].data_ptr())
+        ent = _EMA_TABLES.get(plan_key)
+        lib = _lib.load_library()
+        if ent is None or ent[0] != sig:
+            import numpy as np
+            chunk = lib.rfn_multi_cast_chunk_elems()
+            rows = []
+            for e, l_ in zip(ema_params, live_params):
+                n, ep, lp = e.numel(), e.data_ptr(), l_.data_ptr()
+                rows += [(ep + 4 * off, lp + 4 * off, 0, min(chunk, n - off)) for off in range(0, n, chunk)]
+            table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+            ent = _EMA_TABLES[plan_key] = (sig, table, len(rows))
+        with on_device(dev):
+            rc = lib.rfn_multi_ema_f32(ptr(ent[1]), ent[2], float(momentum), current_stream(dev))
+        _lib.check(rc, "multi_ema_f32")
+    else:
+        ema, live = [p.data for p in ema_params], [p.data for p in live_params]
+        torch._foreach_mul_(ema, momentum)
+        torch._foreach_add_(ema, live, alpha=1.0 - momentum)
+    refresh(ema_params, plan_key=plan_key)
 
 
 def as_dtype(p, dtype):

@@ -33,7 +33,7 @@ from . import refine as refine_mod
 from . import sidework
 from ._tensor import const_tensor, upload_async
 from .graphs import GraphedNoGrad, GraphedStep
-from .params import refresh as refresh_derived
+from .params import ema_update
 from .config import instantiate_class
 from .seg import DeviceBox, draw_crop_offsets, hrda_backbone, hrda_head, predraw_crop, push_device_crop
 
@@ -766,11 +766,12 @@ class DomainAdaptationSegmentationModel(nn.Module):
     @torch.no_grad()
     def update_momentum_encoder(self):
         m = min(1.0 - 1 / (float(self.global_step) + 1.0), self.ema_momentum)
-        ema = [p.data for p in self.ema_parameters()]
-        live = [p.data for p in self.live_parameters()]
-        torch._foreach_mul_(ema, m)                   # one multi-tensor launch per op instead of ~1090 x 3
-        torch._foreach_add_(ema, live, alpha=1.0 - m)
-        refresh_derived(self.ema_parameters())        # cached bf16 copies of the teacher weights (params.py)
+        # ONE kernel launch for the ~1090 parameter tensors (csrc/reduce.hip) + the refresh of the teacher's cached 16-bit /
+        # packed weight copies from a plan built once (params.py)
+        lists = self.__dict__.get("_ema_lists")
+        if lists is None:                             # the parameter objects never change: walk the module tree once
+            lists = self.__dict__["_ema_lists"] = (list(self.ema_parameters()), list(self.live_parameters()))
+        ema_update(lists[0], lists[1], m, plan_key=("ema", id(self)))
 
     def train(self, mode=True):
         """(:691-701) alignment nets and the ImageNet encoder always in eval; the reference's attempt to disable
