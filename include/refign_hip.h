@@ -315,6 +315,8 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
  * Training-mode BatchNorm2d (+ ReLU) on channels-last 16-bit tensors viewed as (T = B*H*W, C): the norm + activation of
  * the decode heads' ConvBNReLU blocks (models/modules.py:16-56), which use BATCH statistics in the student and in the EMA
  * teacher.  dtype 1 = bf16, 2 = f16; statistics, affine parameters and running buffers fp32; C % 8 == 0.
+ * `relu`: activation after the affine map, 0 none, 1 ReLU, 3 LeakyReLU(0.1) (the codes of rfn_gemm_nt; the flow decoders
+ * of the matcher use LeakyReLU, models/modules.py:395-477).
  * Statistics buffer `sums`: 2 C + 1 floats = (sum x, sum x^2, number of rows); the apply passes normalise with the row
  * count they find THERE, so a SUM all-reduce of the buffer between a stats pass and an apply pass turns batch statistics
  * into cross-replica ones -- SyncBatchNorm (torch/nn/modules/_functions.py:SyncBatchNorm; the reference trains with

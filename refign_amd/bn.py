@@ -51,7 +51,7 @@ def _apply_fwd(xh, weight, bias, y, sums, bn, relu):
     with on_device(xh.device):
         _lib.check(_lib.load_library().rfn_bn_apply_fwd(ptr(xh), ptr(weight), ptr(bias), ptr(y), ptr(sums),
                                                         ptr(bn.running_mean), ptr(bn.running_var), T, C, float(bn.eps),
-                                                        float(bn.momentum), 1 if relu else 0, _DT16[xh.dtype],
+                                                        float(bn.momentum), int(relu), _DT16[xh.dtype],
                                                         current_stream(xh.device)), "bn_apply_fwd")
 
 
@@ -59,7 +59,7 @@ def _stats_bwd(xh, gy, sums, weight, bias, bsums, eps, relu):
     T, C = xh.numel() // xh.shape[-1], xh.shape[-1]
     with on_device(xh.device):
         _lib.check(_lib.load_library().rfn_bn_stats_bwd(ptr(xh), ptr(gy), ptr(sums), ptr(weight), ptr(bias), ptr(bsums), T, C,
-                                                        eps, 1 if relu else 0, _DT16[xh.dtype], current_stream(xh.device)),
+                                                        eps, int(relu), _DT16[xh.dtype], current_stream(xh.device)),
                    "bn_stats_bwd")
 
 
@@ -67,7 +67,7 @@ def _apply_bwd(xh, gy, sums, bsums, weight, bias, gx, eps, relu):
     T, C = xh.numel() // xh.shape[-1], xh.shape[-1]
     with on_device(xh.device):
         _lib.check(_lib.load_library().rfn_bn_apply_bwd(ptr(xh), ptr(gy), ptr(sums), ptr(bsums), ptr(weight), ptr(bias),
-                                                        ptr(gx), T, C, eps, 1 if relu else 0, _DT16[xh.dtype],
+                                                        ptr(gx), T, C, eps, int(relu), _DT16[xh.dtype],
                                                         current_stream(xh.device)), "bn_apply_bwd")
 
 
@@ -121,7 +121,8 @@ class _BNActTrain(torch.autograd.Function):
 
 
 def bn_act_train(x, bn, relu, dtype):
-    """relu?(bn(x)) with batch statistics; x NCHW-shaped (any memory format, converted to channels-last 16-bit if it is
+    """act(bn(x)) with batch statistics, `relu`: False / 0 none, True / 1 ReLU, 3 LeakyReLU(0.1) (the activation codes of
+    the GEMM entry points); x NCHW-shaped (any memory format, converted to channels-last 16-bit if it is
     not already); returns an NCHW-shaped channels-last tensor."""
     xh = x.permute(0, 2, 3, 1)
     if xh.dtype != dtype:

@@ -52,7 +52,7 @@ template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ g,
                                                        const float* __restrict__ fwd_sums, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ sums, long T,
-                                                       int C, int cvb, float eps, int relu) {
+                                                       int C, int cvb, float eps, int relu, float slope) {
   __shared__ float red[2][256][8];
   const int CV = C / 8, pl = 256 / cvb;
   const int cv = blockIdx.x * cvb + threadIdx.x % cvb, rl = threadIdx.x / cvb;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
         for (int i = 0; i < 8; ++i) {
           const float xh = (xv[i] - mean[i]) * a[i];
           const float z = xh * b[i] + (beta ? beta[c0 + i] : 0.f);
-          const float gp = (relu && z <= 0.f) ? 0.f : gv[i];
+          const float gp = (relu && z <= 0.f) ? slope * gv[i] : gv[i];
           s0[i] += gp;
           s1[i] += gp * xh;
         }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        uint16_t* __restrict__ out, float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, long T, int C, int cvb, float eps,
-                                                       float momentum, int relu) {
+                                                       float momentum, int relu, float slope) {
   const int CV = C / 8, pl = 256 / cvb;
   const int cv = blockIdx.x * cvb + threadIdx.x % cvb, rl = threadIdx.x / cvb;
   const float cnt = fwd_sums[2 * C];                   // rows behind the statistics (all ranks')
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float z = (xv[i] - mean[i]) * rstd[i] * gm[i] + bt[i];
-        o[i] = relu ? fmaxf(z, 0.f) : z;
+        o[i] = (relu && z <= 0.f) ? slope * z : z;
       }
     } else {
       float gv[8];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
       for (int i = 0; i < 8; ++i) {
         const float xh = (xv[i] - mean[i]) * rstd[i];
         const float z = xh * gm[i] + bt[i];
-        const float gp = (relu && z <= 0.f) ? 0.f : gv[i];
+        const float gp = (relu && z <= 0.f) ? slope * gv[i] : gv[i];
         o[i] = gm[i] * rstd[i] * (gp - k0[i] - xh * k1[i]);
       }
     }
@@ -174,24 +174,24 @@ static inline int bn_cvb(int CV) { return CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV >
 template <int DT>
 static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const float* fwd_sums, float* sums_or_bwd,
                      const float* gamma, const float* beta, void* out, float* rmean, float* rvar, long T, int C, float eps,
-                     float momentum, int relu, hipStream_t s) {
+                     float momentum, int relu, float slope, hipStream_t s) {
   const int CV = C / 8, cvb = bn_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(T, (long)pl * 4), (256L * 8) / gx));
   dim3 grid(gx, gy), block(256);
   if (!apply) {
     if (bwd)
       hipLaunchKernelGGL((bn_stats_kernel<DT, true>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)g, fwd_sums,
-                         gamma, beta, sums_or_bwd, T, C, cvb, eps, relu);
+                         gamma, beta, sums_or_bwd, T, C, cvb, eps, relu, slope);
     else
       hipLaunchKernelGGL((bn_stats_kernel<DT, false>), grid, block, 0, s, (const uint16_t*)x, nullptr, nullptr, nullptr,
-                         nullptr, sums_or_bwd, T, C, cvb, eps, relu);
+                         nullptr, sums_or_bwd, T, C, cvb, eps, relu, slope);
   } else {
     if (bwd)
       hipLaunchKernelGGL((bn_apply_kernel<DT, true>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)g, fwd_sums,
-                         sums_or_bwd, gamma, beta, (uint16_t*)out, nullptr, nullptr, T, C, cvb, eps, momentum, relu);
+                         sums_or_bwd, gamma, beta, (uint16_t*)out, nullptr, nullptr, T, C, cvb, eps, momentum, relu, slope);
     else
       hipLaunchKernelGGL((bn_apply_kernel<DT, false>), grid, block, 0, s, (const uint16_t*)x, nullptr, fwd_sums, nullptr,
-                         gamma, beta, (uint16_t*)out, rmean, rvar, T, C, cvb, eps, momentum, relu);
+                         gamma, beta, (uint16_t*)out, rmean, rvar, T, C, cvb, eps, momentum, relu, slope);
   }
   return check_launch("bn kernel");
 }
@@ -202,6 +202,9 @@ extern "C" {
 using namespace rfn;
 
 #define RFN_BN_DISPATCH(...) (dtype == 1 ? bn_launch<1>(__VA_ARGS__) : bn_launch<2>(__VA_ARGS__))
+
+// activation code of the entry points (as rfn_gemm_nt): 0 none, 1 ReLU, 3 LeakyReLU(0.1)
+static inline float bn_slope(int act) { return act == 3 ? 0.1f : 0.f; }
 
 static int bn_check(const char* what, long T, int C, int dtype) {
   RFN_REQUIRE(T >= 1 && C > 0 && C % 8 == 0, "%s: T=%ld C=%d (C %% 8)", what, T, C);
@@ -214,15 +217,15 @@ int rfn_bn_stats_fwd(const void* x, float* sums, long T, int C, int dtype, rfn_s
   if (int rc = bn_check("bn_stats_fwd", T, C, dtype)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, (2 * (size_t)C + 1) * sizeof(float), s) != hipSuccess) return fail(RFN_ELAUNCH, "bn_stats_fwd: memset");
-  return RFN_BN_DISPATCH(false, false, x, nullptr, nullptr, sums, nullptr, nullptr, nullptr, nullptr, nullptr, T, C, 0.f, 0.f, 0, s);
+  return RFN_BN_DISPATCH(false, false, x, nullptr, nullptr, sums, nullptr, nullptr, nullptr, nullptr, nullptr, T, C, 0.f, 0.f, 0, 0.f, s);
 }
 
 int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* running_mean,
                      float* running_var, long T, int C, float eps, float momentum, int relu, int dtype, rfn_stream_t stream) {
   RFN_REQUIRE(x && y && sums, "bn_apply_fwd: null pointer");
   if (int rc = bn_check("bn_apply_fwd", T, C, dtype)) return rc;
-  return RFN_BN_DISPATCH(false, true, x, nullptr, sums, nullptr, gamma, beta, y, running_mean, running_var, T, C, eps, momentum, relu,
-                         (hipStream_t)stream);
+  return RFN_BN_DISPATCH(false, true, x, nullptr, sums, nullptr, gamma, beta, y, running_mean, running_var, T, C, eps, momentum,
+                         relu != 0, bn_slope(relu), (hipStream_t)stream);
 }
 
 int rfn_bn_stats_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
@@ -231,7 +234,7 @@ int rfn_bn_stats_bwd(const void* x, const void* grad_y, const float* fwd_sums, c
   if (int rc = bn_check("bn_stats_bwd", T, C, dtype)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(bwd_sums, 0, 2 * (size_t)C * sizeof(float), s) != hipSuccess) return fail(RFN_ELAUNCH, "bn_stats_bwd: memset");
-  return RFN_BN_DISPATCH(true, false, x, grad_y, fwd_sums, bwd_sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, 0.f, relu, s);
+  return RFN_BN_DISPATCH(true, false, x, grad_y, fwd_sums, bwd_sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, 0.f, relu != 0, bn_slope(relu), s);
 }
 
 int rfn_bn_apply_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* bwd_sums, const float* gamma,
@@ -239,7 +242,7 @@ int rfn_bn_apply_bwd(const void* x, const void* grad_y, const float* fwd_sums, c
   RFN_REQUIRE(x && grad_y && fwd_sums && bwd_sums && grad_x, "bn_apply_bwd: null pointer");
   if (int rc = bn_check("bn_apply_bwd", T, C, dtype)) return rc;
   return RFN_BN_DISPATCH(true, true, x, grad_y, fwd_sums, const_cast<float*>(bwd_sums), gamma, beta, grad_x, nullptr, nullptr, T, C, eps,
-                         0.f, relu, (hipStream_t)stream);
+                         0.f, relu != 0, bn_slope(relu), (hipStream_t)stream);
 }
 
 // one rank: stats + apply back to back (`sums`: 2 C + 1 floats)

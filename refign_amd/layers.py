@@ -131,7 +131,8 @@ class ConvBNReLU(nn.Module):
         if self.use_norm and not self.training and not torch.is_grad_enabled():
             x = self._conv2d(x, *self.folded())
         else:
-            if x.is_cuda and self.use_norm and self.training and self.act in (None, 'relu') and \
+            if x.is_cuda and self.use_norm and self.training and \
+                    (self.act in (None, 'relu') or (self.act == 'leaky' and self.act_slope == LEAKY_SLOPE)) and \
                     os.environ.get("RFN_BN_KERNEL", "1") != "0":
                 # decode heads (student and EMA teacher run BatchNorm with batch statistics): convolution on the
                 # hand-written kernels where they exist for the pass, then ONE fused BatchNorm(train) + ReLU (csrc/bn.hip)
@@ -139,7 +140,7 @@ class ConvBNReLU(nn.Module):
                 from .params import compute_dtype
                 cd = compute_dtype(x)
                 if bnk.usable(x, self.bn, cd):
-                    return bnk.bn_act_train(self._conv_train(x, cd), self.bn, self.act == 'relu', cd)
+                    return bnk.bn_act_train(self._conv_train(x, cd), self.bn, {None: 0, 'relu': 1, 'leaky': 3}[self.act], cd)
             x = self._conv2d(x, c.weight, c.bias)
             if self.use_norm:
                 x = self.bn(x)

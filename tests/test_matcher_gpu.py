@@ -174,3 +174,22 @@ def test_matcher_trains(dev):
         vals.append(float(model.logged["train_ss_loss"]))
         assert np.isfinite(vals[-1])
     assert vals[-1] < vals[0]
+
+
+def test_matcher_step_under_fp16_autocast_is_bounded(dev):
+    """The reference's recipe for matcher training is --trainer.precision 16 (README.md:289-294): decoders under fp16
+    autocast (library convolutions, hand-written BatchNorm + LeakyReLU kernels), correlation / warp / losses in fp32.
+    One step in that mode against the fp32 golden step: both losses within 2 %, gradient norms of the flow decoders
+    within 15 % (fp16 activations through four pyramid levels and three head passes)."""
+    z = golden("matcher_step_128x160")
+    model = build_matcher(dev)
+    batch = matcher_batch(z, dev)
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = model.training_step(batch, 0)
+    loss.backward()
+    assert abs(float(model.logged["train_ss_loss"]) - float(z["ss_loss"])) <= 0.02 * float(z["ss_loss"])
+    assert abs(float(model.logged["train_us_loss"]) - float(z["us_loss"])) <= 0.02 * float(z["us_loss"])
+    for name in ("decoder4", "decoder3", "decoder2", "decoder1"):
+        g = [p.grad for p in getattr(model.alignment_head, name).parameters() if p.grad is not None]
+        norm = float(torch.sqrt(sum((x.double() ** 2).sum() for x in g)))
+        assert abs(norm - float(z["gradnorm/" + name])) <= 0.15 * float(z["gradnorm/" + name]), (name, norm)

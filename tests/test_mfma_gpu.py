@@ -211,7 +211,8 @@ def test_linear_module_uses_mfma_kernels(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,C,H,W,relu", [(2, 256, 17, 23, True), (4, 64, 9, 5, False), (1, 1024, 12, 20, True)])
+@pytest.mark.parametrize("B,C,H,W,relu", [(2, 256, 17, 23, True), (4, 64, 9, 5, False), (1, 1024, 12, 20, True),
+                                          (2, 96, 33, 31, 3), (3, 32, 8, 8, 3)])
 def test_batchnorm_relu_train_kernels(dev, dtype, B, C, H, W, relu):
     """csrc/bn.hip against fp32 nn.BatchNorm2d(train) [+ ReLU] on the same 16-bit input: output, input gradient, affine
     gradients, running statistics (unbiased variance, momentum 0.1) and num_batches_tracked."""
@@ -229,7 +230,7 @@ def test_batchnorm_relu_train_kernels(dev, dtype, B, C, H, W, relu):
     y.backward(g)
     xr = x.detach().float().requires_grad_(True)
     yr = ref(xr)
-    yr = torch.relu(yr) if relu else yr
+    yr = torch.nn.functional.leaky_relu(yr, 0.1) if relu == 3 else (torch.relu(yr) if relu else yr)   # 3 = LeakyReLU(0.1)
     yr.backward(g.float())
     e = EPS[dtype]
     assert float((y.float() - yr).abs().max()) <= 4 * e * float(yr.abs().max()) + 1e-3

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--b", type=int, default=6)
     ap.add_argument("--size", type=int, default=520)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+                    help="fp16 = the reference's recipe for matcher training (README.md:289-294: --trainer.precision 16): "
+                         "fp16 autocast + loss scaling, correlation / warp / losses in fp32")
     ap.add_argument("--tune", default="", help="directory: run MIOpen's find for every convolution problem of the step "
                                               "(minutes) and leave the user find-db there")
     args = ap.parse_args()
@@ -63,11 +66,16 @@ def main():
         srcs = torch.stack([(batch["image_ref"], batch["image_trg"])[k][i] for i, k in enumerate(batch["prime_trg_idx"])])
         batch["image_prime"] = warp(srcs, batch["flow_prime"])
 
+    amp = args.precision == "fp16"
+    scaler = torch.amp.GradScaler("cuda", enabled=amp)
+
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = model.training_step(batch, 0)
-        loss.backward()
-        opt.step()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            loss = model.training_step(batch, 0)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
         sch["scheduler"].step()
         return loss
 
@@ -79,7 +87,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f"matcher training step b={b} {S}x{S}: {dt * 1e3:.1f} ms/step, {b / dt:.2f} image-triplets/s, "
+    print(f"matcher training step b={b} {S}x{S} {args.precision}: {dt * 1e3:.1f} ms/step, {b / dt:.2f} image-triplets/s, "
           f"loss {float(loss):.3f}, max mem {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
 
 

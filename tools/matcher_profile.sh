@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 R=$PWD
-timeout 600 python tools/matcher_bench.py 2>&1 | grep -v "MIOpen\|amdgpu.ids" | tail -3
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_m -o m --output-format csv -- python $R/tools/matcher_bench.py --steps 5 --warmup 2 > /tmp/m.log 2>&1
+timeout 600 python tools/matcher_bench.py $MB_ARGS 2>&1 | grep -v "MIOpen\|amdgpu.ids" | tail -3
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_m -o m --output-format csv -- python $R/tools/matcher_bench.py --steps 5 --warmup 2 $MB_ARGS > /tmp/m.log 2>&1
 python - "$(find /tmp/prof_m -name '*kernel_stats.csv' | head -1)" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
