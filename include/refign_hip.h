@@ -119,6 +119,14 @@ int rfn_refine_f32(const float* logits_trg, const float* logits_ref, const unsig
                    const float* certs, float* out, void* workspace, int B, int C, int H, int W, float gamma,
                    int flags, rfn_stream_t stream);
 
+/* Majority label per scale x scale window (models/segmentation_model.py:637-668, downscale_label_ratio -- the labels the
+ * ImageNet feature-distance loss is masked with): gt (B,H,W) int64 -> out (B, ceil(H/scale), ceil(W/scale)) int64 = the
+ * most frequent class of the window (smallest index among equals), or ignore_index when that is the ignore label or its
+ * share of the window is below min_ratio.  Edge windows are partial (share = count / pixels inside the image).
+ * n_classes <= 32. */
+int rfn_label_majority(const long* gt, long* out, int B, int H, int W, int scale, int n_classes, int ignore_index,
+                       float min_ratio, rfn_stream_t stream);
+
 /* Tail of align() (segmentation_model.py:514-522) fused: bilinear (align_corners=False) upsampling of the
  * quarter-resolution flow (B,2,h,w) and log-variance (B,1,h,w) to (H,W), confidence
  * P_R = 1 - exp(-1/(2 exp(logvar))) (matching_utils.py:52-57), and warp of logits_ref (B,C,H,W) with the

@@ -123,6 +123,44 @@ __global__ __launch_bounds__(256) void refine_blend_kernel(const float* __restri
   }
 }
 
+// Majority label of every scale x scale window with its share (models/segmentation_model.py:637-668,
+// downscale_label_ratio: one-hot -> avg_pool2d -> max over classes): out = the most frequent class of the window (the
+// smallest index among equals, as torch.max), or `ignore` when that class is the ignore bin or covers less than
+// min_ratio of the window.  Windows at the bottom / right edge may be partial (avg_pool2d ceil_mode: the divisor is the
+// number of pixels inside the image).  One wave per window, histogram in registers via ballot.
+__global__ __launch_bounds__(64) void label_majority_kernel(const long* __restrict__ gt, long* __restrict__ out, int H,
+                                                            int W, int oh, int ow, int scale, int n_classes, int ignore,
+                                                            float min_ratio) {
+  const int cell = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const int cy = cell / ow, cx = cell % ow;
+  const int y0 = cy * scale, x0 = cx * scale;
+  const int hh = min(scale, H - y0), ww = min(scale, W - x0);
+  const long* g = gt + (size_t)n * H * W;
+  const int nb = n_classes + 1;                        // bin n_classes = ignore
+  int cnt[33];
+#pragma unroll
+  for (int c = 0; c < 33; ++c) cnt[c] = 0;
+  for (int i = lane; i < hh * ww; i += 64) {
+    const int y = y0 + i / ww, x = x0 + i % ww;
+    long v = g[(size_t)y * W + x];
+    const int bin = (v == ignore) ? n_classes : (int)v;
+#pragma unroll
+    for (int c = 0; c < 33; ++c) cnt[c] += (c < nb && bin == c) ? 1 : 0;
+  }
+  int best = 0, bestc = -1;
+#pragma unroll
+  for (int c = 0; c < 33; ++c) {
+    int t = cnt[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (c < nb && t > bestc) { bestc = t; best = c; }
+  }
+  if (lane == 0) {
+    const float ratio = (float)bestc / (float)(hh * ww);
+    out[((size_t)n * oh + cy) * ow + cx] = (best == n_classes || ratio < min_ratio) ? (long)ignore : (long)best;
+  }
+}
+
 }  // namespace rfn
 
 using namespace rfn;
@@ -145,6 +183,17 @@ int rfn_refine_f32(const float* logits_trg, const float* logits_ref, const unsig
   hipLaunchKernelGGL(refine_blend_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, st, logits_trg, logits_ref,
                      warp_mask, certs, out, (const double*)workspace, HW, gamma, flags);
   return check_launch("refine_blend_kernel");
+}
+
+int rfn_label_majority(const long* gt, long* out, int B, int H, int W, int scale, int n_classes, int ignore_index,
+                       float min_ratio, rfn_stream_t stream) {
+  RFN_REQUIRE(gt && out, "rfn_label_majority: null pointer");
+  RFN_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && scale > 1 && n_classes > 0 && n_classes <= 32,
+              "rfn_label_majority: B=%d H=%d W=%d scale=%d classes=%d (<= 32)", B, H, W, scale, n_classes);
+  const int oh = rfn::cdiv(H, scale), ow = rfn::cdiv(W, scale);
+  hipLaunchKernelGGL(rfn::label_majority_kernel, dim3(oh * ow, B), dim3(64), 0, (hipStream_t)stream, gt, out, H, W, oh, ow,
+                     scale, n_classes, ignore_index, min_ratio);
+  return rfn::check_launch("label_majority_kernel");
 }
 
 }  // extern "C"

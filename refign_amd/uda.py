@@ -718,6 +718,19 @@ class DomainAdaptationSegmentationModel(nn.Module):
         assert scale_factor > 1
         b, c, H, W = gt.shape
         assert c == 1
+        oh, ow = -(-H // scale_factor), -(-W // scale_factor)
+        if gt.is_cuda and gt.dtype == torch.long and n_classes <= 32 and gt.is_contiguous() and \
+                (out_size is None or tuple(out_size) == (oh, ow)) and \
+                (out_size is not None or (H % scale_factor == 0 and W % scale_factor == 0)):
+            # one kernel instead of a 330 MB one-hot tensor, a pooling pass and a max (csrc/refine.hip)
+            from . import _lib
+            from ._tensor import current_stream, on_device, ptr
+            out = torch.empty((b, 1, oh, ow), dtype=torch.long, device=gt.device)
+            with on_device(gt.device):
+                rc = _lib.load_library().rfn_label_majority(ptr(gt), ptr(out), b, H, W, int(scale_factor), int(n_classes),
+                                                            int(ignore_index), float(min_ratio), current_stream(gt.device))
+            _lib.check(rc, "label_majority")
+            return out
         out = gt.clone()
         out[out == ignore_index] = n_classes
         # one-hot directly in contiguous NCHW (the reference's F.one_hot(...).permute(...) is a channels-last int64

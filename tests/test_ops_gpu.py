@@ -330,3 +330,24 @@ def test_corr9_matrix_pipe_variants_match_fp64_formulation(cfg):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "worst" in r.stdout and " OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,scale,minr", [(64, 96, 32, 0.75), (1080 // 4, 1920 // 4, 32, 0.75), (40, 56, 8, 0.5),
+                                            (33, 47, 16, 0.3)])
+def test_label_majority_kernel_matches_one_hot_pooling(H, W, scale, minr):
+    """rfn_label_majority (the mask labels of the ImageNet feature-distance loss) == the reference's one-hot ->
+    avg_pool2d -> max formulation (segmentation_model.py:637-668), exactly: random labels with ignore pixels, constant
+    blocks (ties between equal counts resolve to the smallest class), partial windows at the bottom / right edge."""
+    from refign_amd.uda import DomainAdaptationSegmentationModel as M
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * W)
+    gt = torch.randint(0, 19, (2, 1, H, W), generator=g)
+    gt[:, :, : H // 2, : W // 2] = torch.randint(0, 19, (2, 1, 1, 1), generator=g)      # large constant regions
+    gt[:, :, ::2, W // 2:] = 3                                                          # exact 50 % ties with noise rows
+    gt[torch.rand(2, 1, H, W, generator=g) < 0.1] = 255
+    oh, ow = -(-H // scale), -(-W // scale)
+    want = M.downscale_label_ratio(gt, scale, minr, 19, out_size=(oh, ow))             # CPU: the tensor formulation
+    got = M.downscale_label_ratio(gt.to(dev), scale, minr, 19, out_size=(oh, ow))
+    assert got.device.type == "cuda" and tuple(got.shape) == (2, 1, oh, ow)
+    assert torch.equal(got.cpu(), want)
