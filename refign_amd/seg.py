@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import linear as _linear
 from . import mfma
 from ._tensor import const_tensor
 from .align import BaseHead
@@ -214,15 +215,15 @@ class Block(nn.Module):
             x = self.attn(self.norm1(x), H, W, res=x, rowscale=None if masks32 is None else masks32[0])
             return self.mlp(self.norm2(x), H, W, res=x, rowscale=None if masks32 is None else masks32[1])
         if masks is not None:                       # pre-drawn stochastic-depth masks (MixVisionTransformer)
-            if x.is_cuda and masks32 is not None:
-                # training: the same fusion under autograd (linear._LinearFn: residual + per-sample scale in the proj /
+            if x.is_cuda and masks32 is not None and _linear._FUSED_RESIDUAL:
+                # training (opt-in, RFN_FUSED_RESIDUAL=1: measured neutral): the same fusion under autograd (linear._LinearFn: residual + per-sample scale in the proj /
                 # fc2 GEMM epilogue; in the backward the scale rides in the input- and weight-gradient kernels)
                 x = self.attn(self.norm1(x), H, W, res=x, rowscale=masks32[0])
                 return self.mlp(self.norm2(x), H, W, res=x, rowscale=masks32[1])
             x = torch.addcmul(x, self.attn(self.norm1(x), H, W), masks[0])
             return torch.addcmul(x, self.mlp(self.norm2(x), H, W), masks[1])
         dp = self.drop_path
-        if x.is_cuda and not (self.training and isinstance(dp, DropPath) and dp.drop_prob > 0.):
+        if x.is_cuda and _linear._FUSED_RESIDUAL and not (self.training and isinstance(dp, DropPath) and dp.drop_prob > 0.):
             x = self.attn(self.norm1(x), H, W, res=x)
             return self.mlp(self.norm2(x), H, W, res=x)
         res = dp.residual if isinstance(dp, DropPath) else torch.add
