@@ -176,9 +176,16 @@ class UncertaintyModule(nn.Module):
             c = y.shape[1]
             return y.view(b, c, h, k + 2, w, k + 2)[:, :, :, :k, :, :k].reshape(b, c, k * h, k * w)
 
+        from . import bn as bnk
+        from .params import compute_dtype
         x = corr.view(b, 9, 9, h, w).permute(0, 3, 1, 4, 2).reshape(b, 1, 9 * h, 9 * w)
         for m, k in ((self.conv_0, 7), (self.conv_1, 5), (self.conv_2, 3)):
             x = retile(F.conv2d(x, m.conv.weight, m.conv.bias), k)
+            cd = compute_dtype(x)
+            if m.use_norm and m.act == 'leaky' and m.act_slope == LEAKY_SLOPE and x.is_cuda and \
+                    os.environ.get("RFN_BN_KERNEL", "1") != "0" and bnk.usable(x, m.bn, cd):
+                x = bnk.bn_act_train(x, m.bn, 3, cd)         # BatchNorm(train) + LeakyReLU in two passes (csrc/bn.hip)
+                continue
             if m.use_norm:
                 x = m.bn(x)
             x = F.leaky_relu(x, m.act_slope, inplace=True) if m.act == 'leaky' else F.relu(x, inplace=True)
