@@ -281,12 +281,15 @@ class RefignAlignRefine(RefignStep):
 
 def pmc_traffic():
     """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md; separate passes) -- profiles/r01_pmc_traffic_corr9.json; null if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_corr9.json")) as f:
-            return int(json.load(f)["hbm_traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    MI355X_MICROARCH.md; separate passes) -- the latest profiles/rNN_pmc_traffic_corr9.json; null if absent."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_corr9.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return int(json.load(f)["hbm_traffic_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
 
 
 WORKLOADS = {AlignRefineKernels.name: AlignRefineKernels, RefignStep.name: RefignStep,
