@@ -222,6 +222,12 @@ int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream)
  * bf16* copy_or_NULL, long n} in device memory (chunks of at most rfn_multi_cast_chunk_elems() elements); where a chunk
  * has a bf16 copy pointer, the rounded new value is written there in the same pass (the teacher's cached 16-bit weight). */
 int rfn_multi_ema_f32(const void* table, int nchunks, float momentum, rfn_stream_t stream);
+/* AdamW step of a whole parameter set in ONE launch (what the reference's optimizer section instantiates:
+ * torch.optim.AdamW, decoupled weight decay, no amsgrad / maximize; fp32 state).  table = nchunks x {float* p,
+ * const float* grad, float* exp_avg, float* exp_avg_sq, long n | group << 56} in DEVICE memory; group_args = HOST array of
+ * ngroups (<= 8) x {lr, beta1, beta2, eps, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t), 1 - beta1, 1 - beta2} for this
+ * step (the derived values computed in double by the host, as torch does). */
+int rfn_multi_adamw_f32(const void* table, int nchunks, const float* group_args, int ngroups, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * The three GEMMs of a token-wise nn.Linear (mix_transformer.py: q / kv / proj / fc1 / fc2) on the ROCm library

@@ -322,9 +322,68 @@ __global__ __launch_bounds__(256) void multi_ema_kernel(const EmaChunk* __restri
   }
 }
 
+// AdamW over a whole parameter set in one launch (torch.optim.AdamW, decoupled weight decay, no amsgrad / maximize; the
+// arithmetic of its fused implementation, fp32):  p -= lr wd p;  m = m + (1 - b1) (g - m);  v = b2 v + (1 - b2) g^2;
+// p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The host passes the per-group scalars of this step.
+struct AdamChunk {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long n;          // low 56 bits: elements; the group index rides in the top byte
+};
+struct AdamGroups {
+  float lr[8], beta1[8], beta2[8], eps[8], wd[8], bc1[8], bc2_sqrt[8], omb1[8], omb2[8];   // omb = 1 - beta, rounded from double
+};
+
+__global__ __launch_bounds__(256) void multi_adamw_kernel(const AdamChunk* __restrict__ table, AdamGroups gr) {
+  const AdamChunk c = table[blockIdx.x];
+  const int gi = (int)((unsigned long)c.n >> 56);
+  const long n = c.n & ((1L << 56) - 1);
+  const float lr = gr.lr[gi], b1 = gr.beta1[gi], b2 = gr.beta2[gi], eps = gr.eps[gi], wd = gr.wd[gi];
+  const float step_size = lr / gr.bc1[gi], bc2s = gr.bc2_sqrt[gi], omb1 = gr.omb1[gi], omb2 = gr.omb2[gi];
+  auto upd = [&](float& p, float g, float& m, float& v) {
+    p -= lr * wd * p;
+    m = m + omb1 * (g - m);
+    v = b2 * v + omb2 * g * g;
+    p -= step_size * m / (sqrtf(v) / bc2s + eps);
+  };
+  const bool aligned = ((((size_t)c.p | (size_t)c.g | (size_t)c.m | (size_t)c.v) & 15) == 0);
+  long i = (long)threadIdx.x * 4;
+  if (aligned) {
+    for (; i + 3 < n; i += 256 * 4) {
+      float4 p = *reinterpret_cast<const float4*>(c.p + i), m = *reinterpret_cast<const float4*>(c.m + i);
+      float4 v = *reinterpret_cast<const float4*>(c.v + i);
+      const float4 g = *reinterpret_cast<const float4*>(c.g + i);
+      upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+      *reinterpret_cast<float4*>(c.p + i) = p;
+      *reinterpret_cast<float4*>(c.m + i) = m;
+      *reinterpret_cast<float4*>(c.v + i) = v;
+    }
+  }
+  for (long j = aligned ? (n & ~3L) + threadIdx.x : threadIdx.x; j < n; j += 256) {
+    float p = c.p[j], m = c.m[j], v = c.v[j];
+    upd(p, c.g[j], m, v);
+    c.p[j] = p; c.m[j] = m; c.v[j] = v;
+  }
+}
+
 }  // namespace rfn
 
 extern "C" {
+
+int rfn_multi_adamw_f32(const void* table, int nchunks, const float* group_args, int ngroups, rfn_stream_t stream) {
+  RFN_REQUIRE(table && nchunks > 0 && group_args && ngroups > 0 && ngroups <= 8, "rfn_multi_adamw_f32: bad arguments");
+  rfn::AdamGroups gr{};
+  for (int g = 0; g < ngroups; ++g) {                   // host array, 9 floats per group
+    const float* a = group_args + 9 * g;
+    gr.lr[g] = a[0]; gr.beta1[g] = a[1]; gr.beta2[g] = a[2]; gr.eps[g] = a[3]; gr.wd[g] = a[4]; gr.bc1[g] = a[5];
+    gr.bc2_sqrt[g] = a[6]; gr.omb1[g] = a[7]; gr.omb2[g] = a[8];
+  }
+  hipLaunchKernelGGL(rfn::multi_adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                     (const rfn::AdamChunk*)table, gr);
+  return rfn::check_launch("multi_adamw_kernel");
+}
 
 int rfn_multi_ema_f32(const void* table, int nchunks, float momentum, rfn_stream_t stream) {
   RFN_REQUIRE(table && nchunks > 0, "rfn_multi_ema_f32: empty table");

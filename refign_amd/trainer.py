@@ -158,6 +158,11 @@ class Trainer:
                                     "init_args": {**model.optimizer_init["init_args"], "fused": True}}
         (opt,), (sch,) = model.configure_optimizers()
         self.optimizer, self.scheduler = opt, sch
+        self.fast_step = None
+        if fused_optimizer and type(opt) is torch.optim.AdamW and next(model.parameters()).is_cuda and \
+                os.environ.get("RFN_ADAMW_KERNEL", "1") != "0":
+            from .optim import MultiTensorAdamW
+            self.fast_step = MultiTensorAdamW(opt)            # one launch per step; torch's step() where it declines
         groups = model.grad_ready_groups() if hasattr(model, "grad_ready_groups") else None
         self.grads = FlatGradBuffer([p for g in opt.param_groups for p in g["params"]], groups, bucket_mb)
         self.bucket_mb = bucket_mb
@@ -233,7 +238,10 @@ class _OptimizerProxy:
 
     def step(self):
         self.t.grads.all_reduce_mean(self.t.bucket_mb)
-        self.t.optimizer.step()
+        if self.t.fast_step is not None:
+            self.t.fast_step.step()
+        else:
+            self.t.optimizer.step()
 
     def __getattr__(self, name):
         return getattr(self.t.optimizer, name)

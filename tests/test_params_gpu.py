@@ -228,3 +228,57 @@ def test_patchify_tokens_kernel(dev, dt, B, H, W, C, r):
     ref = torch.zeros(B, H, W, C, device=dev, dtype=dt)
     ref[:, :Hr * r, :Wr * r] = x.view(B, H, W, C)[:, :Hr * r, :Wr * r]
     assert torch.equal(back, ref.view(B, H * W, C))
+
+
+def test_multi_tensor_adamw_matches_torch_fused(dev=None):
+    """refign_amd/optim.py: AdamW of a whole parameter set as one kernel launch == torch.optim.AdamW(fused=True) over 6
+    steps with fresh gradients each step: 3 parameter groups (different lr / weight decay), odd sizes (unaligned tails),
+    an LR schedule that changes group['lr'] every step; parameters and both moments to 2e-6 relative, `step` counters
+    equal (the optimizer state a checkpoint stores stays torch's)."""
+    import copy
+    from refign_amd.optim import MultiTensorAdamW
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    shapes = [(257, 33), (64,), (3, 3, 16, 16), (70001,), (5,), (128, 128)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+
+    def mk(params):
+        return torch.optim.AdamW([{"params": params[:2], "lr": 1e-3, "weight_decay": 0.01},
+                                  {"params": params[2:4], "lr": 3e-4, "weight_decay": 0.0},
+                                  {"params": params[4:], "lr": 1e-2, "weight_decay": 0.1, "betas": (0.8, 0.99)}], fused=True)
+    ref, mine = mk(ps), mk(qs)
+    fast = MultiTensorAdamW(mine)
+    flat = torch.zeros(sum(q.numel() for q in qs), device=dev)      # gradients as persistent views, as in the trainer
+    o = 0
+    for q in qs:
+        q.grad = flat[o:o + q.numel()].view_as(q)
+        o += q.numel()
+    for it in range(6):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p) * (0.1 + it)
+            p.grad = g.clone()
+            q.grad.copy_(g)
+        for opt in (ref, mine):
+            for gi, grp in enumerate(opt.param_groups):
+                grp["lr"] = [1e-3, 3e-4, 1e-2][gi] * (1.0 - 0.1 * it)
+        ref.step()
+        fast.step()
+    assert fast.launches == 5                                        # torch made the first step (state creation)
+    for grp in mine.param_groups:                                    # hand-over back to torch keeps counting correctly
+        grp["lr"] = 1e-3
+    for p, q in zip(ps, qs):
+        assert float((p - q).abs().max()) <= 2e-6 * float(p.abs().max())
+        for k in ("exp_avg", "exp_avg_sq"):
+            a, b = ref.state[p][k], mine.state[q][k]
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-12
+    sd = mine.state_dict()                                           # looking at the state brings the counters up to date
+    assert all(float(s["step"]) == 6.0 for s in sd["state"].values())
+    for p, q in zip(ps, qs):
+        assert float(ref.state[p]["step"]) == float(mine.state[q]["step"]) == 6.0
+    # a configuration outside plain AdamW stays on torch's step
+    ams = torch.optim.AdamW([torch.nn.Parameter(torch.randn(8, device=dev))], amsgrad=True)
+    ams.param_groups[0]["params"][0].grad = torch.ones(8, device=dev)
+    f2 = MultiTensorAdamW(ams)
+    f2.step(); f2.step()
+    assert f2.launches == 0
