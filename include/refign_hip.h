@@ -222,6 +222,10 @@ int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream)
  * bf16* copy_or_NULL, long n} in device memory (chunks of at most rfn_multi_cast_chunk_elems() elements); where a chunk
  * has a bf16 copy pointer, the rounded new value is written there in the same pass (the teacher's cached 16-bit weight). */
 int rfn_multi_ema_f32(const void* table, int nchunks, float momentum, rfn_stream_t stream);
+/* Transposed bf16 copies of a set of fp32 matrices in ONE launch: dst (K, N) = bf16(src (N, K)^T), both row-major and
+ * contiguous; table = ntiles x {const float* src, bf16* dst, int N, int K, int n0, int k0} (one 32 x 32 tile each) in device
+ * memory.  (The cached W^T operands of the input-gradient GEMMs, refreshed after optimiser / EMA updates.) */
+int rfn_multi_transpose_cast_f32_bf16(const void* table, int ntiles, rfn_stream_t stream);
 /* AdamW step of a whole parameter set in ONE launch (what the reference's optimizer section instantiates:
  * torch.optim.AdamW, decoupled weight decay, no amsgrad / maximize; fp32 state).  table = nchunks x {float* p,
  * const float* grad, float* exp_avg, float* exp_avg_sq, long n | group << 56} in DEVICE memory; group_args = HOST array of

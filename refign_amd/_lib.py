@@ -55,6 +55,7 @@ SIGNATURES = {
     "rfn_multi_cast_chunk_elems": (c_int, []),
     "rfn_multi_cast_f32_bf16": (c_int, [c_void_p, c_int, c_void_p]),
     "rfn_multi_ema_f32": (c_int, [c_void_p, c_int, c_float, c_void_p]),
+    "rfn_multi_transpose_cast_f32_bf16": (c_int, [c_void_p, c_int, c_void_p]),
     "rfn_multi_adamw_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "rfn_gemm_nt": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p] + [ctypes.c_long] * 6 + [c_int, c_void_p]),
     "rfn_conv2d_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int,

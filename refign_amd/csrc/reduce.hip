@@ -322,6 +322,32 @@ __global__ __launch_bounds__(256) void multi_ema_kernel(const EmaChunk* __restri
   }
 }
 
+// Transposed 16-bit copies of a set of fp32 matrices in one launch (the W^T operands of the input-gradient GEMMs,
+// refreshed after every optimiser / EMA update): one 32 x 32 tile per workgroup, rows read coalesced, transposed through
+// LDS, columns written coalesced.  dst[k][n] = bf16(src[n][k]), src (N, K) row-major, dst (K, N) row-major.
+struct TransposeTile {
+  const float* src;
+  unsigned short* dst;
+  int N, K, n0, k0;
+};
+
+__global__ __launch_bounds__(256) void multi_transpose_cast_kernel(const TransposeTile* __restrict__ table) {
+  __shared__ float tile[32][33];
+  const TransposeTile t = table[blockIdx.x];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int n = t.n0 + r, k = t.k0 + tx;
+    tile[r][tx] = (n < t.N && k < t.K) ? t.src[(size_t)n * t.K + k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int k = t.k0 + r, n = t.n0 + tx;
+    if (k < t.K && n < t.N) t.dst[(size_t)k * t.N + n] = (unsigned short)f32_to_bf16_bits(tile[tx][r]);
+  }
+}
+
 // AdamW over a whole parameter set in one launch (torch.optim.AdamW, decoupled weight decay, no amsgrad / maximize; the
 // arithmetic of its fused implementation, fp32):  p -= lr wd p;  m = m + (1 - b1) (g - m);  v = b2 v + (1 - b2) g^2;
 // p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The host passes the per-group scalars of this step.
@@ -371,6 +397,13 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const AdamChunk* __res
 }  // namespace rfn
 
 extern "C" {
+
+int rfn_multi_transpose_cast_f32_bf16(const void* table, int ntiles, rfn_stream_t stream) {
+  RFN_REQUIRE(table && ntiles > 0, "rfn_multi_transpose_cast_f32_bf16: empty table");
+  hipLaunchKernelGGL(rfn::multi_transpose_cast_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream,
+                     (const rfn::TransposeTile*)table);
+  return rfn::check_launch("multi_transpose_cast_kernel");
+}
 
 int rfn_multi_adamw_f32(const void* table, int nchunks, const float* group_args, int ngroups, rfn_stream_t stream) {
   RFN_REQUIRE(table && nchunks > 0 && group_args && ngroups > 0 && ngroups <= 8, "rfn_multi_adamw_f32: bad arguments");

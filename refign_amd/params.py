@@ -74,7 +74,22 @@ def _build_plan(params):
         skip = set(fast)
     else:
         skip = set()
-    return {"entries": entries,
+    # transposed bf16 copies (W^T of the Linear weights): one launch of the tile-transpose kernel instead of one strided
+    # copy per tensor
+    rest = [i for i in range(len(dst)) if i not in skip]
+    tr = [i for i in rest if dst[i].is_cuda and dst[i].dtype == torch.bfloat16 and src[i].dtype == torch.float32
+          and dst[i].dim() == 2 and dst[i].is_contiguous() and src[i].dim() == 2 and src[i].t().is_contiguous()
+          and src[i].numel() > 0]
+    transposes = []
+    if len(tr) >= 4:
+        by_dev = {}
+        for i in tr:
+            by_dev.setdefault(dst[i].device, []).append(i)
+        for dev, idx in by_dev.items():
+            transposes.append(_transpose_table([dst[i] for i in idx], [src[i] for i in idx], dev) +
+                              (dev, [dst[i] for i in idx], [src[i] for i in idx]))
+        skip = skip | set(tr)
+    return {"entries": entries, "transposes": transposes,
             # (the tensors are kept next to the table: they own the memory the table points into)
             "casts": [_cast_table([dst[i] for i in idx], [src[i] for i in idx], dev) + (dev, [dst[i] for i in idx],
                                                                                          [src[i] for i in idx])
@@ -91,6 +106,20 @@ def _cast_table(dst, src, dev):
     for s_, d in zip(src, dst):
         n, sp, dp = s_.numel(), s_.data_ptr(), d.data_ptr()
         rows += [(sp + 4 * off, dp + 2 * off, min(chunk, n - off)) for off in range(0, n, chunk)]
+    return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows)
+
+
+def _transpose_table(dst, src, dev):
+    """Tile table of the multi-tensor transpose + cast kernel: src views are (K, N) transposes of contiguous (N, K)
+    fp32 parameters, dst the contiguous (K, N) bf16 copies."""
+    import numpy as np
+    rows = []
+    for s_, d in zip(src, dst):
+        K, N = s_.shape                                   # view (K, N) of a parameter stored (N, K)
+        sp, dp = s_.data_ptr(), d.data_ptr()
+        for n0 in range(0, N, 32):
+            for k0 in range(0, K, 32):
+                rows.append((sp, dp, N | (K << 32), n0 | (k0 << 32)))
     return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows)
 
 
@@ -139,6 +168,10 @@ def refresh(params, plan_key=None):
     with torch.no_grad():
         for table, nrows, dev, _, _ in plan["casts"]:
             _multi_cast(table, nrows, dev)
+        for table, ntiles, dev, _, _ in plan["transposes"]:
+            with on_device(dev):
+                rc = _lib.load_library().rfn_multi_transpose_cast_f32_bf16(ptr(table), ntiles, current_stream(dev))
+            _lib.check(rc, "multi_transpose_cast")
         if plan["rest"][0]:
             torch._foreach_copy_(*plan["rest"])
 
