@@ -553,6 +553,35 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def test_epoch_end(self, outs=None):
         return self._epoch_end(self.test_metrics)
 
+    # Cityscapes train-id colours (the dataset's public label definition), (R, G, B) per train id
+    CITYSCAPES_COLOURS = (
+        ("road", (128, 64, 128)), ("sidewalk", (244, 35, 232)), ("building", (70, 70, 70)), ("wall", (102, 102, 156)),
+        ("fence", (190, 153, 153)), ("pole", (153, 153, 153)), ("traffic light", (250, 170, 30)),
+        ("traffic sign", (220, 220, 0)), ("vegetation", (107, 142, 35)), ("terrain", (152, 251, 152)),
+        ("sky", (70, 130, 180)), ("person", (220, 20, 60)), ("rider", (255, 0, 0)), ("car", (0, 0, 142)),
+        ("truck", (0, 0, 70)), ("bus", (0, 60, 100)), ("train", (0, 80, 100)), ("motorcycle", (0, 0, 230)),
+        ("bicycle", (119, 11, 32)))
+
+    @torch.no_grad()
+    def predict_step(self, batch, batch_idx=0, dataloader_idx=0, save_dir=None, orig_size=None):
+        """segmentation_model.py:283-302: arg-max label maps of a batch as PNGs -- `<save_dir>/preds/<filename>` holds the
+        train ids (8-bit), `<save_dir>/color_preds/<filename>` the same image with the Cityscapes palette.  The reference
+        takes `save_dir` from the Lightning checkpoint directory and `orig_size` from the data module."""
+        from PIL import Image
+        preds = torch.argmax(self.forward(batch['image'], orig_size), dim=1).to(torch.uint8).cpu().numpy()
+        if save_dir is not None:
+            pal = [v for _, rgb in self.CITYSCAPES_COLOURS for v in rgb]
+            pal += [0] * (768 - len(pal))
+            for sub in ('preds', 'color_preds'):
+                os.makedirs(os.path.join(save_dir, sub), exist_ok=True)
+            for arr, name in zip(preds, batch['filename']):
+                image = Image.fromarray(arr)
+                image.save(os.path.join(save_dir, 'preds', name))
+                col = image.convert('P')
+                col.putpalette(pal)
+                col.save(os.path.join(save_dir, 'color_preds', name))
+        return preds
+
     # -- inference (:304-382) ------------------------------------------------------------------------------------
     def forward(self, x, out_size=None):
         logits = self.slide_inference(x) if self.use_slide_inference else self.whole_inference(x)

@@ -65,3 +65,21 @@ def test_validation_step_accumulates_iou(dev):
     assert abs(float(out["val_DarkZurich_IoU"]) - float(want)) < 1e-6
     assert int(model.valid_metrics["val_ACDC_IoU"].confmat.sum()) == 0          # other dataset's metric untouched
     assert int(model.valid_metrics["val_DarkZurich_IoU"].confmat.sum()) == 0    # reset at epoch end
+
+
+@torch.no_grad()
+def test_predict_step_writes_label_and_colour_pngs(dev, tmp_path):
+    from PIL import Image
+    model = build(False, dev).eval()
+    x = torch.from_numpy((hashed_uniform((2, 3, 96, 160), "g15/img") * 4 - 2).astype(np.float32)).to(dev)
+    preds = model.predict_step({"image": x, "filename": ["a.png", "b.png"]}, save_dir=str(tmp_path), orig_size=(120, 200))
+    assert preds.shape == (2, 120, 200) and preds.dtype == np.uint8
+    want = model(x, out_size=(120, 200)).argmax(1).cpu().numpy()
+    for i, name in enumerate(("a.png", "b.png")):
+        ids = np.array(Image.open(tmp_path / "preds" / name))
+        assert np.array_equal(ids, want[i])
+        col = Image.open(tmp_path / "color_preds" / name)
+        assert col.mode == "P" and np.array_equal(np.array(col), want[i])
+        rgb = np.array(col.convert("RGB"))
+        if (want[i] == 0).any():
+            assert tuple(rgb[want[i] == 0][0]) == (128, 64, 128)       # road
