@@ -410,7 +410,22 @@ class UAWarpCHead(BaseHead):
         if eu:
             u3 = u3 + diag_term
         if self.iterative_refinement and not self.training:
-            raise NotImplementedError("iterative_refinement is unset in every refign_* config (uawarpc.py:28,175)")
+            # uawarpc.py:175-207 (set in the megadepth configs, unset in every refign_* config): for images of 1086 pixels
+            # or more the jump from the 32x32 level to 1/8 resolution is bridged by extra passes of the LEVEL-2 decoder
+            # at 1/16, 1/32, ... resolution on area-down-sampled level-2 features, so that no up-sampling step exceeds 2x.
+            R = float(max(H, W)) / 8.0 / 32.0
+            extra = max(0, int(round(math.log(R / 3.0) / math.log(2))))
+            for n in range(extra):
+                ratio = 1.0 / (8.0 * 2 ** (extra - n))
+                size = (int(H * ratio), int(W * ratio))
+                up_flow, up_u = _up(flow3, size), (_up(u3, size) if eu else None)
+                c2s = F.interpolate(c22, size=size, mode='area')
+                c1s = F.interpolate(c12, size=size, mode='area')
+                corr = self.local_corr(c2s, c1s, flow=(up_flow * ratio).contiguous())
+                res, x3b = self.decoder2(torch.cat([corr, up_flow] + ([up_u] if eu else []), 1))
+                flow3 = res.float() + up_flow
+                if eu:
+                    u3 = self.estimate_uncertainty_components2(corr, x3b, up_u, up_flow).float()
 
         # level 2: 1/8 resolution, original pixel units (uawarpc.py:209-234)
         s2 = c12.shape[-2:]

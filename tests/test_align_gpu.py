@@ -91,6 +91,30 @@ def test_uawarpc_head_golden(dev, name, H, W):
 
 
 @torch.no_grad()
+def test_uawarpc_head_iterative_refinement_golden(dev):
+    """The head as the megadepth configs build it (iterative_refinement=True, uawarpc.py:175-207) on a 1280x192
+    pyramid: one extra pass of the level-2 decoder at 1/16 resolution between the 32x32 level and 1/8 resolution; all
+    four (flow, log-variance) levels against the reference, and the extra pass must matter (the golden records that the
+    finest flow differs from the non-iterative head's by 19 px)."""
+    from refign_amd.align import UAWarpCHead
+    name, H, W = "iter_1280x192", 1280, 192
+    g = golden("head_" + name)
+    assert float(g["plain_flow1_absdiff_max"]) > 1.0
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True,
+                                        iterative_refinement=True)).to(dev).eval()
+    p = _pyramids(name, H, W)
+    args = ([T(x, dev) for x in p["trg"]], [T(x, dev) for x in p["src"]], [T(x, dev) for x in p["trg256"]],
+            [T(x, dev) for x in p["src256"]], (H, W))
+    outs = head(*args)
+    for lvl, (fl, un) in zip((4, 3, 2, 1), outs):
+        np.testing.assert_allclose(fl.cpu().numpy(), g[f"flow{lvl}"], rtol=1e-3, atol=3e-2, err_msg=f"flow{lvl}")
+        np.testing.assert_allclose(un.cpu().numpy(), g[f"uncert{lvl}"], rtol=1e-3, atol=5e-3, err_msg=f"uncert{lvl}")
+    head.iterative_refinement = False
+    plain = head(*args)
+    assert abs(float((plain[3][0] - outs[3][0]).abs().max()) - float(g["plain_flow1_absdiff_max"])) < 0.1
+
+
+@torch.no_grad()
 def test_align_end_to_end_golden(dev):
     """G7: VGG-16 + head + fused tail on a 128x160 pair: warped logits <= 1e-3 (north star), mask exact, argmax exact
     where the reference's top-2 margin is above the tolerance; AlignmentModel.forward flow/uncertainty."""
