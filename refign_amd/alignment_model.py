@@ -29,6 +29,8 @@ class AlignmentModel(nn.Module):
         self.selfsupervised_loss, self.unsupervised_loss = selfsupervised_loss, unsupervised_loss
         self.apply_constant_flow_weights = apply_constant_flow_weights
         self.logged = {}
+        from .metrics import build_collections
+        self.valid_metrics, self.test_metrics = build_collections(metrics, config.instantiate_class)
         if pretrained is not None:
             ckpt = torch.load(pretrained, map_location='cpu')
             self.load_state_dict(ckpt.get('state_dict', ckpt), strict=True)
@@ -39,6 +41,37 @@ class AlignmentModel(nn.Module):
     @torch.no_grad()
     def forward(self, images_i, images_j):
         return align_mod.alignment_forward(self.alignment_backbone, self.alignment_head, images_i, images_j)
+
+    # -- evaluation (alignment_model.py:148-190) -----------------------------------------------------------------------
+    def _eval_step(self, metrics, batch, src_name):
+        """Flow target -> reference at full resolution and its confidence, every metric of this dataset accumulates
+        (`src_name`: what the reference reads from trainer.datamodule.idx_to_name[split][dataloader_idx])."""
+        images_ref, images_trg = batch['image_ref'], batch['image']
+        h, w = images_ref.shape[-2:]
+        flow, uncert = self.forward(images_trg, images_ref)
+        for k, m in metrics.items():
+            if src_name in k:
+                m(flow, batch['corr_pts_ref'], batch['corr_pts'], (h, w), uncert)
+        return flow, uncert
+
+    def validation_step(self, batch, batch_idx=0, dataloader_idx=0, src_name=""):
+        return self._eval_step(self.valid_metrics, batch, src_name)
+
+    def test_step(self, batch, batch_idx=0, dataloader_idx=0, src_name=""):
+        return self._eval_step(self.test_metrics, batch, src_name)
+
+    def _epoch_end(self, metrics):
+        out = metrics.compute()
+        metrics.reset()
+        for k, v in out.items():
+            self.log(k, v)
+        return out
+
+    def validation_epoch_end(self, outs=None):
+        return self._epoch_end(self.valid_metrics)
+
+    def test_epoch_end(self, outs=None):
+        return self._epoch_end(self.test_metrics)
 
     def train(self, mode=True):
         """alignment_model.py:233-238: the frozen backbone's norm layers never leave eval mode."""

@@ -24,6 +24,7 @@ ALIASES = {
     "models.losses.MultiScaleFlowLoss": "refign_amd.losses.MultiScaleFlowLoss",
     "models.losses.WBipathLoss": "refign_amd.losses.WBipathLoss",
     "helpers.metrics.IoU": "refign_amd.metrics.IoU",
+    "helpers.metrics.SparseEPE": "refign_amd.metrics.SparseEPE",
     "helpers.lr_scheduler.LinearWarmupPolynomialLR": "refign_amd.trainer.LinearWarmupPolynomialLR",
     "helpers.callbacks.ValEveryNSteps": "refign_amd.trainer.ValEveryNSteps",
 }

@@ -100,3 +100,86 @@ def build_collections(metrics_cfg, instantiate):
                     pass
         out.append(MyMetricCollection(items))
     return out
+
+
+class SparseEPE(nn.Module):
+    """helpers/metrics.py:35-262 without torchmetrics: end-point error of a dense flow at sparse ground-truth
+    correspondences (the matcher's evaluation on MegaDepth / RobotCar), PCK at 1 / 3 / 5 / 10 px, and -- with
+    `uncertainty_estimation` -- the area under the sparsification-error curve of the predicted confidence (AUSE, 50
+    quantile intervals: EPE of the pixels that remain when the most uncertain q % are removed, against the oracle that
+    removes the worst q % first).  Seven running sums, summed over ranks at compute() (`dist_reduce_fx="sum"`).
+
+    update(t_s_flow (B,2,h,w), corr_pts_s, corr_pts_t [B x (n,2) pixel coordinates (x, y)], out_size (h,w),
+    uncertainty_est (B,1,h,w) or None): the flow is looked up at the ROUNDED target points."""
+
+    def __init__(self, uncertainty_estimation=False, compute_on_step=None, **kwargs):
+        super().__init__()
+        self.uncertainty_estimation = uncertainty_estimation
+        for name in ("AEPE", "PCK_1", "PCK_3", "PCK_5", "PCK_10", "AUSE_AEPE"):
+            self.register_buffer(name, torch.zeros((), dtype=torch.double), persistent=False)
+        for name in ("nbr_valid_corr", "nbr_samples"):
+            self.register_buffer(name, torch.zeros((), dtype=torch.long), persistent=False)
+
+    def reset(self):
+        for b in self.buffers():
+            b.zero_()
+
+    @torch.no_grad()
+    def update(self, t_s_flow, corr_pts_s, corr_pts_t, out_size, uncertainty_est=None):
+        h, w = out_size
+        assert tuple(t_s_flow.shape[-2:]) == (h, w)
+        if self.AEPE.device != t_s_flow.device:
+            self.to(t_s_flow.device)
+        for b in range(t_s_flow.shape[0]):
+            xs, ys, xt, yt = corr_pts_s[b][:, 0], corr_pts_s[b][:, 1], corr_pts_t[b][:, 0], corr_pts_t[b][:, 1]
+            ok = (torch.round(xs) >= 0) & (torch.round(xs) < w) & (torch.round(ys) >= 0) & (torch.round(ys) < h) & \
+                (torch.round(xt) >= 0) & (torch.round(xt) < w) & (torch.round(yt) >= 0) & (torch.round(yt) < h)
+            n = int(ok.sum())
+            if n == 0:
+                continue
+            xs, ys, xt, yt = xs[ok], ys[ok], xt[ok], yt[ok]
+            iy, ix = torch.round(yt).long(), torch.round(xt).long()
+            gt = torch.stack([xs - xt, ys - yt], dim=1)
+            est = torch.stack([t_s_flow[b, 0, iy, ix], t_s_flow[b, 1, iy, ix]], dim=1)
+            epe = torch.linalg.norm(gt - est, ord=2, dim=1)
+            self.AEPE += epe.mean()
+            self.PCK_1 += (epe <= 1.0).sum()
+            self.PCK_3 += (epe <= 3.0).sum()
+            self.PCK_5 += (epe <= 5.0).sum()
+            self.PCK_10 += (epe <= 10.0).sum()
+            self.nbr_valid_corr += n
+            self.nbr_samples += 1
+            if self.uncertainty_estimation:
+                self.AUSE_AEPE += self.compute_aucs(gt, est, uncertainty_est[b, 0, iy, ix])['EPE']
+
+    __call__ = update
+
+    @staticmethod
+    def compute_aucs(gt, pred, uncert, intervals=50):
+        epe = torch.linalg.norm(gt - pred, ord=2, dim=1)
+        quants = [t / intervals for t in range(intervals)]
+        plotx = torch.tensor([t / intervals for t in range(intervals + 1)], device=gt.device)
+
+        def curve(score):                               # score: high = removed first; keep `score >= its q-quantile` of -score
+            keep_first = -score
+            vals = [epe[keep_first >= torch.quantile(keep_first.float(), q)].mean() for q in quants]
+            return torch.stack(vals + [torch.zeros((), device=gt.device)])
+        sparse, oracle = curve(uncert), curve(epe)
+        mmax = oracle.max() + 1e-6
+        return {'EPE': torch.abs(torch.trapz(sparse / mmax, x=plotx) - torch.trapz(oracle / mmax, x=plotx))}
+
+    @torch.no_grad()
+    def compute(self):
+        vals = {k: getattr(self, k).clone() for k in ("AEPE", "PCK_1", "PCK_3", "PCK_5", "PCK_10", "AUSE_AEPE",
+                                                      "nbr_valid_corr", "nbr_samples")}
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            for v in vals.values():
+                dist.all_reduce(v)
+        out = {'AEPE': vals["AEPE"] / vals["nbr_samples"].double(),
+               'PCK_1': vals["PCK_1"] / vals["nbr_valid_corr"].double(),
+               'PCK_3': vals["PCK_3"] / vals["nbr_valid_corr"].double(),
+               'PCK_5': vals["PCK_5"] / vals["nbr_valid_corr"].double(),
+               'PCK_10': vals["PCK_10"] / vals["nbr_valid_corr"].double()}
+        if self.uncertainty_estimation:
+            out['AUSE_AEPE'] = vals["AUSE_AEPE"] / vals["nbr_samples"].double()
+        return out

@@ -193,3 +193,31 @@ def test_matcher_step_under_fp16_autocast_is_bounded(dev):
         g = [p.grad for p in getattr(model.alignment_head, name).parameters() if p.grad is not None]
         norm = float(torch.sqrt(sum((x.double() ** 2).sum() for x in g)))
         assert abs(norm - float(z["gradnorm/" + name])) <= 0.15 * float(z["gradnorm/" + name]), (name, norm)
+
+
+@torch.no_grad()
+def test_matcher_validation_step_feeds_sparse_epe(dev):
+    """AlignmentModel.validation_step (alignment_model.py:148-161): flow target -> reference + confidence from forward(),
+    SparseEPE of the named dataset accumulates them, *_epoch_end computes and resets."""
+    from refign_amd.metrics import MyMetricCollection, SparseEPE
+    z = golden("matcher_step_128x160")
+    model = build_matcher(dev).eval()
+    model.valid_metrics = MyMetricCollection({"val_MegaDepth_SparseEPE": SparseEPE(uncertainty_estimation=True),
+                                              "val_RobotCarMatching_SparseEPE": SparseEPE(uncertainty_estimation=True)})
+    b = matcher_batch(z, dev)
+    H, W = b["image_trg"].shape[-2:]
+    g = torch.Generator().manual_seed(0)
+    pts_t = [torch.stack([torch.rand(300, generator=g) * (W - 1), torch.rand(300, generator=g) * (H - 1)], 1).to(dev)
+             for _ in range(2)]
+    pts_r = [p + torch.randn(300, 2, generator=g).to(dev) * 3 for p in pts_t]
+    batch = {"image": b["image_trg"], "image_ref": b["image_ref"], "corr_pts": pts_t, "corr_pts_ref": pts_r}
+    flow, unc = model.validation_step(batch, 0, 0, src_name="MegaDepth")
+    assert tuple(flow.shape) == (2, 2, H, W) and tuple(unc.shape) == (2, 1, H, W)
+    direct = SparseEPE(uncertainty_estimation=True)
+    direct(flow, pts_r, pts_t, (H, W), unc)
+    want = direct.compute()
+    out = model.validation_epoch_end()
+    for k, v in want.items():
+        assert abs(float(out["val_MegaDepth_SparseEPE_" + k]) - float(v)) < 1e-9
+    assert int(model.valid_metrics["val_RobotCarMatching_SparseEPE"].nbr_samples) == 0
+    assert int(model.valid_metrics["val_MegaDepth_SparseEPE"].nbr_samples) == 0

@@ -95,7 +95,34 @@ def test_metric_collections_of_a_reference_config():
                                     "init_args": {"ignore_index": 255, "num_classes": 19, "compute_on_step": False}}],
                     "RobotCarMatching": [{"class_path": "helpers.metrics.SparseEPE", "init_args": {}}]}}
     val, test = build_collections(cfg, instantiate_class)
-    assert list(val.keys()) == ["val_DarkZurich_IoU"] and list(test.keys()) == ["test_DarkZurich_IoU"]
+    assert list(val.keys()) == ["val_DarkZurich_IoU"]
+    assert list(test.keys()) == ["test_DarkZurich_IoU", "test_RobotCarMatching_SparseEPE"]
     assert isinstance(val["val_DarkZurich_IoU"], IoU) and val["val_DarkZurich_IoU"].num_classes == 19
     val["val_DarkZurich_IoU"](torch.zeros(1, 4, 4, dtype=torch.long), torch.zeros(1, 4, 4, dtype=torch.long))
     assert set(val.compute()) == {"val_DarkZurich_IoU"}
+
+
+def test_sparse_epe_matches_reference():
+    """refign_amd.metrics.SparseEPE against values computed by the reference's own class (G16: AEPE, PCK at 1/3/5/10 px,
+    AUSE of the sparsification curves, correspondences outside the image dropped) -- accumulated over two samples, and
+    the deterministic variant on one."""
+    from conftest import golden
+    from refign_amd.metrics import SparseEPE
+    z = golden("metric_sparse_epe")
+    flow, unc = torch.from_numpy(z["flow"]), torch.from_numpy(z["unc"])
+    ps, pt = [torch.from_numpy(p) for p in z["pts_s"]], [torch.from_numpy(p) for p in z["pts_t"]]
+    m = SparseEPE(uncertainty_estimation=True)
+    for b in range(2):                                   # sample by sample == one batched update
+        m(flow[b:b + 1], ps[b:b + 1], pt[b:b + 1], tuple(flow.shape[-2:]), unc[b:b + 1])
+    assert int(m.nbr_valid_corr) == int(z["nbr_valid_corr"]) and int(m.nbr_samples) == 2
+    out = m.compute()
+    for k in ("AEPE", "PCK_1", "PCK_3", "PCK_5", "PCK_10", "AUSE_AEPE"):
+        assert abs(float(out[k]) - float(z[k])) <= 1e-5 * max(abs(float(z[k])), 1e-3), k
+    m2 = SparseEPE()
+    m2.update(flow[:1], ps[:1], pt[:1], tuple(flow.shape[-2:]))
+    out2 = m2.compute()
+    assert "AUSE_AEPE" not in out2
+    for k in ("AEPE", "PCK_1", "PCK_10"):
+        assert abs(float(out2[k]) - float(z[k + "_first"])) <= 1e-5 * max(abs(float(z[k + "_first"])), 1e-3), k
+    m.reset()
+    assert int(m.nbr_samples) == 0 and float(m.AEPE) == 0.0
