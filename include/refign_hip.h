@@ -192,7 +192,8 @@ int rfn_uncertainty9_frontend_f32(const float* corr, const float* weights, float
 
 /* ------------------------------------------------------------------------------------------------------------
  * out[i] (+)= sum_{s < S} x[s*n + i]: sum over the leading dimension of a row-major (S, n) matrix into float32.
- * Two uses on the training step, both formerly a library reduction followed by a separate gradient-accumulation add:
+ * (Replaces what autograd's backward of nn.Linear launches for the layers of models/backbones/mix_transformer.py:47-78,
+ * 100-186 and models/heads/daformer.py, segformer.py.)  Two uses on the training step, both formerly a library reduction followed by a separate gradient-accumulation add:
  *   - bias gradient of every token-wise Linear: x = grad_y (tokens, features), S = tokens (8 160 ... 259 200)
  *   - reduction of the split-T weight-gradient partials (refign_amd/linear.py): x = (S <= 64, N*K)
  * x dtype 0 = float32, 1 = bfloat16; n must be a multiple of 8.  accumulate != 0: out += sum (out is the parameter's
@@ -211,7 +212,8 @@ int rfn_linear_param_grads(const void* grad_y, float* grad_bias, void* workspace
 
 /* ------------------------------------------------------------------------------------------------------------
  * Multi-tensor cast float32 -> bfloat16 (round to nearest even) in one launch: refresh of the cached bf16 copies of
- * all parameters after an optimizer step / EMA update.  `table`: DEVICE array of nchunks entries
+ * all parameters after an optimizer step / EMA update -- the per-use weight casts torch.autocast performs under the
+ * reference's `--trainer.precision 16` recipe (README.md:262), done once per update instead.  `table`: DEVICE array of nchunks entries
  * { const float* src; uint16_t* dst; long n; } (24 bytes each), one per chunk of at most
  * rfn_multi_cast_chunk_elems() elements; the host splits every tensor into such chunks once per parameter set.
  * ---------------------------------------------------------------------------------------------------------- */
@@ -222,11 +224,12 @@ int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream)
  * bf16* copy_or_NULL, long n} in device memory (chunks of at most rfn_multi_cast_chunk_elems() elements); where a chunk
  * has a bf16 copy pointer, the rounded new value is written there in the same pass (the teacher's cached 16-bit weight). */
 int rfn_multi_ema_f32(const void* table, int nchunks, float momentum, rfn_stream_t stream);
-/* Transposed bf16 copies of a set of fp32 matrices in ONE launch: dst (K, N) = bf16(src (N, K)^T), both row-major and
+/* (Same purpose as rfn_multi_cast_f32_bf16.)  Transposed bf16 copies of a set of fp32 matrices in ONE launch: dst (K, N) = bf16(src (N, K)^T), both row-major and
  * contiguous; table = ntiles x {const float* src, bf16* dst, int N, int K, int n0, int k0} (one 32 x 32 tile each) in device
  * memory.  (The cached W^T operands of the input-gradient GEMMs, refreshed after optimiser / EMA updates.) */
 int rfn_multi_transpose_cast_f32_bf16(const void* table, int ntiles, rfn_stream_t stream);
-/* AdamW step of a whole parameter set in ONE launch (what the reference's optimizer section instantiates:
+/* AdamW step of a whole parameter set in ONE launch (what the reference's optimizer section instantiates --
+ * configs/cityscapes_darkzurich/refign_hrda_star.yaml:176-180, stepped by models/segmentation_model.py:252 --
  * torch.optim.AdamW, decoupled weight decay, no amsgrad / maximize; fp32 state).  table = nchunks x {float* p,
  * const float* grad, float* exp_avg, float* exp_avg_sq, long n | group << 56} in DEVICE memory; group_args = HOST array of
  * ngroups (<= 8) x {lr, beta1, beta2, eps, weight_decay, 1 - beta1^t, sqrt(1 - beta2^t), 1 - beta1, 1 - beta2} for this
