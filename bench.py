@@ -186,6 +186,9 @@ REF_CFG = {  # the `model:` / `optimizer:` / `lr_scheduler:` sections of refign_
 }
 
 
+PIPELINE_NEXT_BATCH = os.environ.get("RFN_PREFETCH_NEXT", "1") != "0"
+
+
 class RefignStep:
     name = "refign_hrda_step_1080x1920"
     use_hrda = True
@@ -222,8 +225,10 @@ class RefignStep:
         self._kern = None
 
     def step(self):
+        # next_batch: what a prefetching loader hands over one step early (here the same synthetic batch) -- the frozen
+        # ImageNet encoder's features of the next source images are then computed while this step's mixed pass runs
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.precision == "bf16"):
-            self.trainer.step(self.batch)
+            self.trainer.step(self.batch, next_batch=self.batch if PIPELINE_NEXT_BATCH else None)
 
     # roofline kernel + CPU baseline are those of the align/refine kernel workload at the same image size
     def _kernels(self):
@@ -448,6 +453,11 @@ def main():
             st = {k: [("replay" if s_["graph"] is not None else ("eager (capture failed)" if s_["failed"] else "eager"))
                       for s_ in g.states.values()] for k, g in graphs.items()}
             line["config"]["hipgraph_regions"] = {k: (v[0] if len(v) == 1 else v) for k, v in st.items() if v}
+        if isinstance(wl, RefignStep) and type(wl) is not RefignAlignRefine:
+            line["config"]["next_batch_prefetch"] = (
+                "frozen ImageNet-encoder features of the next step's source images computed during this step's mixed pass "
+                "(same work per step; RFN_PREFETCH_NEXT=0 computes them inside the source pass)") if PIPELINE_NEXT_BATCH \
+                else "off"
         print(json.dumps(line))
 
 

@@ -165,7 +165,10 @@ class GraphedStep:
             if s.data_ptr() != t.data_ptr():
                 s.copy_(t)
         st["graph"].replay()
-        return st["outputs"]
+        # copies, not the pool tensors themselves: the passes of a model share one pool and are not always replayed in the
+        # order they were captured in (a second input signature of the source pass is captured AFTER the mixed pass and
+        # replayed before it) -- a later replay of the other pass may then reuse the blocks these few scalars live in
+        return tuple(o.clone() for o in st["outputs"])
 
     def _capture(self, st, tensors):
         inputs = [t.clone() for t in tensors]

@@ -189,7 +189,12 @@ class Trainer:
         for t in list(self.model.parameters()) + list(self.model.buffers()):
             dist.broadcast(t.data, src=0)
 
-    def step(self, batch, batch_idx=0):
+    def step(self, batch, batch_idx=0, next_batch=None):
+        """`next_batch` (optional): the batch of the following step, already on the device -- lets the model compute
+        what depends on its inputs only (the frozen ImageNet encoder's features of the next source images) while this
+        step's mixed pass runs (uda.prefetch_imnet_features)."""
+        if next_batch is not None:
+            batch = dict(batch, image_src_next=next_batch["image_src"])
         # Python's cyclic collector fires on allocation counts; a step allocates ~10^5 autograd / tensor wrapper objects
         # and a generation-2 pass in the middle of a step stalls the launch thread for ~100 ms (seen as one slow step in
         # ten).  Collect at a step boundary every `gc_interval` steps instead, with the automatic collector off.

@@ -379,8 +379,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
         dev.copy_(upload_async(list(off), torch.long, images.device), non_blocking=True)
         return dev
 
-    def _source_pass_device_crop(self, images_src, gt_src, off):
-        """SOURCE (:156-179) + ImageNet feature distance (:181-189), forward and both backward passes."""
+    def _source_pass_device_crop(self, images_src, gt_src, off, feat_imnet_last=None):
+        """SOURCE (:156-179) + ImageNet feature distance (:181-189), forward and both backward passes.
+        `feat_imnet_last`: the frozen ImageNet encoder's last-stage feature of `images_src` when it was computed ahead
+        of the step (prefetch_imnet_features); else it is computed here."""
         push_device_crop(off, self.hrda_output_stride * 2.0)
         feats_src = self.backbone(images_src)
         logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
@@ -391,10 +393,38 @@ class DomainAdaptationSegmentationModel(nn.Module):
         self.manual_backward(loss_src, retain_graph=self.enable_fdist)
         out = [loss_src.detach()]
         if self.enable_fdist:
-            loss_fd = self.calc_feat_dist(images_src, gt_src, feats_src)
+            loss_fd = self.calc_feat_dist(images_src, gt_src, feats_src,
+                                          feat_imnet=None if feat_imnet_last is None else [feat_imnet_last])
             self.manual_backward(loss_fd)
             out.append(loss_fd.detach())
         return tuple(out)
+
+    @torch.no_grad()
+    def prefetch_imnet_features(self, images_src_next, after=None):
+        """Software pipelining across steps (optional; Trainer.step(batch, next_batch=...)): the ImageNet feature of the
+        NEXT step's source images depends on nothing that training changes (frozen encoder, :98-105), so it can be
+        computed on the side stream while THIS step's mixed pass runs alone on the main stream, instead of inside the
+        next source pass where it competes with the teacher branch.  Same numbers, same work per step.
+        `after`: event on the main stream that the side stream waits for (the source pass of this step has consumed the
+        previous prefetch's buffers)."""
+        if not (self.enable_fdist and images_src_next.is_cuda and self._overlap_teacher(images_src_next)):
+            return
+        self._ensure_side_stream(images_src_next.device)
+        if after is not None:
+            self._side_stream.wait_event(after)
+        with torch.cuda.stream(self._side_stream):
+            with torch.autocast("cuda", dtype=torch.get_autocast_dtype("cuda"), enabled=torch.is_autocast_enabled("cuda")):
+                feat = self._imnet_forward(images_src_next)[-1]
+            done = self._side_stream.record_event()
+        self._imnet_prefetch = (images_src_next, images_src_next._version, images_src_next.data_ptr(), feat, done)
+
+    def _take_imnet_prefetch(self, images_src):
+        pf, self._imnet_prefetch = getattr(self, "_imnet_prefetch", None), None
+        if pf is None or pf[0] is not images_src or pf[1] != images_src._version or pf[2] != images_src.data_ptr():
+            return None
+        torch.cuda.current_stream().wait_event(pf[4])
+        pf[3].record_stream(torch.cuda.current_stream())
+        return pf[3]
 
     def _mixed_pass_device_crop(self, mixed_img, mixed_lbl, mixed_weight, off):
         """MIXED (:226-250), forward and backward."""
@@ -416,7 +446,12 @@ class DomainAdaptationSegmentationModel(nn.Module):
         (measured in round 2: 65 ms of every 236 ms step had only the side stream busy)."""
         ready = torch.cuda.current_stream().record_event() if self._overlap_teacher(images_src) else None
         off = self._crop_offsets(images_src, "src")
-        losses = self._graphs["source_pass"](images_src, gt_src, off)
+        feat_next = self._take_imnet_prefetch(images_src) if self.enable_fdist else None
+        if feat_next is not None:
+            losses = self._graphs["source_pass"](images_src, gt_src, off, feat_next)
+        else:
+            losses = self._graphs["source_pass"](images_src, gt_src, off)
+        source_done = torch.cuda.current_stream().record_event()
         early = None if ready is None else self._start_target_branch(batch, images_src, after=ready)
         self.log("train_loss_src", losses[0])
         if self.enable_fdist:
@@ -436,6 +471,9 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # 16-bit image on the steps where it fires (a second signature = a second capture with its own eager warm-up)
         (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.to(images_src.dtype).contiguous(), mixed_lbl.contiguous(),
                                                    mixed_weight.to(torch.float32).contiguous(), off)
+        nxt = batch.get("image_src_next")
+        if nxt is not None:                              # the mixed pass has the device to itself: fill the side stream
+            self.prefetch_imnet_features(nxt, after=source_done)
         self.log("train_loss_uda_trg", mixed_loss)
         opt.step()
         sch.step()

@@ -294,3 +294,31 @@ def test_checkpoint_round_trip_on_gpu(dev, tmp_path):
         _ = a.align(ya.float(), batch["image_ref"], batch["image_trg"])
     assert torch.equal(ya, yb)
     assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
+
+
+def test_prefetched_imnet_features_give_the_same_trajectory(dev, monkeypatch):
+    """Trainer.step(batch, next_batch=...): the frozen ImageNet encoder's features of the NEXT source images are computed
+    on the side stream during this step's mixed pass and handed to the next source pass -- same losses and parameters
+    as computing them inside the source pass (5 steps, different source images every step, graphs on)."""
+    from refign_amd.trainer import Trainer
+    monkeypatch.setenv("RFN_GRAPH_STUDENT", "1")
+    traj = {}
+    for mode in (True, False):
+        model = build(True, dev)
+        trainer = Trainer(model, fused_optimizer=False)
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        batches = []
+        for it in range(6):
+            bt = make_batch(2, 128, 128, 64, dev)
+            bt["image_src"] = bt["image_src"] + 0.1 * it
+            batches.append(bt)
+        rows, used = [], 0
+        for it in range(5):
+            if mode and getattr(model, "_imnet_prefetch", None) is not None:
+                used += 1
+            trainer.step(batches[it], it, next_batch=batches[it + 1] if mode else None)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+        traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), used)
+    assert traj[True][2] == 4, "the prefetched features were not picked up"
+    np.testing.assert_allclose(traj[True][0], traj[False][0], rtol=2e-3)
+    assert abs(traj[True][1] - traj[False][1]) < 1e-5 * traj[False][1]
