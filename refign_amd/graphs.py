@@ -117,10 +117,15 @@ class GraphedStep:
     The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
     throws leaves the pass eager for good, like GraphedNoGrad."""
 
-    def __init__(self, fn, name, warmup=2, shared=None):
+    def __init__(self, fn, name, warmup=2, shared=None, capture_context=None):
         """`shared`: a dict the passes of ONE model share -- they are never live at the same time, so their graphs
-        capture into one memory pool (held there; it dies with the model's graphs, never outlives them)."""
+        capture into one memory pool (held there; it dies with the model's graphs, never outlives them).  A pass that
+        may run NEXT TO another one gets a pool of its own (shared=None).
+        `capture_context`: callable returning a context manager the capture runs inside (e.g. the gradient buffer the
+        captured backward kernels are to accumulate into)."""
         self.fn, self.name, self.warmup = fn, name, warmup
+        self.capture_context = capture_context
+        self._last = None
         self.shared = {} if shared is None else shared
         self.generation = 0
         self.states = {}
@@ -128,7 +133,12 @@ class GraphedStep:
     def reset(self):
         self.generation += 1
         self.states.clear()
+        self._last = None
         self.shared.pop("pool", None)
+
+    def captured(self):
+        """True once the most recently used input signature replays from a graph."""
+        return self._last is not None and self._last["graph"] is not None
 
     @staticmethod
     def usable(t):
@@ -147,6 +157,7 @@ class GraphedStep:
         st = self.states.get(key)
         if st is None:
             st = self.states[key] = {"calls": 0, "graph": None, "failed": False}
+        self._last = st
         if st["failed"]:
             return self.fn(*tensors)
         if st["graph"] is None:
@@ -175,9 +186,12 @@ class GraphedStep:
         cur = torch.cuda.current_stream()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        import contextlib
+        ctx = self.capture_context() if self.capture_context is not None else contextlib.nullcontext()
         try:
-            with torch.cuda.graph(g, pool=self.shared.get("pool"), capture_error_mode="thread_local"):
-                outputs = self.fn(*inputs)
+            with ctx:
+                with torch.cuda.graph(g, pool=self.shared.get("pool"), capture_error_mode="thread_local"):
+                    outputs = self.fn(*inputs)
         except BaseException:
             torch.cuda.set_stream(cur)
             raise

@@ -91,9 +91,40 @@ class FlatGradBuffer:
             off += pad(p.numel())
         self.bucket_mb = bucket_mb
         self._works, self._released = [], []
+        self._order, self.flat2 = order, None
 
     def zero(self):
         self.flat.zero_()
+        if self.flat2 is not None:
+            self.flat2.zero_()
+
+    def into_second(self):
+        """Context manager: inside it every parameter's `.grad` is its view of a SECOND flat buffer.  Used around the
+        hipGraph capture of a backward pass that is to run concurrently with another one (the captured kernels keep the
+        addresses they saw): two passes accumulating into one buffer from two streams would race on every
+        read-modify-write; `merge_second()` adds the second buffer to the first before the optimiser looks."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if self.flat2 is None:
+                self.flat2 = torch.zeros_like(self.flat)
+            saved, off = [], 0
+            pad = lambda k: (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN  # noqa: E731
+            for p in self._order:
+                saved.append(p.grad)
+                p.grad = self.flat2[off:off + p.numel()].view_as(p)
+                off += pad(p.numel())
+            try:
+                yield
+            finally:
+                for p, g_ in zip(self._order, saved):
+                    p.grad = g_
+        return ctx()
+
+    def merge_second(self):
+        if self.flat2 is not None:
+            self.flat.add_(self.flat2)
 
     def _reduce_range(self, a, b):
         step = max(1, int(self.bucket_mb * 1024 * 1024 // 4))
@@ -167,6 +198,7 @@ class Trainer:
         self.grads = FlatGradBuffer([p for g in opt.param_groups for p in g["params"]], groups, bucket_mb)
         self.bucket_mb = bucket_mb
         model._optimizer = _OptimizerProxy(self)
+        model._grad_buffer = self.grads                      # uda: second buffer for the concurrently running mixed pass
         model._scheduler = sch
         model._backward = self._backward
         if dist.is_available() and dist.is_initialized():
@@ -242,6 +274,7 @@ class _OptimizerProxy:
         self.t.grads.zero()
 
     def step(self):
+        self.t.grads.merge_second()                           # what a concurrently run pass accumulated on the side
         self.t.grads.all_reduce_mean(self.t.bucket_mb)
         if self.t.fast_step is not None:
             self.t.fast_step.step()

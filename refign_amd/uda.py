@@ -246,7 +246,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # forward + backward of the student passes (single process; eager under DDP: SyncBatchNorm collectives)
         shared = {}
         self._graphs["source_pass"] = GraphedStep(self._source_pass_device_crop, "student source pass", shared=shared)
-        self._graphs["mixed_pass"] = GraphedStep(self._mixed_pass_device_crop, "student mixed pass", shared=shared)
+        # the mixed pass may run NEXT TO the tail of the source pass (see _training_step_graphed): a memory pool of its own,
+        # and its captured backward kernels accumulate into the second flat gradient buffer
+        self._graphs["mixed_pass"] = GraphedStep(self._mixed_pass_device_crop, "student mixed pass", shared=None,
+                                                 capture_context=self._mixed_capture_context)
         self.load_weights(pretrained)
 
     # -- trainer hooks (what Lightning provides in the reference) ---------------------------------------------------
@@ -436,6 +439,33 @@ class DomainAdaptationSegmentationModel(nn.Module):
         self.manual_backward(mixed_loss)
         return (mixed_loss.detach(),)
 
+    def _mixed_capture_context(self):
+        import contextlib
+        buf = getattr(self, "_grad_buffer", None)
+        if buf is None or os.environ.get("RFN_MIXED_CONCURRENT", "1") == "0":
+            self._mixed_on_second = False
+            return contextlib.nullcontext()
+        self._mixed_on_second = True
+        return buf.into_second()
+
+    def _mixed_stream(self, x):
+        """The stream the DACS mix and the mixed pass run on.  Once both student passes replay from graphs and the mixed
+        pass accumulates its gradients into the second flat buffer, that is a stream of its own which waits for the
+        TEACHER only: the mixed pass does not depend on the source pass (same weights, separate gradient buffer, separate
+        memory pool), so it starts when the pseudo-labels are there and runs next to the last ~40 ms of the source pass
+        (the feature-distance backward, which otherwise has the device to itself at 10-25 us per latency-bound kernel).
+        What the two passes still share are the BatchNorm running statistics of the decode head, updated by both
+        forwards: the mixed pass's head forward comes a whole teacher branch (>= 90 ms here) after the source pass's,
+        which is why this is limited to the Refign configuration (teacher + align + refine before the mix)."""
+        if not (self.use_refign and self.use_align):
+            return None
+        if not (getattr(self, "_mixed_on_second", False) and self._graphs["mixed_pass"].captured()
+                and self._graphs["source_pass"].captured() and self._overlap_teacher(x)):
+            return None
+        if getattr(self, "_mix_stream", None) is None or self._mix_stream.device != x.device:
+            self._mix_stream = torch.cuda.Stream(device=x.device)
+        return self._mix_stream
+
     def _training_step_graphed(self, batch, images_src, gt_src, src_classes, opt, sch):
         """training_step with the two student passes replayed from hipGraphs.  Same order of host random draws as the
         reference: source crop, adapt_to_ref coin, DACS parameters, mixed crop.
@@ -446,34 +476,48 @@ class DomainAdaptationSegmentationModel(nn.Module):
         (measured in round 2: 65 ms of every 236 ms step had only the side stream busy)."""
         ready = torch.cuda.current_stream().record_event() if self._overlap_teacher(images_src) else None
         off = self._crop_offsets(images_src, "src")
+        cur = torch.cuda.current_stream()
         feat_next = self._take_imnet_prefetch(images_src) if self.enable_fdist else None
         if feat_next is not None:
+            feat_next = feat_next.clone()
+            prefetch_free = cur.record_event()           # the prefetch buffer is free again from here on
             losses = self._graphs["source_pass"](images_src, gt_src, off, feat_next)
         else:
             losses = self._graphs["source_pass"](images_src, gt_src, off)
-        source_done = torch.cuda.current_stream().record_event()
+            prefetch_free = cur.record_event()           # (the encoder ran inside the pass: its buffers are busy until then)
         early = None if ready is None else self._start_target_branch(batch, images_src, after=ready)
         self.log("train_loss_src", losses[0])
         if self.enable_fdist:
             self.log("train_loss_featdist_src", losses[1])
-        with torch.no_grad():
-            if early is None:
-                images_trg, m_probs_trg = self._target_branch(batch)
-            else:
-                images_trg, m_probs_trg = early
-                cur = torch.cuda.current_stream()
-                cur.wait_stream(self._side_stream)
-                m_probs_trg.record_stream(cur)
-            mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src,
-                                                                   src_classes)
-        off = self._crop_offsets(mixed_img, "mix")
-        # one input signature for the replay: the blur of the DACS augmentation runs under autocast and hands back a
-        # 16-bit image on the steps where it fires (a second signature = a second capture with its own eager warm-up)
-        (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.to(images_src.dtype).contiguous(), mixed_lbl.contiguous(),
-                                                   mixed_weight.to(torch.float32).contiguous(), off)
+        mix = self._mixed_stream(images_src) if early is not None else None
+        run_on = cur if mix is None else mix
+        if mix is not None:
+            self.__dict__["_mixed_concurrent_steps"] = self.__dict__.get("_mixed_concurrent_steps", 0) + 1   # diagnostics
+            mix.wait_event(ready)                        # gradient buffers zeroed, EMA done, batch resident
+            mix.wait_stream(self._side_stream)           # pseudo-labels
+        with torch.cuda.stream(run_on):
+            with torch.no_grad():
+                if early is None:
+                    images_trg, m_probs_trg = self._target_branch(batch)
+                else:
+                    images_trg, m_probs_trg = early
+                    if mix is None:
+                        cur.wait_stream(self._side_stream)
+                    m_probs_trg.record_stream(run_on)
+                mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src,
+                                                                       src_classes)
+            off = self._crop_offsets(mixed_img, "mix")
+            # one input signature for the replay: the blur of the DACS augmentation runs under autocast and hands back a
+            # 16-bit image on the steps where it fires (a second signature = a second capture with its own eager warm-up)
+            (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.to(images_src.dtype).contiguous(),
+                                                       mixed_lbl.contiguous(),
+                                                       mixed_weight.to(torch.float32).contiguous(), off)
+        if mix is not None:
+            cur.wait_stream(mix)                         # both passes done before the optimiser merges their gradients
+            mixed_loss.record_stream(cur)
         nxt = batch.get("image_src_next")
-        if nxt is not None:                              # the mixed pass has the device to itself: fill the side stream
-            self.prefetch_imnet_features(nxt, after=source_done)
+        if nxt is not None:                              # after the teacher branch the side stream is idle: fill it
+            self.prefetch_imnet_features(nxt, after=prefetch_free)
         self.log("train_loss_uda_trg", mixed_loss)
         opt.step()
         sch.step()

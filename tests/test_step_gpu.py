@@ -322,3 +322,33 @@ def test_prefetched_imnet_features_give_the_same_trajectory(dev, monkeypatch):
     assert traj[True][2] == 4, "the prefetched features were not picked up"
     np.testing.assert_allclose(traj[True][0], traj[False][0], rtol=2e-3)
     assert abs(traj[True][1] - traj[False][1]) < 1e-5 * traj[False][1]
+
+
+def test_concurrent_mixed_pass_equals_serial(dev, monkeypatch):
+    """Once both student passes replay from graphs the mixed pass runs on its own stream next to the tail of the source
+    pass (separate gradient buffer, separate memory pool, waits for the teacher only).  8 steps with that against 8
+    steps with the passes one after the other: same losses per step, same parameters, same BatchNorm running statistics
+    of the student's decode head (they are updated by both passes' forwards) -- and the concurrent path must really
+    have been taken."""
+    from refign_amd.trainer import Trainer
+    monkeypatch.setenv("RFN_GRAPH_STUDENT", "1")
+    H, W = 192, 256
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RFN_MIXED_CONCURRENT", mode)
+        model = build(True, dev)
+        trainer = Trainer(model, fused_optimizer=False)
+        random.seed(11); np.random.seed(11); torch.manual_seed(11)
+        rows = []
+        for it in range(8):
+            batch = make_batch(2, H, W, 64, dev)
+            batch["image_src"] = batch["image_src"] + 0.05 * it
+            trainer.step(batch, it)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+        bn = torch.cat([b.flatten().double() for n, b in model.head.named_buffers() if "running" in n])
+        out[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), bn.cpu(),
+                     model.__dict__.get("_mixed_concurrent_steps", 0))
+    assert out["1"][3] >= 4 and out["0"][3] == 0
+    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=2e-3)
+    assert abs(out["1"][1] - out["0"][1]) < 1e-5 * out["0"][1]
+    assert float((out["1"][2] - out["0"][2]).abs().max()) < 1e-4 * float(out["0"][2].abs().max())
