@@ -26,8 +26,6 @@ import time
 
 import torch
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see refign_amd/__init__.py (before the HIP runtime initialises)
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -351,6 +349,25 @@ def cpu_baseline(wl, args):
                       f" + OpenMP, all other ops torch-CPU ATen (what the reference's CPU path calls)"}
 
 
+def _ddp_guard(rank, world, progress):
+    """N > 1 only.  The multi-rank step could only ever be rehearsed with ONE rank on the one-GPU development boxes
+    (RFN_DDP_REHEARSAL).  If a multi-rank run makes no progress for RFN_BENCH_STALL_S seconds, say where it stopped and
+    exit non-zero instead of hanging the node."""
+    import threading
+    limit = float(os.environ.get("RFN_BENCH_STALL_S", "900"))
+
+    def watch():
+        while True:
+            time.sleep(5.0)
+            idle = time.monotonic() - progress[0]
+            if idle > limit:
+                print(f"bench.py rank {rank}/{world}: no progress for {idle:.0f} s after '{progress[1]}' "
+                      f"(RFN_GRAPH_DDP={os.environ.get('RFN_GRAPH_DDP', '0')}); giving up", file=sys.stderr, flush=True)
+                os._exit(17)
+
+    threading.Thread(target=watch, daemon=True, name="bench-stall-guard").start()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -363,10 +380,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    progress = [time.monotonic(), "start"]
     if world > 1 or "RANK" in os.environ:     # under torchrun always go through RCCL, also for a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if world > 1:
+            _ddp_guard(rank, world, progress)
+        if os.environ.get("RFN_BENCH_LAZY_PG", "0") == "1":       # experiment: communicator created at the first collective
+            dist.init_process_group("nccl")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import refign_amd
     from refign_amd.tuning import use_shipped_miopen_db
@@ -382,16 +405,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(getattr(wl, "prime_steps", 0)):     # set-up, not warm-up: solver selection, caches, hipGraph capture
+    def tick(what):
+        progress[0], progress[1] = time.monotonic(), what
+
+    for i in range(getattr(wl, "prime_steps", 0)):     # set-up, not warm-up: solver selection, caches, hipGraph capture
         wl.step()
-    for _ in range(args.warmup):
+        if world > 1:                                  # (N > 1 only: keeps the guard's clock honest, off the N=1 path)
+            torch.cuda.synchronize()
+        tick(f"prime step {i}")
+    for i in range(args.warmup):
         wl.step()
+        if world > 1:
+            torch.cuda.synchronize()
+        tick(f"warm-up step {i}")
     barrier()
+    tick("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
     barrier()
     dt = time.perf_counter() - t0
+    tick("after the timed region")
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -453,6 +487,10 @@ def main():
             st = {k: [("replay" if s_["graph"] is not None else ("eager (capture failed)" if s_["failed"] else "eager"))
                       for s_ in g.states.values()] for k, g in graphs.items()}
             line["config"]["hipgraph_regions"] = {k: (v[0] if len(v) == 1 else v) for k, v in st.items() if v}
+            steps_m = getattr(wl.model, "_mixed_concurrent_steps", None)
+            if steps_m is not None:
+                line["config"]["mixed_pass"] = ("own stream next to the tail of the source pass" if steps_m else
+                                                "in stream order after the source pass")
         if isinstance(wl, RefignStep) and type(wl) is not RefignAlignRefine:
             line["config"]["next_batch_prefetch"] = (
                 "frozen ImageNet-encoder features of the next step's source images computed during this step's mixed pass "

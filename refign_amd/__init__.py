@@ -9,14 +9,12 @@ Host side mirrors the reference's operator/module interface for this path (brdav
 All compute goes through the C ABI of lib/librefign_hip.so (include/refign_hip.h).  There is NO CPU fallback:
 calling an op without the HIP library or with CPU tensors raises.
 """
-import os as _os
-
-# The step runs the gradient-free teacher branch on a side stream next to the student forward/backward
-# (refign_amd/uda.py).  ROCm multiplexes a process's streams onto 4 hardware queues by default and streams that share a
-# queue do not overlap; an RCCL communicator takes several.  8 queues keeps the two compute streams apart (measured on
-# MI355X with a 1-rank process group: 328 -> 300 ms/step).  Read by the HIP runtime when it initialises, i.e. at the
-# first device call -- importing this package before that is enough; an explicit setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# GPU_MAX_HW_QUEUES (how many hardware queues ROCm multiplexes a process's streams onto; default 4) is left alone.
+# Round 1 raised it to 8 for the eager step next to an RCCL communicator (328 -> 300 ms/step); with the student passes
+# replayed from hipGraphs it is the other way round: next to an eagerly initialised communicator, 8 / 16 / 32 queues make
+# the graph replays 1.5-1.7x slower (280-289 ms/step against 201.8 with 4; kernel durations unchanged, the three compute
+# streams still run concurrently -- tools/micro/stream_probe.py), and without a communicator 4 / 8 / 16 are the same
+# (199.7 / 200.9 / 200.2 ms).  profiles/r02_dist_1rank_queues.txt.
 
 from ._lib import abi_version, library_path, load_library  # noqa: E402,F401
 

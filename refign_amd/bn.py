@@ -22,13 +22,23 @@ from .params import grad_sink
 _DT16 = {torch.bfloat16: 1, torch.float16: 2}
 
 
+def data_parallel():
+    """True when the step has to behave as one rank of several: a world of more than one process -- or a 1-rank group with
+    RFN_DDP_REHEARSAL=1, which makes every exchange of the N > 1 step for real on the one GPU of a development box
+    (SyncBatchNorm all-reduces inside the captured student passes, the teacher's communicator, the student passes in
+    stream order, the flat gradient all-reduce): everything but the link traffic and the waiting for peers."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("RFN_DDP_REHEARSAL", "0") == "1"
+
+
 def sync_group(bn):
     """The process group a module's statistics are exchanged over: None for plain BatchNorm2d and for a world of one
     (torch's SyncBatchNorm also normalises locally then), else the module's group (default: the world)."""
-    if not isinstance(bn, torch.nn.SyncBatchNorm) or not (dist.is_available() and dist.is_initialized()):
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not data_parallel():
         return None
-    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-    return group if dist.get_world_size(group) > 1 else None
+    return bn.process_group if bn.process_group is not None else dist.group.WORLD
 
 
 def usable(x, bn, dtype):

@@ -112,8 +112,14 @@ class GraphedStep:
     parameters / cached 16-bit copies are only updated in place between replays; BatchNorm statistics are in-place
     buffer updates.  Under data parallelism the pass contains the SyncBatchNorm statistics exchanges of the decode heads
     (refign_amd/bn.py: RCCL all-reduces, which are capturable -- tools/micro/rccl_capture.py); replaying them has only been
-    run with a 1-rank group (one-GPU development boxes), so for more than one rank the capture is OPT-IN
-    (RFN_GRAPH_DDP=1) and the default is the eager pass.
+    run with a 1-rank group here (one-GPU development boxes: RFN_DDP_REHEARSAL=1 makes a 1-rank group do everything one
+    rank of N does).  Every rank captures on the same call, a capture records but does not execute its collectives, and a
+    rank whose capture throws runs the same collectives eagerly, so the ranks stay matched either way.  It is OPT-IN for
+    more than one rank (RFN_GRAPH_DDP=1, RCCL backend) because it buys nothing there yet: with the launch count where
+    it is now the eager student pass keeps up with the device (rehearsal: 228.4 ms/step eager, 227.9 ms graphed with the
+    two passes in stream order -- profiles/r02_dist_1rank_queues.txt), the eager pass overlaps the gradient all-reduce
+    with the last backward, and what makes the graphed step faster for one GPU (the mixed pass next to the source pass)
+    needs a communicator per pass under data parallelism.
     The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
     throws leaves the pass eager for good, like GraphedNoGrad."""
 
@@ -145,7 +151,8 @@ class GraphedStep:
         if not (t.is_cuda and enabled() and os.environ.get("RFN_GRAPH_STUDENT", "1") != "0"):
             return False
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        from .bn import data_parallel
+        if data_parallel():
             return os.environ.get("RFN_GRAPH_DDP", "0") == "1" and dist.get_backend() == "nccl"
         return True
 

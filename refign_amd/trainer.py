@@ -172,6 +172,8 @@ class Trainer:
             gc_interval = int(os.environ.get("RFN_GC_INTERVAL", "100"))
         self.gc_interval, self._steps_done = gc_interval, 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        from .bn import data_parallel
+        self.data_parallel = data_parallel()                 # world > 1, or a 1-rank rehearsal of it
         if sync_batchnorm and dist.is_available() and dist.is_initialized():
             nn.SyncBatchNorm.convert_sync_batchnorm(model)   # student AND teacher BNs (reference: sync_batchnorm: True)
             # The EMA teacher runs on a side stream next to the student (and next to hipGraph replays that contain the
@@ -179,7 +181,7 @@ class Trainer:
             # two streams never interleave collectives of ONE communicator in a rank-dependent order.
             teacher = [m for n, mod in model.named_children() if n.startswith("m_") for m in mod.modules()
                        if isinstance(m, nn.SyncBatchNorm)]
-            if teacher and self.world > 1:
+            if teacher and self.data_parallel:
                 group = dist.new_group()
                 for m in teacher:
                     m.process_group = group
@@ -209,7 +211,7 @@ class Trainer:
         the readiness marks of the MiT stages release finished ranges of the flat gradient buffer to the all-reduce."""
         from . import seg
         # (not inside a hipGraph capture of the pass: the replayed pass is followed by one reduce of the whole buffer)
-        overlap = last and self.world > 1 and os.environ.get("RFN_DDP_OVERLAP", "1") != "0" and \
+        overlap = last and self.data_parallel and os.environ.get("RFN_DDP_OVERLAP", "1") != "0" and \
             not (loss.is_cuda and torch.cuda.is_current_stream_capturing())
         seg._GRAD_READY_CB = self.grads.on_ready if overlap else None
         try:

@@ -442,7 +442,12 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def _mixed_capture_context(self):
         import contextlib
         buf = getattr(self, "_grad_buffer", None)
-        if buf is None or os.environ.get("RFN_MIXED_CONCURRENT", "1") == "0":
+        from .bn import data_parallel
+        # Under data parallelism both student passes contain the SyncBatchNorm exchanges of the decode head on ONE
+        # communicator: two streams must not issue collectives of one communicator in a rank-dependent order, so the
+        # passes stay in stream order there (one more communicator for the mixed pass would lift this; not done: it
+        # could not be run on more than one rank here).
+        if buf is None or data_parallel() or os.environ.get("RFN_MIXED_CONCURRENT", "1") == "0":
             self._mixed_on_second = False
             return contextlib.nullcontext()
         self._mixed_on_second = True

@@ -81,3 +81,20 @@ def test_reference_yaml_builds_unmodified(path):
         assert m.use_refign == bool(init.get("use_refign", False)) if hasattr(m, "use_refign") else True
         (opt,), (sch,) = m.configure_optimizers()
         assert type(opt).__name__ == cfg["optimizer"]["class_path"].rsplit(".", 1)[-1]
+
+
+def test_bench_stall_guard_exits_with_a_message():
+    """bench.py, N > 1: a run that stops making progress (the multi-rank step has only ever been rehearsed with one
+    rank on the development boxes) exits non-zero and says where it stopped instead of hanging the node."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "p = [time.monotonic() - 100.0, 'warm-up step 1']\n"
+            "bench._ddp_guard(1, 2, p)\n"
+            "time.sleep(30)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RFN_BENCH_STALL_S="1"), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 17, r.stderr
+    assert "no progress" in r.stderr and "warm-up step 1" in r.stderr and "rank 1/2" in r.stderr

@@ -11,6 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
+if "RANK" in os.environ:                                   # same path as bench.py under torchrun (1 rank here)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=dev)
 wl = bench.RefignStep(dev, 2, 1234)
 for _ in range(6):
     wl.step()
