@@ -440,13 +440,16 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return (mixed_loss.detach(),)
 
     def _mixed_capture_context(self):
+        """What the capture of the mixed pass runs inside when the pass is to run NEXT TO the source pass: parameter
+        gradients are views of the second flat buffer (trainer.FlatGradBuffer.into_second).  Not under data parallelism:
+        both passes contain the SyncBatchNorm exchanges of the decode head on ONE communicator, and two streams must not
+        issue collectives of one communicator in a rank-dependent order.  A communicator per pass was built and measured
+        in the 1-rank rehearsal (RFN_DDP_REHEARSAL): 237.9 ms/step against 222.5 ms with the graphed passes in stream
+        order -- a captured collective is a cross-stream branch of the graph, and hipGraph replays those with a
+        synchronisation per edge, which two replays running next to each other pay for -- so it was dropped."""
         import contextlib
-        buf = getattr(self, "_grad_buffer", None)
         from .bn import data_parallel
-        # Under data parallelism both student passes contain the SyncBatchNorm exchanges of the decode head on ONE
-        # communicator: two streams must not issue collectives of one communicator in a rank-dependent order, so the
-        # passes stay in stream order there (one more communicator for the mixed pass would lift this; not done: it
-        # could not be run on more than one rank here).
+        buf = getattr(self, "_grad_buffer", None)
         if buf is None or data_parallel() or os.environ.get("RFN_MIXED_CONCURRENT", "1") == "0":
             self._mixed_on_second = False
             return contextlib.nullcontext()

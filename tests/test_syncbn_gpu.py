@@ -130,50 +130,70 @@ def test_two_processes_on_one_gpu_exchange_statistics(dev, tmp_path):
 
 
 def _rccl_step_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RFN_GRAPH_DDP="1")
+    # a 1-rank RCCL group doing everything one rank of N does (RFN_DDP_REHEARSAL): the exchanges are really issued
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RFN_DDP_REHEARSAL="1")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import random
     import test_step_gpu as T
-    from refign_amd import bn as bnk, graphs
+    from refign_amd import bn as bnk
     from refign_amd.trainer import Trainer
     dev = torch.device("cuda:0")
-    world_group = dist.group.WORLD
-    # a 1-rank group: force the exchanges (and the capture policy of N > 1) on, so that the RCCL calls are really made
-    bnk.sync_group = lambda bn: world_group if isinstance(bn, torch.nn.SyncBatchNorm) else None
-    real_usable = graphs.GraphedStep.usable
-    graphs.GraphedStep.usable = staticmethod(
-        lambda t: t.is_cuda and graphs.enabled() and os.environ.get("RFN_GRAPH_STUDENT", "1") != "0")
+    calls = {"n": 0, "groups": set()}
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        if "group" in k:                          # the statistics exchanges (the gradient buckets go without a group)
+            calls["n"] += 1
+            calls["groups"].add(id(k["group"]))
+        return real_all_reduce(t, *a, **k)
     traj = {}
-    for mode in ("1", "0"):
-        os.environ["RFN_GRAPH_STUDENT"] = mode
+    for mode in ("1", "0"):                       # student passes graphed (opt-in under data parallelism) / eager
+        os.environ["RFN_GRAPH_DDP"] = mode
         model = T.build(True, dev)
         trainer = Trainer(model, sync_batchnorm=True, fused_optimizer=False)
         n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
+        assert bnk.data_parallel() and trainer.data_parallel
         random.seed(5); np.random.seed(5); torch.manual_seed(5)
         rows = []
-        for it in range(5):
-            batch = T.make_batch(2, 128, 128, 64, dev)
-            batch["image_src"] = batch["image_src"] + 0.1 * it
-            with torch.autocast("cuda", dtype=torch.bfloat16):   # the BatchNorm kernels are the 16-bit path
-                trainer.step(batch, it)
-            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src",
-                                                          "train_loss_uda_trg")])
-        captured = all(len(model._graphs[n].states) == 1 and list(model._graphs[n].states.values())[0]["graph"] is not None
-                       for n in ("source_pass", "mixed_pass")) if mode == "1" else None
-        traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), captured, n_sync)
-    graphs.GraphedStep.usable = real_usable
+        bnk.dist.all_reduce = counting_all_reduce
+        calls["n"], calls["groups"] = 0, set()
+        try:
+            for it in range(5):
+                batch = T.make_batch(2, 128, 128, 64, dev)
+                batch["image_src"] = batch["image_src"] + 0.1 * it
+                with torch.autocast("cuda", dtype=torch.bfloat16):   # the BatchNorm kernels are the 16-bit path
+                    trainer.step(batch, it)
+                rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src",
+                                                              "train_loss_uda_trg")])
+        finally:
+            bnk.dist.all_reduce = real_all_reduce
+        captured = all(g.captured() for n, g in model._graphs.items() if n in ("source_pass", "mixed_pass")) \
+            if mode == "1" else None
+        bn = torch.cat([b.flatten().double() for n, b in model.head.named_buffers() if "running" in n]).cpu()
+        traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), captured, n_sync,
+                      calls["n"], len(calls["groups"]), model.__dict__.get("_mixed_concurrent_steps", 0), bn)
     torch.save(traj, f"{out}/traj.pt")
     dist.destroy_process_group()
 
 
 def test_student_graphs_with_rccl_statistics_exchange_inside(dev, tmp_path):
+    """What one rank of N > 1 runs, on a 1-rank RCCL group (RFN_DDP_REHEARSAL=1): 5 steps with the student passes
+    captured into hipGraphs WITH the SyncBatchNorm exchanges inside (RFN_GRAPH_DDP=1; the two passes in stream order)
+    against 5 eager steps (the N > 1 default)."""
     port, out = _free_port(), str(tmp_path)
     mp.spawn(_rccl_step_worker, args=(1, port, out), nprocs=1, join=True)
     traj = torch.load(f"{out}/traj.pt", weights_only=False)
-    assert traj["1"][3] > 0, "no SyncBatchNorm module in the model: nothing was exchanged"
-    assert traj["1"][2], "student passes were not captured"
+    g, e = traj["1"], traj["0"]
+    assert g[3] > 0, "no SyncBatchNorm module in the model: nothing was exchanged"
+    assert g[2], "student passes were not captured"
+    # eager: every exchange goes through dist.all_reduce each step, over two communicators (student, teacher); graphed:
+    # the student's are recorded once (at capture), the eager teacher head keeps calling
+    assert e[4] > 5 * 4 and e[5] == 2, e[4:6]
+    assert g[5] == 2 and g[4] < e[4], g[4:6]
+    assert g[6] == 0 and e[6] == 0, "two passes with exchanges on one communicator must stay in stream order"
     # bf16 passes with atomics in the weight-gradient kernels: the two trajectories agree to rounding, not to the bit
-    np.testing.assert_allclose(traj["1"][0], traj["0"][0], rtol=3e-2)
-    assert abs(traj["1"][1] - traj["0"][1]) < 1e-4 * traj["0"][1]
+    np.testing.assert_allclose(g[0], e[0], rtol=3e-2)
+    assert abs(g[1] - e[1]) < 1e-4 * e[1]
+    assert float((g[7] - e[7]).abs().max()) < 5e-2 * float(e[7].abs().max())
