@@ -573,8 +573,8 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
               "attn_bwd_dkv: B=%d heads=%d Nq=%d Nkv=%d nqblk=%d nqpad=%d nkpad=%d chunk=%d", B, heads, Nq, Nkv, nqblk,
               nqpad, nkpad, blocks_per_chunk);
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(accT, 0, (size_t)B * heads * 2 * 64 * nkpad * sizeof(float), s);
-  if (e != hipSuccess) return fail(RFN_ELAUNCH, "attn_bwd_dkv: memset: %s", hipGetErrorString(e));
+  // (a kernel, not a memset node, when the pass is captured into a hipGraph: capi.hip zero_async)
+  if (int rc = zero_async(accT, (size_t)B * heads * 2 * 64 * nkpad * sizeof(float), s)) return rc;
   dim3 grid(cdiv(Nkv, 256), cdiv(nqblk, blocks_per_chunk), B * heads);
 #define RFN_DKV_LAUNCH(D)                                                                                               \
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, grid, dim3(512), 0, s, (const uint16_t*)K, (const uint16_t*)V,            \

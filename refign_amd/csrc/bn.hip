@@ -216,7 +216,7 @@ int rfn_bn_stats_fwd(const void* x, float* sums, long T, int C, int dtype, rfn_s
   RFN_REQUIRE(x && sums, "bn_stats_fwd: null pointer");
   if (int rc = bn_check("bn_stats_fwd", T, C, dtype)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, (2 * (size_t)C + 1) * sizeof(float), s) != hipSuccess) return fail(RFN_ELAUNCH, "bn_stats_fwd: memset");
+  if (int rc = zero_async(sums, (2 * (size_t)C + 1) * sizeof(float), s)) return rc;   // kernel, not a memset node (capi.hip)
   return RFN_BN_DISPATCH(false, false, x, nullptr, nullptr, sums, nullptr, nullptr, nullptr, nullptr, nullptr, T, C, 0.f, 0.f, 0, 0.f, s);
 }
 
@@ -233,7 +233,7 @@ int rfn_bn_stats_bwd(const void* x, const void* grad_y, const float* fwd_sums, c
   RFN_REQUIRE(x && grad_y && fwd_sums && bwd_sums, "bn_stats_bwd: null pointer");
   if (int rc = bn_check("bn_stats_bwd", T, C, dtype)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(bwd_sums, 0, 2 * (size_t)C * sizeof(float), s) != hipSuccess) return fail(RFN_ELAUNCH, "bn_stats_bwd: memset");
+  if (int rc = zero_async(bwd_sums, 2 * (size_t)C * sizeof(float), s)) return rc;
   return RFN_BN_DISPATCH(true, false, x, grad_y, fwd_sums, bwd_sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, 0.f, relu != 0, bn_slope(relu), s);
 }
 

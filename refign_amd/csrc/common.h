@@ -34,6 +34,9 @@ __device__ __forceinline__ float wave_max(float v) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// zero-fill as a kernel on `st` (capi.hip: why not hipMemsetAsync)
+int zero_async(void* p, size_t bytes, hipStream_t st);
+
 }  // namespace rfn
 
 #define RFN_REQUIRE(cond, ...) \

@@ -1,0 +1,16 @@
+#!/bin/bash
+# tools/final_check.sh OUT -- what gets copied into profiles/ at the end of a round: full GPU test suite, bench line,
+# step phases from HIP events, rocprofv3 kernel stats of the timed region + per-queue view (run on the GPU box)
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/${1:-final}; mkdir -p $O
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
+timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_n1.json
+timeout 300 python tools/opt_phase_debug.py 2>&1 | grep "^step" > $O/step_phases_events.txt
+timeout 300 python tools/overlap_debug.py 2>&1 | grep "step\|host" >> $O/step_phases_events.txt
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench --output-format csv -- python $R/bench.py --no-cpu --steps 6 --warmup 3 > /tmp/prof_bench.log 2>&1
+cd $R
+grep '^{"metric"' /tmp/prof_bench.log > $O/bench_under_rocprof.json
+find /tmp/prof_bench -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_bench_kernel_stats.csv \;
+python tools/trace_window_stats.py $(find /tmp/prof_bench -name "*kernel_trace.csv") $O/bench_under_rocprof.json $O/rocprofv3_bench_kernel_stats_timed_region.csv > $O/trace_window.txt
+python tools/trace_queues.py $(find /tmp/prof_bench -name "*kernel_trace.csv") $O/bench_under_rocprof.json > $O/queues.txt 2>&1

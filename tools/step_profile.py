@@ -22,6 +22,7 @@ ap.add_argument("--rows", type=int, default=45)
 ap.add_argument("--shapes", action="store_true")
 ap.add_argument("--cpu", action="store_true", help="rank ops by host (self CPU) time instead of device time")
 ap.add_argument("--stacks", default="", help="aten op name: list its call sites (python stacks) by launch count")
+ap.add_argument("--by-time", action="store_true", help="--stacks: order call sites by device time, not by count")
 ap.add_argument("--ops", default="", help="comma-separated aten op names for --shapes (default: the dense ops)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -52,8 +53,10 @@ if a.stacks:
         key = "  <-  ".join(chain) + "   " + shp
         cnt[key] += 1
         dev_t[key] += e.device_time_total
-    for k, n in cnt.most_common(a.rows):
-        print(f"n={n:5d} {dev_t[k] / 1e3:8.2f} ms  {k}")
+    order = sorted(cnt, key=lambda k: -dev_t[k]) if a.by_time else [k for k, _ in cnt.most_common()]
+    print(f"total: n={sum(cnt.values())} {sum(dev_t.values()) / 1e3:.2f} ms")
+    for k in order[:a.rows]:
+        print(f"n={cnt[k]:5d} {dev_t[k] / 1e3:8.2f} ms  {k}")
 elif a.shapes:
     keys = tuple(a.ops.split(",")) if a.ops else None
     rows = [e for e in prof.key_averages(group_by_input_shape=True)
