@@ -247,8 +247,7 @@ class RefignStep:
                 with torch.autocast("cuda", enabled=dt != torch.float32, dtype=dt if dt != torch.float32 else None):
                     pt, pr, _, _ = A.extract_pyramids(self.model.alignment_backbone, self.batch["image_ref"].float(),
                                                       self.batch["image_trg"].float())
-                self._l1 = (l2_normalize_channels(pr[0].float().contiguous()),
-                            l2_normalize_channels(pt[0].float().contiguous()))
+                self._l1 = (l2_normalize_channels(pr[0]), l2_normalize_channels(pt[0]))
         return self._l1
 
     def roofline_launch(self):
@@ -290,6 +289,26 @@ def pmc_traffic():
         try:
             with open(path) as f:
                 return int(json.load(f)["hbm_traffic_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
+
+
+def rocprof_in_step_us():
+    """Average duration of the roofline kernel INSIDE the timed steps from the committed rocprofv3 kernel trace of this
+    command (profiles/rNN_rocprofv3_bench_kernel_stats_timed_region.csv, written by tools/final_check.sh): there the
+    launch sits between other kernels, the HIP-event figure of this run is 20 launches back to back (a sustained fp32
+    load at a lower clock: DESIGN.md section 4.2).  Reported next to it, never instead of it; null if absent."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_bench_kernel_stats_timed_region.csv")),
+                       reverse=True):
+        try:
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    if "corr9_dma_kernel<16, 32" in r["Name"]:
+                        return {"avg_launch_us": round(float(r["AverageNs"]) / 1e3, 2), "launches": int(r["Calls"]),
+                                "source": os.path.relpath(path, ROOT)}
         except Exception:
             continue
     return None
@@ -448,7 +467,7 @@ def main():
         roof = {"kernel": "corr9_dma_kernel<16x32 tiles, fused ReLU+L2norm> level 1 (C=128, 270x480, b=%d)" % wl.b,
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(), "avg_launch_us": round(us, 2),
-                "algorithmic_bytes_per_launch": wl.roofline_bytes()}
+                "algorithmic_bytes_per_launch": wl.roofline_bytes(), "rocprofv3_in_step": rocprof_in_step_us()}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

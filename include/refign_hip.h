@@ -109,6 +109,12 @@ int rfn_area_resize_f32(const float* x, float* out, int planes, int H, int W, in
 /* F.normalize(x, p=2, dim=1) on NCHW (uawarpc.py:101-108), eps 1e-12. */
 int rfn_l2norm_channels_f32(const float* x, float* out, int B, int C, int HW, rfn_stream_t stream);
 
+/* The same (uawarpc.py:101-108) from what the matcher's convolutions deliver under the AMP recipe: x is channels-last
+ * 16-bit, (B, HW, C) contiguous, dtype 1 = bfloat16, 2 = float16; out is NCHW float32, (B, C, HW).  The 16-bit values
+ * are widened exactly, the norm and the division are fp32 -- what `.float()` -> NCHW copy -> rfn_l2norm_channels_f32
+ * computes, in one pass.  C a multiple of 8, <= 2048. */
+int rfn_l2norm_channels_nhwc16_f32(const void* x, float* out, int B, int C, int HW, int dtype, rfn_stream_t stream);
+
 /* refine() + eta() (segmentation_model.py:438-491), gamma = trust-score exponent.
  * logits_trg, logits_ref: (B,19,H,W); warp_mask (nullable): (B,H,W) uint8; certs (nullable): (B,1,H,W);
  * out: (B,19,H,W) refined probabilities (NOT a simplex);

@@ -385,7 +385,7 @@ class UAWarpCHead(BaseHead):
         c13, c14 = self._transform_inputs(trg_256)
         c21, c22 = self._transform_inputs(src)
         c23, c24 = self._transform_inputs(src_256)
-        c11, c12, c13, c14, c21, c22, c23, c24 = [matching.l2_normalize_channels(c.float())
+        c11, c12, c13, c14, c21, c22, c23, c24 = [matching.l2_normalize_channels(c)
                                                   for c in (c11, c12, c13, c14, c21, c22, c23, c24)]
         H, W = out_size
         eu = self.estimate_uncertainty

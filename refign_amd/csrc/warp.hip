@@ -8,6 +8,9 @@
 //
 // HBM-bound gathers: one thread per output pixel computes the four taps once and streams the channels, so every
 // global access of a wave is contiguous along w for the store and near-contiguous (smooth flow) for the loads.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace rfn {
@@ -228,6 +231,66 @@ __global__ __launch_bounds__(256) void l2norm_channels_reg_kernel(const float* _
   }
 }
 
+// The same from the layout and precision the matcher's convolutions deliver under the reference's AMP recipe:
+// channels-last 16-bit features (B, HW, C) -> NCHW fp32, L2-normalised over the channels.  Replaces a cast kernel, a
+// strided NHWC -> NCHW copy (1.1 ms for 2 x 128 x 270 x 480: 0.25 TB/s) and the NCHW normalisation with one pass: a
+// workgroup stages 32 pixels x C channels as fp32 in LDS (16-byte loads along the channels), eight lanes per pixel
+// sum the squares, and the write-out runs along the pixels (32 consecutive floats per channel; LDS pitch C + 1 keeps
+// both directions conflict-free).
+template <typename T16>
+__device__ __forceinline__ float to_f32(uint16_t raw);
+template <>
+__device__ __forceinline__ float to_f32<__half>(uint16_t raw) {
+  return __half2float(__ushort_as_half(raw));
+}
+template <>
+__device__ __forceinline__ float to_f32<__hip_bfloat16>(uint16_t raw) {
+  return __uint_as_float((uint32_t)raw << 16);
+}
+
+template <typename T16>
+__global__ __launch_bounds__(256) void l2norm_nhwc16_to_nchw_kernel(const uint16_t* __restrict__ x,
+                                                                    float* __restrict__ out, int C, int HW) {
+  extern __shared__ float tile[];                 // [32][C + 1] + inv[32]
+  constexpr int PX = 32;
+  const int P = C + 1, tid = threadIdx.x, pix0 = blockIdx.x * PX;
+  const int npx = min(PX, HW - pix0);
+  float* inv = tile + PX * P;
+  const uint16_t* src = x + ((size_t)blockIdx.y * HW + pix0) * C;
+  const int nvec = npx * C / 8;                    // C % 8 == 0: the tile is a contiguous run of 16-byte vectors
+  for (int v = tid; v < nvec; v += 256) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(src + (size_t)v * 8);
+    const int px = (v * 8) / C, c = (v * 8) % C;
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tile[px * P + c + 2 * k] = to_f32<T16>((uint16_t)(w[k] & 0xffffu));
+      tile[px * P + c + 2 * k + 1] = to_f32<T16>((uint16_t)(w[k] >> 16));
+    }
+  }
+  __syncthreads();
+  {
+    const int px = tid >> 3, part = tid & 7;
+    float ss = 0.0f;
+    if (px < npx)
+      for (int c = part; c < C; c += 8) {
+        const float v = tile[px * P + c];
+        ss = fmaf(v, v, ss);
+      }
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    ss += __shfl_xor(ss, 4, 64);
+    if (part == 0) inv[px] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  }
+  __syncthreads();
+  const int px = tid & 31;
+  if (px < npx) {
+    const float d = 1.0f / inv[px];                // divide, as F.normalize does (x / max(norm, eps))
+    float* o = out + (size_t)blockIdx.y * C * HW + pix0 + px;
+    for (int c = tid >> 5; c < C; c += 8) o[(size_t)c * HW] = tile[px * P + c] / d;
+  }
+}
+
 // F.interpolate(mode='area') == adaptive average pooling: out[oy,ox] = mean of in[floor(oy*H/OH) .. ceil((oy+1)*H/OH))
 // x the same along W (ATen start_index/end_index).  One thread per output element; windows are <= ~5x8 at 1080->256.
 __global__ __launch_bounds__(256) void area_resize_kernel(const float* __restrict__ x, float* __restrict__ out, int H,
@@ -316,6 +379,29 @@ int rfn_l2norm_channels_f32(const float* x, float* out, int B, int C, int HW, rf
   else
     hipLaunchKernelGGL(l2norm_channels_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, st, x, out, C, HW);
   return check_launch("l2norm_channels_kernel");
+}
+
+int rfn_l2norm_channels_nhwc16_f32(const void* x, float* out, int B, int C, int HW, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && out, "rfn_l2norm_channels_nhwc16_f32: null pointer");
+  RFN_REQUIRE(B > 0 && B <= 65535 && C > 0 && C % 8 == 0 && C <= 2048 && HW > 0,
+              "rfn_l2norm_channels_nhwc16_f32: B=%d C=%d (multiple of 8, <= 2048) HW=%d", B, C, HW);
+  RFN_REQUIRE(dtype == 1 || dtype == 2, "rfn_l2norm_channels_nhwc16_f32: dtype %d (1 = bf16, 2 = f16)", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = ((size_t)32 * (C + 1) + 32) * sizeof(float);
+  dim3 grid(cdiv(HW, 32), B);
+  if (dtype == 2) {
+    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)l2norm_nhwc16_to_nchw_kernel<__half>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(RFN_ELAUNCH, "l2norm_nhwc16_to_nchw_kernel: %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(l2norm_nhwc16_to_nchw_kernel<__half>, grid, dim3(256), lds, st, (const uint16_t*)x, out, C, HW);
+  } else {
+    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)l2norm_nhwc16_to_nchw_kernel<__hip_bfloat16>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(RFN_ELAUNCH, "l2norm_nhwc16_to_nchw_kernel: %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(l2norm_nhwc16_to_nchw_kernel<__hip_bfloat16>, grid, dim3(256), lds, st, (const uint16_t*)x, out, C,
+                       HW);
+  }
+  return check_launch("l2norm_nhwc16_to_nchw_kernel");
 }
 
 }  // extern "C"

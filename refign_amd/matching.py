@@ -1,5 +1,7 @@
 """Host mirror of helpers/matching_utils.py for the functions on the hot path (warp, mapping->flow, confidence),
 backed by the HIP kernels in csrc/warp.hip.  Same names, argument meaning and return conventions."""
+import os
+
 import torch
 
 from . import _lib
@@ -69,13 +71,26 @@ def warp_nocheck(x, flo, return_mask=False):
     return out
 
 
+_DT16 = {torch.bfloat16: 1, torch.float16: 2}
+
+
 def l2_normalize_channels(x):
-    """F.normalize(x, p=2, dim=1) for NCHW features (uawarpc.py:101-108)."""
-    x = require_device_tensor(x.contiguous(), "x", torch.float32)
+    """F.normalize(x.float(), p=2, dim=1) for (B, C, H, W) features (uawarpc.py:101-108) -> NCHW float32.  Channels-last
+    16-bit features (what the matcher's convolutions deliver under the AMP recipe) are widened, re-laid out and
+    normalised in one kernel; anything else is made NCHW float32 first."""
+    lib = _lib.load_library()
+    if x.is_cuda and x.dim() == 4 and x.dtype in _DT16 and x.shape[1] % 8 == 0 and x.shape[1] <= 2048 and \
+            x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("RFN_L2NORM_NHWC16", "1") != "0":
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        with on_device(x.device):
+            rc = lib.rfn_l2norm_channels_nhwc16_f32(ptr(x), ptr(out), B, C, H * W, _DT16[x.dtype], current_stream(x.device))
+        _lib.check(rc, "l2_normalize_channels (channels-last 16-bit)")
+        return out
+    x = require_device_tensor(x.float().contiguous(), "x", torch.float32)
     B, C = x.shape[:2]
     hw = x[0, 0].numel()
     out = torch.empty_like(x)
-    lib = _lib.load_library()
     with on_device(x.device):
         rc = lib.rfn_l2norm_channels_f32(ptr(x), ptr(out), B, C, hw, current_stream(x.device))
     _lib.check(rc, "l2_normalize_channels")

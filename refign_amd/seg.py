@@ -373,6 +373,14 @@ def _up(x, size):
     return F.interpolate(x, size=size, mode='bilinear', align_corners=False)
 
 
+def _up_logits(x, size):
+    """_up for class logits that go straight into the loss: re-laid out to NCHW at the LOW resolution, so that the
+    up-sampled tensor is NCHW-contiguous and log_softmax does not copy it (uda._upsample_logits)."""
+    if x.is_cuda and os.environ.get("RFN_LOGITS_NCHW", "1") != "0":
+        x = x.contiguous()
+    return _up(x, size)
+
+
 class DepthwiseSeparableASPPModule(nn.ModuleList):
     """daformer.py:10-62: branch 0 is a 1x1 ConvBNReLU, dilated branches are depthwise-separable 3x3."""
 
@@ -646,7 +654,7 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
                 up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
                 up_att = F.interpolate(att, scale_factor=2, mode='bilinear', align_corners=False)
                 inserted = box.insert(hr_seg, up_lr.shape[2:], head_os)
-                return up_att * inserted + up_lr, _up(hr_seg, (box.h, box.w)), box
+                return up_att * inserted + up_lr, _up_logits(hr_seg, (box.h, box.w)), box
             if self.training and not is_teacher:
                 box = boxes[0]
                 crop_size = (box[1] - box[0], box[3] - box[2])
@@ -659,7 +667,7 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
                 inserted = torch.zeros_like(up_lr)
                 sy, sx = hr_crop_slice(box, head_os)
                 inserted[:, :, sy, sx] = hr_seg
-                hr_logits = _up(hr_seg, crop_size)
+                hr_logits = _up_logits(hr_seg, crop_size)
                 return up_att * inserted + up_lr, hr_logits, box
             up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
             # overlap-average the sliding crops (the reference rescales `hr_boxes` in place, hrda.py:207-208)

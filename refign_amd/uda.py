@@ -149,6 +149,18 @@ def strong_transform(param, data=None, target=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def _upsample_logits(logits, size):
+    """F.interpolate(logits, size, mode='bilinear', align_corners=False) of class logits to the image size
+    (segmentation_model.py:163, :169, :206, :220, :230, :239).  The decode heads hand over channels-last logits; up-sampled
+    in that layout, the 19 x H x W result is channels-last too and everything after it wants NCHW (log_softmax / the
+    refine kernels copy 315 MB per image pair at 1080x1920, 0.95 ms each).  Re-laying-out the LOW-resolution logits first
+    (20 MB) makes the up-sampled tensor NCHW-contiguous from the start: same arithmetic, no copy (RFN_LOGITS_NCHW=0: as
+    before)."""
+    if logits.is_cuda and os.environ.get("RFN_LOGITS_NCHW", "1") != "0":
+        logits = logits.contiguous()
+    return F.interpolate(logits, size, mode='bilinear', align_corners=False)
+
+
 class DomainAdaptationSegmentationModel(nn.Module):
     """models/segmentation_model.py:25-701.  Constructor keywords are the reference's."""
 
@@ -305,11 +317,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if self.use_hrda:
             feats_src = feats_src[0]                                     # low-resolution features
             logits_src, hr_logits_src, crop_box_src = logits_src
-            logits_src = F.interpolate(logits_src, images_src.shape[-2:], mode='bilinear', align_corners=False)
+            logits_src = _upsample_logits(logits_src, images_src.shape[-2:])
             loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
                 self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
         else:
-            logits_src = F.interpolate(logits_src, images_src.shape[-2:], mode='bilinear', align_corners=False)
+            logits_src = _upsample_logits(logits_src, images_src.shape[-2:])
             loss_src = self.loss(logits_src, gt_src)
         self.log("train_loss_src", loss_src)
         self.manual_backward(loss_src, retain_graph=self.enable_fdist)
@@ -344,12 +356,12 @@ class DomainAdaptationSegmentationModel(nn.Module):
         mixed_pred = self.head(self.backbone(mixed_img))
         if self.use_hrda:
             mixed_pred, hr_mixed_pred, box = mixed_pred
-            mixed_pred = F.interpolate(mixed_pred, mixed_img.shape[-2:], mode='bilinear', align_corners=False)
+            mixed_pred = _upsample_logits(mixed_pred, mixed_img.shape[-2:])
             mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
                 self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box),
                                                 pixel_weight=crop(mixed_weight, box))
         else:
-            mixed_pred = F.interpolate(mixed_pred, mixed_img.shape[-2:], mode='bilinear', align_corners=False)
+            mixed_pred = _upsample_logits(mixed_pred, mixed_img.shape[-2:])
             mixed_loss = self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight)
         self.log("train_loss_uda_trg", mixed_loss)
         self.manual_backward(mixed_loss, last=True)
@@ -390,7 +402,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         feats_src = self.backbone(images_src)
         logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
         feats_src = feats_src[0]
-        logits_src = F.interpolate(logits_src, images_src.shape[-2:], mode='bilinear', align_corners=False)
+        logits_src = _upsample_logits(logits_src, images_src.shape[-2:])
         loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
             self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
         self.manual_backward(loss_src, retain_graph=self.enable_fdist)
@@ -433,7 +445,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         """MIXED (:226-250), forward and backward."""
         push_device_crop(off, self.hrda_output_stride * 2.0)
         mixed_pred, hr_mixed_pred, box = self.head(self.backbone(mixed_img))
-        mixed_pred = F.interpolate(mixed_pred, mixed_img.shape[-2:], mode='bilinear', align_corners=False)
+        mixed_pred = _upsample_logits(mixed_pred, mixed_img.shape[-2:])
         mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
             self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
         self.manual_backward(mixed_loss)
@@ -543,7 +555,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
             # replayed from hipGraphs after the first eager call (refign_amd/graphs.py)
             return images_trg, self._teacher_align_refine(images_trg, batch['image_ref'])
         m_logits_trg = self.m_head(self.m_backbone(images_trg))
-        m_logits_trg = F.interpolate(m_logits_trg, size=images_trg.shape[-2:], mode='bilinear', align_corners=False)
+        m_logits_trg = _upsample_logits(m_logits_trg, images_trg.shape[-2:])
         return images_trg, F.softmax(m_logits_trg, dim=1)
 
     def _overlap_teacher(self, x):
@@ -582,7 +594,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         b = images_trg.shape[0]
         m_input = torch.cat((images_trg, images_ref))
         m_logits = self.m_head(self._graphs["teacher_backbone"](m_input))
-        m_logits = F.interpolate(m_logits, size=m_input.shape[-2:], mode='bilinear', align_corners=False)
+        m_logits = _upsample_logits(m_logits, m_input.shape[-2:])
         m_logits_trg, m_logits_ref = torch.split(m_logits, [b, b], dim=0)
         if self.use_align:
             return self._graphs["align_refine"](m_logits_trg.contiguous(), m_logits_ref.contiguous(), images_ref,

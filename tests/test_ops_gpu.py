@@ -223,6 +223,27 @@ def test_l2_normalize_channels(dev, B, C, H, W):
     assert float(got[0, :, 0, 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 128, 9, 11), (1, 256, 17, 33), (2, 512, 16, 16), (1, 128, 270, 480), (3, 8, 5, 7),
+                                     (1, 1024, 3, 45)])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_l2_normalize_channels_from_channels_last_16bit(dev, B, C, H, W, dt):
+    """The layout and precision the matcher's convolutions deliver under the AMP recipe: channels-last 16-bit features ->
+    NCHW float32 == F.normalize(x.float(), p=2, dim=1) (uawarpc.py:101-108), ragged pixel counts (tiles of 32), an
+    all-zero pixel; and the result is what the composite path (cast, NCHW copy, NCHW kernel) gives."""
+    from fill import hashed_uniform
+    from refign_amd.matching import l2_normalize_channels
+    x = (T(hashed_uniform((B, C, H, W), f"l2n16/{B}/{C}/{H}/{W}") * 4 - 2, dev)).to(dt)
+    x[0, :, 0, 0] = 0
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    got = l2_normalize_channels(xcl)
+    assert got.dtype == torch.float32 and got.is_contiguous() and tuple(got.shape) == (B, C, H, W)
+    want = torch.nn.functional.normalize(x.float(), p=2, dim=1)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), float((got - want).abs().max())
+    assert float(got[0, :, 0, 0].abs().max()) == 0.0
+    composite = l2_normalize_channels(x.float().contiguous())
+    assert torch.allclose(got, composite, rtol=1e-6, atol=1e-7)
+
+
 # ------------------------------------------------------------------ full-size (K4) properties of the remaining kernels
 def test_warp_full_size_properties(dev):
     """feature warp at the K4 level-1 size (2 x 128 x 270 x 480): integer flows are exact shifts with zero fill and the

@@ -22,6 +22,7 @@ ap.add_argument("--rows", type=int, default=45)
 ap.add_argument("--shapes", action="store_true")
 ap.add_argument("--cpu", action="store_true", help="rank ops by host (self CPU) time instead of device time")
 ap.add_argument("--stacks", default="", help="aten op name: list its call sites (python stacks) by launch count")
+ap.add_argument("--pystack", action="store_true", help="--stacks: add the innermost python frames of this repository")
 ap.add_argument("--by-time", action="store_true", help="--stacks: order call sites by device time, not by count")
 ap.add_argument("--ops", default="", help="comma-separated aten op names for --shapes (default: the dense ops)")
 a = ap.parse_args()
@@ -35,7 +36,8 @@ wl = bench.WORKLOADS[a.workload](dev, 2, 1234, a.height, a.width, a.precision)
 for _ in range(2):
     wl.step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=a.shapes or bool(a.stacks)) as prof:
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=a.shapes or bool(a.stacks),
+             with_stack=a.pystack) as prof:
     wl.step()
     torch.cuda.synchronize()
 if a.stacks:
@@ -51,6 +53,9 @@ if a.stacks:
             p = p.cpu_parent
         shp = str(e.input_shapes)[:60] if e.input_shapes else ""
         key = "  <-  ".join(chain) + "   " + shp
+        if a.pystack:                                     # innermost python frames inside this repository
+            fr = [f for f in (e.stack or []) if "refign_amd/" in f or "bench.py" in f][:2]
+            key = " | ".join(f.split("refign_amd/")[-1][:60] for f in fr) + "   " + key
         cnt[key] += 1
         dev_t[key] += e.device_time_total
     order = sorted(cnt, key=lambda k: -dev_t[k]) if a.by_time else [k for k, _ in cnt.most_common()]
