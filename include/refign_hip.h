@@ -266,6 +266,12 @@ int rfn_linear_gemm(int kind, const void* A, const void* B, void* C, const void*
 int rfn_upsample_concat_nhwc(const void* src0, const void* src1, const void* src2, const void* src3, const int* hs,
                              const int* ws, const int* cs, int nlev, void* out, int n, int H, int W, int dtype,
                              rfn_stream_t stream);
+/* Its backward (what autograd runs for F.interpolate + torch.cat of daformer.py:205-222 / segformer.py:86-104):
+ * grad_out (n, H, W, sum C_l) channels-last -> grad_l (n, hs[l]*ws[l], cs[l]) for every level, in one pass; the
+ * bilinear weights of the forward, fp32 accumulation.  Deterministic (a gather, no atomics). */
+int rfn_upsample_concat_nhwc_bwd(const void* grad_out, void* grad0, void* grad1, void* grad2, void* grad3, const int* hs,
+                                 const int* ws, const int* cs, int nlev, int n, int H, int W, int dtype,
+                                 rfn_stream_t stream);
 
 /* Token map (B, H*W, C) -> non-overlapping r x r patches (B*(H/r)*(W/r), r*r*C) with (ry, rx, c) fastest (inverse = 0),
  * or back (inverse = 1; a ragged border of the token map is NOT written -- zero it first): gather / scatter around the

@@ -50,6 +50,7 @@ SIGNATURES = {
                                        ctypes.c_long, c_int, c_int, c_void_p]),
     "rfn_upsample_concat_nhwc": (c_int, [c_void_p] * 4 + [ctypes.POINTER(c_int)] * 3 + [c_int, c_void_p] + [c_int] * 4
                                  + [c_void_p]),
+    "rfn_upsample_concat_nhwc_bwd": (c_int, [c_void_p] * 5 + [ctypes.POINTER(c_int)] * 3 + [c_int] * 5 + [c_void_p]),
     "rfn_patchify_tokens": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rfn_gemm_workspace_bytes": (ctypes.c_ulong, []),
     "rfn_linear_gemm": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_long] * 3 + [c_int, c_int, c_void_p]),

@@ -103,6 +103,87 @@ __global__ __launch_bounds__(256) void upcat_nhwc_kernel(UpcatArgs a, T* __restr
   }
 }
 
+// Backward of the above: the gradient of every SOURCE vector in one pass over the concatenated gradient.  One thread =
+// one 8-channel vector of one source pixel (ys, xs) of level l; it gathers over the output pixels whose bilinear
+// footprint contains the source pixel -- a contiguous window of about 2 H/h_l x 2 W/w_l pixels -- with the weights the
+// forward used, recomputed by the forward's own float arithmetic (a candidate row / column that does not reference the
+// source pixel gets weight 0, so the window only has to be generous).  Reads the (n, H, W, sum C) gradient in place with
+// the level's channel offset: no slicing, no per-level scatter (the library's up-sampling backward on channel slices of
+// the fused gradient: 310 us per level and pass, plus the strided slice copies).  fp32 accumulation, one rounding.
+struct UpcatBwdArgs {
+  void* dst[4];
+  int h[4], w[4], cv0[5];
+  long vec0[5];                // prefix sum of n * h_l * w_l * (C_l / 8): thread ranges of the levels
+  int nlev;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_bwd_nhwc_kernel(UpcatBwdArgs a, const T* __restrict__ g, int H, int W,
+                                                             long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < a.nlev && idx >= a.vec0[i]) l = i;
+  const int CV = a.cv0[a.nlev], CVl = a.cv0[l + 1] - a.cv0[l], hl = a.h[l], wl = a.w[l];
+  long loc = idx - a.vec0[l];
+  const int cl = (int)(loc % CVl);
+  loc /= CVl;
+  const int xs = (int)(loc % wl);
+  loc /= wl;
+  const int ys = (int)(loc % hl);
+  const int n = (int)(loc / hl);
+  const T* gb = g + (size_t)n * H * W * CV * 8 + (size_t)(a.cv0[l] + cl) * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto add = [&](const T* p, float wgt) {
+    float v[8];
+    if constexpr (sizeof(T) == 2) unpack8(*reinterpret_cast<const uint4*>(p), v);
+    else {
+      const float4 u = *reinterpret_cast<const float4*>(p), t = *reinterpret_cast<const float4*>(p + 4);
+      v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; v[4] = t.x; v[5] = t.y; v[6] = t.z; v[7] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(wgt, v[i], acc[i]);
+  };
+  if (hl == H && wl == W) {
+    add(gb + ((size_t)ys * W + xs) * CV * 8, 1.0f);
+  } else {
+    const float ry = (float)hl / (float)H, rx = (float)wl / (float)W;       // the forward's scales
+    const int ylo = max(0, (int)floorf(((float)ys - 0.5f) / ry - 0.5f) - 1);
+    const int yhi = min(H - 1, (int)ceilf(((float)ys + 1.5f) / ry - 0.5f) + 1);
+    const int xlo = max(0, (int)floorf(((float)xs - 0.5f) / rx - 0.5f) - 1);
+    const int xhi = min(W - 1, (int)ceilf(((float)xs + 1.5f) / rx - 0.5f) + 1);
+    for (int y = ylo; y <= yhi; ++y) {
+      const float sy = fmaxf(((float)y + 0.5f) * ry - 0.5f, 0.0f);
+      const int y0 = (int)sy, y1 = min(y0 + 1, hl - 1);
+      const float ly = sy - (float)y0;
+      const float wy = (y0 == ys ? 1.0f - ly : 0.0f) + (y1 == ys ? ly : 0.0f);
+      if (wy == 0.0f) continue;
+      const T* row = gb + (size_t)y * W * CV * 8;
+      for (int x = xlo; x <= xhi; ++x) {
+        const float sx = fmaxf(((float)x + 0.5f) * rx - 0.5f, 0.0f);
+        const int x0 = (int)sx, x1 = min(x0 + 1, wl - 1);
+        const float lx = sx - (float)x0;
+        const float wx = (x0 == xs ? 1.0f - lx : 0.0f) + (x1 == xs ? lx : 0.0f);
+        if (wx != 0.0f) add(row + (size_t)x * CV * 8, wy * wx);
+      }
+    }
+  }
+  T* o = reinterpret_cast<T*>(a.dst[l]) + (((size_t)n * hl + ys) * wl + xs) * (size_t)CVl * 8 + (size_t)cl * 8;
+  if constexpr (sizeof(T) == 2) {
+    uint4 t;
+    t.x = rne16(acc[0]) | (rne16(acc[1]) << 16);
+    t.y = rne16(acc[2]) | (rne16(acc[3]) << 16);
+    t.z = rne16(acc[4]) | (rne16(acc[5]) << 16);
+    t.w = rne16(acc[6]) | (rne16(acc[7]) << 16);
+    *reinterpret_cast<uint4*>(o) = t;
+  } else {
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
 }  // namespace rfn
 
 using namespace rfn;
@@ -142,6 +223,45 @@ int rfn_upsample_concat_nhwc(const void* src0, const void* src1, const void* src
   else
     return fail(RFN_EINVAL, "rfn_upsample_concat_nhwc: dtype must be 0 (f32) or 1 (bf16)");
   return check_launch("upcat_nhwc_kernel");
+}
+
+int rfn_upsample_concat_nhwc_bwd(const void* grad_out, void* grad0, void* grad1, void* grad2, void* grad3, const int* hs,
+                                 const int* ws, const int* cs, int nlev, int n, int H, int W, int dtype,
+                                 rfn_stream_t stream) {
+  RFN_REQUIRE(nlev >= 1 && nlev <= 4 && grad_out && hs && ws && cs && n > 0 && H > 0 && W > 0,
+              "rfn_upsample_concat_nhwc_bwd: bad arguments");
+  UpcatBwdArgs a;
+  void* dsts[4] = {grad0, grad1, grad2, grad3};
+  a.nlev = nlev;
+  a.cv0[0] = 0;
+  a.vec0[0] = 0;
+  for (int l = 0; l < 4; ++l) {
+    a.dst[l] = l < nlev ? dsts[l] : nullptr;
+    a.h[l] = l < nlev ? hs[l] : 1;
+    a.w[l] = l < nlev ? ws[l] : 1;
+    if (l < nlev) {
+      RFN_REQUIRE(dsts[l] && hs[l] > 0 && ws[l] > 0 && hs[l] <= H && ws[l] <= W && cs[l] > 0 && cs[l] % 8 == 0,
+                  "rfn_upsample_concat_nhwc_bwd: level %d: null gradient, channels not a multiple of 8 or larger than the "
+                  "output", l);
+      a.cv0[l + 1] = a.cv0[l] + cs[l] / 8;
+      a.vec0[l + 1] = a.vec0[l] + (long)n * hs[l] * ws[l] * (cs[l] / 8);
+    } else {
+      a.cv0[l + 1] = a.cv0[l];
+      a.vec0[l + 1] = a.vec0[l];
+    }
+  }
+  const long total = a.vec0[nlev];
+  RFN_REQUIRE(total / 256 < 0x7fffffffL, "rfn_upsample_concat_nhwc_bwd: too large");
+  const int grid = cdiv(total, 256);
+  if (dtype == 1)
+    hipLaunchKernelGGL((upcat_bwd_nhwc_kernel<__hip_bfloat16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a,
+                       (const __hip_bfloat16*)grad_out, H, W, total);
+  else if (dtype == 0)
+    hipLaunchKernelGGL((upcat_bwd_nhwc_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a,
+                       (const float*)grad_out, H, W, total);
+  else
+    return fail(RFN_EINVAL, "rfn_upsample_concat_nhwc_bwd: dtype must be 0 (f32) or 1 (bf16)");
+  return check_launch("upcat_bwd_nhwc_kernel");
 }
 
 }  // extern "C"

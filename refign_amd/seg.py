@@ -136,6 +136,12 @@ def _sdpa_backend():
 
 _SDPA_BACKEND = _sdpa_backend()
 _FUSED_UPCAT = os.environ.get("RFN_FUSED_UPCAT", "1") != "0"       # decode heads: up-sampling + concat in one kernel
+
+
+def _fused_upcat_here():
+    """gradient-free passes always; under autograd with the gather backward kernel (RFN_FUSED_UPCAT_GRAD=0: the unfused
+    graph -- the library's bilinear backward on channel slices of the fused gradient was 34 ms/step slower than that)"""
+    return _FUSED_UPCAT and (not torch.is_grad_enabled() or os.environ.get("RFN_FUSED_UPCAT_GRAD", "1") != "0")
 _SR_AS_LINEAR = os.environ.get("RFN_SR_AS_LINEAR", "1") != "0"     # spatial-reduction conv as a Linear over patches
 
 
@@ -444,10 +450,8 @@ class DAFormerHead(BaseHead):
         x = self._transform_inputs(x)
         size = x[0].shape[2:]
         toks = [self.embed_layers[str(i)](f) for i, f in enumerate(x)]          # (n, h_l*w_l, embed) token maps
-        # one pass (csrc/upcat.hip) on the gradient-free paths (teacher, inference); with autograd the library's bilinear
-        # backward on the channel slices of the fused gradient measured 34 ms/step slower than on the unfused graph
-        cat = upsample_concat(toks, [f.shape[2:] for f in x], size) \
-            if (_FUSED_UPCAT and not torch.is_grad_enabled()) else None
+        # one pass (csrc/upcat.hip), forward and backward
+        cat = upsample_concat(toks, [f.shape[2:] for f in x], size) if _fused_upcat_here() else None
         if cat is None:
             cs = []
             for c, f in zip(toks, x):
@@ -488,8 +492,7 @@ class SegFormerHead(BaseHead):
 
         feats = [c4, c3, c2, c1]                     # concat order of the reference (segformer.py:97)
         toks = [layer(f) for layer, f in zip((self.linear_c4, self.linear_c3, self.linear_c2, self.linear_c1), feats)]
-        cat = upsample_concat(toks, [f.shape[2:] for f in feats], size) \
-            if (_FUSED_UPCAT and not torch.is_grad_enabled()) else None
+        cat = upsample_concat(toks, [f.shape[2:] for f in feats], size) if _fused_upcat_here() else None
         if cat is None:
             parts = []
             for t, f in zip(toks, feats):

@@ -4,10 +4,11 @@
 the embedding Linear -- bilinearly up-sampled (align_corners=False) to `out_size` and concatenated along channels in ONE
 pass, returned as an NCHW-shaped, channels-last tensor (n, sum C_l, H, W): what
 `torch.cat([F.interpolate(t.transpose(1, 2).reshape(n, C_l, h_l, w_l), out_size, mode='bilinear') ...], 1)` gives
-(daformer.py:205-222, segformer.py:86-104).  Backward: the concat's gradient is sliced per level and goes through the
-library's bilinear backward (a scatter, no fusion to gain there).
+(daformer.py:205-222, segformer.py:86-104).  Backward: one gather kernel over the concatenated gradient for all levels
+(rfn_upsample_concat_nhwc_bwd; RFN_UPCAT_BWD=0: the library's bilinear backward on the channel slices).
 """
 import ctypes
+import os
 
 import torch
 
@@ -38,6 +39,19 @@ class _UpCat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         n, H, W, cs, sizes = ctx.geom
+        if os.environ.get("RFN_UPCAT_BWD", "1") != "0" and g.dtype in _DT:
+            gn = g.permute(0, 2, 3, 1)
+            if not gn.is_contiguous():
+                gn = gn.contiguous()
+            grads = [torch.empty((n, h * w, c), dtype=g.dtype, device=g.device) for c, (h, w) in zip(cs, sizes)]
+            arr = ctypes.c_int * len(cs)
+            dsts = [ptr(t) for t in grads] + [None] * (4 - len(cs))
+            with on_device(g.device):
+                rc = _lib.load_library().rfn_upsample_concat_nhwc_bwd(
+                    ptr(gn), dsts[0], dsts[1], dsts[2], dsts[3], arr(*[s_[0] for s_ in sizes]), arr(*[s_[1] for s_ in sizes]),
+                    arr(*cs), len(cs), n, H, W, _DT[g.dtype], current_stream(g.device))
+            _lib.check(rc, "upsample_concat_nhwc_bwd")
+            return (None, None) + tuple(t if ctx.needs_input_grad[2 + i] else None for i, t in enumerate(grads))
         grads, off = [], 0
         for i, (c, (h, w)) in enumerate(zip(cs, sizes)):
             if not ctx.needs_input_grad[2 + i]:

@@ -39,12 +39,18 @@ def test_loss_golden_gpu(dev):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("sizes,chans", [([(34, 60), (17, 30), (9, 15), (5, 8)], [32, 32, 32, 32]),
                                          ([(5, 8), (9, 15), (17, 30), (34, 60)], [16, 24, 8, 40]),
-                                         ([(12, 12), (6, 6)], [64, 8])])
-def test_upsample_concat_fused_matches_interpolate_cat(dev, dt, sizes, chans):
+                                         ([(12, 12), (6, 6)], [64, 8]),
+                                         ([(135, 240), (68, 120), (34, 60), (17, 30)], [8, 16, 8, 8]),
+                                         ([(7, 9), (7, 9), (1, 1)], [8, 8, 8])])
+@pytest.mark.parametrize("bwd", ["kernel", "library"])
+def test_upsample_concat_fused_matches_interpolate_cat(dev, dt, sizes, chans, bwd, monkeypatch):
     """csrc/upcat.hip (decode-head fusion front end) == cat([interpolate(bilinear, align_corners=False)...], 1):
-    forward and the gradients w.r.t. every level's token map; ragged size ratios, levels in any order."""
+    forward and the gradients w.r.t. every level's token map (the gather kernel over the concatenated gradient, and the
+    library's bilinear backward on its channel slices); ragged size ratios (MiT's 135x240 / 68x120 / 34x60 / 17x30),
+    levels in any order, a level that already has the output size, a 1x1 level."""
     import torch.nn.functional as F
     from refign_amd.upcat import upsample_concat
+    monkeypatch.setenv("RFN_UPCAT_BWD", "1" if bwd == "kernel" else "0")
     g = torch.Generator().manual_seed(len(sizes) * 7 + chans[0])
     n = 3
     H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)
