@@ -55,9 +55,31 @@ def main():
         add(f"corr9 +warp+relu+l2n {lvl} C={C} {H}x{W}", timeit(lambda: correlation.local_correlation_layer(f2, f1, flow=fl)), nb + 8 * b * H * W, fp)
         add(f"warp features        {lvl} C={C} {H}x{W}", timeit(lambda: matching.warp_nocheck(f2, fl)), 4 * b * H * W * (2 * C + 2))
         add(f"l2norm channels      {lvl} C={C} {H}x{W}", timeit(lambda: matching.l2_normalize_channels(f2)), 4 * b * H * W * 2 * C)
+        f16 = f2.half().contiguous(memory_format=torch.channels_last)
+        add(f"l2norm nhwc16->nchw  {lvl} C={C} {H}x{W}", timeit(lambda: matching.l2_normalize_channels(f16)), 6 * b * H * W * C)
+        add(f"  cast + copy + norm {lvl} C={C} {H}x{W}", timeit(lambda: matching.l2_normalize_channels(f16.float().contiguous())), 6 * b * H * W * C)
         if lvl == "L1":
             go = torch.randn(b, 9, 9, H, W, generator=g).to(dev)
             add(f"corr9 backward       {lvl} C={C} {H}x{W}", timeit(lambda: correlation.backward(f1, f2, go, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1), reps=5), 4 * b * H * W * (4 * C + 81))
+    if not args.only or "upcat" in args.only:
+        # decode-head fusion front end at the student's (n = 4) and the teacher's (n = 40) sizes: forward, and the gather
+        # backward over the concatenated gradient against the library's bilinear backward on its channel slices
+        import os
+        from refign_amd.upcat import upsample_concat
+        sizes = [(135, 240), (68, 120), (34, 60), (17, 30)]
+        for n_ in (4, 40):
+            toks = [torch.randn(n_, h * w, 256, device=dev).bfloat16().requires_grad_(n_ == 4) for h, w in sizes]
+            nbytes = 2 * (n_ * 135 * 240 * 1024 + sum(n_ * h * w * 256 for h, w in sizes))
+            with torch.no_grad():
+                add(f"upcat fwd n={n_} 4 x 256 -> 135x240x1024 bf16", timeit(lambda: upsample_concat(toks, sizes, sizes[0])), nbytes)
+            if n_ == 4:
+                out = upsample_concat(toks, sizes, sizes[0])
+                go = torch.randn_like(out)
+                for mode in ("1", "0"):
+                    os.environ["RFN_UPCAT_BWD"] = mode
+                    add(f"upcat bwd n={n_} ({'gather kernel' if mode == '1' else 'library on slices'})",
+                        timeit(lambda: torch.autograd.grad(out, toks, go, retain_graph=True), reps=10), nbytes)
+                os.environ["RFN_UPCAT_BWD"] = "1"
     if not args.only or "dw" in args.only:
         from refign_amd.dwconv import dwconv3x3_nhwc
         for (B_, H, W, C, dil, dt) in [(40, 135, 240, 1024, 6, torch.bfloat16), (40, 34, 60, 1280, 1, torch.bfloat16),
