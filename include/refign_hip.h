@@ -79,6 +79,14 @@ int rfn_corr_bwd_f64(const double* in1, const double* in2, const double* grad_ou
 int rfn_local_corr_layer_f32(const float* feature_target, const float* feature_source, const float* flow,
                              float* out, int B, int C, int H, int W, rfn_stream_t stream);
 
+/* The same for SMALL maps (no flow): the channels are split into `splits` chunks that run as separate workgroups (a
+ * 2 x 256 x 32 x 32 level is 8 tiles -- 8 workgroups walking 256 channels serially, ~100 us of latency), partial sums go
+ * to `workspace` (splits * B * 81 * H * W floats) and a second kernel adds them in chunk order and applies ReLU +
+ * L2 norm.  Deterministic; differs from the one-kernel path by the rounding of the chunked channel sum only.
+ * W % 4 == 0, C % splits == 0, (C / splits) % 8 == 0, 2 <= splits <= 64. */
+int rfn_local_corr_layer_split_f32(const float* feature_target, const float* feature_source, float* out,
+                                   float* workspace, int B, int C, int H, int W, int splits, rfn_stream_t stream);
+
 /* GlobalFeatureCorrelationLayer.forward (modules.py:294-308): '3D' H-first correlation (modules.py:361-375),
  * mutual matching with eps 1e-5 (modules.py:310-333), ReLU, L2-normalise over the source axis.
  * src: (B,C,Hs,Ws), trg: (B,C,Ht,Wt) -> out: (B,Hs*Ws,Ht,Wt).  Requires Hs*Ws <= 1024 and Ht*Wt <= 1024

@@ -10,6 +10,8 @@ Mirrors, name for name, what the reference exposes for this op:
 Inputs are borrowed and must be contiguous NCHW on one HIP device; outputs are freshly allocated and returned by
 value (the reference: torch::zeros / zeros_like, correlation_cuda_kernel.cu:259,291-292).  Errors are RuntimeError.
 """
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
@@ -137,8 +139,35 @@ def local_correlation_layer(feature_source, feature_target, flow=None, single_ke
         feature_source, flow = warp_nocheck(feature_source, flow), None
     out = torch.empty((B, 81, H, W), dtype=torch.float32, device=dev)
     lib = _lib.load_library()
+    splits = _channel_splits(B, C, H, W) if flow is None else 1
     with on_device(dev):
-        rc = lib.rfn_local_corr_layer_f32(ptr(feature_target), ptr(feature_source), ptr(flow), ptr(out), B, C, H, W,
-                                          current_stream(dev))
+        if splits > 1:
+            ws = torch.empty((splits, B, 81, H, W), dtype=torch.float32, device=dev)
+            rc = lib.rfn_local_corr_layer_split_f32(ptr(feature_target), ptr(feature_source), ptr(out), ptr(ws), B, C, H, W,
+                                                    splits, current_stream(dev))
+        else:
+            rc = lib.rfn_local_corr_layer_f32(ptr(feature_target), ptr(feature_source), ptr(flow), ptr(out), B, C, H, W,
+                                              current_stream(dev))
     _lib.check(rc, "local_correlation_layer")
     return out
+
+
+def _channel_splits(B, C, H, W):
+    """How many channel chunks the patch-9 kernel of a TINY map is split into (csrc/corr.hip launch_corr9_split): the
+    tiled kernel walks the channels of a tile serially, so a map of a few 8x64 tiles (2 x 256 x 32 x 32: 8 workgroups on
+    256 CUs) is ~100 us of pure latency.  Measured (profiles/r02_kbench_corr_split.txt): it pays for such maps only --
+    at 2 x 256 x 135 x 240 (136 tiles) two or four chunks are SLOWER than the one-kernel path (134-141 vs 106 us: the
+    per-workgroup set-up and the extra pass over the partial sums cost more than the second half of the chip gives).
+    1 = the one-kernel path; RFN_CORR_SPLIT=0 switches the split off, RFN_CORR_SPLITS=n forces n chunks."""
+    if os.environ.get("RFN_CORR_SPLIT", "1") == "0" or W % 4 or C % 8:
+        return 1
+    forced = int(os.environ.get("RFN_CORR_SPLITS", "0"))                # tuning knob
+    if forced:
+        return forced if (forced > 1 and C % forced == 0 and (C // forced) % 8 == 0) else 1
+    tiles = B * -(-W // 64) * -(-H // 8)
+    if tiles > 32:
+        return 1
+    s = 1
+    while tiles * s < 64 and s < 8 and C % (2 * s) == 0 and (C // (2 * s)) % 8 == 0 and C // (2 * s) >= 16:
+        s *= 2
+    return s

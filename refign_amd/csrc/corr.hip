@@ -288,7 +288,9 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
 template <int TH, int TW, int CC, bool FUSE, int MINW, int UNR, int NTILE, bool ILV>
 __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_kernel(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
-    int tilesX, int tilesY, int ntiles, int xcd_remap, int ablate) {
+    int tilesX, int tilesY, int ntiles, int xcd_remap, int ablate, int Ctot, long part_stride) {
+  // Channel split (small maps, launch_corr9_split below): blockIdx.y selects a chunk of C of the Ctot channels and
+  // the workgroup writes its partial sums to out + blockIdx.y * part_stride.  One chunk: Ctot == C, part_stride == 0.
   static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
   constexpr int STRIPS = TW / 4;                     // 4-pixel strips per tile row
   constexpr int RPW = 64 / STRIPS;                   // tile rows covered by one wave (4 or 8)
@@ -344,8 +346,9 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_ker
   const int strip = (TW == 64) ? ((q & 1) ? ((j + 14) & 15) : j) : (j ^ ((((q & 3) == 1) || ((q & 3) == 2)) ? 4 : 0));
 
   const size_t plane = (size_t)H * W;
-  const float* p1 = in1 + (size_t)n * C * plane;
-  const float* p2 = in2 + (size_t)n * C * plane;
+  const float* p1 = in1 + ((size_t)n * Ctot + (size_t)blockIdx.y * C) * plane;
+  const float* p2 = in2 + ((size_t)n * Ctot + (size_t)blockIdx.y * C) * plane;
+  out += (size_t)blockIdx.y * part_stride;
 
   // zero both buffers once (out-of-image slots stay zero forever)
   for (int i = tid; i < BUF / 4; i += NT) {
@@ -775,7 +778,7 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
     if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
     hipLaunchKernelGGL((corr9_dma_kernel<TH_, TW_, CC_, FUSE, MINW_, UNR_, NTILE_, ILV_>), dim3((unsigned)blocks), \
                        dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
-                       (int)ntiles, xcd_remap, ablate);                                                           \
+                       (int)ntiles, xcd_remap, ablate, C, 0L);                                                    \
     return check_launch("corr9_dma_kernel");                                                                      \
   }
 #define RFN_LAUNCH_PIPE(TH_, TW_, MINW_, NTILE_)                                                                  \
@@ -826,6 +829,82 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
   hipLaunchKernelGGL((corr9_tile_kernel<TH, CC, FUSE, WARP>), dim3((unsigned)blocks), dim3(TH * kStrips * 3), 0,
                      st, in1, in2, flow, out, C, H, W, tilesX, tilesY);
   return check_launch("corr9_tile_kernel");
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Channel split for small maps.  The tiled kernels walk the C channels of a tile serially: a 2 x 256 x 32 x 32 level
+// is 8 tiles = 8 workgroups on 256 CUs and takes the same ~100 us as the 2 x 128 x 270 x 480 level (pure latency:
+// 64 chunk hand-offs of ~1.5 us).  Here S workgroups share a tile, each over C / S channels, writing raw partial sums
+// to a workspace (S, B, 81, H, W); the reduce kernel adds them in chunk order (deterministic) and applies the fused
+// ReLU + L2-norm epilogue of the one-kernel path.
+// --------------------------------------------------------------------------------------------------------
+// 32 pixels x 8 shift lanes per workgroup: lane (px, k) adds the S partials of shifts k, k+8, ... (coalesced over the
+// pixels) into an LDS tile [81][32]; three lanes per pixel then take the squares of the three vertical-shift groups in
+// the one-kernel epilogue's order, and everybody scales and stores.
+template <bool FUSE>
+__global__ __launch_bounds__(256) void corr9_split_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                 int S, long part_stride, long plane, long total) {
+  __shared__ float tile[81][33];
+  __shared__ float ssq[3][32];
+  const int px = threadIdx.x & 31, k = threadIdx.x >> 5;
+  const long idx = (long)blockIdx.x * 32 + px;                   // (n, pixel)
+  const bool ok = idx < total;
+  const long n = ok ? idx / plane : 0, pix = ok ? idx % plane : 0;
+  const float* p = part + n * 81 * plane + pix;
+  for (int d = k; d < 81; d += 8) {
+    float v = 0.0f;
+    if (ok) {
+      // chunk order, four loads in flight at a time (the adds stay sequential: same sum for every launch geometry)
+      const float* q = p + (long)d * plane;
+      v = q[0];
+      int s = 1;
+      for (; s + 3 < S; s += 4) {
+        const float t0 = q[(long)s * part_stride], t1 = q[(long)(s + 1) * part_stride];
+        const float t2 = q[(long)(s + 2) * part_stride], t3 = q[(long)(s + 3) * part_stride];
+        v = (((v + t0) + t1) + t2) + t3;
+      }
+      for (; s < S; ++s) v += q[(long)s * part_stride];
+    }
+    tile[d][px] = FUSE ? fmaxf(v, 0.0f) : v;
+  }
+  __syncthreads();
+  float scale = 1.0f;
+  if constexpr (FUSE) {
+    if (k < 3) {
+      float ss = 0.0f;
+#pragma unroll
+      for (int d = 0; d < 27; ++d) {
+        const float r = tile[k * 27 + d][px];
+        ss = fmaf(r, r, ss);
+      }
+      ssq[k][px] = ss;
+    }
+    __syncthreads();
+    scale = 1.0f / fmaxf(sqrtf(ssq[0][px] + ssq[1][px] + ssq[2][px]), 1e-12f);
+  }
+  if (ok) {
+    float* o = out + n * 81 * plane + pix;
+    for (int d = k; d < 81; d += 8) o[(long)d * plane] = tile[d][px] * scale;
+  }
+}
+
+template <bool FUSE>
+static int launch_corr9_split(const float* in1, const float* in2, float* out, float* workspace, int B, int C, int H, int W,
+                              int S, hipStream_t st) {
+  constexpr int TH = 8, TW = 64;
+  const int Cc = C / S;
+  const int tilesX = cdiv(W, TW), tilesY = cdiv(H, TH);
+  const long ntiles = (long)B * tilesX * tilesY;
+  if (ntiles <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9 split: grid too large");
+  const long plane = (long)H * W, part_stride = (long)B * 81 * plane;
+  hipLaunchKernelGGL((corr9_dma_kernel<TH, TW, 4, false, 3, 1, 1, false>), dim3((unsigned)ntiles, (unsigned)S),
+                     dim3(TH * (TW / 4) * 3), 0, st, in1, in2, workspace, Cc, H, W, tilesX, tilesY, (int)ntiles, 0, 0, C,
+                     part_stride);
+  if (int rc = check_launch("corr9_dma_kernel (channel split)")) return rc;
+  const long total = (long)B * plane;
+  hipLaunchKernelGGL((corr9_split_reduce_kernel<FUSE>), dim3(cdiv(total, 32)), dim3(256), 0, st, workspace, out, S,
+                     part_stride, plane, total);
+  return check_launch("corr9_split_reduce_kernel");
 }
 
 // --------------------------------------------------------------------------------------------------------
@@ -1132,6 +1211,16 @@ int rfn_local_corr_layer_f32(const float* feature_target, const float* feature_s
   hipStream_t st = (hipStream_t)stream;
   if (flow) return launch_corr9<true, true>(feature_target, feature_source, flow, out, B, C, H, W, st);
   return launch_corr9<true, false>(feature_target, feature_source, nullptr, out, B, C, H, W, st);
+}
+
+int rfn_local_corr_layer_split_f32(const float* feature_target, const float* feature_source, float* out,
+                                   float* workspace, int B, int C, int H, int W, int splits, rfn_stream_t stream) {
+  RFN_REQUIRE(feature_target && feature_source && out && workspace, "rfn_local_corr_layer_split_f32: null pointer");
+  RFN_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (W & 3) == 0, "rfn_local_corr_layer_split_f32: B=%d C=%d H=%d W=%d (W %% 4 == 0)",
+              B, C, H, W);
+  RFN_REQUIRE(splits >= 2 && splits <= 64 && C % splits == 0 && (C / splits) % 8 == 0,
+              "rfn_local_corr_layer_split_f32: %d channels in %d chunks (chunks of a multiple of 8 channels)", C, splits);
+  return launch_corr9_split<true>(feature_target, feature_source, out, workspace, B, C, H, W, splits, (hipStream_t)stream);
 }
 
 }  // extern "C"

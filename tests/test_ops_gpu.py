@@ -244,6 +244,28 @@ def test_l2_normalize_channels_from_channels_last_16bit(dev, B, C, H, W, dt):
     assert torch.allclose(got, composite, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 32, 32), (1, 128, 9, 12), (2, 64, 17, 64), (1, 512, 16, 16), (3, 32, 8, 4)])
+def test_local_correlation_layer_channel_split_matches_one_kernel_path(dev, oracle, B, C, H, W, monkeypatch):
+    """Small maps split their channels over several workgroups (csrc/corr.hip launch_corr9_split: partial sums + a
+    reduce kernel with the fused ReLU + L2-norm epilogue): same result as the one-kernel path up to the rounding of the
+    chunked channel sum, equal to the CPU oracle within the correlation tolerance, deterministic, ragged sizes."""
+    from refign_amd import correlation
+    rng = np.random.default_rng(B * C + H * W)
+    src = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    trg = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    s = correlation._channel_splits(B, C, H, W)
+    assert s > 1, "this size is supposed to take the split path"
+    got = correlation.local_correlation_layer(T(src, dev), T(trg, dev))
+    again = correlation.local_correlation_layer(T(src, dev), T(trg, dev))
+    assert torch.equal(got, again)
+    monkeypatch.setenv("RFN_CORR_SPLIT", "0")
+    one = correlation.local_correlation_layer(T(src, dev), T(trg, dev))
+    assert float((got - one).abs().max()) < 2e-6
+    if B * H * W <= 4096:
+        want = oracle.local_correlation_layer(src, trg)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------ full-size (K4) properties of the remaining kernels
 def test_warp_full_size_properties(dev):
     """feature warp at the K4 level-1 size (2 x 128 x 270 x 480): integer flows are exact shifts with zero fill and the
