@@ -116,8 +116,8 @@ class GraphedStep:
     rank of N does).  Every rank captures on the same call, a capture records but does not execute its collectives, and a
     rank whose capture throws runs the same collectives eagerly, so the ranks stay matched either way.  It is OPT-IN for
     more than one rank (RFN_GRAPH_DDP=1, RCCL backend) because it buys nothing there yet: with the launch count where
-    it is now the eager student pass keeps up with the device to within 3 % (rehearsal: 228.5 ms/step eager, 222.5 ms graphed
-    with the two passes in stream order -- profiles/r02_dist_1rank_queues.txt), the eager pass overlaps the gradient all-reduce
+    it is now the eager student pass keeps up with the device (rehearsal: 214.5 ms/step eager, 215.4 ms graphed with the two
+    passes in stream order -- profiles/r02_ddp_rehearsal.txt), the eager pass overlaps the gradient all-reduce
     with the last backward, and what makes the graphed step faster for one GPU (the mixed pass next to the source pass)
     does not pay with captured collectives inside (uda._mixed_capture_context).
     The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
