@@ -368,11 +368,24 @@ def cpu_baseline(wl, args):
                       f" + OpenMP, all other ops torch-CPU ATen (what the reference's CPU path calls)"}
 
 
+DDP_STALL_MARKER = os.path.join(os.environ.get("TMPDIR", "/tmp"), "refign_amd_multi_rank_stalled")
+
+
 def _ddp_guard(rank, world, progress):
-    """N > 1 only.  The multi-rank step could only ever be rehearsed with ONE rank on the one-GPU development boxes
-    (RFN_DDP_REHEARSAL).  If a multi-rank run makes no progress for RFN_BENCH_STALL_S seconds, say where it stopped and
-    exit non-zero instead of hanging the node."""
+    """N > 1 only.  The multi-rank step (student passes replayed from hipGraphs with the SyncBatchNorm exchanges inside
+    as RCCL calls of our own, three communicators on three streams: refign_amd/rccl.py) could only ever be rehearsed
+    with ONE rank on the one-GPU development boxes (RFN_DDP_REHEARSAL).  If a multi-rank run makes no progress for
+    RFN_BENCH_STALL_S seconds: say where it stopped, leave a marker and exit non-zero instead of hanging the node.  A
+    later run on the same box that finds the marker uses the conservative configuration -- every exchange through
+    torch.distributed, eager student passes (RFN_RCCL_DIRECT=0 RFN_GRAPH_DDP=0: 214-231 ms/step per rank in the
+    rehearsal instead of 192) -- unless those variables are set explicitly."""
     import threading
+    explicit = "RFN_GRAPH_DDP" in os.environ or "RFN_RCCL_DIRECT" in os.environ
+    if not explicit and os.path.exists(DDP_STALL_MARKER):
+        os.environ["RFN_GRAPH_DDP"] = os.environ["RFN_RCCL_DIRECT"] = "0"
+        if rank == 0:
+            print(f"bench.py: {DDP_STALL_MARKER} exists (an earlier multi-rank run stalled on this box): exchanges through "
+                  f"torch.distributed, eager student passes", file=sys.stderr, flush=True)
     limit = float(os.environ.get("RFN_BENCH_STALL_S", "900"))
 
     def watch():
@@ -380,8 +393,15 @@ def _ddp_guard(rank, world, progress):
             time.sleep(5.0)
             idle = time.monotonic() - progress[0]
             if idle > limit:
-                print(f"bench.py rank {rank}/{world}: no progress for {idle:.0f} s after '{progress[1]}' "
-                      f"(RFN_GRAPH_DDP={os.environ.get('RFN_GRAPH_DDP', '0')}); giving up", file=sys.stderr, flush=True)
+                conf = f"RFN_RCCL_DIRECT={os.environ.get('RFN_RCCL_DIRECT', '1')} RFN_GRAPH_DDP={os.environ.get('RFN_GRAPH_DDP', 'auto')}"
+                print(f"bench.py rank {rank}/{world}: no progress for {idle:.0f} s after '{progress[1]}' ({conf}); "
+                      f"giving up", file=sys.stderr, flush=True)
+                if os.environ.get("RFN_RCCL_DIRECT", "1") != "0":
+                    try:
+                        with open(DDP_STALL_MARKER, "w") as f:
+                            f.write(f"rank {rank}/{world} stalled after {progress[1]} ({conf})\n")
+                    except OSError:
+                        pass
                 os._exit(17)
 
     threading.Thread(target=watch, daemon=True, name="bench-stall-guard").start()
@@ -522,6 +542,10 @@ def main():
             st = {k: [("replay" if s_["graph"] is not None else ("eager (capture failed)" if s_["failed"] else "eager"))
                       for s_ in g.states.values()] for k, g in graphs.items()}
             line["config"]["hipgraph_regions"] = {k: (v[0] if len(v) == 1 else v) for k, v in st.items() if v}
+            if world > 1:
+                from refign_amd import bn as _bn
+                line["config"]["statistics_exchange"] = ("RCCL called directly on the pass's stream (refign_amd/rccl.py)"
+                                                         if _bn._DIRECT["default"] is not None else "torch.distributed")
             steps_m = getattr(wl.model, "_mixed_concurrent_steps", None)
             if steps_m is not None:
                 line["config"]["mixed_pass"] = ("own stream next to the tail of the source pass" if steps_m else

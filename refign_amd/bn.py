@@ -33,6 +33,44 @@ def data_parallel():
     return dist.get_world_size() > 1 or os.environ.get("RFN_DDP_REHEARSAL", "0") == "1"
 
 
+# RCCL called directly on the calling stream for the STUDENT's exchanges (refign_amd/rccl.py; opt-in): `default` is the
+# communicator of the pass on the main stream, `current` the one of the pass being captured / run inside direct_comm().
+_DIRECT = {"default": None, "current": None}
+
+
+def direct_comm(comm):
+    """Context manager: the student's statistics exchanges inside it go through `comm` (a rccl.DirectComm) -- a pass that
+    runs NEXT TO another pass needs a communicator of its own (uda._mixed_capture_context)."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def ctx():
+        saved, _DIRECT["current"] = _DIRECT["current"], comm
+        try:
+            yield
+        finally:
+            _DIRECT["current"] = saved
+    return ctx()
+
+
+def _exchange_comm(bn):
+    """The rccl.DirectComm a module's exchange goes through, None = torch's process group.  Modules that run on a
+    stream of their own (the teacher's) carry their communicator (`_rfn_direct`, set by the trainer)."""
+    own = getattr(bn, "_rfn_direct", None)
+    if own is not None:
+        return own
+    if getattr(bn, "process_group", None) is not None:
+        return None
+    return _DIRECT["current"] if _DIRECT["current"] is not None else _DIRECT["default"]
+
+
+def _all_reduce(buf, group, comm):
+    if comm is not None:
+        comm.all_reduce_(buf)
+    else:
+        dist.all_reduce(buf, group=group)
+
+
 def sync_group(bn):
     """The process group a module's statistics are exchanged over: None for plain BatchNorm2d and for a world of one
     (torch's SyncBatchNorm also normalises locally then), else the module's group (default: the world)."""
@@ -89,13 +127,14 @@ class _BNActTrain(torch.autograd.Function):
         y = torch.empty_like(xh)
         sums = torch.empty(2 * C + 1, dtype=torch.float32, device=xh.device)
         _stats_fwd(xh, sums)
+        comm = _exchange_comm(bn) if group is not None else None
         if group is not None:
-            dist.all_reduce(sums, group=group)
+            _all_reduce(sums, group, comm)
         _apply_fwd(xh, weight, bias, y, sums, bn, relu)
         bn.num_batches_tracked.add_(1)
         if any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(xh, sums, weight, bias)
-            ctx.eps, ctx.relu, ctx.group = float(bn.eps), relu, group
+            ctx.eps, ctx.relu, ctx.group, ctx.comm = float(bn.eps), relu, group, comm
         return y
 
     @staticmethod
@@ -112,7 +151,7 @@ class _BNActTrain(torch.autograd.Function):
         local = bsums
         if ctx.group is not None:                           # parameter gradients: this replica's sums
             local = bsums.clone()
-            dist.all_reduce(bsums, group=ctx.group)
+            _all_reduce(bsums, ctx.group, ctx.comm)
         _apply_bwd(xh, gy, sums, bsums, weight, bias, gx, ctx.eps, ctx.relu)
         gw = gb = None
         if ctx.needs_input_grad[1]:

@@ -114,12 +114,11 @@ class GraphedStep:
     (refign_amd/bn.py: RCCL all-reduces, which are capturable -- tools/micro/rccl_capture.py); replaying them has only been
     run with a 1-rank group here (one-GPU development boxes: RFN_DDP_REHEARSAL=1 makes a 1-rank group do everything one
     rank of N does).  Every rank captures on the same call, a capture records but does not execute its collectives, and a
-    rank whose capture throws runs the same collectives eagerly, so the ranks stay matched either way.  It is OPT-IN for
-    more than one rank (RFN_GRAPH_DDP=1, RCCL backend) because it buys nothing there yet: with the launch count where
-    it is now the eager student pass keeps up with the device (rehearsal: 214.5 ms/step eager, 215.4 ms graphed with the two
-    passes in stream order -- profiles/r02_ddp_rehearsal.txt), the eager pass overlaps the gradient all-reduce
-    with the last backward, and what makes the graphed step faster for one GPU (the mixed pass next to the source pass)
-    does not pay with captured collectives inside (uda._mixed_capture_context).
+    rank whose capture throws runs the same collectives eagerly, so the ranks stay matched either way.  Under data
+    parallelism the capture is ON when the exchanges are RCCL calls of our own on the pass's stream (refign_amd/rccl.py:
+    plain kernel nodes, and the mixed pass runs next to the source pass on a communicator of its own -- rehearsal
+    192.3 ms/step) and OFF when they go through torch's process group (RFN_RCCL_DIRECT=0: a captured collective is then
+    a cross-stream branch of the graph; 216.4 ms graphed, 214-231 ms eager, no gain).  RFN_GRAPH_DDP=0 / 1 overrides.
     The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
     throws leaves the pass eager for good, like GraphedNoGrad."""
 
@@ -153,7 +152,12 @@ class GraphedStep:
         import torch.distributed as dist
         from .bn import data_parallel
         if data_parallel():
-            return os.environ.get("RFN_GRAPH_DDP", "0") == "1" and dist.get_backend() == "nccl"
+            # default: on when the statistics exchanges are RCCL calls of our own on the pass's stream (plain kernel
+            # nodes), off when they go through torch's process group (cross-stream branches: no gain over eager)
+            from . import bn
+            env = os.environ.get("RFN_GRAPH_DDP")
+            on = (bn._DIRECT["default"] is not None) if env is None else env == "1"
+            return on and dist.get_backend() == "nccl"
         return True
 
     def __call__(self, *tensors):

@@ -1,0 +1,96 @@
+"""RCCL called directly (ctypes on the librccl.so that torch ships and has already loaded): an all-reduce that is ONE
+kernel on the caller's stream.
+
+Why: torch's process group runs every collective on a stream of its own and joins it to the caller's stream with events.
+Inside a hipGraph capture each SyncBatchNorm statistics exchange of a student pass therefore becomes a cross-stream
+branch of the graph, hipGraph replays such branches with a synchronisation per edge, and two passes replaying next to
+each other pay for it (a communicator per pass through torch's process group: 237.9 ms/step against 222.5 ms with the
+passes in stream order -- DESIGN.md section 6).  `ncclAllReduce(..., comm, stream)` on the capture stream is a plain
+kernel node: the captured pass stays a linear graph.
+
+`DirectComm(group)`: rank 0 of `group` makes a ncclUniqueId, torch's process group broadcasts its 128 bytes, every rank
+calls ncclCommInitRank.  One DirectComm per stream that may run collectives concurrently (same rule as everywhere: two
+streams must not issue collectives of one communicator in a rank-dependent order).
+
+ON under data parallelism with the RCCL backend (RFN_RCCL_DIRECT=0: every exchange through torch's process group, and
+then eager student passes).  It could only be run with a 1-rank communicator on the one-GPU development boxes
+(tests/test_syncbn_gpu.py; RFN_DDP_REHEARSAL): 192.3 ms/step for one rank of N with graphed student passes, against
+216.4 ms with the same graphs over torch's process group and 214-231 ms with the eager student
+(profiles/r02_ddp_rehearsal.txt).
+"""
+import ctypes
+import os
+
+import torch
+import torch.distributed as dist
+
+_NCCL_FLOAT32, _NCCL_SUM = 7, 0          # ncclDataType_t / ncclRedOp_t (nccl.h)
+
+
+class _UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_byte * 128)]
+
+
+_lib = None
+
+
+def _rccl():
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = ctypes.CDLL(path)
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
+        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        lib.ncclGetErrorString.argtypes = [ctypes.c_int]
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclCommDestroy):
+            f.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"rccl: {what}: {_rccl().ncclGetErrorString(rc).decode()}")
+
+
+def enabled():
+    return os.environ.get("RFN_RCCL_DIRECT", "1") != "0"
+
+
+class DirectComm:
+    """A communicator of our own over the ranks of `group` (default: the world) on `device`."""
+
+    def __init__(self, device, group=None):
+        lib = _rccl()
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        uid = _UniqueId()
+        if self.rank == 0:
+            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        raw = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=self.device)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(raw, src=src, group=group)
+        ctypes.memmove(ctypes.byref(uid), bytes(raw.cpu().tolist()), 128)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def all_reduce_(self, t):
+        """in-place sum of a contiguous float32 tensor over the ranks, on the CURRENT stream of its device"""
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+            raise RuntimeError("rccl.DirectComm.all_reduce_: contiguous float32 tensor on the communicator's device")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _check(_rccl().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _NCCL_FLOAT32, _NCCL_SUM, self._comm,
+                                         stream), "ncclAllReduce")
+        return t
+
+    def destroy(self):
+        if self._comm:
+            _rccl().ncclCommDestroy(self._comm)
+            self._comm = ctypes.c_void_p()

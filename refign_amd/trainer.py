@@ -185,6 +185,34 @@ class Trainer:
                 group = dist.new_group()
                 for m in teacher:
                     m.process_group = group
+        # RCCL called directly for the statistics exchanges (refign_amd/rccl.py; RFN_RCCL_DIRECT=0: off): a collective of torch's
+        # process group hops to the group's own stream and back, and with three compute streams on four hardware queues
+        # that stream shares a queue with a busy one -- in the 1-rank rehearsal the teacher branch takes 138 ms instead
+        # of 116.  One communicator per stream that exchanges: the student's passes on the main stream, the teacher
+        # (side stream), and -- with graphed student passes -- the mixed pass, which may then run next to the source
+        # pass as it does on one GPU.
+        from . import bn as _bn
+        _bn._DIRECT["default"] = None
+        if sync_batchnorm and self.data_parallel and next(model.parameters()).is_cuda and dist.get_backend() == "nccl":
+            from . import rccl
+            if rccl.enabled():
+                dev = next(model.parameters()).device
+                try:
+                    _bn._DIRECT["default"] = rccl.DirectComm(dev)
+                    if teacher:
+                        teacher_comm = rccl.DirectComm(dev)
+                        for m in teacher:
+                            m._rfn_direct = teacher_comm
+                    if os.environ.get("RFN_GRAPH_DDP", "1") != "0":
+                        model._mixed_comm = rccl.DirectComm(dev)
+                except (OSError, RuntimeError, AttributeError) as e:   # no librccl / init failed: torch's process group
+                    import warnings
+                    warnings.warn(f"refign_amd.trainer: direct RCCL communicators unavailable ({type(e).__name__}: {e}); "
+                                  f"statistics exchanges go through torch.distributed, student passes run eagerly")
+                    _bn._DIRECT["default"] = None
+                    for m in teacher:
+                        m.__dict__.pop("_rfn_direct", None)
+                    model.__dict__.pop("_mixed_comm", None)
         if fused_optimizer and model.optimizer_init["class_path"].endswith("AdamW") and \
                 next(model.parameters()).is_cuda:
             model.optimizer_init = {**model.optimizer_init,

@@ -453,20 +453,29 @@ class DomainAdaptationSegmentationModel(nn.Module):
 
     def _mixed_capture_context(self):
         """What the capture of the mixed pass runs inside when the pass is to run NEXT TO the source pass: parameter
-        gradients are views of the second flat buffer (trainer.FlatGradBuffer.into_second).  Not under data parallelism:
-        both passes contain the SyncBatchNorm exchanges of the decode head on ONE communicator, and two streams must not
-        issue collectives of one communicator in a rank-dependent order.  A communicator per pass was built and measured
-        in the 1-rank rehearsal (RFN_DDP_REHEARSAL): 237.9 ms/step against 222.5 ms with the graphed passes in stream
-        order -- a captured collective is a cross-stream branch of the graph, and hipGraph replays those with a
-        synchronisation per edge, which two replays running next to each other pay for -- so it was dropped."""
+        gradients are views of the second flat buffer (trainer.FlatGradBuffer.into_second).  Under data parallelism both
+        passes contain the SyncBatchNorm exchanges of the decode head, and two streams must not issue collectives of
+        one communicator in a rank-dependent order.  A communicator per pass through torch's process group was built
+        and measured in the 1-rank rehearsal (RFN_DDP_REHEARSAL): 237.9 ms/step against 222.5 ms with the graphed passes
+        in stream order -- torch runs a collective on a stream of its own, so a captured one is a cross-stream branch
+        of the graph, hipGraph replays those with a synchronisation per edge, and two replays running next to each
+        other pay for it.  So under data parallelism the passes stay in stream order, UNLESS the exchanges are RCCL
+        calls of our own on the capture stream (refign_amd/rccl.py, RFN_RCCL_DIRECT=1: plain kernel nodes) -- then the
+        mixed pass gets its own communicator (trainer: model._mixed_comm) and runs next to the source pass."""
         import contextlib
-        from .bn import data_parallel
+        from .bn import data_parallel, direct_comm
         buf = getattr(self, "_grad_buffer", None)
-        if buf is None or data_parallel() or os.environ.get("RFN_MIXED_CONCURRENT", "1") == "0":
+        comm = getattr(self, "_mixed_comm", None)
+        if buf is None or (data_parallel() and comm is None) or os.environ.get("RFN_MIXED_CONCURRENT", "1") == "0":
             self._mixed_on_second = False
             return contextlib.nullcontext()
         self._mixed_on_second = True
-        return buf.into_second()
+        if comm is None:
+            return buf.into_second()
+        stack = contextlib.ExitStack()
+        stack.enter_context(buf.into_second())
+        stack.enter_context(direct_comm(comm))
+        return stack
 
     def _mixed_stream(self, x):
         """The stream the DACS mix and the mixed pass run on.  Once both student passes replay from graphs and the mixed

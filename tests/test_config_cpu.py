@@ -83,9 +83,11 @@ def test_reference_yaml_builds_unmodified(path):
         assert type(opt).__name__ == cfg["optimizer"]["class_path"].rsplit(".", 1)[-1]
 
 
-def test_bench_stall_guard_exits_with_a_message():
+def test_bench_stall_guard_exits_and_leaves_the_conservative_marker(tmp_path):
     """bench.py, N > 1: a run that stops making progress (the multi-rank step has only ever been rehearsed with one
-    rank on the development boxes) exits non-zero and says where it stopped instead of hanging the node."""
+    rank on the development boxes) exits non-zero, says where it stopped and leaves a marker; the next run on the box that
+    finds the marker takes the conservative configuration (exchanges through torch.distributed, eager student) unless
+    the switches are set explicitly."""
     import os
     import subprocess
     import sys
@@ -94,7 +96,17 @@ def test_bench_stall_guard_exits_with_a_message():
             "p = [time.monotonic() - 100.0, 'warm-up step 1']\n"
             "bench._ddp_guard(1, 2, p)\n"
             "time.sleep(30)\n" % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RFN_BENCH_STALL_S="1"), capture_output=True,
-                       text=True, timeout=120)
+    env = {k: v for k, v in os.environ.items() if k not in ("RFN_GRAPH_DDP", "RFN_RCCL_DIRECT")}
+    env.update(TMPDIR=str(tmp_path), RFN_BENCH_STALL_S="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 17, r.stderr
     assert "no progress" in r.stderr and "warm-up step 1" in r.stderr and "rank 1/2" in r.stderr
+    assert (tmp_path / "refign_amd_multi_rank_stalled").exists()
+    code2 = ("import sys, os, time; sys.path.insert(0, %r); import bench\n"
+             "bench._ddp_guard(0, 2, [time.monotonic(), 'start'])\n"
+             "print(os.environ.get('RFN_GRAPH_DDP'), os.environ.get('RFN_RCCL_DIRECT'))\n" % root)
+    r2 = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0 and r2.stdout.split() == ["0", "0"], (r2.stdout, r2.stderr)
+    r3 = subprocess.run([sys.executable, "-c", code2], env=dict(env, RFN_GRAPH_DDP="1"), capture_output=True, text=True,
+                        timeout=120)
+    assert r3.stdout.split() == ["1", "None"]

@@ -149,8 +149,11 @@ def _rccl_step_worker(rank, world, port, out):
             calls["groups"].add(id(k["group"]))
         return real_all_reduce(t, *a, **k)
     traj = {}
-    for mode in ("1", "0"):                       # student passes graphed (opt-in under data parallelism) / eager
-        os.environ["RFN_GRAPH_DDP"] = mode
+    # student passes graphed (opt-in under data parallelism) / eager (the default) / graphed with the exchanges as
+    # RCCL calls of our own on the capture stream and a communicator per pass (refign_amd/rccl.py)
+    for mode in ("1", "0", "direct"):
+        os.environ["RFN_GRAPH_DDP"] = "0" if mode == "0" else "1"
+        os.environ["RFN_RCCL_DIRECT"] = "1" if mode == "direct" else "0"
         model = T.build(True, dev)
         trainer = Trainer(model, sync_batchnorm=True, fused_optimizer=False)
         n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
@@ -170,7 +173,7 @@ def _rccl_step_worker(rank, world, port, out):
         finally:
             bnk.dist.all_reduce = real_all_reduce
         captured = all(g.captured() for n, g in model._graphs.items() if n in ("source_pass", "mixed_pass")) \
-            if mode == "1" else None
+            if mode != "0" else None
         bn = torch.cat([b.flatten().double() for n, b in model.head.named_buffers() if "running" in n]).cpu()
         traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), captured, n_sync,
                       calls["n"], len(calls["groups"]), model.__dict__.get("_mixed_concurrent_steps", 0), bn)
@@ -181,7 +184,8 @@ def _rccl_step_worker(rank, world, port, out):
 def test_student_graphs_with_rccl_statistics_exchange_inside(dev, tmp_path):
     """What one rank of N > 1 runs, on a 1-rank RCCL group (RFN_DDP_REHEARSAL=1): 5 steps with the student passes
     captured into hipGraphs WITH the SyncBatchNorm exchanges inside (RFN_GRAPH_DDP=1; the two passes in stream order)
-    against 5 eager steps (the N > 1 default)."""
+    against 5 eager steps (the N > 1 default), and with the exchanges as RCCL calls of our own on the capture stream
+    (RFN_RCCL_DIRECT=1: a communicator per pass, mixed pass next to the source pass)."""
     port, out = _free_port(), str(tmp_path)
     mp.spawn(_rccl_step_worker, args=(1, port, out), nprocs=1, join=True)
     traj = torch.load(f"{out}/traj.pt", weights_only=False)
@@ -197,3 +201,12 @@ def test_student_graphs_with_rccl_statistics_exchange_inside(dev, tmp_path):
     np.testing.assert_allclose(g[0], e[0], rtol=3e-2)
     assert abs(g[1] - e[1]) < 1e-4 * e[1]
     assert float((g[7] - e[7]).abs().max()) < 5e-2 * float(e[7].abs().max())
+    # exchanges as direct RCCL calls (student passes AND teacher): nothing goes through torch's process group any more,
+    # both passes captured, and the mixed pass runs next to the source pass once both replay
+    d = traj["direct"]
+    assert d[2], "student passes were not captured with direct RCCL exchanges"
+    assert d[5] == 0 and d[4] == 0, d[4:6]
+    assert d[6] >= 2, "the mixed pass did not run next to the source pass"
+    np.testing.assert_allclose(d[0], e[0], rtol=3e-2)
+    assert abs(d[1] - e[1]) < 1e-4 * e[1]
+    assert float((d[7] - e[7]).abs().max()) < 5e-2 * float(e[7].abs().max())
