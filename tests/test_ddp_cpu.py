@@ -232,3 +232,90 @@ def test_sync_batchnorm_statistics_exchange_equals_full_batch(tmp_path):
             assert err.pop("nbt") == 1
             for k, v in err.items():
                 assert v < 2e-5, (rank, key, k, v)          # the exchanged statistics are fp32, as in the kernels
+
+
+class _StandInComm:
+    """What refign_amd/rccl.DirectComm is to bn.py -- `all_reduce_(t)`: in-place sum over the ranks on the caller's
+    stream -- over a gloo group, counting its calls."""
+
+    def __init__(self, group):
+        self.group, self.calls = group, 0
+
+    def all_reduce_(self, t):
+        self.calls += 1
+        dist.all_reduce(t, group=self.group)
+        return t
+
+
+def _direct_routing_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bn_standin
+    from refign_amd import bn as bnk
+    bn_standin.install(bnk)
+    torch.manual_seed(11)
+    C, per = 8, 2
+    full = torch.randn(world * per, C, 4, 5, dtype=torch.float64) + 0.25
+    gfull = torch.randn(world * per, C, 4, 5, dtype=torch.float64)
+    main, mixed, teacher_c = (_StandInComm(dist.new_group()) for _ in range(3))
+    teacher_group = dist.new_group()
+
+    def run(mod, grad):
+        ref = nn.BatchNorm2d(C).double().train()
+        x = full[rank * per:(rank + 1) * per].clone().requires_grad_(grad)
+        xr = full.clone().requires_grad_(grad)
+        with torch.set_grad_enabled(grad):
+            y = bnk._BNActTrain.apply(x.permute(0, 2, 3, 1).contiguous(), mod.weight, mod.bias, mod, True,
+                                      bnk.sync_group(mod)).permute(0, 3, 1, 2)
+            yr = torch.relu(ref(xr))
+        err = (y - yr[rank * per:(rank + 1) * per]).abs().max().item()
+        if grad:
+            y.backward(gfull[rank * per:(rank + 1) * per])
+            yr.backward(gfull)
+            err = max(err, (x.grad - xr.grad[rank * per:(rank + 1) * per]).abs().max().item())
+        return err
+
+    student = nn.SyncBatchNorm(C).double().train()
+    teacher = nn.SyncBatchNorm(C).double().train()
+    teacher.process_group = teacher_group
+    res = {}
+    # 1. no direct communicators: everything through torch.distributed
+    bnk._DIRECT["default"] = None
+    res["torch"] = (run(student, True), main.calls + mixed.calls + teacher_c.calls)
+    # 2. the pass on the main stream: forward + backward exchange through the default communicator
+    bnk._DIRECT["default"] = main
+    res["main"] = (run(student, True), main.calls, mixed.calls)
+    # 3. a pass captured / run inside direct_comm(): its own communicator, the default one untouched
+    with bnk.direct_comm(mixed):
+        res["mixed"] = (run(student, True), main.calls, mixed.calls)
+    res["after"] = (run(student, False), main.calls, mixed.calls)
+    # 4. the teacher: a module with a group of its own stays on torch.distributed unless it carries a communicator,
+    #    and then it uses that one whatever the context says
+    res["teacher_torch"] = (run(teacher, False), main.calls, mixed.calls, teacher_c.calls)
+    teacher._rfn_direct = teacher_c
+    with bnk.direct_comm(mixed):
+        res["teacher_direct"] = (run(teacher, False), main.calls, mixed.calls, teacher_c.calls)
+    bnk._DIRECT["default"] = None
+    torch.save(res, f"{out}/routing_{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_statistics_exchange_routing_over_direct_communicators(tmp_path):
+    """Which communicator a SyncBatchNorm exchange goes through (refign_amd/bn.py: _exchange_comm, direct_comm) -- 2 ranks
+    over gloo with stand-ins for rccl.DirectComm: the student's exchanges use the default communicator (forward AND
+    backward), a pass inside direct_comm() its own, the teacher's modules theirs regardless of the context, and without
+    any of them torch.distributed; every variant == nn.BatchNorm2d on the whole batch."""
+    port, out = _free_port(), str(tmp_path)
+    mp.spawn(_direct_routing_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in range(2):
+        r = torch.load(f"{out}/routing_{rank}.pt")
+        for k, v in r.items():
+            assert v[0] < 2e-5, (rank, k, v)
+        assert r["torch"][1] == 0
+        assert r["main"][1:] == (2, 0)                       # forward + backward
+        assert r["mixed"][1:] == (2, 2)
+        assert r["after"][1:] == (3, 2)                      # no-grad forward: one exchange, default communicator again
+        assert r["teacher_torch"][1:] == (3, 2, 0)
+        assert r["teacher_direct"][1:] == (3, 2, 1)
