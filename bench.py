@@ -511,6 +511,9 @@ def main():
 
     if dist is not None:
         dist.barrier()
+        torch.cuda.synchronize()
+        from refign_amd import rccl
+        rccl.destroy_all()                         # our own communicators (SyncBatchNorm exchanges), creation order
         dist.destroy_process_group()
 
     if rank == 0:

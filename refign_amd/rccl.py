@@ -32,6 +32,7 @@ class _UniqueId(ctypes.Structure):
 
 
 _lib = None
+_LIVE = []          # communicators in creation order (the same on every rank)
 
 
 def _rccl():
@@ -79,6 +80,7 @@ class DirectComm:
         self._comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _check(lib.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+        _LIVE.append(self)
 
     def all_reduce_(self, t):
         """in-place sum of a contiguous float32 tensor over the ranks, on the CURRENT stream of its device"""
@@ -94,3 +96,12 @@ class DirectComm:
         if self._comm:
             _rccl().ncclCommDestroy(self._comm)
             self._comm = ctypes.c_void_p()
+        if self in _LIVE:
+            _LIVE.remove(self)
+
+
+def destroy_all():
+    """Every rank, same order, after the last collective has completed (call torch.cuda.synchronize() first) and before
+    torch.distributed.destroy_process_group()."""
+    for c in list(_LIVE):
+        c.destroy()

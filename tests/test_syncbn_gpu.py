@@ -178,6 +178,11 @@ def _rccl_step_worker(rank, world, port, out):
         traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), captured, n_sync,
                       calls["n"], len(calls["groups"]), model.__dict__.get("_mixed_concurrent_steps", 0), bn)
     torch.save(traj, f"{out}/traj.pt")
+    torch.cuda.synchronize()
+    from refign_amd import rccl
+    n_live = len(rccl._LIVE)
+    rccl.destroy_all()
+    assert n_live >= 3 and not rccl._LIVE
     dist.destroy_process_group()
 
 
