@@ -25,15 +25,15 @@ _DT16 = {torch.bfloat16: 1, torch.float16: 2}
 def data_parallel():
     """True when the step has to behave as one rank of several: a world of more than one process -- or a 1-rank group with
     RFN_DDP_REHEARSAL=1, which makes every exchange of the N > 1 step for real on the one GPU of a development box
-    (SyncBatchNorm all-reduces inside the captured student passes, the teacher's communicator, the student passes in
-    stream order, the flat gradient all-reduce): everything but the link traffic and the waiting for peers."""
+    (SyncBatchNorm all-reduces inside the captured student passes, the communicators of the teacher and of the mixed
+    pass, the flat gradient all-reduce): everything but the link traffic and the waiting for peers."""
     import os
     if not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size() > 1 or os.environ.get("RFN_DDP_REHEARSAL", "0") == "1"
 
 
-# RCCL called directly on the calling stream for the STUDENT's exchanges (refign_amd/rccl.py; opt-in): `default` is the
+# RCCL called directly on the calling stream for the STUDENT's exchanges (refign_amd/rccl.py; set up by the trainer): `default` is the
 # communicator of the pass on the main stream, `current` the one of the pass being captured / run inside direct_comm().
 _DIRECT = {"default": None, "current": None}
 

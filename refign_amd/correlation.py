@@ -156,7 +156,7 @@ def _channel_splits(B, C, H, W):
     """How many channel chunks the patch-9 kernel of a TINY map is split into (csrc/corr.hip launch_corr9_split): the
     tiled kernel walks the channels of a tile serially, so a map of a few 8x64 tiles (2 x 256 x 32 x 32: 8 workgroups on
     256 CUs) is ~100 us of pure latency.  Measured (profiles/r02_kbench_corr_split.txt): it pays for such maps only --
-    at 2 x 256 x 135 x 240 (136 tiles) two or four chunks are SLOWER than the one-kernel path (134-141 vs 106 us: the
+    at 2 x 256 x 135 x 240 (136 tiles) two or four chunks are SLOWER than the one-kernel path (127 / 120 vs 107 us: the
     per-workgroup set-up and the extra pass over the partial sums cost more than the second half of the chip gives).
     1 = the one-kernel path; RFN_CORR_SPLIT=0 switches the split off, RFN_CORR_SPLITS=n forces n chunks."""
     if os.environ.get("RFN_CORR_SPLIT", "1") == "0" or W % 4 or C % 8:
