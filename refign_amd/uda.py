@@ -17,6 +17,7 @@ What is done differently, for the hardware:
     drop-path and batch-statistics BatchNorm), refine() output is not renormalised (D8), the pseudo-label
     weight is batch-global, get_class_masks draws classes from the whole batch.
 """
+import contextlib
 import copy
 import math
 import os
@@ -538,9 +539,15 @@ class DomainAdaptationSegmentationModel(nn.Module):
             off = self._crop_offsets(mixed_img, "mix")
             # one input signature for the replay: the blur of the DACS augmentation runs under autocast and hands back a
             # 16-bit image on the steps where it fires (a second signature = a second capture with its own eager warm-up)
-            (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.to(images_src.dtype).contiguous(),
-                                                       mixed_lbl.contiguous(),
-                                                       mixed_weight.to(torch.float32).contiguous(), off)
+            # (data parallelism with direct RCCL exchanges: the mixed pass ALWAYS exchanges over its own communicator --
+            # eager warm-up, capture, replay and the eager fallback of a failed capture alike -- so that a rank whose
+            # capture fails still meets its peers on the communicator their graphs were captured with)
+            from .bn import direct_comm
+            comm = getattr(self, "_mixed_comm", None)
+            with (direct_comm(comm) if comm is not None else contextlib.nullcontext()):
+                (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.to(images_src.dtype).contiguous(),
+                                                           mixed_lbl.contiguous(),
+                                                           mixed_weight.to(torch.float32).contiguous(), off)
         if mix is not None:
             cur.wait_stream(mix)                         # both passes done before the optimiser merges their gradients
             mixed_loss.record_stream(cur)
