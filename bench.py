@@ -38,9 +38,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="refign_hrda_step_1080x1920")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "k5"],
                     help="segmentation networks: bf16 autocast (the reference trains with --trainer.precision 16) or "
-                         "fp32; the align/refine kernels are always fp32 (the reference forces fp32 there too)")
+                         "fp32; the align/refine kernels are always fp32 (the reference forces fp32 there too); k5 = "
+                         "BASELINE.json config 5: bf16 + the EMA teacher's MiT blocks on the fp8 (e4m3) matrix-core "
+                         "kernels (refign_amd/f8.py)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--pairs-per-gpu", type=int, default=2)
@@ -210,7 +212,8 @@ class RefignStep:
                 "alignment_head.init_args.pretrained": None, "adapt_to_ref": False}
         self.model = config.build_model(cfg, over).to(dev).train()
         self.trainer = Trainer(self.model, sync_batchnorm=sync_bn and os.environ.get("RFN_BENCH_SYNC_BN", "1") != "0")
-        self.precision = precision
+        self.model.teacher_f8 = precision == "k5"                   # K5: EMA-teacher backbone on the fp8 kernels
+        self.precision = precision = "bf16" if precision == "k5" else precision
         self.b, self.H, self.W = b, H, W
         g = torch.Generator(device="cpu").manual_seed(seed)
         lbl = torch.randint(0, 19, (b, (H + 31) // 32, (W + 31) // 32), generator=g)
@@ -526,11 +529,15 @@ def main():
             "value": round(pairs / dt, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if (args.workload == AlignRefineKernels.name or args.precision == "fp32") else "bf16",
+            "dtype": "f32" if (args.workload == AlignRefineKernels.name or args.precision == "fp32") else
+                     ("bf16+fp8(e4m3) teacher" if args.precision == "k5" else "bf16"),
             "data": "synthetic",
             "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": f"{args.height}x{args.width}",
-                       "model": "HRDA MiT-B5 + DAFormer head + VGG-16/UAWarpC align (random init)",
+                       "networks": "HRDA MiT-B5 + DAFormer head + VGG-16/UAWarpC align (random init)",
                        "precision_map": ("fp32 everywhere" if args.precision == "fp32" else
+                                         ("K5: as the bf16 map, plus the EMA teacher's MiT blocks (Linear layers and "
+                                          "attention core, 40 views) on fp8 e4m3 MFMA kernels; " if args.precision == "k5"
+                                          else "") +
                                          "reference AMP recipe: seg nets bf16 autocast (fp32 master weights, grads, "
                                          "norm statistics, losses); align convolutions fp16 autocast; correlation, "
                                          "warp, L2-norm, uncertainty and refine kernels fp32"),

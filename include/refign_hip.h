@@ -382,6 +382,42 @@ int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void*
 int rfn_bn_train_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
                      void* grad_x, float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * K5 (BASELINE.json config 5, "bf16 HRDA + fp8 MFMA attention"): fp8 (OCP e4m3, fp32 accumulate) matrix-core path of
+ * the gradient-free EMA teacher (segmentation_model.py:204-209 runs MiT-B5, mix_transformer.py:96-103,137-164, on 40
+ * HRDA views per GPU).  No reference analogue (the reference's recipe is 16-bit AMP, README.md:262); csrc/f8.hip.
+ * Scales: `x_scale` / `q_scale` / ... = what a stored e4m3 byte is multiplied by to give the value; `out_q` = what a value
+ * is multiplied by before it is stored as e4m3 (saturating at +-448, round to nearest even).
+ *   rfn_gemm_nt_f8      Y[M,N] = res + rowscale[m / rows_per_sample] * act( x_scale * wscale[n] * (X8[M,K] . W8[N,K]^T) + bias[n] )
+ *                       X8, W8 e4m3 bytes (ldx, ldw in bytes, % 16); wscale fp32 [N]; bias / res bf16 or NULL;
+ *                       out_f8 = 0: Y bf16 (ldy in elements); out_f8 = 1: Y e4m3 = act(...) * out_q (ldy in bytes; no res).
+ *                       K % 16 == 0 (need not be a multiple of the 128-byte K-step), N % 16 == 0.  act: 0 none, 1 ReLU.
+ *   rfn_quant_rows_f8   multi-tensor weight quantisation.  table: nchunks rows of 4 int64 {bf16 src row 0, e4m3 dst row 0,
+ *                       fp32 scales, K | nrows << 32} (nrows <= 4 consecutive rows of K % 4 == 0 elements): dst = rne(src /
+ *                       scale), scale = amax(row) / 448.
+ *   rfn_quant_f8        y8[i] = e4m3(x_bf16[i] * q), n % 4 == 0 (entry of an fp8 chain, tests).
+ *   rfn_layernorm_fwd_f8          LayerNorm over C of bf16 rows, result * out_q stored as e4m3 (C % 8 == 0, C <= 1024).
+ *   rfn_dwconv3x3_gelu_nhwc_fwd_f8  GELU(depthwise 3x3 + bias) of the Mix-FFN on e4m3 channels-last maps, weights (9, C) fp32.
+ *   rfn_attn_pack_f8    K / V of an e4m3 kv tensor (B, Nkv, 2 * heads * 64; strides in bytes) -> nst = ceil(Nkv / 64) stages of
+ *                       8 192 bytes per (batch, head) in MFMA operand order (zero padded).
+ *   rfn_attn_fwd_f8     O8 = softmax(scale Q K^T) V per head of 64, Q8 / O8 (B, Nq, heads * 64) e4m3, fp32 softmax, the
+ *                       probabilities enter the P.V product as e4m3(256 p).
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_gemm_nt_f8(const void* X8, const void* W8, const float* wscale, float x_scale, const void* bias, const void* res,
+                   const float* rowscale, int rows_per_sample, int act, void* Y, int out_f8, float out_q, long M, long N,
+                   long K, long ldx, long ldw, long ldy, rfn_stream_t stream);
+int rfn_quant_rows_f8(const void* table, int nchunks, rfn_stream_t stream);
+int rfn_quant_f8(const void* x_bf16, void* y8, long n, float q, rfn_stream_t stream);
+int rfn_layernorm_fwd_f8(const void* x_bf16, const float* gamma, const float* beta, void* y8, long rows, int C, float eps,
+                         float out_q, rfn_stream_t stream);
+int rfn_dwconv3x3_gelu_nhwc_fwd_f8(const void* x8, const float* weight, const float* bias, void* y8, int B, int H, int W, int C,
+                                   float x_scale, float out_q, rfn_stream_t stream);
+int rfn_attn_pack_f8(const void* kv8, long batch_stride, long row_stride, int B, int heads, int Nkv, int nst, void* pack,
+                     rfn_stream_t stream);
+int rfn_attn_fwd_f8(const void* q8, long q_batch_stride, long q_row_stride, const void* pack, void* o8, long o_batch_stride,
+                    long o_row_stride, int B, int heads, int Nq, int Nkv, int nst, float scale, float q_scale, float k_scale,
+                    float v_scale, float out_q, rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

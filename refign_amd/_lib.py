@@ -79,6 +79,15 @@ SIGNATURES = {
     "rfn_bn_apply_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
     "rfn_bn_train_fwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_float, c_int, c_int, c_void_p]),
     "rfn_bn_train_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
+    "rfn_gemm_nt_f8": (c_int, [c_void_p] * 3 + [c_float] + [c_void_p] * 3 + [c_int, c_int, c_void_p, c_int, c_float]
+                       + [ctypes.c_long] * 6 + [c_void_p]),
+    "rfn_quant_rows_f8": (c_int, [c_void_p, c_int, c_void_p]),
+    "rfn_quant_f8": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_float, c_void_p]),
+    "rfn_layernorm_fwd_f8": (c_int, [c_void_p] * 4 + [ctypes.c_long, c_int, c_float, c_float, c_void_p]),
+    "rfn_dwconv3x3_gelu_nhwc_fwd_f8": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float, c_float, c_void_p]),
+    "rfn_attn_pack_f8": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] + [c_int] * 4 + [c_void_p, c_void_p]),
+    "rfn_attn_fwd_f8": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long]
+                        + [c_int] * 5 + [c_float] * 5 + [c_void_p]),
     "rfn_uncertainty9_weights_len": (c_int, []),
     "rfn_uncertainty9_frontend_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }

@@ -21,7 +21,10 @@
 //                  one workspace row per stripe -> fixed-order reduction kernel: deterministic, no atomics)
 #include <hip/hip_bf16.h>
 
+#include <type_traits>
+
 #include "common.h"
+#include "mfma.h"
 
 namespace rfn {
 
@@ -89,6 +92,24 @@ struct VecIO<__hip_bfloat16> {
   }
 };
 
+// K5: e4m3 activations, 8 channels per lane (8-byte vectors); dequantisation / quantisation scales are kernel arguments
+template <>
+struct VecIO<f8e4m3> {
+  static constexpr int N = 8;
+  typedef uint2 Raw;
+  __device__ static Raw load_raw(const f8e4m3* p) { return *reinterpret_cast<const uint2*>(p); }
+  typedef float Pair __attribute__((ext_vector_type(2)));
+  __device__ static void unpack2(const Raw& t, Pair (&v)[4]) {
+    v[0] = __builtin_amdgcn_cvt_pk_f32_fp8((int)t.x, false);
+    v[1] = __builtin_amdgcn_cvt_pk_f32_fp8((int)t.x, true);
+    v[2] = __builtin_amdgcn_cvt_pk_f32_fp8((int)t.y, false);
+    v[3] = __builtin_amdgcn_cvt_pk_f32_fp8((int)t.y, true);
+  }
+  __device__ static void store(f8e4m3* p, const float (&v)[8]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(quant4(v[0], v[1], v[2], v[3]), quant4(v[4], v[5], v[6], v[7]));
+  }
+};
+
 constexpr int kPX = 4;   // pixels along W per thread
 
 // A "quad" is 4 pixels of one image row spaced by the dilation: w0, w0+d, w0+2d, w0+3d.  Their 3x3 dilated taps fall on
@@ -114,6 +135,7 @@ __device__ __forceinline__ float4 mask_raw(const float4& t, bool ok) {
   return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ uint4 mask_raw(const uint4& t, bool ok) { return ok ? t : make_uint4(0u, 0u, 0u, 0u); }
+__device__ __forceinline__ uint2 mask_raw(const uint2& t, bool ok) { return ok ? t : make_uint2(0u, 0u); }
 
 // ACT: the Mix-FFN applies GELU (exact erf) right after this convolution (mix_transformer.py:99-101): with ACT the
 // activation is computed on the fp32 accumulators and written to `ya`; the pre-activation goes to `y` only if that
@@ -123,7 +145,11 @@ template <typename T, bool FLIP, bool ACT = false>
 __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, T* __restrict__ y, int B,
                                                             int H, int W, int C, int dil, int cvb,
-                                                            T* __restrict__ ya = nullptr) {
+                                                            T* __restrict__ ya = nullptr, float xs = 1.f,
+                                                            float oq = 1.f) {
+  // xs / oq (e4m3 activations only): stored input bytes mean xs * value -- folded into the weights; outputs are stored as
+  // value * oq
+  constexpr bool F8 = std::is_same<T, f8e4m3>::value;
   constexpr int V = VecIO<T>::N, V2 = V / 2;
   const int CV = C / V, WQ = quads_per_row(W, dil);
   const int pl = 256 / cvb;
@@ -140,6 +166,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
       const float4 t4 = *reinterpret_cast<const float4*>(wp + i);
       wr[k][i / 2] = f32x2{t4.x, t4.y};
       wr[k][i / 2 + 1] = f32x2{t4.z, t4.w};
+      if constexpr (F8) {
+        wr[k][i / 2] *= xs;
+        wr[k][i / 2 + 1] *= xs;
+      }
     }
   }
   f32x2 bs[V2];
@@ -195,7 +225,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
         if (!ACT || y != nullptr) VecIO<T>::store(y + obase + (size_t)(w0 + p * dil) * C, o);
         if (ACT) {
 #pragma unroll
-          for (int i = 0; i < V; ++i) o[i] = 0.5f * o[i] * (1.f + erff(o[i] * 0.70710678118654752440f));
+          for (int i = 0; i < V; ++i) o[i] = 0.5f * o[i] * (1.f + erff(o[i] * 0.70710678118654752440f)) * (F8 ? oq : 1.f);
           VecIO<T>::store(ya + obase + (size_t)(w0 + p * dil) * C, o);
         }
       }
@@ -328,13 +358,13 @@ constexpr int kMaxStripes = 128;
 
 template <typename T>
 static int launch_fwd_gelu(const void* x, const float* w, const float* bias, void* y, void* ya, int B, int H, int W,
-                           int C, hipStream_t st) {
+                           int C, hipStream_t st, float xs = 1.f, float oq = 1.f) {
   constexpr int V = VecIO<T>::N;
   const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
   const long nquads = (long)B * H * ((W + kPX - 1) / kPX);
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(nquads, pl), (256L * 16) / gx));
   hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, true>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias,
-                     (T*)y, B, H, W, C, 1, cvb, (T*)ya);
+                     (T*)y, B, H, W, C, 1, cvb, (T*)ya, xs, oq);
   return check_launch("dwconv3x3_fwd_kernel<gelu>");
 }
 
@@ -404,6 +434,13 @@ int rfn_dwconv3x3_gelu_nhwc_fwd(const void* x, const float* weight, const float*
     return launch_fwd_gelu<__hip_bfloat16>(x, weight, bias, y_pre, y_act, B, H, W, C, (hipStream_t)stream);
   }
   return fail(RFN_EINVAL, "rfn_dwconv3x3_gelu_nhwc_fwd: dtype must be 0 (f32) or 1 (bf16)");
+}
+
+int rfn_dwconv3x3_gelu_nhwc_fwd_f8(const void* x8, const float* weight, const float* bias, void* y8, int B, int H, int W, int C,
+                                   float x_scale, float out_q, rfn_stream_t stream) {
+  RFN_REQUIRE(x8 && weight && y8, "rfn_dwconv3x3_gelu_nhwc_fwd_f8: null pointer");
+  RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "rfn_dwconv3x3_gelu_nhwc_fwd_f8: bad size (C %% 8)");
+  return launch_fwd_gelu<f8e4m3>(x8, weight, bias, nullptr, y8, B, H, W, C, (hipStream_t)stream, x_scale, out_q);
 }
 
 unsigned long rfn_dwconv3x3_bwd_weight_workspace_bytes(int C) {

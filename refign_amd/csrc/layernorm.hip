@@ -15,6 +15,7 @@
 #include <hip/hip_bf16.h>
 
 #include "common.h"
+#include "mfma.h"
 
 namespace rfn {
 
@@ -39,6 +40,9 @@ __device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16* p, float v) {
   unsigned r = ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
   *reinterpret_cast<unsigned short*>(p) = (unsigned short)r;
 }
+
+template <>
+__device__ __forceinline__ void st<f8e4m3>(f8e4m3* p, float v) { p->v = (unsigned char)(quant4(v, 0.f, 0.f, 0.f) & 0xffu); }
 
 template <typename TI, typename TO, int NPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
@@ -186,6 +190,10 @@ __device__ __forceinline__ void st8<__hip_bfloat16>(__hip_bfloat16* p, const flo
   t.w = bf16_rne(v[6]) | (bf16_rne(v[7]) << 16);
   *reinterpret_cast<uint4*>(p) = t;
 }
+template <>
+__device__ __forceinline__ void st8<f8e4m3>(f8e4m3* p, const float (&v)[8]) {       // K5: e4m3 bytes, saturating RNE
+  *reinterpret_cast<uint2*>(p) = make_uint2(quant4(v[0], v[1], v[2], v[3]), quant4(v[4], v[5], v[6], v[7]));
+}
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -197,7 +205,9 @@ template <typename TI, typename TO, int LPR, int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, TO* __restrict__ y,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
-                                                                long rows, int C, float eps) {
+                                                                long rows, int C, float eps, float oscale) {
+  // oscale: the result is multiplied by it before it is stored (1 for everything but the e4m3 output of the K5 path,
+  // where it is the quantisation scale of the consumer GEMM; x * 1.f is exact)
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
   float g[NV][8], b[NV][8];
@@ -240,10 +250,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const TI* __rest
       if (valid && act[j]) {
         float o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = fmaf((v[j][i] - mu) * rs, g[j][i], b[j][i]);
+        for (int i = 0; i < 8; ++i) o[i] = fmaf((v[j][i] - mu) * rs, g[j][i], b[j][i]) * oscale;
         st8<TO>(y + r * C + (sub + LPR * j) * 8, o);
       }
-    if (valid && sub == 0) {
+    if (valid && sub == 0 && mean != nullptr) {
       mean[r] = mu;
       rstd[r] = rs;
     }
@@ -364,12 +374,12 @@ static inline int ln_grid(long rows, int cap) { return (int)std::max<long>(1, st
 
 template <typename TI, typename TO>
 static int ln_fwd_dispatch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, long rows,
-                           int C, float eps, hipStream_t st) {
+                           int C, float eps, hipStream_t st, float oscale = 1.f) {
   if (C % 8 == 0) {
 #define RFN_LN_FWDV(LPR, NV)                                                                                         \
   hipLaunchKernelGGL((layernorm_fwd_vec_kernel<TI, TO, LPR, NV>),                                                    \
                      dim3((int)std::max<long>(1, std::min<long>(cdiv(rows, 4 * (64 / LPR)), 256 * 16))), dim3(256), \
-                     0, st, (const TI*)x, g, b, (TO*)y, mean, rstd, rows, C, eps)
+                     0, st, (const TI*)x, g, b, (TO*)y, mean, rstd, rows, C, eps, oscale)
     if (C <= 64) RFN_LN_FWDV(8, 1);
     else if (C <= 128) RFN_LN_FWDV(16, 1);
     else if (C <= 256) RFN_LN_FWDV(32, 1);
@@ -449,6 +459,14 @@ int rfn_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
   if (in_dtype == 1 && out_dtype == 0)
     return ln_fwd_dispatch<__hip_bfloat16, float>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
   return fail(RFN_EINVAL, "rfn_layernorm_fwd: dtype codes must be 0 (f32) or 1 (bf16)");
+}
+
+int rfn_layernorm_fwd_f8(const void* x_bf16, const float* gamma, const float* beta, void* y8, long rows, int C, float eps,
+                         float out_q, rfn_stream_t stream) {
+  RFN_REQUIRE(x_bf16 && gamma && beta && y8, "rfn_layernorm_fwd_f8: null pointer");
+  RFN_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * kLnMaxPerLane, "rfn_layernorm_fwd_f8: need C %% 8 == 0, C <= 1024 (got %d)", C);
+  return ln_fwd_dispatch<__hip_bfloat16, f8e4m3>(x_bf16, gamma, beta, y8, nullptr, nullptr, rows, C, eps, (hipStream_t)stream,
+                                                 out_q);
 }
 
 int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, const float* mean, const float* rstd,

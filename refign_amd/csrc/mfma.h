@@ -99,4 +99,24 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// ---- fp8 (OCP e4m3) helpers of the K5 teacher path (csrc/f8.hip; producers in layernorm.hip / dwconv.hip) --------------
+struct f8e4m3 { unsigned char v; };          // storage tag: one e4m3 byte
+constexpr float kF8Max = 448.f;
+// 4 floats -> 4 e4m3 bytes (round to nearest even, saturating at +-448), byte e = value e
+__device__ __forceinline__ unsigned quant4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -kF8Max, kF8Max);
+  b = __builtin_amdgcn_fmed3f(b, -kF8Max, kF8Max);
+  c = __builtin_amdgcn_fmed3f(c, -kF8Max, kF8Max);
+  d = __builtin_amdgcn_fmed3f(d, -kF8Max, kF8Max);
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+__device__ __forceinline__ void dequant4(unsigned w, float (&f)[4]) {
+  auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+  auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+}
+
 }  // namespace rfn

@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import f8 as _f8
 from . import linear as _linear
 from . import mfma
 from ._tensor import const_tensor
@@ -218,6 +219,8 @@ class Block(nn.Module):
                                            and self.drop_path.drop_prob > 0.)):
             # gradient-free passes (EMA teacher, ImageNet features, inference): the residual add and the per-sample
             # stochastic-depth scale ride in the epilogue of the proj / fc2 GEMMs
+            if _f8.active() and _f8.block_supported(self, x):
+                return _f8.block_forward(self, x, H, W, masks32)      # K5: the block on the fp8 matrix-core kernels
             x = self.attn(self.norm1(x), H, W, res=x, rowscale=None if masks32 is None else masks32[0])
             return self.mlp(self.norm2(x), H, W, res=x, rowscale=None if masks32 is None else masks32[1])
         if masks is not None:                       # pre-drawn stochastic-depth masks (MixVisionTransformer)

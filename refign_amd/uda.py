@@ -33,6 +33,7 @@ from . import align as align_mod
 from . import refine as refine_mod
 from . import sidework
 from ._tensor import const_tensor, upload_async
+from . import f8 as _f8
 from .graphs import GraphedNoGrad, GraphedStep
 from .params import ema_update
 from .config import instantiate_class
@@ -263,6 +264,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # and its captured backward kernels accumulate into the second flat gradient buffer
         self._graphs["mixed_pass"] = GraphedStep(self._mixed_pass_device_crop, "student mixed pass", shared=None,
                                                  capture_context=self._mixed_capture_context)
+        self.teacher_f8 = _f8.ENV_DEFAULT                # K5: EMA-teacher backbone in fp8 (no reference analogue)
         self.load_weights(pretrained)
 
     # -- trainer hooks (what Lightning provides in the reference) ---------------------------------------------------
@@ -622,7 +624,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return self.refine(logits_trg, warped, warp_mask, warp_certs)
 
     def _teacher_backbone(self, x):
-        return self.m_backbone(x)
+        # K5 (RFN_TEACHER_F8=1 / bench.py --precision k5): the EMA teacher's MiT blocks on the fp8 matrix-core kernels
+        # (refign_amd/f8.py); everything else of the step is unchanged
+        with _f8.teacher_f8(self.teacher_f8 and x.is_cuda and torch.is_autocast_enabled("cuda")
+                            and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return self.m_backbone(x)
 
     def _imnet_features(self, img):
         f = self.imnet_backbone(img)
@@ -932,6 +938,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if lists is None:                             # the parameter objects never change: walk the module tree once
             lists = self.__dict__["_ema_lists"] = (list(self.ema_parameters()), list(self.live_parameters()))
         ema_update(lists[0], lists[1], m, plan_key=("ema", id(self)))
+        if self.teacher_f8:
+            _f8.requantize()                          # K5: e4m3 weight copies follow the refreshed bf16 copies, in place
 
     def train(self, mode=True):
         """(:691-701) alignment nets and the ImageNet encoder always in eval; the reference's attempt to disable
