@@ -545,6 +545,10 @@ def main():
                                       f"gradient all-reduce per step over RCCL"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        from refign_amd import mfma as _mfma
+        # dense ops that ended up in a ROCm library (hipBLASLt / MIOpen / fused SDPA) instead of a hand-written kernel,
+        # by call site and dtype, over the whole run (refign_amd/mfma.py: note_library)
+        line["config"]["library_fallbacks"] = _mfma.library_summary()
         graphs = getattr(getattr(wl, "model", None), "_graphs", None)
         if graphs:
             # which regions of the step replay from hipGraphs (a failed capture falls back to eager launches: slower,

@@ -251,20 +251,6 @@ int rfn_multi_transpose_cast_f32_bf16(const void* table, int ntiles, rfn_stream_
 int rfn_multi_adamw_f32(const void* table, int nchunks, const float* group_args, int ngroups, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * The three GEMMs of a token-wise nn.Linear (mix_transformer.py: q / kv / proj / fc1 / fc2) on the ROCm library
- * (hipBLASLt) through a per-problem plan cache: descriptors, layouts and the heuristic's algorithm are made once per
- * (kind, T, N, K, S, dtype, bias) and reused, so a call costs a map lookup + hipblasLtMatmul instead of ~35 us of
- * framework host time.  Row-major operands; dtype 1 = bfloat16 in/out (fp32 accumulate), 0 = float32.
- *   kind 0  forward  C[T,N]     = B[T,K] . A[N,K]^T (+ bias[N], same dtype)      A = weight,  B = x
- *   kind 1  dgrad    C[T,K]     = B[T,N] . A[N,K]                                A = weight,  B = grad_y
- *   kind 2  wgrad    C[S][N,K]  = B_s[T/S,N]^T . A_s[T/S,K] for the S row slabs  A = x,       B = grad_y
- * workspace: rfn_gemm_workspace_bytes() bytes of device memory.
- * ---------------------------------------------------------------------------------------------------------- */
-unsigned long rfn_gemm_workspace_bytes(void);
-int rfn_linear_gemm(int kind, const void* A, const void* B, void* C, const void* bias, void* workspace, long T, long N,
-                    long K, int S, int dtype, rfn_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------------------------
  * Multi-resolution fusion front end of the decode heads (DAFormerHead.forward, models/heads/daformer.py:205-222;
  * SegFormerHead.forward, models/heads/segformer.py:86-104): bilinear up-sampling (align_corners=False) of up to four
  * embedded stage maps to (H, W) and their channel concatenation, one pass, channels-last output (n, H, W, sum C_l).
@@ -381,6 +367,21 @@ int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void*
                      rfn_stream_t stream);
 int rfn_bn_train_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
                      void* grad_x, float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
+
+/* Backward of rfn_conv2d_nhwc on the same kernels (the student's trainable convolutions: DAFormer 3x3 bottleneck
+ * daformer.py:65-126, MiT overlap patch embeddings mix_transformer.py:210-242, 19-class 1x1; matcher decoders modules.py:395-477).
+ *   rfn_conv2d_nhwc_dgrad  DX (B, H, W, C) = data gradient.  GY (B, OH, OW, N) channels-last, Wt[c][(ky, kx, n)] rows zero-padded
+ *                          to ldw >= roundup(KH*KW*N, 64); the implicit-GEMM kernel in transposed-gather mode (no flipped copy of
+ *                          the filter, no col2im buffer).  stride must be a power of two.  C % 8 == 0, N % 8 == 0.
+ *   rfn_conv2d_nhwc_wgrad  P = weight gradient in the PACKED layout [n][(ky, kx, c)], row length Kpad (% 64, >= KH*KW*C), fp32:
+ *                          the split-T kernel of rfn_gemm_tn with the im2col rows gathered on the fly.  accumulate = 0: one
+ *                          (N, Kpad) partial per slab of rows_per_slab output pixels; 1: atomics into one.  grad_bias (may be
+ *                          NULL) += column sums of GY.  N % 64 == 0, C % 2 == 0, ldg = row stride of GY in elements. */
+int rfn_conv2d_nhwc_dgrad(const void* GY, const void* Wt, void* DX, int B, int H, int W, int C, int N, int KH, int KW,
+                          int stride, int pad, int dil, long ldw, long ldy, int dtype, rfn_stream_t stream);
+int rfn_conv2d_nhwc_wgrad(const void* GY, const void* X, float* P, float* grad_bias, int B, int H, int W, int C, int N, int KH,
+                          int KW, int stride, int pad, int dil, long ldg, long Kpad, int rows_per_slab, int accumulate,
+                          int dtype, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * K5 (BASELINE.json config 5, "bf16 HRDA + fp8 MFMA attention"): fp8 (OCP e4m3, fp32 accumulate) matrix-core path of

@@ -53,8 +53,6 @@ SIGNATURES = {
                                  + [c_void_p]),
     "rfn_upsample_concat_nhwc_bwd": (c_int, [c_void_p] * 5 + [ctypes.POINTER(c_int)] * 3 + [c_int] * 5 + [c_void_p]),
     "rfn_patchify_tokens": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
-    "rfn_gemm_workspace_bytes": (ctypes.c_ulong, []),
-    "rfn_linear_gemm": (c_int, [c_int] + [c_void_p] * 5 + [ctypes.c_long] * 3 + [c_int, c_int, c_void_p]),
     "rfn_multi_cast_chunk_elems": (c_int, []),
     "rfn_multi_cast_f32_bf16": (c_int, [c_void_p, c_int, c_void_p]),
     "rfn_multi_ema_f32": (c_int, [c_void_p, c_int, c_float, c_void_p]),
@@ -63,6 +61,9 @@ SIGNATURES = {
     "rfn_gemm_nt": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p] + [ctypes.c_long] * 6 + [c_int, c_void_p]),
     "rfn_conv2d_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int,
                                                                                        c_void_p]),
+    "rfn_conv2d_nhwc_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int, c_void_p]),
+    "rfn_conv2d_nhwc_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int, c_int, c_int,
+                                      c_void_p]),
     "rfn_gemm_tn": (c_int, [c_void_p] * 3 + [ctypes.c_long] * 5 + [c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                             c_void_p]),
     "rfn_attn_pack": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] + [c_int] * 4 + [c_void_p] * 6),

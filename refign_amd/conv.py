@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from . import mfma as _mfma
 from ._tensor import current_stream, on_device, ptr
 from .params import _identity, as_dtype, compute_dtype, derived, grad_sink
 
@@ -63,13 +64,19 @@ class Conv2d(nn.Conv2d):
         b_c = as_dtype(self.bias, cd)
         if x.dtype != cd:
             x = x.to(cd)
-        if torch.is_grad_enabled() and self.weight.requires_grad:
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            if self.groups == 1:
+                y = conv2d_mfma_grad(x, self.weight, self.bias, self.stride, self.padding, self.dilation, cd)
+                if y is not None:
+                    return y
+            _mfma.note_library("conv2d.autograd", x, self.weight)
             return _Conv2dFn.apply(x, self.weight, self.bias, w_c, b_c, self.stride, self.padding, self.dilation,
                                    self.groups)
         if self.groups == 1 and not torch.is_grad_enabled():
             y = conv2d_mfma(x, self.weight, self.bias, self.stride, self.padding, self.dilation, dtype=cd)
             if y is not None:
                 return y
+        _mfma.note_library("conv2d", x, self.weight)
         return F.conv2d(x, w_c, b_c, self.stride, self.padding, self.dilation, self.groups)
 
 
@@ -130,6 +137,8 @@ class _PatchLinearFn(torch.autograd.Function):
         ctx.weight, ctx.bias = weight, bias
         ctx.geom = (x.shape, H, W, r, Hr, Wr)
         y = _mfma.gemm_nt(patches, w2, b_c)
+        if y is None:
+            _mfma.note_library("patch_linear.fwd", patches, w2)
         return (F.linear(patches, w2, b_c) if y is None else y).view(x.shape[0], Hr * Wr, w2.shape[0])
 
     @staticmethod
@@ -152,10 +161,14 @@ class _PatchLinearFn(torch.autograd.Function):
             wT = derived(ctx.weight, (w2.dtype, "patch_linear_T"),
                          lambda t: t.to(w2.dtype).permute(2, 3, 1, 0).contiguous(), _krsc_view).view(K, Co)
             gp = _mfma.gemm_nt(g2, wT)
+            if gp is None:
+                _mfma.note_library("patch_linear.dgrad", g2, w2)
             gx = _from_patches(torch.mm(g2, w2) if gp is None else gp, B, H, W, C, r, Hr, Wr)
         T = g2.shape[0]
         S = _split(T)
         part = _mfma.gemm_tn(g2, patches)                                               # fp32 slab partials (S, Co, K)
+        if part is None:
+            _mfma.note_library("patch_linear.wgrad", g2, patches)
         if part is not None:
             part = part.view(part.shape[0], Co * K)
         elif S > 1:
@@ -196,6 +209,8 @@ def patch_conv_tokens(x, H, W, conv):
         return _PatchLinearFn.apply(x, conv.weight, conv.bias, w2, b_c, H, W, r)
     patches, Hr, Wr = _to_patches(x, H, W, r)
     y = _mfma.gemm_nt(patches, w2, b_c)
+    if y is None:
+        _mfma.note_library("patch_linear.fwd", patches, w2)
     return (F.linear(patches, w2, b_c) if y is None else y).view(x.shape[0], Hr * Wr, Co)
 
 
@@ -208,8 +223,6 @@ def patch_conv_tokens(x, H, W, conv):
 # ---------------------------------------------------------------------------------------------------------------------
 import os as _os
 
-from . import mfma as _mfma
-
 _ACT = {None: 0, 'relu': 1, 'leaky': 3}
 _CONV_MFMA = _os.environ.get("RFN_CONV_MFMA", "1") != "0"
 
@@ -218,31 +231,143 @@ def _nhwc_view(p):
     return p.permute(0, 2, 3, 1)
 
 
-def _packed(weight, bias, dtype):
-    """Cached ([N8, Kpad] tap-major 16-bit weight with the output channels padded to 8, bias padded likewise).  What is
+def _packed(weight, bias, dtype, n_mult=8):
+    """Cached ([Np, Kpad] tap-major 16-bit weight with the output channels padded to `n_mult`, bias padded likewise).  What is
     cached per parameter is the (N, KH, KW, C) VIEW into the padded buffer -- the same shape as `weight.permute(0, 2, 3, 1)`
     -- so that params.refresh() re-fills it IN PLACE after an optimizer / EMA update: a captured graph keeps pointing
     at live weights (a re-made copy would leave the replay with stale ones)."""
     def make(t):
         N, C, KH, KW = t.shape
-        N8, Cp = -(-N // 8) * 8, -(-C // 8) * 8
+        N8, Cp = -(-N // n_mult) * n_mult, -(-C // 8) * 8
         Kp = -(-(KH * KW * Cp) // 64) * 64
         base = torch.zeros((N8, Kp), dtype=dtype, device=t.device)
         view = base[:N, :KH * KW * Cp].view(N, KH, KW, Cp)[..., :C]
         view.copy_(t.permute(0, 2, 3, 1))
         view._rfn_base = base
         return view
-    wp = derived(weight, ("igemm", dtype), make, _nhwc_view)._rfn_base
+    wp = derived(weight, ("igemm", dtype, n_mult), make, _nhwc_view)._rfn_base
     bp = None
     if bias is not None:
         def makeb(t):
-            base = torch.zeros(-(-t.shape[0] // 8) * 8, dtype=dtype, device=t.device)
+            base = torch.zeros(-(-t.shape[0] // n_mult) * n_mult, dtype=dtype, device=t.device)
             view = base[:t.shape[0]]
             view.copy_(t)
             view._rfn_base = base
             return view
-        bp = derived(bias, ("igemm_bias", dtype), makeb, _identity)._rfn_base
+        bp = derived(bias, ("igemm_bias", dtype, n_mult), makeb, _identity)._rfn_base
     return wp, bp
+
+
+def _cnhw_view(p):
+    return p.permute(1, 2, 3, 0)
+
+
+def _packed_t(weight, dtype, n_mult):
+    """The filter of the DATA-gradient product: rows c (padded to 8), columns [tap][n] with n padded to `n_mult` like the
+    forward's output channels -- Wt of rfn_conv2d_nhwc_dgrad.  Cached / re-filled in place like _packed."""
+    def make(t):
+        N, C, KH, KW = t.shape
+        Np, Cp = -(-N // n_mult) * n_mult, -(-C // 8) * 8
+        Kp = -(-(KH * KW * Np) // 64) * 64
+        base = torch.zeros((Cp, Kp), dtype=dtype, device=t.device)
+        view = base[:C, :KH * KW * Np].view(C, KH, KW, Np)[..., :N]
+        view.copy_(t.permute(1, 2, 3, 0))
+        view._rfn_base = base
+        return view
+    return derived(weight, ("igemm_T", dtype, n_mult), make, _cnhw_view)._rfn_base
+
+
+def _nhwc16(x, dtype, Cp):
+    """NCHW-shaped tensor (any strides) -> contiguous channels-last (B, H, W, Cp) in `dtype`, channels zero-padded to Cp."""
+    xh = x.permute(0, 2, 3, 1)
+    C = xh.shape[-1]
+    if Cp != C:
+        buf = torch.zeros(xh.shape[:3] + (Cp,), dtype=dtype, device=x.device)
+        buf[..., :C] = xh
+        return buf
+    if xh.dtype != dtype or not xh.is_contiguous():
+        xh = xh.to(dtype).contiguous()
+    return xh
+
+
+class _ConvMfmaFn(torch.autograd.Function):
+    """Dense convolution (groups 1, square kernel / stride / padding / dilation) with forward, data gradient and weight
+    gradient on the hand-written matrix-core kernels: implicit GEMM (csrc/mfma_gemm.hip: rfn_conv2d_nhwc), the same kernel
+    in transposed-gather mode (rfn_conv2d_nhwc_dgrad) and the split-T weight-gradient kernel with gathered im2col rows
+    (rfn_conv2d_nhwc_wgrad).  The trainable convolutions of the student: DAFormer 3x3 bottleneck (daformer.py:65-126), MiT
+    overlap patch embeddings (mix_transformer.py:210-242), the 19-class 1x1s (output channels padded to 64 inside)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias, s, p, d, dtype, act):
+        N, C, KH, KW = weight.shape
+        Cp, Np = -(-C // 8) * 8, -(-N // 64) * 64
+        wp, bp = _packed(weight, bias, dtype, 64)
+        xh = _nhwc16(x, dtype, Cp)
+        y = _mfma.conv2d_nhwc(xh, wp, bp, KH, KW, s, p, d, act=0)
+        if y is None:
+            raise RuntimeError("conv2d (MFMA, autograd): operands outside the kernel's domain")
+        ctx.save_for_backward(xh)
+        ctx.weight, ctx.bias, ctx.conf, ctx.dtype = weight, bias, (s, p, d), dtype
+        ctx.xshape = x.shape
+        return (y[..., :N] if Np != N else y).permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        from .params import sum_rows
+        (xh,) = ctx.saved_tensors
+        weight, bias, (s, p, d), dtype = ctx.weight, ctx.bias, ctx.conf, ctx.dtype
+        N, C, KH, KW = weight.shape
+        B, H, W, Cp = xh.shape
+        Np = -(-N // 64) * 64
+        gh = _nhwc16(gy, dtype, Np)                                  # (B, OH, OW, Np), zero in the padded channels
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            dx = _mfma.conv2d_nhwc_dgrad(gh, _packed_t(weight, dtype, 64), H, W, Cp, KH, KW, s, p, d)
+            if dx is None:
+                raise RuntimeError("conv2d dgrad (MFMA): operands outside the kernel's domain")
+            gx = (dx[..., :C] if Cp != C else dx).permute(0, 3, 1, 2)
+        need_w = ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            sw, sb = grad_sink(weight), grad_sink(bias)
+            Kp = -(-(KH * KW * Cp) // 64) * 64
+            bsum = torch.zeros(Np, dtype=torch.float32, device=gh.device) if need_b else None
+            part = _mfma.conv2d_nhwc_wgrad(gh, xh, KH, KW, Kp, s, p, d, bias_out=bsum)
+            if part is None:
+                raise RuntimeError("conv2d wgrad (MFMA): operands outside the kernel's domain")
+            if need_w:
+                S = part.shape[0]
+                g2 = sum_rows(part.view(S, Np * Kp)).view(Np, Kp)[:N, :KH * KW * Cp].view(N, KH, KW, Cp)[..., :C]
+                if sw is not None:
+                    sw.permute(0, 2, 3, 1).add_(g2)                  # the parameter is (N, C, KH, KW)
+                else:
+                    gw = g2.permute(0, 3, 1, 2).to(weight.dtype)
+            if need_b:
+                if sb is not None:
+                    sb.add_(bsum[:N])
+                else:
+                    gb = bsum[:N].to(bias.dtype)
+        return gx, gw, gb, None, None, None, None, None
+
+
+def conv2d_mfma_grad(x, weight, bias, stride, padding, dilation, dtype):
+    """conv2d under autograd on the hand-written kernels (see _ConvMfmaFn); None outside their domain (caller takes the
+    library path and records it)."""
+    if not (_CONV_MFMA and _mfma.ENABLED and x.is_cuda and x.dim() == 4 and dtype in (torch.float16, torch.bfloat16)
+            and _os.environ.get("RFN_CONV_MFMA_GRAD", "1") != "0"):
+        return None
+    for v in (stride, padding, dilation):
+        if isinstance(v, (tuple, list)) and v[0] != v[1]:
+            return None
+    s, p, d = (v[0] if isinstance(v, (tuple, list)) else v for v in (stride, padding, dilation))
+    N, C, KH, KW = weight.shape
+    Cp = -(-C // 8) * 8
+    if x.shape[1] != C or s & (s - 1) or isinstance(p, str) or -(-(KH * KW * Cp) // 64) * 64 >= 65536 \
+            or KH * KW * (-(-N // 64) * 64) // 8 >= 65536:
+        return None
+    return _ConvMfmaFn.apply(x, weight, bias, s, p, d, dtype, None)
 
 
 def conv2d_mfma(x, weight, bias, stride=1, padding=0, dilation=1, act=None, dtype=None):

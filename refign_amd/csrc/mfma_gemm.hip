@@ -54,6 +54,11 @@ struct ConvGeom {
   unsigned c8_magic;       // ceil(2^32 / C8): piece index / C8 (exact for piece < 2^16)
   unsigned kw_magic;       // ceil(2^32 / KW)
   const void* zero;        // >= 16 bytes of zeros
+  // transposed = 1: the DATA gradient of the convolution (rfn_conv2d_nhwc_dgrad).  X is then grad_y (B, H, W, C) = the
+  // convolution's OUTPUT side, the result rows m are the convolution's INPUT pixels (b, iy, ix) (OH, OW = their extent) and
+  //   DX[m, c] = sum_{tap, n} GY[b, (iy + pad - ky dil) / stride, (ix + pad - kx dil) / stride, n] * Wt[c, (tap, n)]
+  // over the taps whose numerators are non-negative multiples of the stride (power of two: sshift) and land inside GY.
+  int transposed, sshift;
 };
 
 // Persistent workgroups: a workgroup owns every G-th output tile (m-major, n fastest) and runs ONE software pipeline
@@ -121,8 +126,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
         const int ohw = cg.OH * cg.OW;
         const int b = m / ohw, rem = m - b * ohw, oy = rem / cg.OW, ox = rem - oy * cg.OW;
         xsrc[q] = (const unsigned char*)(X + (long)b * cg.H * cg.W * cg.C);
-        iy0[q] = oy * cg.stride - cg.pad;
-        ix0[q] = ox * cg.stride - cg.pad;
+        iy0[q] = cg.transposed ? oy + cg.pad : oy * cg.stride - cg.pad;
+        ix0[q] = cg.transposed ? ox + cg.pad : ox * cg.stride - cg.pad;
       } else {
         xsrc[q] = (const unsigned char*)(X + (long)m * ldx) + 16 * dpiece;
       }
@@ -144,8 +149,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
       const int dy = (int)ky * cg.dil, dx = (int)kx * cg.dil;
 #pragma unroll
       for (int q = 0; q < XI; ++q) {
-        const int iy = iy0[q] + dy, ix = ix0[q] + dx;
-        const bool ok = tap_ok && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
+        int iy = iy0[q] + dy, ix = ix0[q] + dx;
+        bool ok = tap_ok;
+        if (cg.transposed) {                     // wave-uniform
+          const int ty = iy0[q] - dy, tx = ix0[q] - dx, smask = (1 << cg.sshift) - 1;
+          ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0;
+          iy = ty >> cg.sshift;
+          ix = tx >> cg.sshift;
+        }
+        ok = ok && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
         const unsigned char* src = ok ? xsrc[q] + ((long)(iy * cg.W + ix) * cg.C + c8 * 8) * 2
                                       : (const unsigned char*)cg.zero;
         lds_dma16(src, xs + 1024 * (NW * q + wave));
@@ -291,11 +303,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
 // and both MFMA operands are then plain 8-byte LDS reads: A[i = n][slots] = G^T, B[slots][j = k] = X.
 // Slot order inside a 16-row k-step follows mfma.h: slot (g, e) = row {0-3, 8-11}[e] + 4 g.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DT, int BN, int BK>
+// GATHER: the weight gradient of a convolution (rfn_conv2d_nhwc_wgrad): row t of the X operand is the im2col row of output
+// pixel t = (b, oy, ox), column k = (tap, c) reads x[b, oy s - p + ky d, ox s - p + kx d, c] (zero outside the image / past
+// the last tap) -- no im2col buffer; a thread's column pair is fixed, so its (tap, c) is decomposed once.
+struct WgradGeom {
+  int H, W, C, OH, OW, KH, KW, stride, pad, dil;
+  unsigned c_magic, kw_magic;                          // ceil(2^32 / d) for C, KW (dividends < 2^16)
+};
+
+template <int DT, int BN, int BK, bool GATHER = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
                                                       float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
                                                       int R, int tiles_k, int accumulate, float* __restrict__ gbias,
-                                                      const float* __restrict__ rowscale, int rows_per_sample) {
+                                                      const float* __restrict__ rowscale, int rows_per_sample,
+                                                      WgradGeom wg = WgradGeom{}) {
   using E = Elem<DT>;
   constexpr int BT = 32;                   // rows of the reduction per stage (two 16-slot k-steps)
   constexpr int IB = BN / 64, JB = BK / 64;
@@ -321,6 +342,33 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
   // keeps the running sums of its two columns; only the k-tile-0 workgroups of each (n tile, slab) contribute
   const bool do_bias = (gbias != nullptr) && (k0 == 0);
   float bsum[2] = {0.f, 0.f};
+  // GATHER: (tap, channel) of this thread's X column pair (the same in every stage and for all its items)
+  int gdy = 0, gdx = 0, gc = 0;
+  bool gtap_ok = true;
+  if constexpr (GATHER) {
+    const unsigned k = (unsigned)(k0 + 2 * (threadIdx.x % XP));
+    const unsigned tap = wg.C == 1 ? k : __umulhi(k, wg.c_magic);
+    gc = (int)(k - tap * wg.C);
+    const unsigned ky = wg.KW == 1 ? tap : __umulhi(tap, wg.kw_magic), kx = tap - ky * wg.KW;
+    gtap_ok = (int)ky < wg.KH;
+    gdy = (int)ky * wg.dil - wg.pad;
+    gdx = (int)kx * wg.dil - wg.pad;
+  }
+  // (image, oy, ox) of the rows this thread stages, advanced by BT per stage (no division in the loop)
+  int gb[GATHER ? XPT : 1][4], goy[GATHER ? XPT : 1][4], gox[GATHER ? XPT : 1][4];
+  if constexpr (GATHER) {
+#pragma unroll
+    for (int u = 0; u < XPT; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long t = t0 + 4 * ((u * 256 + (int)threadIdx.x) / XP) + r;
+        const long ohw = (long)wg.OH * wg.OW;
+        gb[u][r] = (int)(t / ohw);
+        const int rem = (int)(t - gb[u][r] * ohw);
+        goy[u][r] = rem / wg.OW;
+        gox[u][r] = rem - goy[u][r] * wg.OW;
+      }
+  }
   auto load_stage = [&](int it) {
     const long tb = t0 + (long)it * BT;
 #pragma unroll
@@ -346,8 +394,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
     for (int u = 0; u < XPT; ++u) {
       const int item = u * 256 + threadIdx.x, q = item / XP, cp = item % XP;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        xreg[u][r] = (tb + 4 * q + r < T) ? *(const unsigned*)(X + (tb + 4 * q + r) * ldx + k0 + 2 * cp) : 0u;
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (GATHER) {
+          const long t = tb + 4 * q + r;
+          const int iy = goy[u][r] * wg.stride + gdy, ix = gox[u][r] * wg.stride + gdx;
+          const bool ok = t < T && gtap_ok && (unsigned)iy < (unsigned)wg.H && (unsigned)ix < (unsigned)wg.W;
+          xreg[u][r] = ok ? *(const unsigned*)(X + (((long)gb[u][r] * wg.H + iy) * wg.W + ix) * wg.C + gc) : 0u;
+          gox[u][r] += BT;                              // the same row of the NEXT stage
+          while (gox[u][r] >= wg.OW) {
+            gox[u][r] -= wg.OW;
+            if (++goy[u][r] == wg.OH) {
+              goy[u][r] = 0;
+              ++gb[u][r];
+            }
+          }
+        } else {
+          xreg[u][r] = (tb + 4 * q + r < T) ? *(const unsigned*)(X + (tb + 4 * q + r) * ldx + k0 + 2 * cp) : 0u;
+        }
+      }
     }
   };
   auto write_stage = [&](int buf) {
@@ -453,6 +517,215 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TN kernel, second generation (round 3): the same product and the same LDS image / MFMA operand order as above, but the
+// operand tiles are fetched with 16-BYTE loads and transposed in registers.  128 threads stage the G tile, 128 the X tile;
+// a thread owns ONE 4-row x 8-column block per stage: 4 x global_load_dwordx4 (a 16-lane group reads 256 contiguous bytes
+// of a row), 16 v_perm_b32, 4 x ds_write_b128 -- a quarter of the load instructions per element of the first generation
+// (4-byte loads), which was paced by load issue.  The 16-byte piece j (column pair j of the block) of block cv is stored at
+// piece slot j ^ ((cv >> 1) & 3): the 8 lanes of a ds_write_b128 group then cover the eight 16-byte slots of a 128-byte
+// bank row, and a fragment read stays a permutation inside its 256-byte span (conflict-free both ways).
+// BT = rows of the reduction per stage: 32 for the 128 x 128 tile, 64 for the 64 x 64 tile (128 blocks per operand either
+// way).  GATHER: im2col rows of a convolution (see WgradGeom); a thread's block is 8 channels of ONE tap of 4 consecutive
+// output pixels.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned perm_lo(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }  // {a.lo, b.lo}
+__device__ __forceinline__ unsigned perm_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }  // {a.hi, b.hi}
+
+template <int DT, int BN, int BK, int BT, bool GATHER>
+__global__ __launch_bounds__(256) void gemm_tn2_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
+                                                       float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
+                                                       int R, int tiles_k, int accumulate, float* __restrict__ gbias,
+                                                       const float* __restrict__ rowscale, int rows_per_sample,
+                                                       WgradGeom wg) {
+  using E = Elem<DT>;
+  constexpr int IB = BN / 64, JB = BK / 64;
+  constexpr int NQ = BT / 4;                                     // row quads per stage
+  constexpr int GBYTES = NQ * BN * 8, XBYTES = NQ * BK * 8, STAGE = GBYTES + XBYTES;
+  static_assert(NQ * (BN / 8) == 128 && NQ * (BK / 8) == 128, "128 blocks per operand and stage");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles = (N / BN) * tiles_k;
+  const int slab = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
+  const long t0 = (long)slab * R;
+
+  // staging role: threads 0..127 the G tile, 128..255 the X tile; block (q, cv) = 4 rows x 8 columns
+  const bool isx = threadIdx.x >= 128;
+  const int bid = threadIdx.x & 127;
+  const int cols8 = (isx ? BK : BN) / 8;
+  const int cv = bid % cols8, q = bid / cols8;
+  const int sw = (cv >> 1) & 3;
+  const bool do_bias = (gbias != nullptr) && (k0 == 0) && !isx;
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  // GATHER (X threads): (tap, channel) of the block's 8 columns, and the (image, oy, ox) of its 4 rows, advanced per stage
+  int gdy = 0, gdx = 0, gc = 0;
+  bool gtap_ok = true;
+  int gb[4], goy[4], gox[4];
+  if constexpr (GATHER) {
+    const unsigned k = (unsigned)(k0 + 8 * cv);
+    const unsigned tap = __umulhi(k, wg.c_magic);
+    gc = (int)(k - tap * wg.C);
+    const unsigned ky = wg.KW == 1 ? tap : __umulhi(tap, wg.kw_magic), kx = tap - ky * wg.KW;
+    gtap_ok = (int)ky < wg.KH;
+    gdy = (int)ky * wg.dil - wg.pad;
+    gdx = (int)kx * wg.dil - wg.pad;
+    const long ohw = (long)wg.OH * wg.OW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long t = t0 + 4 * q + r;
+      gb[r] = (int)(t / ohw);
+      const int rem = (int)(t - gb[r] * ohw);
+      goy[r] = rem / wg.OW;
+      gox[r] = rem - goy[r] * wg.OW;
+    }
+  }
+  const uint16_t* base = isx ? X + k0 + 8 * cv : G + n0 + 8 * cv;
+  const long ld = isx ? ldx : ldg;
+  const long tend = min((long)T, t0 + R);             // a slab need not be a multiple of BT rows: mask at its end
+  u32x4 reg[4];
+  auto load_stage = [&](int it) {
+    const long tb = t0 + (long)it * BT + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long t = tb + r;
+      bool ok = t < tend;
+      const uint16_t* src;
+      if (GATHER && isx) {
+        const int iy = goy[r] * wg.stride + gdy, ix = gox[r] * wg.stride + gdx;
+        ok = ok && gtap_ok && (unsigned)iy < (unsigned)wg.H && (unsigned)ix < (unsigned)wg.W;
+        src = X + (((long)gb[r] * wg.H + iy) * wg.W + ix) * wg.C + gc;
+        gox[r] += BT;
+        while (gox[r] >= wg.OW) {
+          gox[r] -= wg.OW;
+          if (++goy[r] == wg.OH) {
+            goy[r] = 0;
+            ++gb[r];
+          }
+        }
+      } else {
+        src = base + t * ld;
+      }
+      reg[r] = ok ? *(const u32x4*)src : u32x4{0u, 0u, 0u, 0u};
+    }
+    if (rowscale != nullptr && !isx) {
+      // G <- diag(rowscale[row / rows_per_sample]) G, scaled in fp32 and rounded back like the eager g * mask
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = tb + r;
+        const float sc = row < tend ? rowscale[row / rows_per_sample] : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float f[4];
+          unpack4<DT>(u32x2{reg[r][2 * h], reg[r][2 * h + 1]}, f);
+          const u32x2 o = pack4<DT>(f[0] * sc, f[1] * sc, f[2] * sc, f[3] * sc);
+          reg[r][2 * h] = o[0];
+          reg[r][2 * h + 1] = o[1];
+        }
+      }
+    }
+  };
+  auto write_stage = [&](int buf) {
+    unsigned char* dst = smem + buf * STAGE + (isx ? GBYTES : 0) + (q * (isx ? BK : BN) + 8 * cv) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // column pair j: dword j of the four rows -> {even column: 4 rows, odd column: 4 rows}
+      u32x4 o;
+      o[0] = perm_lo(reg[0][j], reg[1][j]);
+      o[1] = perm_lo(reg[2][j], reg[3][j]);
+      o[2] = perm_hi(reg[0][j], reg[1][j]);
+      o[3] = perm_hi(reg[2][j], reg[3][j]);
+      *(u32x4*)(dst + 16 * (j ^ sw)) = o;
+      if (do_bias) {
+        float f[4];
+        unpack4<DT>(u32x2{o[0], o[1]}, f);
+        bsum[2 * j] += (f[0] + f[1]) + (f[2] + f[3]);
+        unpack4<DT>(u32x2{o[2], o[3]}, f);
+        bsum[2 * j + 1] += (f[0] + f[1]) + (f[2] + f[3]);
+      }
+    }
+  };
+
+  f32x16 acc[IB][JB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int g = lane >> 5, col = lane & 31;
+  // byte offset of column c inside a quad's row of the image (swizzled 16-byte pieces inside 64-byte blocks)
+  auto coff = [](int c) { return (c & ~7) * 8 + 16 * (((c >> 1) & 3) ^ ((c >> 4) & 3)) + 8 * (c & 1); };
+  int aoff[IB], boff[JB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i) aoff[i] = coff(wn * (BN / 2) + i * 32 + col);
+#pragma unroll
+  for (int j = 0; j < JB; ++j) boff[j] = coff(wk * (BK / 2) + j * 32 + col);
+
+  const int nit = (int)((min((long)R, (long)T - t0) + BT - 1) / BT);
+  load_stage(0);
+  write_stage(0);
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) load_stage(it + 1);
+    const unsigned char* gs = smem + buf * STAGE;
+    const unsigned char* xs = gs + GBYTES;
+#pragma unroll
+    for (int ks = 0; ks < BT / 16; ++ks) {
+      const int qa = 4 * ks + g, qb = 4 * ks + 2 + g;
+      typename E::vec8 af[IB], bf[JB];
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+        af[i] = join8<DT>(*(const u32x2*)(gs + qa * BN * 8 + aoff[i]), *(const u32x2*)(gs + qb * BN * 8 + aoff[i]));
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+        bf[j] = join8<DT>(*(const u32x2*)(xs + qa * BK * 8 + boff[j]), *(const u32x2*)(xs + qb * BK * 8 + boff[j]));
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(af[i], bf[j], acc[i][j]);
+    }
+    if (it + 1 < nit) write_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = accumulate ? P : P + (long)slab * N * K;
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int kk = k0 + wk * (BK / 2) + j * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * (BN / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (accumulate) atomicAdd(out + (long)n * K + kk, acc[i][j][r]);
+        else out[(long)n * K + kk] = acc[i][j][r];
+      }
+    }
+  if (gbias != nullptr && k0 == 0) {             // the G threads' column sums over their row quads, one atomic per column
+    float* red = (float*)smem;                   // [128 blocks][8]
+    if (!isx) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[bid * 8 + e] = bsum[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < BN) {
+      const int c8 = threadIdx.x >> 3, e = threadIdx.x & 7;
+      float sum = 0.f;
+      for (int qq = 0; qq < NQ; ++qq) sum += red[(qq * (BN / 8) + c8) * 8 + e];
+      atomicAdd(gbias + n0 + threadIdx.x, sum);
+    }
+  }
+}
+
 __device__ uint4 g_zero_page[4];          // zero-initialised: DMA source of out-of-image / padding pieces
 
 template <int DT, bool GATHER>
@@ -510,19 +783,34 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   return check_launch("gemm_nt");
 }
 
-template <int DT>
+template <int DT, bool GATHER = false>
 static int launch_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int R,
-                     int accumulate, float* gbias, const float* rowscale, int rps, hipStream_t s) {
+                     int accumulate, float* gbias, const float* rowscale, int rps, hipStream_t s,
+                     WgradGeom wg = WgradGeom{}) {
   const int S = cdiv(T, R);
   dim3 block(256);
+  static const bool v1 = getenv("RFN_TN_V1") != nullptr && atoi(getenv("RFN_TN_V1")) != 0;   // A/B: first-generation kernel
+  const bool vec = (GATHER ? wg.C % 8 == 0 : (ldx % 8 == 0 && ((size_t)X & 15) == 0)) && ldg % 8 == 0 && ((size_t)G & 15) == 0;
+  if (!v1 && vec) {
+    if (N % 128 == 0 && K % 128 == 0) {
+      dim3 grid((unsigned)((N / 128) * (K / 128) * S));
+      hipLaunchKernelGGL((gemm_tn2_kernel<DT, 128, 128, 32, GATHER>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X,
+                         P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps, wg);
+    } else {
+      dim3 grid((unsigned)((N / 64) * (K / 64) * S));
+      hipLaunchKernelGGL((gemm_tn2_kernel<DT, 64, 64, 64, GATHER>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X,
+                         P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps, wg);
+    }
+    return check_launch("gemm_tn2");
+  }
   if (N % 128 == 0 && K % 128 == 0) {
     dim3 grid((unsigned)((N / 128) * (K / 128) * S));
-    hipLaunchKernelGGL((gemm_tn_kernel<DT, 128, 128>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps);
+    hipLaunchKernelGGL((gemm_tn_kernel<DT, 128, 128, GATHER>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
+                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps, wg);
   } else {
     dim3 grid((unsigned)((N / 64) * (K / 64) * S));
-    hipLaunchKernelGGL((gemm_tn_kernel<DT, 64, 64>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps);
+    hipLaunchKernelGGL((gemm_tn_kernel<DT, 64, 64, GATHER>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
+                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps, wg);
   }
   return check_launch("gemm_tn");
 }
@@ -569,10 +857,60 @@ int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* 
   RFN_REQUIRE(act == 0 || act == 1 || act == 3, "conv2d_nhwc: act (0 none, 1 ReLU, 3 LeakyReLU 0.1)");
   GemmEpi epi{(const uint16_t*)bias, (const uint16_t*)res, nullptr, 1, act};
   ConvGeom cg{H, Wd, C, OH, OW, KH, KW, stride, pad, dil, C / 8, (unsigned)((0x100000000ULL + C / 8 - 1) / (C / 8)),
-              (unsigned)((0x100000000ULL + KW - 1) / KW), nullptr};
+              (unsigned)((0x100000000ULL + KW - 1) / KW), nullptr, 0, 0};
   hipStream_t s = (hipStream_t)stream;
   return dtype == 1 ? launch_nt<1, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s)
                     : launch_nt<2, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s);
+}
+
+int rfn_conv2d_nhwc_dgrad(const void* GY, const void* Wt, void* DX, int B, int H, int Wd, int C, int N, int KH, int KW,
+                          int stride, int pad, int dil, long ldw, long ldy, int dtype, rfn_stream_t stream) {
+  using namespace rfn;
+  RFN_REQUIRE(GY && Wt && DX, "conv2d_nhwc_dgrad: null operand");
+  RFN_REQUIRE(dtype == 1 || dtype == 2, "conv2d_nhwc_dgrad: dtype %d (1 = bf16, 2 = f16)", dtype);
+  RFN_REQUIRE(B > 0 && H > 0 && Wd > 0 && C > 0 && C % 8 == 0 && N > 0 && N % 8 == 0, "conv2d_nhwc_dgrad: B=%d H=%d W=%d C=%d "
+              "N=%d (C %% 8, N %% 8)", B, H, Wd, C, N);
+  RFN_REQUIRE(KH > 0 && KW > 0 && stride > 0 && (stride & (stride - 1)) == 0 && dil > 0 && pad >= 0,
+              "conv2d_nhwc_dgrad: kernel %dx%d stride %d (power of two) pad %d dil %d", KH, KW, stride, pad, dil);
+  const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (Wd + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  RFN_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc_dgrad: empty output");
+  // GEMM view: rows = input pixels (B, H, W), reduction = (tap, n) over grad_y's channels, result columns = C
+  const long K = ((long)KH * KW * N + 63) / 64 * 64, M = (long)B * H * Wd;
+  RFN_REQUIRE(ldw % 8 == 0 && ldw >= K && ldy % 8 == 0 && ldy >= C, "conv2d_nhwc_dgrad: ldw=%ld (>= %ld, padded k) ldy=%ld", ldw,
+              K, ldy);
+  RFN_REQUIRE(M < (1L << 31) && K / 8 < 65536 && (long)OH * OW * N < (1L << 31), "conv2d_nhwc_dgrad: extent");
+  int sshift = 0;
+  while ((1 << sshift) < stride) ++sshift;
+  GemmEpi epi{nullptr, nullptr, nullptr, 1, 0};
+  ConvGeom cg{OH, OW, N, H, Wd, KH, KW, stride, pad, dil, N / 8, (unsigned)((0x100000000ULL + N / 8 - 1) / (N / 8)),
+              (unsigned)((0x100000000ULL + KW - 1) / KW), nullptr, 1, sshift};
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == 1 ? launch_nt<1, true>(GY, Wt, DX, M, C, K, 0, ldw, ldy, epi, cg, s)
+                    : launch_nt<2, true>(GY, Wt, DX, M, C, K, 0, ldw, ldy, epi, cg, s);
+}
+
+int rfn_conv2d_nhwc_wgrad(const void* GY, const void* X, float* P, float* grad_bias, int B, int H, int Wd, int C, int N, int KH,
+                          int KW, int stride, int pad, int dil, long ldg, long Kpad, int rows_per_slab, int accumulate,
+                          int dtype, rfn_stream_t stream) {
+  using namespace rfn;
+  RFN_REQUIRE(GY && X && P, "conv2d_nhwc_wgrad: null operand");
+  RFN_REQUIRE(dtype == 1 || dtype == 2, "conv2d_nhwc_wgrad: dtype %d", dtype);
+  RFN_REQUIRE(B > 0 && H > 0 && Wd > 0 && C > 0 && C % 2 == 0 && N > 0 && N % 64 == 0, "conv2d_nhwc_wgrad: B=%d H=%d W=%d C=%d N=%d "
+              "(C %% 2, N %% 64)", B, H, Wd, C, N);
+  RFN_REQUIRE(KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d_nhwc_wgrad: kernel %dx%d stride %d pad %d dil %d", KH,
+              KW, stride, pad, dil);
+  const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (Wd + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  RFN_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc_wgrad: empty output");
+  const long T = (long)B * OH * OW;
+  RFN_REQUIRE(Kpad % 64 == 0 && Kpad >= (long)KH * KW * C && ldg % 2 == 0 && ldg >= N, "conv2d_nhwc_wgrad: Kpad=%ld ldg=%ld", Kpad, ldg);
+  RFN_REQUIRE(T < (1L << 31) && (long)B * H * Wd * C < (1L << 31) && rows_per_slab > 0 && rows_per_slab % 32 == 0,
+              "conv2d_nhwc_wgrad: extent / rows_per_slab");
+  auto magic = [](long d) { return (unsigned)((0x100000000ULL + d - 1) / d); };
+  RFN_REQUIRE(Kpad < 65536, "conv2d_nhwc_wgrad: Kpad=%ld", Kpad);
+  WgradGeom wg{H, Wd, C, OH, OW, KH, KW, stride, pad, dil, magic(C), magic(KW)};
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == 1 ? launch_tn<1, true>(GY, X, P, T, N, Kpad, ldg, 0, rows_per_slab, accumulate, grad_bias, nullptr, 0, s, wg)
+                    : launch_tn<2, true>(GY, X, P, T, N, Kpad, ldg, 0, rows_per_slab, accumulate, grad_bias, nullptr, 0, s, wg);
 }
 
 int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int rows_per_slab,

@@ -88,6 +88,9 @@ class ConvBNReLU(nn.Module):
             xh = x.permute(0, 2, 3, 1)                       # free for channels_last inputs
             y = dwconv3x3_nhwc(xh if xh.is_contiguous() else xh.contiguous(), w, b, c.dilation[0])
             return y.permute(0, 3, 1, 2)                     # NCHW-shaped, channels_last strides
+        if x.is_cuda:
+            from . import mfma
+            mfma.note_library("conv2d.autograd" if torch.is_grad_enabled() else "conv2d", x, w)
         return F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
 
     def _conv_train(self, x, cd):
@@ -110,6 +113,13 @@ class ConvBNReLU(nn.Module):
         if c.groups == 1 and not torch.is_grad_enabled():
             from .conv import conv2d_mfma
             y = conv2d_mfma(x, c.weight, c.bias, c.stride, c.padding, c.dilation, dtype=cd)
+            if y is not None:
+                return y
+        if c.groups == 1 and torch.is_grad_enabled():
+            # dense k x k under autograd (the student's 3x3 bottleneck): forward, data and weight gradient on the implicit-GEMM
+            # kernels (conv._ConvMfmaFn)
+            from .conv import conv2d_mfma_grad
+            y = conv2d_mfma_grad(x, c.weight, c.bias, c.stride, c.padding, c.dilation, cd)
             if y is not None:
                 return y
         return self._conv2d(x, c.weight, c.bias)

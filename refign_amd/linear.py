@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import mfma, sidework
-from .params import as_dtype, compute_dtype, grad_sink, linear_gemm, linear_param_grads, sum_rows, transposed
+from .params import as_dtype, compute_dtype, grad_sink, linear_param_grads, sum_rows, transposed
 
 
 _FUSED_GRADS = os.environ.get("RFN_LINEAR_FUSED_GRADS", "1") != "0"      # A/B switch (tools)
@@ -59,7 +59,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w_c, None)
         y = mfma.gemm_nt(x2, w_c, b_c)                       # hand-written MFMA kernel (16-bit operands)
         if y is None:
-            y = linear_gemm(0, w_c, x2, (x2.shape[0], N), b_c, x2.shape[0], N, K) if x2.is_contiguous() else None
+            mfma.note_library("linear.fwd", x2, w_c)
         return F.linear(x, w_c, b_c) if y is None else y.view(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -84,7 +84,7 @@ class _LinearFn(torch.autograd.Function):
             gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype)) if mfma.ENABLED and w_c.dtype != torch.float32 \
                 else None
             if gx is None:
-                gx = linear_gemm(1, w_c, g2, (g2.shape[0], K), None, g2.shape[0], N, K)
+                mfma.note_library("linear.dgrad", g2, w_c)
             gx = (torch.mm(g2, w_c) if gx is None else gx).view(x.shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]
         sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
@@ -104,8 +104,7 @@ class _LinearFn(torch.autograd.Function):
                 part = part.view(part.shape[0], N * K)
             S = _split(T)
             if part is None:
-                part = linear_gemm(2, x2, g2, (S, N * K), None, T, N, K, S) if x2.is_contiguous() else None
-            if part is None:
+                mfma.note_library("linear.wgrad", g2, x2)
                 if S > 1:
                     part = torch.bmm(g2.view(S, T // S, N).transpose(1, 2), x2.view(S, T // S, K)).view(S, N * K)
                 else:
@@ -167,6 +166,8 @@ def linear_tokens(x2, weight, bias, cd):
     if torch.is_grad_enabled() and (weight.requires_grad or x2.requires_grad):
         return _LinearFn.apply(x2, weight, bias, w_c, b_c, None, None)
     y = mfma.gemm_nt(x2, w_c, b_c)
+    if y is None:
+        mfma.note_library("linear.fwd", x2, w_c)
     return F.linear(x2, w_c, b_c) if y is None else y
 
 
@@ -197,6 +198,8 @@ class Linear(nn.Linear):
             if y is not None:
                 return y.view(x.shape[:-1] + (N,))
         y = mfma.gemm_nt(x2, w_c, b_c)
+        if y is None:
+            mfma.note_library("linear.fwd", x2, w_c)
         y = F.linear(x, w_c, b_c) if y is None else y.view(x.shape[:-1] + (N,))
         return y if res is None else _residual(res, y, rowscale)
 

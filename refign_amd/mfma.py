@@ -17,6 +17,38 @@ from ._tensor import current_stream, on_device, ptr
 _DT16 = {torch.bfloat16: 1, torch.float16: 2}
 ENABLED = os.environ.get("RFN_MFMA", "1") != "0"            # A/B switch: 0 = library GEMM / SDPA everywhere
 
+# Every dense op of a HIP tensor that ends up in a ROCm LIBRARY (hipBLASLt / MIOpen / fused SDPA behind F.linear, torch.mm,
+# F.conv2d, scaled_dot_product_attention) instead of a hand-written kernel is recorded here by its call site:
+# (kind, dtype, shape signature) -> number of calls.  bench.py prints the table as `config.library_fallbacks`: in its
+# default (reduced-precision) mode the only entries allowed are the ones DESIGN.md lists.  fp32 parity mode runs fp32
+# operands, for which no matrix-core kernel exists -- those calls are recorded too (dtype float32).
+LIBRARY_CALLS = {}
+_NOTE = os.environ.get("RFN_NOTE_LIBRARY", "1") != "0"
+
+
+def note_library(kind, *tensors):
+    """Record a dense library call made for HIP tensors (no-op for CPU tensors: host-side unit tests)."""
+    if not _NOTE or not tensors or not tensors[0].is_cuda:
+        return
+    key = (kind, str(tensors[0].dtype).replace("torch.", ""), tuple(tuple(t.shape) for t in tensors))
+    n = LIBRARY_CALLS.get(key)
+    if n is None and len(LIBRARY_CALLS) < 4096:
+        if os.environ.get("RFN_LOG_LIBRARY", "0") == "1":
+            print(f"[refign_amd] library fallback: {kind} {key[1]} {key[2]}", flush=True)
+        LIBRARY_CALLS[key] = 1
+    elif n is not None:
+        LIBRARY_CALLS[key] = n + 1
+
+
+def library_summary():
+    """{kind/dtype: {"calls": n, "shapes": distinct signatures}} of the calls recorded so far."""
+    out = {}
+    for (kind, dt, _), n in LIBRARY_CALLS.items():
+        e = out.setdefault(f"{kind}/{dt}", {"calls": 0, "shapes": 0})
+        e["calls"] += n
+        e["shapes"] += 1
+    return out
+
 
 def _row_major(t):
     return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.stride(0) >= t.shape[1] \
@@ -90,6 +122,50 @@ def conv2d_nhwc(x, wp, bias, KH, KW, stride=1, pad=0, dil=1, act=0, res=None, ou
                                  pad, dil, wp.stride(0), out.stride(2), _DT16[x.dtype], current_stream(x.device))
     _lib.check(rc, "conv2d_nhwc")
     return out
+
+
+def conv2d_nhwc_dgrad(gy, wt, H, W, C, KH, KW, stride=1, pad=0, dil=1):
+    """Data gradient of conv2d_nhwc.  gy (B, OH, OW, N) channels-last contiguous, wt (C, >= roundup(KH*KW*N, 64)) rows of
+    [tap][n] (the filter's permute(1, 2, 3, 0), zero padded) -> (B, H, W, C).  None outside the kernel's domain."""
+    if not (ENABLED and gy.is_cuda and gy.dtype in _DT16 and wt.dtype == gy.dtype and gy.dim() == 4 and gy.is_contiguous()
+            and wt.is_contiguous() and stride & (stride - 1) == 0):
+        return None
+    B, OH, OW, N = gy.shape
+    if N % 8 or C % 8 or wt.shape[0] != C or wt.shape[1] < KH * KW * N or wt.shape[1] % 64:
+        return None
+    if (OH, OW) != ((H + 2 * pad - dil * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1):
+        return None
+    dx = torch.empty((B, H, W, C), dtype=gy.dtype, device=gy.device)
+    with on_device(gy.device):
+        rc = _lib.load_library().rfn_conv2d_nhwc_dgrad(ptr(gy), ptr(wt), ptr(dx), B, H, W, C, N, KH, KW, stride, pad, dil,
+                                                       wt.stride(0), C, _DT16[gy.dtype], current_stream(gy.device))
+    _lib.check(rc, "conv2d_nhwc_dgrad")
+    return dx
+
+
+def conv2d_nhwc_wgrad(gy, x, KH, KW, Kpad, stride=1, pad=0, dil=1, bias_out=None):
+    """Weight gradient of conv2d_nhwc in the packed layout.  gy (B, OH, OW, N), x (B, H, W, C) channels-last contiguous ->
+    fp32 slab partials (S, N, Kpad) whose sum over S is dW[n][(ky, kx, c)] (columns past KH*KW*C are zero); `bias_out` (N,)
+    fp32, if given, += column sums of gy.  None outside the kernel's domain."""
+    if not (ENABLED and gy.is_cuda and gy.dtype in _DT16 and x.dtype == gy.dtype and gy.dim() == 4 and x.dim() == 4
+            and gy.is_contiguous() and x.is_contiguous()):
+        return None
+    B, OH, OW, N = gy.shape
+    _, H, W, C = x.shape
+    if N % 64 or C % 2 or Kpad % 64 or Kpad < KH * KW * C or Kpad >= 65536 or x.shape[0] != B:
+        return None
+    if (OH, OW) != ((H + 2 * pad - dil * (KH - 1) - 1) // stride + 1, (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1):
+        return None
+    T = B * OH * OW
+    tile = 128 if (N % 128 == 0 and Kpad % 128 == 0) else 64
+    rows = slab_rows(T, (N // tile) * (Kpad // tile))
+    S = -(-T // rows)
+    part = torch.empty((S, N, Kpad), dtype=torch.float32, device=gy.device)
+    with on_device(gy.device):
+        rc = _lib.load_library().rfn_conv2d_nhwc_wgrad(ptr(gy), ptr(x), ptr(part), ptr(bias_out), B, H, W, C, N, KH, KW, stride,
+                                                       pad, dil, N, Kpad, rows, 0, _DT16[gy.dtype], current_stream(gy.device))
+    _lib.check(rc, "conv2d_nhwc_wgrad")
+    return part
 
 
 def slab_rows(T, tiles):

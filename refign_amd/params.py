@@ -286,30 +286,3 @@ def linear_param_grads(g2, part, gb_out, gw_out):
                                         _DT[g2.dtype], current_stream(g2.device))
     _lib.check(rc, "linear_param_grads")
     return True
-
-
-# Off by default: measured neutral on the step (293 vs 292 ms) once the teacher branch overlaps on a second stream -- the
-# step is then GPU-bound (340 ms of kernel time in a 290 ms step) and the ~15 us of host time saved per GEMM call are
-# not on the critical path any more.  RFN_LINEAR_GEMM=1 switches it on (all GPU tests pass either way).
-_GEMM_OK = os.environ.get("RFN_LINEAR_GEMM", "0") == "1"
-_GEMM_WS_BYTES = None
-
-
-def linear_gemm(kind, a, b, out_shape, bias=None, T=0, N=0, K=0, S=1):
-    """One of the three GEMMs of a token-wise Linear on hipBLASLt through the plan cache of csrc/gemm.hip
-    (kind 0: y = x W^T + b with a = W, b = x; kind 1: dx = dy W with a = W, b = dy; kind 2: per-slab dW partials with
-    a = x, b = dy).  Returns None when the call is outside its domain (caller uses the framework op)."""
-    global _GEMM_WS_BYTES
-    if not (_GEMM_OK and a.is_cuda and a.dtype == b.dtype and a.dtype in _DT and a.is_contiguous()
-            and b.is_contiguous() and (bias is None or (bias.dtype == a.dtype and bias.is_contiguous()))):
-        return None
-    lib = _lib.load_library()
-    if _GEMM_WS_BYTES is None:
-        _GEMM_WS_BYTES = lib.rfn_gemm_workspace_bytes()
-    out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
-    ws = workspace(_GEMM_WS_BYTES, a.device)
-    with on_device(a.device):
-        rc = lib.rfn_linear_gemm(kind, ptr(a), ptr(b), ptr(out), ptr(bias), ptr(ws), T, N, K, S, _DT[a.dtype],
-                                 current_stream(a.device))
-    _lib.check(rc, "linear_gemm")
-    return out

@@ -178,6 +178,7 @@ class Attention(nn.Module):
         # hand-written MFMA attention (csrc/attn.hip): head_dim 64, 16-bit operands, no attention dropout
         o = mfma.attention(q, kv, h, self.scale) if (d == 64 and p == 0.0 and _SDPA_BACKEND is None) else None
         if o is None:
+            mfma.note_library("sdpa", q, kv)
             q = q.view(B, N, h, d).transpose(1, 2)                           # (B,h,N,d)
             # unbind, not kv[0] / kv[1]: its backward is ONE stack of (dK, dV) instead of two zero-fills, two slice
             # copies and an add
@@ -390,6 +391,25 @@ def _up_logits(x, size):
     return _up(x, size)
 
 
+def _class_logits(conv, y):
+    """The 19-class 1x1 convolution of a decode head (daformer.py:225, segformer.py:109).  On the GPU in a 16-bit pass it
+    runs on the implicit-GEMM kernels (output channels padded to 64 inside, conv._ConvMfmaFn / conv2d_mfma); elsewhere
+    it is the module itself."""
+    if y.is_cuda and conv.kernel_size == (1, 1):
+        from .conv import conv2d_mfma, conv2d_mfma_grad
+        from .params import compute_dtype
+        cd = compute_dtype(y)
+        if cd in (torch.float16, torch.bfloat16):
+            if torch.is_grad_enabled() and (conv.weight.requires_grad or y.requires_grad):
+                o = conv2d_mfma_grad(y, conv.weight, conv.bias, 1, 0, 1, cd)
+            else:
+                o = conv2d_mfma(y, conv.weight, conv.bias, 1, 0, 1, dtype=cd)
+            if o is not None:
+                return o
+        mfma.note_library("conv2d.autograd" if torch.is_grad_enabled() else "conv2d", y, conv.weight)
+    return conv(y)
+
+
 class DepthwiseSeparableASPPModule(nn.ModuleList):
     """daformer.py:10-62: branch 0 is a 1x1 ConvBNReLU, dilated branches are depthwise-separable 3x3."""
 
@@ -465,7 +485,7 @@ class DAFormerHead(BaseHead):
         y = self.fuse_layer(cat)
         if self.dropout is not None:
             y = self.dropout(y)
-        return self.conv_seg(y)
+        return _class_logits(self.conv_seg, y)
 
 
 class SegFormerHead(BaseHead):
@@ -506,7 +526,7 @@ class SegFormerHead(BaseHead):
         y = self.linear_fuse(cat)
         if self.dropout is not None:
             y = self.dropout(y)
-        return self.linear_pred(y)
+        return _class_logits(self.linear_pred, y)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -98,6 +98,44 @@ def test_conv2d_implicit_gemm_matches_fp32_reference(dev, dtype, B, H, W, C, N, 
     assert torch.equal(wide[..., 8:8 + N], got) and float(wide[..., :8].abs().max()) == 0.0
 
 
+GRAD_CASES = CONV_CASES + [  # true channel counts of the student's convolutions (padded inside the autograd function)
+    (2, 36, 44, 3, 64, 7, 4, 3, 1),          # MiT patch_embed1 on RGB
+    (2, 27, 30, 256, 19, 1, 1, 0, 1),        # 19-class 1x1
+    (2, 21, 26, 320, 512, 3, 2, 1, 1),       # MiT patch_embed4
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,C,N,k,stride,pad,dil", GRAD_CASES)
+def test_conv2d_autograd_on_mfma_kernels_matches_fp32_autograd(dev, dtype, B, H, W, C, N, k, stride, pad, dil):
+    """conv._ConvMfmaFn (forward = implicit GEMM, data gradient = the same kernel in transposed-gather mode, weight /
+    bias gradient = split-T kernel with gathered im2col rows) against fp32 F.conv2d autograd on the same 16-bit operands
+    (daformer.py:65-126, mix_transformer.py:210-242).  16-bit rounding of the result is the only difference: output and
+    input gradient are rounded to the 16-bit type, the weight gradient is fp32 (sum over up to B*OH*OW products)."""
+    import torch.nn.functional as F
+    from refign_amd.conv import conv2d_mfma_grad
+    if stride & (stride - 1):
+        pytest.skip("data gradient needs a power-of-two stride")
+    x = _rand((B, C, H, W), dev, dtype, 40).requires_grad_(True)
+    w = _rand((N, C, k, k), dev, torch.float32, 41, (C * k * k) ** -0.5).requires_grad_(True)
+    b = _rand((N,), dev, torch.float32, 42).requires_grad_(True)
+    w16, b16 = w.detach().to(dtype).float().requires_grad_(True), b.detach().to(dtype).float().requires_grad_(True)
+    x32 = x.detach().float().requires_grad_(True)
+    want = F.conv2d(x32, w16, b16, stride, pad, dil)
+    gy = _rand(tuple(want.shape), dev, dtype, 43)
+    want.backward(gy.float())
+    got = conv2d_mfma_grad(x, w, b, stride, pad, dil, dtype)
+    assert got is not None and got.shape == want.shape
+    got.backward(gy)
+    e = EPS[dtype]
+    assert float((got.float() - want).abs().max()) <= 2 * e * float(want.abs().max()) + 1e-3
+    assert float((x.grad.float() - x32.grad).abs().max()) <= 2 * e * float(x32.grad.abs().max()) + 1e-3
+    T = want.numel() // N
+    tol = 1e-5 * math.sqrt(T / 1000 + 1)
+    assert float((w.grad - w16.grad).abs().max()) <= tol * float(w16.grad.abs().max()) + 1e-3
+    assert float((b.grad - b16.grad).abs().max()) <= tol * float(b16.grad.abs().max()) + 1e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("T,N,K,rows", [(8160, 320, 320, None), (2040, 512, 2048, None), (1000, 64, 256, 96),
                                         (4111, 128, 128, 512), (129600, 64, 64, None)])

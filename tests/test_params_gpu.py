@@ -154,35 +154,6 @@ def test_python_side_workspace_sizes_match_the_abi(dev):
         assert lib.rfn_dwconv3x3_bwd_weight_workspace_bytes(C) == dwconv._DW_WS_STRIPES * 10 * C * 4
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_linear_gemm_plan_cache_matches_framework_gemms(dev, dt):
-    """csrc/gemm.hip: the three GEMMs of a Linear through the hipBLASLt plan cache == torch's own calls."""
-    from refign_amd import params
-    params._GEMM_OK = True
-    try:
-        g = torch.Generator().manual_seed(11)
-        T, N, K, S = 4096, 160, 96, 8
-        x = torch.randn(T, K, generator=g).to(dev).to(dt)
-        w = (0.1 * torch.randn(N, K, generator=g)).to(dev).to(dt)
-        b = torch.randn(N, generator=g).to(dev).to(dt)
-        gy = torch.randn(T, N, generator=g).to(dev).to(dt)
-        tol = dict(rtol=2e-2, atol=2e-1) if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
-        y = params.linear_gemm(0, w, x, (T, N), b, T, N, K)
-        assert y is not None and torch.allclose(y.float(), torch.nn.functional.linear(x, w, b).float(), **tol)
-        y2 = params.linear_gemm(0, w, x, (T, N), None, T, N, K)
-        assert torch.allclose(y2.float(), (x @ w.t()).float(), **tol)
-        gx = params.linear_gemm(1, w, gy, (T, K), None, T, N, K)
-        assert torch.allclose(gx.float(), (gy @ w).float(), **tol)
-        part = params.linear_gemm(2, x, gy, (S, N * K), None, T, N, K, S)
-        want = torch.bmm(gy.view(S, T // S, N).transpose(1, 2), x.view(S, T // S, K)).reshape(S, N * K)
-        assert torch.allclose(part.float(), want.float(), rtol=2e-2, atol=1.0 if dt == torch.bfloat16 else 1e-2)
-        whole = params.linear_gemm(2, x, gy, (1, N * K), None, T, N, K, 1)
-        assert torch.allclose(whole.float().view(N, K), (gy.float().t() @ x.float()), rtol=2e-2,
-                              atol=2.0 if dt == torch.bfloat16 else 1e-2)
-    finally:
-        params._GEMM_OK = False
-
-
 @pytest.mark.parametrize("H,W,r", [(16, 24, 2), (17, 30, 2), (34, 60, 4), (135, 50, 8), (8, 8, 8)])
 @pytest.mark.parametrize("sink", [False, True])
 def test_spatial_reduction_conv_as_patch_linear(dev, H, W, r, sink):
