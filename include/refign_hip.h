@@ -384,6 +384,28 @@ int rfn_conv2d_nhwc_wgrad(const void* GY, const void* X, float* P, float* grad_b
                           int dtype, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * N4 -- GPU-side data step of the UDA iteration (csrc/dacs.hip): DACS class-mix + colour jitter + Gaussian blur of
+ * helpers/dacs_transforms.py:14-24,43-78,81-112 as called per sample by models/segmentation_model.py:525-582.  Images
+ * (B, 3, H, W) fp32 ImageNet-normalised, labels (B, H, W) int64, weights (B, H, W) fp32; B <= 8, H*W % 4 == 0.
+ *   rfn_dacs_mix_jitter  mixed = mask ? source : target for image / label / weight (source weight 1), mask = label in the class
+ *                        set class_bits[n] (DEVICE int64: bit c = class c, bit 31 = label 255); then, where jitter_on[n], the
+ *                        colour-jitter chain on the de-normalised image: order[4n + k] = operator applied k-th (0 brightness
+ *                        additive, 1 contrast about the image mean, 2 saturation about the luma, 3 hue = 3x3 matrix hue[9n..]),
+ *                        factor[4n + op], clamp to [0, 1] after every operator.  mean_ws: 8 doubles of device scratch.  Host
+ *                        arrays are read at call time (they travel as kernel arguments).
+ *   rfn_dacs_blur        separable Gaussian of ksize_y x ksize_x taps (odd; kornia: ~0.1 x the image extent) normalised over the
+ *                        window, reflect border, where blur_on[n]; tmp = scratch like x.  sigma <= 1.25: taps beyond +-16
+ *                        vanish in fp32 for kornia's sigma range 0.15 ... 1.15, so at most 33 taps are evaluated.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_dacs_mix_jitter(const float* src, const float* trg, const long* gt_src, const long* pseudo_label,
+                        const float* pseudo_weight, float* mixed_img, long* mixed_lbl, float* mixed_weight, double* mean_ws,
+                        int B, int H, int W, const long* class_bits, const int* jitter_on, const int* order,
+                        const float* factor, const float* hue, const float* mean3, const float* std3,
+                        rfn_stream_t stream);
+int rfn_dacs_blur(const float* x, float* tmp, float* y, int B, int C, int H, int W, int ksize_y, int ksize_x, const int* blur_on,
+                  const double* sigma_y, const double* sigma_x, rfn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K5 (BASELINE.json config 5, "bf16 HRDA + fp8 MFMA attention"): fp8 (OCP e4m3, fp32 accumulate) matrix-core path of
  * the gradient-free EMA teacher (segmentation_model.py:204-209 runs MiT-B5, mix_transformer.py:96-103,137-164, on 40
  * HRDA views per GPU).  No reference analogue (the reference's recipe is 16-bit AMP, README.md:262); csrc/f8.hip.

@@ -817,6 +817,12 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
         case 17: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2, true)
         case 18: RFN_LAUNCH_DMA(16, 64, 4, 3, 1, 1, true)
         case 19: RFN_LAUNCH_DMA(8, 64, 4, 3, 1, 1, true)
+        // round 3: 8-channel chunks (half the chunk hand-offs per tile)
+        case 31: RFN_LAUNCH_DMA(8, 64, 8, 3, 1, 1, false)
+        case 32: RFN_LAUNCH_DMA(16, 32, 8, 3, 1, 1, false)
+        case 33: RFN_LAUNCH_DMA(8, 32, 8, 3, 1, 2, false)
+        case 34: RFN_LAUNCH_DMA(8, 32, 8, 3, 1, 1, false)
+        case 35: RFN_LAUNCH_DMA(8, 32, 16, 3, 1, 1, false)
         default: break;   // 9: register-staged kernel below
       }
 #undef RFN_LAUNCH_DMA

@@ -168,10 +168,13 @@ def conv2d_nhwc_wgrad(gy, x, KH, KW, Kpad, stride=1, pad=0, dil=1, bias_out=None
     return part
 
 
+_TN_WGS = int(os.environ.get("RFN_TN_WGS", "1024"))      # target workgroups of a weight-gradient launch (tools sweep)
+
+
 def slab_rows(T, tiles):
     """Rows per slab of the split-T weight-gradient GEMM: enough slabs to fill the chip (~1024 workgroups with the
     output tiles), slabs of at least 256 rows, multiples of 32."""
-    want = max(1, min(64, 1024 // max(tiles, 1)))
+    want = max(1, min(64, _TN_WGS // max(tiles, 1)))
     rows = -(-T // want)
     rows = max(256, -(-rows // 32) * 32)
     return rows

@@ -33,6 +33,7 @@ from . import align as align_mod
 from . import refine as refine_mod
 from . import sidework
 from ._tensor import const_tensor, upload_async
+from . import dacs as _dacs
 from . import f8 as _f8
 from .graphs import GraphedNoGrad, GraphedStep
 from .params import ema_update
@@ -804,6 +805,17 @@ class DomainAdaptationSegmentationModel(nn.Module):
             pseudo_weight[:, :self.psweight_ignore_top, :] = 0
         if self.psweight_ignore_bottom > 0:
             pseudo_weight[:, -self.psweight_ignore_bottom:, :] = 0
+        if os.environ.get("RFN_DACS_KERNEL", "1") != "0" and _dacs.usable(images_src, images_trg, gt_src):
+            # N4: the pixel work of the mix / jitter / blur as HIP kernels (refign_amd/dacs.py); the draws below are made in
+            # the order the per-sample loop further down makes them
+            classes = torch.unique(gt_src) if src_classes is None else src_classes
+            bits = _dacs.draw_class_bits(classes, nb)
+            jit, sig = [], []
+            for i in range(nb):
+                jit.append(_dacs.draw_jitter(self.color_jitter_s) if params['color_jitter'] > params['color_jitter_p']
+                           else None)
+                sig.append(np.random.uniform(0.15, 1.15) if params['blur'] > 0.5 else None)
+            return _dacs.mix(images_src, images_trg, gt_src, pseudo_label, pseudo_weight, bits, jit, sig)
         gt_weight = torch.ones_like(pseudo_weight)
         masks = get_class_masks(gt_src.unsqueeze(1), src_classes)
         mixed_img, mixed_lbl = [None] * nb, [None] * nb
