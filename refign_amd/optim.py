@@ -29,6 +29,14 @@ class MultiTensorAdamW:
         self.launches = 0                                  # diagnostics / tests
         # state['step'] of the 1 000 parameters is brought up to date when somebody looks (checkpoint, torch's own step)
         optimizer.register_state_dict_pre_hook(lambda opt: self._sync_steps())
+        # load_state_dict REPLACES every state tensor (mid-run resume / rollback): the chunk table would keep pointing at
+        # the freed moment buffers and the kernel's own step counter would ignore the loaded one -- drop everything, the
+        # next step() rebuilds from the loaded state
+        optimizer.register_load_state_dict_post_hook(lambda opt: self._reset())
+
+    def _reset(self):
+        self._table = self._sig = self._steps = self._params = None
+        self._t = self._synced_t = 0
 
     def _sync_steps(self):
         if self._steps is not None and self._synced_t != self._t:
@@ -53,8 +61,11 @@ class MultiTensorAdamW:
         if ps is None or len(ps) != sum(len(g["params"]) for g in self.opt.param_groups):
             ps = self._params = [p for g in self.opt.param_groups for p in g["params"]]
         g0, g1 = ps[0].grad, ps[-1].grad
+        # ... and where the first and the last parameter's first moments live: replaced state is seen even without the hook
+        m0, m1 = (self.opt.state.get(p, {}).get("exp_avg") for p in (ps[0], ps[-1]))
         return (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), None if g0 is None else g0.data_ptr(),
-                None if g1 is None else g1.data_ptr(),
+                None if g1 is None else g1.data_ptr(), None if m0 is None else m0.data_ptr(),
+                None if m1 is None else m1.data_ptr(),
                 tuple((g.get("amsgrad"), g.get("maximize"), torch.is_tensor(g["lr"])) for g in self.opt.param_groups))
 
     def _build(self):

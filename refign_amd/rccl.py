@@ -49,8 +49,21 @@ def _rccl():
         lib.ncclGetErrorString.restype = ctypes.c_char_p
         for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclCommDestroy):
             f.restype = ctypes.c_int
+        # ABI check: the enum values and the 128-byte id above are those of the NCCL 2.x API (nccl.h: ncclFloat32 = 7,
+        # ncclSum = 0, NCCL_UNIQUE_ID_BYTES = 128, unchanged since 2.0); refuse anything else instead of guessing
+        lib.ncclGetVersion.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        lib.ncclGetVersion.restype = ctypes.c_int
+        v = ctypes.c_int(0)
+        if lib.ncclGetVersion(ctypes.byref(v)) != 0 or not (20000 <= v.value < 30000 or 2000 <= v.value < 3000):
+            raise RuntimeError(f"rccl: {path} reports version code {v.value}; this binding is written against the NCCL 2.x "
+                               f"API (ncclGetVersion 2xxxx)")
+        global VERSION
+        VERSION = v.value
         _lib = lib
     return _lib
+
+
+VERSION = None
 
 
 def _check(rc, what):

@@ -203,7 +203,13 @@ class Trainer:
                         teacher_comm = rccl.DirectComm(dev)
                         for m in teacher:
                             m._rfn_direct = teacher_comm
-                    if os.environ.get("RFN_GRAPH_DDP", "1") != "0":
+                    # A THIRD communicator (mixed pass on its own stream next to the source pass, as on one GPU) only on
+                    # request: three communicators spinning on three streams of one device have never met a peer (one-GPU
+                    # development boxes), and concurrent collectives of different communicators can deadlock when ranks
+                    # launch them in different orders.  Default under data parallelism: two (student passes in stream
+                    # order on the main stream, teacher on the side stream) -- the pattern of torch DDP + a second process
+                    # group.  RFN_DDP_MIXED_COMM=1 restores the three-communicator mode once a 2-GPU run has proved it.
+                    if os.environ.get("RFN_GRAPH_DDP", "1") != "0" and os.environ.get("RFN_DDP_MIXED_COMM", "0") == "1":
                         model._mixed_comm = rccl.DirectComm(dev)
                 except (OSError, RuntimeError, AttributeError) as e:   # no librccl / init failed: torch's process group
                     import warnings

@@ -253,3 +253,46 @@ def test_multi_tensor_adamw_matches_torch_fused(dev=None):
     f2 = MultiTensorAdamW(ams)
     f2.step(); f2.step()
     assert f2.launches == 0
+
+
+def test_multi_tensor_adamw_follows_load_state_dict():
+    """optimizer.load_state_dict() in mid-run (resume / rollback) replaces every moment tensor and the step counters: the
+    one-launch AdamW must continue from the LOADED state, not from its cached pointers and its own counter."""
+    import copy
+    from refign_amd.optim import MultiTensorAdamW
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    shapes = [(129, 17), (33,), (4097,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref, mine = torch.optim.AdamW(ps, lr=1e-2, fused=True), torch.optim.AdamW(qs, lr=1e-2, fused=True)
+    fast = MultiTensorAdamW(mine)
+    grads = [[torch.randn_like(p) for p in ps] for _ in range(7)]
+
+    def run(it):
+        for p, q, g in zip(ps, qs, grads[it]):
+            p.grad = g.clone()
+            if q.grad is None:
+                q.grad = g.clone()
+            else:
+                q.grad.copy_(g)
+        ref.step()
+        fast.step()
+    for it in range(3):
+        run(it)
+    saved = (copy.deepcopy(ref.state_dict()), [p.detach().clone() for p in ps],
+             copy.deepcopy(mine.state_dict()), [q.detach().clone() for q in qs])
+    run(3)
+    run(4)
+    ref.load_state_dict(saved[0])                                       # roll both back to the state after step 3
+    mine.load_state_dict(saved[2])
+    with torch.no_grad():
+        for p, q, a, b in zip(ps, qs, saved[1], saved[3]):
+            p.copy_(a)
+            q.copy_(b)
+    run(5)
+    run(6)
+    assert fast.launches >= 5
+    for p, q in zip(ps, qs):
+        assert float((p - q).abs().max()) <= 2e-6 * float(p.abs().max())
+        assert float(mine.state_dict()["state"][0]["step"]) == float(ref.state[ps[0]]["step"]) == 5.0
