@@ -368,6 +368,16 @@ int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void*
 int rfn_bn_train_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
                      void* grad_x, float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
 
+/* fp32-RESULT variants (split-bf16 parity mode, refign_amd/split32.py): bf16 operands whose reduction index carries the
+ * three split products side by side, fp32 accumulate, fp32 bias / residual / result (leading dimension ldy in floats).
+ * rfn_conv2d_nhwc_o32: (B, H, W, C) = the convolution's input side, N output channels; transposed = 0: Y (B, OH, OW, N) from
+ * X (B, H, W, C), W[n][(tap, c)]; transposed = 1: the data gradient Y (B, H, W, C) from X = grad_y (B, OH, OW, N), W[c][(tap, n)]. */
+int rfn_gemm_nt_o32(const void* X, const void* W, const float* bias, const float* res, const float* rowscale,
+                    int rows_per_sample, int act, float* Y, long M, long N, long K, long ldx, long ldw, long ldy,
+                    rfn_stream_t stream);
+int rfn_conv2d_nhwc_o32(const void* X, const void* W, const float* bias, int act, float* Y, int B, int H, int Wd, int C, int N,
+                        int KH, int KW, int stride, int pad, int dil, long ldw, long ldy, int transposed,
+                        rfn_stream_t stream);
 /* Backward of rfn_conv2d_nhwc on the same kernels (the student's trainable convolutions: DAFormer 3x3 bottleneck
  * daformer.py:65-126, MiT overlap patch embeddings mix_transformer.py:210-242, 19-class 1x1; matcher decoders modules.py:395-477).
  *   rfn_conv2d_nhwc_dgrad  DX (B, H, W, C) = data gradient.  GY (B, OH, OW, N) channels-last, Wt[c][(ky, kx, n)] rows zero-padded

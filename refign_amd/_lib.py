@@ -61,6 +61,9 @@ SIGNATURES = {
     "rfn_gemm_nt": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p] + [ctypes.c_long] * 6 + [c_int, c_void_p]),
     "rfn_conv2d_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int,
                                                                                        c_void_p]),
+    "rfn_gemm_nt_o32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p] + [ctypes.c_long] * 6 + [c_void_p]),
+    "rfn_conv2d_nhwc_o32": (c_int, [c_void_p] * 3 + [c_int, c_void_p] + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int,
+                                                                                           c_void_p]),
     "rfn_conv2d_nhwc_dgrad": (c_int, [c_void_p] * 3 + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int, c_void_p]),
     "rfn_conv2d_nhwc_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [ctypes.c_long, ctypes.c_long, c_int, c_int, c_int,
                                       c_void_p]),

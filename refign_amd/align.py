@@ -30,6 +30,7 @@ import torch.nn.functional as F
 
 from . import matching
 from ._tensor import const_tensor
+from .conv import Conv2d
 from .layers import LEAKY_SLOPE, ConvBNReLU
 from .modules import GlobalFeatureCorrelationLayer, LocalFeatureCorrelationLayer
 
@@ -53,7 +54,7 @@ class OpticalFlowEstimatorResidualConnection(nn.Module):
         self.conv2_skip = ConvBNReLU(96, 32, 1, norm_layer=nl, activation_layer=None)
         self.conv_3 = ConvBNReLU(96, 64, 3, activation_layer=_leaky, **kw)
         self.conv_4 = ConvBNReLU(64, 32, 3, activation_layer=None, **kw)
-        self.predict_mapping = nn.Conv2d(32, out_channels, kernel_size=3, padding=1, bias=True)
+        self.predict_mapping = Conv2d(32, out_channels, kernel_size=3, padding=1, bias=True)
 
     def forward(self, x):
         x0 = self.conv_0(x)                                             # pre-activation kept for the skip
@@ -75,7 +76,7 @@ class RefinementModule(nn.Module):
         plan = [(in_channels, 128, 1), (128, 128, 2), (128, 128, 4), (128, 96, 8), (96, 64, 16), (64, 32, 1)]
         layers = [ConvBNReLU(ci, co, 3, dilation=d, norm_layer=nl, activation_layer=_leaky, bias=extra_bias)
                   for ci, co, d in plan]
-        layers.append(nn.Conv2d(32, out_channels, kernel_size=3, padding=1, bias=True))
+        layers.append(Conv2d(32, out_channels, kernel_size=3, padding=1, bias=True))
         self.dc_convs = nn.Sequential(*layers)
 
     def forward(self, x):
@@ -104,10 +105,10 @@ class UncertaintyModule(nn.Module):
             self.maxpool = nn.MaxPool2d((2, 2))
         self.conv_1 = ConvBNReLU(32, 32, **kw)
         self.conv_2 = ConvBNReLU(32, 16, **kw)
-        self.predict_uncertainty = nn.Conv2d(16, 6, kernel_size=3, stride=1, padding=0, bias=True)
+        self.predict_uncertainty = Conv2d(16, 6, kernel_size=3, stride=1, padding=0, bias=True)
         self.pred_conv_0 = ConvBNReLU(6 + 32 + add, 32, 3, norm_layer=nl, activation_layer=_leaky)
         self.pred_conv_1 = ConvBNReLU(32, 16, 3, norm_layer=nl, activation_layer=_leaky)
-        self.predict_uncertainty_final = nn.Conv2d(16, 1, kernel_size=3, stride=1, padding=1, bias=True)
+        self.predict_uncertainty_final = Conv2d(16, 1, kernel_size=3, stride=1, padding=1, bias=True)
         self._packed = None
 
     # micro-images per launch of the library conv chain: bounds the (N,32,7,7) intermediates to ~0.8 GB
@@ -180,7 +181,7 @@ class UncertaintyModule(nn.Module):
         from .params import compute_dtype
         x = corr.view(b, 9, 9, h, w).permute(0, 3, 1, 4, 2).reshape(b, 1, 9 * h, 9 * w)
         for m, k in ((self.conv_0, 7), (self.conv_1, 5), (self.conv_2, 3)):
-            x = retile(F.conv2d(x, m.conv.weight, m.conv.bias), k)
+            x = retile(m._conv2d(x, m.conv.weight, m.conv.bias), k)
             cd = compute_dtype(x)
             if m.use_norm and m.act == 'leaky' and m.act_slope == LEAKY_SLOPE and x.is_cuda and \
                     os.environ.get("RFN_BN_KERNEL", "1") != "0" and bnk.usable(x, m.bn, cd):
@@ -189,7 +190,7 @@ class UncertaintyModule(nn.Module):
             if m.use_norm:
                 x = m.bn(x)
             x = F.leaky_relu(x, m.act_slope, inplace=True) if m.act == 'leaky' else F.relu(x, inplace=True)
-        y = F.conv2d(x, self.predict_uncertainty.weight, self.predict_uncertainty.bias)   # (b, 6, 3 h - 2, 3 w - 2)
+        y = self.predict_uncertainty(x)                                                    # (b, 6, 3 h - 2, 3 w - 2)
         return F.pad(y, (0, 2, 0, 2)).view(b, 6, h, 3, w, 3)[:, :, :, 0, :, 0]
 
     def forward(self, corr, feat, up_previous_uncertainty=None, up_previous_flow=None):
@@ -226,7 +227,7 @@ class VGG(nn.Module):
                 layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
                 taps.append(len(layers))
             else:
-                layers.append(nn.Conv2d(cin, v, kernel_size=3, padding=1))
+                layers.append(Conv2d(cin, v, kernel_size=3, padding=1))
                 if bn:
                     layers.append(nn.BatchNorm2d(v))
                 layers.append(nn.ReLU(inplace=True))
@@ -341,7 +342,7 @@ class UAWarpCHead(BaseHead):
         if refinement_at_adaptive_res:
             self.refinement_module_adaptive = RefinementModule(32, batch_norm=batch_norm)
         self.decoder2 = mk(81 + 2 + u)
-        self.reduce = nn.Conv2d(32, 2, kernel_size=1, bias=True)
+        self.reduce = Conv2d(32, 2, kernel_size=1, bias=True)
         self.decoder1 = mk(81 + 2 + 2 + u)
         if refinement_at_finest_level:
             self.refinement_module_finest = RefinementModule(32, batch_norm=batch_norm)

@@ -57,6 +57,13 @@ class Conv2d(nn.Conv2d):
         if not x.is_cuda or self.padding_mode != 'zeros' or isinstance(self.padding, str):
             return super().forward(x)
         cd = compute_dtype(x)
+        if cd == torch.float32 and self.groups == 1:
+            # fp32 parity mode: split-bf16 products on the matrix-core kernels (refign_amd/split32.py)
+            from . import split32
+            if split32.usable(x):
+                y = split32.conv2d(x.float(), self.weight, self.bias, self.stride, self.padding, self.dilation)
+                if y is not None:
+                    return y
         # the MiT token tensors reach the convolutions as channels-last views, and the library then wants the filter in
         # channels-last too: keep the cached copy in that layout instead of converting it at every call
         w_c = derived(self.weight, (cd, "channels_last"),
@@ -89,6 +96,15 @@ class Conv2d(nn.Conv2d):
 # launches of its own plus per-call zero-fill / cast tensor ops (~85 us of GPU time per layer per pass, 240 per step).
 # ---------------------------------------------------------------------------------------------------------------------
 _DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _split32():
+    from . import split32
+    return split32
+
+
+def _split_ok(*ts):
+    return all(t.dtype == torch.float32 for t in ts) and _split32().usable(*ts)
 
 
 def _patchify(src, dst, B, H, W, C, r, inverse):
@@ -137,6 +153,8 @@ class _PatchLinearFn(torch.autograd.Function):
         ctx.weight, ctx.bias = weight, bias
         ctx.geom = (x.shape, H, W, r, Hr, Wr)
         y = _mfma.gemm_nt(patches, w2, b_c)
+        if y is None and _split_ok(patches, w2):
+            y = _split32().gemm_nt(patches, w2, b_c)       # fp32 parity mode (refign_amd/split32.py)
         if y is None:
             _mfma.note_library("patch_linear.fwd", patches, w2)
         return (F.linear(patches, w2, b_c) if y is None else y).view(x.shape[0], Hr * Wr, w2.shape[0])
@@ -161,12 +179,16 @@ class _PatchLinearFn(torch.autograd.Function):
             wT = derived(ctx.weight, (w2.dtype, "patch_linear_T"),
                          lambda t: t.to(w2.dtype).permute(2, 3, 1, 0).contiguous(), _krsc_view).view(K, Co)
             gp = _mfma.gemm_nt(g2, wT)
+            if gp is None and _split_ok(g2, wT):
+                gp = _split32().gemm_nt(g2, wT)
             if gp is None:
                 _mfma.note_library("patch_linear.dgrad", g2, w2)
             gx = _from_patches(torch.mm(g2, w2) if gp is None else gp, B, H, W, C, r, Hr, Wr)
         T = g2.shape[0]
         S = _split(T)
         part = _mfma.gemm_tn(g2, patches)                                               # fp32 slab partials (S, Co, K)
+        if part is None and _split_ok(g2, patches):
+            part = _split32().gemm_tn(g2, patches)[None]
         if part is None:
             _mfma.note_library("patch_linear.wgrad", g2, patches)
         if part is not None:
@@ -209,6 +231,8 @@ def patch_conv_tokens(x, H, W, conv):
         return _PatchLinearFn.apply(x, conv.weight, conv.bias, w2, b_c, H, W, r)
     patches, Hr, Wr = _to_patches(x, H, W, r)
     y = _mfma.gemm_nt(patches, w2, b_c)
+    if y is None and _split_ok(patches, w2):
+        y = _split32().gemm_nt(patches, w2, b_c)
     if y is None:
         _mfma.note_library("patch_linear.fwd", patches, w2)
     return (F.linear(patches, w2, b_c) if y is None else y).view(x.shape[0], Hr * Wr, Co)

@@ -29,6 +29,7 @@
 namespace rfn {
 
 struct GemmEpi {
+  // OUT32 kernels (fp32 result: the split-bf16 parity mode) read bias / res as fp32 through the same pointers
   const uint16_t* bias;     // [N] or null, same 16-bit type as the operands
   const uint16_t* res;      // [M, ldy] residual added to the result, or null
   const float* rowscale;    // per-sample scale of the (acc + bias) term before the residual add, or null
@@ -73,7 +74,7 @@ template <int N> __device__ __forceinline__ void wait_dma_upto() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DT, int BM, int BN, int BK, int NS, bool GATHER, int NW = 4>
+template <int DT, int BM, int BN, int BK, int NS, bool GATHER, int NW = 4, bool OUT32 = false>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                       uint16_t* __restrict__ Y, int M, int N, int K, long ldx, long ldw,
                                                       long ldy, int tiles_n, int total_tiles, GemmEpi epi, ConvGeom cg) {
@@ -238,6 +239,43 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
       constexpr int PITCH = WN * 2 + 16;               // staging row pitch in bytes (16-byte aligned, 2-way at worst)
       constexpr int RPP = 64 / (WN / 8);               // rows per store instruction (8 pieces of 16 B per 64-column row)
       static_assert(NW * 32 * PITCH <= STAGE, "staging block fits the consumed stage");
+      if constexpr (OUT32) {
+        // fp32 result straight from the accumulators (parity mode: correctness path, not a fast one): a lane's run of 4
+        // consecutive n of row m is one 16-byte store; bias / residual are fp32
+        float* Y32 = (float*)Y;
+        const float* bias32 = (const float*)epi.bias;
+        const float* res32 = (const float*)epi.res;
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+          for (int i = 0; i < IB; ++i) {
+            const int m = m0 + wm * (BM / 2) + j * 32 + frow;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int n = n0 + wn * WN + i * 32 + 8 * k + 4 * g;
+              f32x4 v = {acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]};
+              if (m < M && n < N) {
+                if (bias32 != nullptr) v += *(const f32x4*)(bias32 + n);
+                if (epi.act != 0) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], epi.act);
+                }
+                if (res32 != nullptr || epi.rowscale != nullptr) {
+                  const float rs = epi.rowscale != nullptr ? epi.rowscale[m / epi.rows_per_sample] : 1.f;
+                  const f32x4 rr = res32 != nullptr ? *(const f32x4*)(res32 + (long)m * ldy + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                  v = rr + rs * v;
+                }
+                *(f32x4*)(Y32 + (long)m * ldy + n) = v;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+        c_kt = 0;
+        c_tile += G;
+        drained = true;
+        continue;
+      }
       wg_barrier();                                    // every wave is done reading this stage's operands
       unsigned char* stg = const_cast<unsigned char*>(st) + wave * 32 * PITCH;
 #pragma unroll
@@ -730,7 +768,7 @@ __device__ uint4 g_zero_page[4];          // zero-initialised: DMA source of out
 
 template <int DT, bool GATHER>
 static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long K, long ldx, long ldw, long ldy,
-                     const GemmEpi& epi, ConvGeom cg, hipStream_t s) {
+                     const GemmEpi& epi, ConvGeom cg, hipStream_t s, bool out32 = false) {
   if (GATHER) {
     static void* zero_page = nullptr;        // looked up once (first call is an eager warm-up, never inside a capture)
     if (zero_page == nullptr && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero_page)) != hipSuccess)
@@ -761,6 +799,20 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   hipLaunchKernelGGL((gemm_nt_kernel<DT, BM_, BN_, 64, NS_, GATHER>), grid, block, 0, s, (const uint16_t*)X,             \
                      (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tiles_n, (int)total, epi,  \
                      cg)
+  if (out32) {                                  // fp32 result (split-bf16 parity mode): two tile shapes, no persistence
+    bn = (N % 128 == 0) ? 128 : 64;
+    bm = bn;
+    const int tn = cdiv(N, bn);
+    const long tot = (long)cdiv(M, bm) * tn;
+    dim3 g32((unsigned)tot);
+    if (bn == 128)
+      hipLaunchKernelGGL((gemm_nt_kernel<DT, 128, 128, 64, 2, GATHER, 4, true>), g32, block, 0, s, (const uint16_t*)X,
+                         (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tn, (int)tot, epi, cg);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<DT, 64, 64, 64, 2, GATHER, 4, true>), g32, block, 0, s, (const uint16_t*)X,
+                         (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tn, (int)tot, epi, cg);
+    return check_launch("gemm_nt (fp32 result)");
+  }
   const int key = bm * 10000 + bn * 10 + ns;
   switch (key) {
     case 1281282: RFN_NT(128, 128, 2); break;
@@ -861,6 +913,51 @@ int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* 
   hipStream_t s = (hipStream_t)stream;
   return dtype == 1 ? launch_nt<1, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s)
                     : launch_nt<2, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s);
+}
+
+int rfn_gemm_nt_o32(const void* X, const void* W, const float* bias, const float* res, const float* rowscale,
+                    int rows_per_sample, int act, float* Y, long M, long N, long K, long ldx, long ldw, long ldy,
+                    rfn_stream_t stream) {
+  using namespace rfn;
+  RFN_REQUIRE(X && W && Y, "gemm_nt_o32: null operand");
+  RFN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0, "gemm_nt_o32: M=%ld N=%ld K=%ld (K %% 64, N %% 8)", M, N, K);
+  RFN_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0 && ldx >= K && ldw >= K && ldy >= N, "gemm_nt_o32: leading dimensions");
+  RFN_REQUIRE(M < (1L << 31) && N < (1L << 31), "gemm_nt_o32: extent");
+  RFN_REQUIRE(rowscale == nullptr || rows_per_sample > 0, "gemm_nt_o32: rowscale needs rows_per_sample");
+  RFN_REQUIRE(act == 0 || act == 1 || act == 3, "gemm_nt_o32: act");
+  GemmEpi epi{(const uint16_t*)bias, (const uint16_t*)res, rowscale, rows_per_sample > 0 ? rows_per_sample : 1, act};
+  ConvGeom cg{};
+  return launch_nt<1, false>(X, W, Y, M, N, K, ldx, ldw, ldy, epi, cg, (hipStream_t)stream, true);
+}
+
+int rfn_conv2d_nhwc_o32(const void* X, const void* W, const float* bias, int act, float* Y, int B, int H, int Wd, int C, int N,
+                        int KH, int KW, int stride, int pad, int dil, long ldw, long ldy, int transposed,
+                        rfn_stream_t stream) {
+  using namespace rfn;
+  RFN_REQUIRE(X && W && Y, "conv2d_nhwc_o32: null operand");
+  RFN_REQUIRE(B > 0 && H > 0 && Wd > 0 && C > 0 && C % 8 == 0 && N > 0 && N % 8 == 0, "conv2d_nhwc_o32: sizes (C %% 8, N %% 8)");
+  RFN_REQUIRE(KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0 && (!transposed || (stride & (stride - 1)) == 0),
+              "conv2d_nhwc_o32: geometry");
+  RFN_REQUIRE(act == 0 || act == 1 || act == 3, "conv2d_nhwc_o32: act");
+  const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (Wd + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  RFN_REQUIRE(OH > 0 && OW > 0, "conv2d_nhwc_o32: empty output");
+  GemmEpi epi{(const uint16_t*)bias, nullptr, nullptr, 1, act};
+  hipStream_t s = (hipStream_t)stream;
+  if (!transposed) {           // forward: X (B, H, W, C) -> Y (B, OH, OW, N), W[n][(tap, c)]
+    const long K = ((long)KH * KW * C + 63) / 64 * 64, M = (long)B * OH * OW;
+    RFN_REQUIRE(ldw % 8 == 0 && ldw >= K && ldy % 4 == 0 && ldy >= N && M < (1L << 31) && K / 8 < 65536, "conv2d_nhwc_o32: ld");
+    ConvGeom cg{H, Wd, C, OH, OW, KH, KW, stride, pad, dil, C / 8, (unsigned)((0x100000000ULL + C / 8 - 1) / (C / 8)),
+                (unsigned)((0x100000000ULL + KW - 1) / KW), nullptr, 0, 0};
+    return launch_nt<1, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s, true);
+  }
+  // data gradient: X = grad_y (B, OH, OW, N), Y = dx (B, H, W, C), W = Wt[c][(tap, n)]
+  const long K = ((long)KH * KW * N + 63) / 64 * 64, M = (long)B * H * Wd;
+  RFN_REQUIRE(ldw % 8 == 0 && ldw >= K && ldy % 4 == 0 && ldy >= C && M < (1L << 31) && K / 8 < 65536, "conv2d_nhwc_o32: ld");
+  int sshift = 0;
+  while ((1 << sshift) < stride) ++sshift;
+  ConvGeom cg{OH, OW, N, H, Wd, KH, KW, stride, pad, dil, N / 8, (unsigned)((0x100000000ULL + N / 8 - 1) / (N / 8)),
+              (unsigned)((0x100000000ULL + KW - 1) / KW), nullptr, 1, sshift};
+  return launch_nt<1, true>(X, W, Y, M, C, K, 0, ldw, ldy, epi, cg, s, true);
 }
 
 int rfn_conv2d_nhwc_dgrad(const void* GY, const void* Wt, void* DX, int B, int H, int Wd, int C, int N, int KH, int KW,

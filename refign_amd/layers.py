@@ -89,7 +89,11 @@ class ConvBNReLU(nn.Module):
             y = dwconv3x3_nhwc(xh if xh.is_contiguous() else xh.contiguous(), w, b, c.dilation[0])
             return y.permute(0, 3, 1, 2)                     # NCHW-shaped, channels_last strides
         if x.is_cuda:
-            from . import mfma
+            from . import mfma, split32
+            if c.groups == 1 and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and split32.usable(x):
+                y = split32.conv2d(x, w, b, c.stride, c.padding, c.dilation)     # fp32 parity mode (split-bf16 products)
+                if y is not None:
+                    return y
             mfma.note_library("conv2d.autograd" if torch.is_grad_enabled() else "conv2d", x, w)
         return F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
 

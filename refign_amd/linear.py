@@ -180,6 +180,11 @@ class Linear(nn.Linear):
             y = F.linear(x, self.weight, self.bias)
             return y if res is None else _residual(res, y, rowscale)
         cd = compute_dtype(x)
+        if cd == torch.float32:
+            from . import split32
+            if split32.usable(x):                      # fp32 parity mode: split-bf16 products on the matrix-core kernels
+                y = split32.linear(x.float(), self.weight, self.bias)
+                return y if res is None else _residual(res, y, rowscale)
         w_c, b_c = as_dtype(self.weight, cd), as_dtype(self.bias, cd)
         if x.dtype != cd:
             x = x.to(cd)

@@ -177,6 +177,12 @@ class Attention(nn.Module):
         p = self.attn_drop.p if self.training else 0.0
         # hand-written MFMA attention (csrc/attn.hip): head_dim 64, 16-bit operands, no attention dropout
         o = mfma.attention(q, kv, h, self.scale) if (d == 64 and p == 0.0 and _SDPA_BACKEND is None) else None
+        if o is None and q.is_cuda and q.dtype == torch.float32 and p == 0.0 and _SDPA_BACKEND is None:
+            from . import split32
+            if split32.usable(q, kv):                  # fp32 parity mode: explicit products on the matrix-core kernels
+                kk, vv = kv.view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4).unbind(0)
+                o = split32.attention(q.view(B, N, h, d).transpose(1, 2), kk, vv, self.scale)
+                o = o.transpose(1, 2).reshape(B, N, C)
         if o is None:
             mfma.note_library("sdpa", q, kv)
             q = q.view(B, N, h, d).transpose(1, 2)                           # (B,h,N,d)
@@ -406,6 +412,12 @@ def _class_logits(conv, y):
                 o = conv2d_mfma(y, conv.weight, conv.bias, 1, 0, 1, dtype=cd)
             if o is not None:
                 return o
+        if cd == torch.float32:
+            from . import split32
+            if split32.usable(y):
+                o = split32.conv2d(y.float(), conv.weight, conv.bias, 1, 0, 1)
+                if o is not None:
+                    return o
         mfma.note_library("conv2d.autograd" if torch.is_grad_enabled() else "conv2d", y, conv.weight)
     return conv(y)
 

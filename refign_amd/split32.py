@@ -1,0 +1,244 @@
+"""fp32 parity mode of the dense operators on the hand-written matrix-core kernels: split-bf16 products.
+
+The golden-vector tests (and `bench.py --precision fp32`) run fp32 tensors, for which the 16-bit MFMA kernels have no
+direct variant; until round 3 those calls went to the ROCm libraries (hipBLASLt / MIOpen / fused SDPA behind F.linear,
+F.conv2d, scaled_dot_product_attention).  Here an fp32 operand is split into two bf16 terms, x = hi + lo with
+hi = bf16(x), lo = bf16(x - hi) (16 significand bits, fp32's exponent range), and a product x.y is evaluated as
+hi.hi' + hi.lo' + lo.hi' -- three bf16 MFMA products accumulated in fp32 INSIDE ONE launch by concatenating the terms
+along the reduction index:
+    Linear / conv forward, data gradient   [xh | xh | xl] . [wh | wl | wh]^T      (K -> 3K; conv: channels -> 3C per tap)
+    weight gradient                        [gh ; gh ; gl]^T . [xh ; xl ; xh]      (rows T -> 3T; conv: batch -> 3B)
+on csrc/mfma_gemm.hip's kernels with an fp32-result epilogue (rfn_gemm_nt_o32 / rfn_conv2d_nhwc_o32; the weight-gradient
+kernel's result is fp32 anyway).  The dropped lo.lo' term and the second rounding leave ~2^-16 relative error per product
+(fp32: 2^-24): far inside the 1e-3 parity bar of the goldens.  A correctness path, not a fast one (the splits are torch
+element-wise ops, three times the MFMA work).  RFN_FP32_SPLIT=0 switches back to the library calls.
+"""
+import os
+
+import torch
+
+from . import _lib, mfma
+from ._tensor import current_stream, on_device, ptr
+
+ENABLED = os.environ.get("RFN_FP32_SPLIT", "1") != "0"
+BF = torch.bfloat16
+
+
+def usable(*ts):
+    return ENABLED and mfma.ENABLED and all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in ts)
+
+
+def split2(x):
+    hi = x.to(BF)
+    return hi, (x - hi.float()).to(BF)
+
+
+def _cat_k(x, order, pad_to=64):
+    """(rows, K) fp32 -> (rows, 3 Kp) bf16 = terms `order` of (hi, lo) side by side, each zero-padded to Kp = roundup(K, pad_to)."""
+    hi, lo = split2(x)
+    K = x.shape[1]
+    Kp = -(-K // pad_to) * pad_to
+    out = torch.zeros((x.shape[0], 3 * Kp), dtype=BF, device=x.device)
+    for i, which in enumerate(order):
+        out[:, i * Kp:i * Kp + K] = hi if which == "h" else lo
+    return out
+
+
+def gemm_nt(x, w, bias=None, res=None, act=0):
+    """fp32 y[M, N] = res + act(x[M, K] @ w[N, K]^T + bias) through three bf16 products in one launch."""
+    M, K = x.shape
+    N = w.shape[0]
+    Np = -(-N // 8) * 8
+    x3 = _cat_k(x.contiguous(), "hhl")
+    w3 = _cat_k(w.contiguous(), "hlh")
+    if Np != N:
+        w3 = torch.cat([w3, w3.new_zeros((Np - N, w3.shape[1]))])
+        if bias is not None:
+            bias = torch.cat([bias, bias.new_zeros(Np - N)])
+    y = torch.empty((M, Np), dtype=torch.float32, device=x.device)
+    if res is not None and Np != N:
+        res = torch.nn.functional.pad(res, (0, Np - N))
+    with on_device(x.device):
+        rc = _lib.load_library().rfn_gemm_nt_o32(ptr(x3), ptr(w3), ptr(None if bias is None else bias.contiguous()),
+                                                 ptr(None if res is None else res.contiguous()), None, 0, int(act), ptr(y),
+                                                 M, Np, x3.shape[1], x3.stride(0), w3.stride(0), y.stride(0),
+                                                 current_stream(x.device))
+    _lib.check(rc, "gemm_nt_o32")
+    return y if Np == N else y[:, :N]
+
+
+def gemm_tn(g, x):
+    """fp32 (N, K) = g[T, N]^T @ x[T, K]: the three products stacked along T on the split-T weight-gradient kernel."""
+    gh, gl = split2(g.contiguous())
+    xh, xl = split2(x.contiguous())
+    N, K = g.shape[1], x.shape[1]
+    Np, Kp = -(-N // 64) * 64, -(-K // 64) * 64
+    g3 = torch.zeros((3 * g.shape[0], Np), dtype=BF, device=g.device)
+    x3 = torch.zeros((3 * x.shape[0], Kp), dtype=BF, device=g.device)
+    T = g.shape[0]
+    for i, (a, b) in enumerate(((gh, xh), (gh, xl), (gl, xh))):
+        g3[i * T:(i + 1) * T, :N] = a
+        x3[i * T:(i + 1) * T, :K] = b
+    part = mfma.gemm_tn(g3, x3)
+    if part is None:
+        raise RuntimeError("split32.gemm_tn: outside the weight-gradient kernel's domain")
+    return part.sum(0)[:N, :K]
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias, ctx.xshape = bias is not None, x.shape
+        return gemm_nt(x2, weight.view(weight.shape[0], -1), bias).view(x.shape[:-1] + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight = ctx.saved_tensors
+        w2 = weight.view(weight.shape[0], -1)
+        g2 = gy.reshape(-1, w2.shape[0]).float()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_nt(g2, w2.t().contiguous()).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            gw = gemm_tn(g2, x2).reshape(weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """F.linear for fp32 HIP tensors on the hand-written kernels (forward, input / weight / bias gradients)."""
+    return _LinearFn.apply(x, weight, bias)
+
+
+def matmul_nt(a, b):
+    """a[M, K] @ b[N, K]^T with autograd (attention's two products)."""
+    return _LinearFn.apply(a, b, None)
+
+
+def attention(q, k, v, scale):
+    """softmax(scale q k^T) v for (B, h, N, d) fp32 tensors as explicit products on the matrix-core kernels + a torch softmax
+    (mix_transformer.py:150-160 materialises the same score matrix)."""
+    B, h, N, d = q.shape
+    out = []
+    for b in range(B):
+        for hd in range(h):
+            s = matmul_nt(q[b, hd].contiguous(), k[b, hd].contiguous()) * scale
+            p = torch.softmax(s, dim=-1)
+            out.append(matmul_nt(p, v[b, hd].t().contiguous()))
+    return torch.stack(out).view(B, h, N, d)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# convolution (groups == 1, square geometry)
+# ---------------------------------------------------------------------------------------------------------------------
+def _nhwc3(x, order):
+    """NCHW-shaped fp32 -> (B, H, W, 3 Cp) bf16: the split terms `order` concatenated along the channels (Cp = C to 8)."""
+    xh = x.permute(0, 2, 3, 1)
+    hi, lo = split2(xh)
+    C = xh.shape[-1]
+    Cp = -(-C // 8) * 8
+    out = torch.zeros(xh.shape[:3] + (3 * Cp,), dtype=BF, device=x.device)
+    for i, which in enumerate(order):
+        out[..., i * Cp:i * Cp + C] = hi if which == "h" else lo
+    return out, Cp
+
+
+def _w3(w, order):
+    """(N, C, KH, KW) fp32 -> packed bf16 rows [n][(tap, 3 Cp)] with the split terms `order` per tap; N padded to 8."""
+    N, C, KH, KW = w.shape
+    Cp = -(-C // 8) * 8
+    hi, lo = split2(w)
+    w3 = torch.zeros((N, 3 * Cp, KH, KW), dtype=BF, device=w.device)
+    for i, which in enumerate(order):
+        w3[:, i * Cp:i * Cp + C] = hi if which == "h" else lo
+    packed = mfma.pack_conv_weight(w3, BF)
+    Np = -(-N // 8) * 8
+    if Np != N:
+        packed = torch.cat([packed, packed.new_zeros((Np - N, packed.shape[1]))])
+    return packed
+
+
+def _conv_o32(x3, wp, bias, B, H, W, C, N, KH, KW, s, p, d, act, transposed, out_hw):
+    """(H, W, C) = the convolution's INPUT side, N its output channels (C ABI of rfn_conv2d_nhwc_o32); the result has N
+    channels (forward) or C channels (transposed = data gradient)."""
+    oc = C if transposed else N
+    y = torch.empty((B,) + tuple(out_hw) + (oc,), dtype=torch.float32, device=x3.device)
+    with on_device(x3.device):
+        rc = _lib.load_library().rfn_conv2d_nhwc_o32(ptr(x3), ptr(wp), ptr(bias), int(act), ptr(y), B, H, W, C, N, KH, KW,
+                                                     s, p, d, wp.stride(0), oc, 1 if transposed else 0,
+                                                     current_stream(x3.device))
+    _lib.check(rc, "conv2d_nhwc_o32")
+    return y
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, s, p, d, act):
+        N, C, KH, KW = weight.shape
+        B, _, H, W = x.shape
+        x3, Cp = _nhwc3(x, "hhl")
+        Np = -(-N // 8) * 8
+        b = None if bias is None else torch.nn.functional.pad(bias, (0, Np - N)).contiguous()
+        OH = (H + 2 * p - d * (KH - 1) - 1) // s + 1
+        OW = (W + 2 * p - d * (KW - 1) - 1) // s + 1
+        y = _conv_o32(x3, _w3(weight, "hlh"), b, B, H, W, 3 * Cp, Np, KH, KW, s, p, d, act, False, (OH, OW))
+        ctx.save_for_backward(x, weight)
+        ctx.conf, ctx.has_bias = (s, p, d), bias is not None
+        assert act == 0 or not any(ctx.needs_input_grad), "activation epilogue: gradient-free callers only"
+        return y[..., :N].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        s, p, d = ctx.conf
+        N, C, KH, KW = weight.shape
+        B, _, H, W = x.shape
+        gy = gy.float()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            g3, Np = _nhwc3(gy, "hhl")                                            # (B, OH, OW, 3 Np)
+            wt = _w3(weight.permute(1, 0, 2, 3).contiguous(), "hlh")               # rows c, columns [tap][3 Np]
+            Cp = wt.shape[0]
+            dx = _conv_o32(g3, wt, None, B, H, W, Cp, 3 * Np, KH, KW, s, p, d, 0, True, (H, W))
+            gx = dx[..., :C].permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gh, gl = split2(gy.permute(0, 2, 3, 1))
+            xh, xl = split2(x.permute(0, 2, 3, 1))
+            Np, Cp = -(-N // 64) * 64, -(-C // 8) * 8
+            g3 = torch.zeros((3 * B,) + gh.shape[1:3] + (Np,), dtype=BF, device=x.device)
+            x3 = torch.zeros((3 * B, H, W, Cp), dtype=BF, device=x.device)
+            for i, (a, b) in enumerate(((gh, xh), (gh, xl), (gl, xh))):
+                g3[i * B:(i + 1) * B, ..., :N] = a
+                x3[i * B:(i + 1) * B, ..., :C] = b
+            Kp = -(-(KH * KW * Cp) // 64) * 64
+            part = mfma.conv2d_nhwc_wgrad(g3, x3, KH, KW, Kp, s, p, d)
+            if part is None:
+                raise RuntimeError("split32.conv2d: outside the weight-gradient kernel's domain")
+            gw = part.sum(0)[:N, :KH * KW * Cp].view(N, KH, KW, Cp)[..., :C].permute(0, 3, 1, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, act=0):
+    """F.conv2d (groups 1, square geometry, power-of-two stride when a data gradient is needed) for fp32 HIP tensors; None
+    when the geometry is outside the kernels' domain."""
+    vals = []
+    for v in (stride, padding, dilation):
+        if isinstance(v, (tuple, list)):
+            if v[0] != v[1]:
+                return None
+            v = v[0]
+        if isinstance(v, str):
+            return None
+        vals.append(int(v))
+    s, p, d = vals
+    N, C, KH, KW = weight.shape
+    if x.shape[1] != C or (x.requires_grad and torch.is_grad_enabled() and s & (s - 1)):
+        return None
+    if 3 * (-(-C // 8) * 8) * KH * KW // 8 >= 65536 or 3 * (-(-N // 8) * 8) * KH * KW // 8 >= 65536:
+        return None
+    return _Conv2dFn.apply(x, weight, bias, s, p, d, act)

@@ -51,7 +51,7 @@ class Recorder:
         self.opt.step()
 
 
-def run_reference(use_hrda):
+def run_reference(use_hrda, model_type="mit_b0", dims=DIMS):
     sm = R.ref_module("models.segmentation_model")
     mt = R.ref_module("models.backbones.mix_transformer")
     df = R.ref_module("models.heads.daformer")
@@ -83,14 +83,14 @@ def run_reference(use_hrda):
 
     model = Model(
         OPT, SCH,
-        backbone=mt.MixVisionTransformer("mit_b0", drop_path_rate=0.0),
-        head=df.DAFormerHead(DIMS, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0),
+        backbone=mt.MixVisionTransformer(model_type, drop_path_rate=0.0),
+        head=df.DAFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0),
         loss=ls.PixelWeightedCrossEntropyLoss(),
         alignment_backbone=vg.VGG('vgg16', out_indices=[2, 3, 4]),
         alignment_head=ua.UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True),
         backbone_lr_factor=0.1, use_refign=True, adapt_to_ref=False, gamma=0.25, enable_fdist=True,
         color_jitter_p=1.0, blur=False, use_hrda=use_hrda, hrda_output_stride=4,
-        hrda_scale_attention=sf.SegFormerHead(DIMS, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0))
+        hrda_scale_attention=sf.SegFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0))
     closed_form_fill(model)
     model.train()
     opt = torch.optim.AdamW(model.optimizer_parameters(), lr=6e-5, weight_decay=0.01)
@@ -116,4 +116,36 @@ def g13():
     torch.set_grad_enabled(False)
 
 
-GROUPS = {"G13": g13}
+def g13_b5():
+    """G13-B5: the same step with the bench's networks (MiT-B5, HRDA) on one 512 x 512 (source, target, reference) triple --
+    K2/K3-sized tokens per view (256 x 256 views: 4 096 / 1 024 / 256 / 64 tokens per stage, 10 teacher views per image).
+    Besides the scalars: strided samples of the decode head's class-weight gradient and of two updated backbone weights."""
+    torch.set_grad_enabled(True)
+    dims = [64, 128, 320, 512]
+    model = run_reference(True, "mit_b5", dims)
+    H = W = 512
+    batch = make_batch(1, H, W, 64)
+    random.seed(78); np.random.seed(78); torch.manual_seed(78)
+    model.global_step = 3
+    grads = {}
+    real = model._rec.step
+
+    def step():
+        grads["conv_seg"] = model.head.conv_seg.weight.grad.detach().flatten()[::37].clone().numpy()
+        grads["fc1"] = model.backbone.block3[20].mlp.fc1.weight.grad.detach().flatten()[::997].clone().numpy()
+        real()
+    model._rec.step = step
+    model.training_step(batch, 0)
+    ema = float(sum(p.double().abs().sum() for p in model.ema_parameters()))
+    live = float(sum(p.double().abs().sum() for p in model.live_parameters()))
+    save("step_hrda_b5_512x512", losses=np.array([model.logged["train_loss_src"], model.logged["train_loss_featdist_src"],
+                                                  model.logged["train_loss_uda_trg"]]),
+         grad_norms=np.array(model._rec.norms), ema_abs_sum=ema, live_abs_sum=live, size=np.array([H, W]),
+         grad_conv_seg=grads["conv_seg"], grad_fc1=grads["fc1"],
+         w_q=model.backbone.block1[0].attn.q.weight.detach().flatten()[::61].numpy(),
+         w_fuse=model.head.fuse_layer.bottleneck.conv.weight.detach().flatten()[::9973].numpy())
+    print("   ", model.logged, model._rec.norms)
+    torch.set_grad_enabled(False)
+
+
+GROUPS = {"G13": g13, "G13B5": g13_b5}

@@ -44,8 +44,9 @@ def test_layernorm_module_autocast_outputs_bf16(dev):
 
 
 def test_linear_split_weight_grad_matches_nn_linear(dev):
-    """refign_amd.linear.Linear: forward identical, gradients equal to nn.Linear's (fp32), for a token count that
-    triggers the split-T batched weight-gradient GEMM"""
+    """refign_amd.linear.Linear in fp32 (split-bf16 products on the matrix-core kernels, refign_amd/split32.py): forward
+    and gradients equal to nn.Linear's to 2^-15 of the result's scale, for a token count that triggers the split-T
+    weight-gradient kernel"""
     import torch.nn as nn
     from refign_amd.linear import Linear
     torch.manual_seed(0)
@@ -54,7 +55,7 @@ def test_linear_split_weight_grad_matches_nn_linear(dev):
     x = torch.randn(4, 2040, 96, device=dev)
     xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
     ya, yb = a(xa), b(xb)
-    assert torch.equal(ya, yb)
+    assert float((ya - yb).abs().max()) <= 2.0 ** -15 * float(yb.abs().max())
     g = torch.randn_like(ya)
     ya.backward(g)
     yb.backward(g)

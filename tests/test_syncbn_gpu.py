@@ -154,6 +154,7 @@ def _rccl_step_worker(rank, world, port, out):
     for mode in ("1", "0", "direct"):
         os.environ["RFN_GRAPH_DDP"] = "0" if mode == "0" else "1"
         os.environ["RFN_RCCL_DIRECT"] = "1" if mode == "direct" else "0"
+        os.environ["RFN_DDP_MIXED_COMM"] = "1" if mode == "direct" else "0"     # third communicator: opt-in (trainer.py)
         model = T.build(True, dev)
         trainer = Trainer(model, sync_batchnorm=True, fused_optimizer=False)
         n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
