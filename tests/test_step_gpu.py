@@ -26,22 +26,67 @@ def make_batch(b, H, W, blk, dev):
     return {"image_src": t(img("g13/src")), "semantic_src": t(lbl), "image_trg": t(trg), "image_ref": t(ref)}
 
 
-def build(use_hrda, dev):
+def build(use_hrda, dev, model_type="mit_b0", dims=None):
+    dims = dims or DIMS
     from refign_amd.align import VGG, UAWarpCHead
     from refign_amd.seg import DAFormerHead, MixVisionTransformer, PixelWeightedCrossEntropyLoss, SegFormerHead
     from refign_amd.uda import DomainAdaptationSegmentationModel
     model = DomainAdaptationSegmentationModel(
         OPT, SCH,
-        backbone=MixVisionTransformer("mit_b0", drop_path_rate=0.0),
-        head=DAFormerHead(DIMS, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0),
+        backbone=MixVisionTransformer(model_type, drop_path_rate=0.0),
+        head=DAFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0),
         loss=PixelWeightedCrossEntropyLoss(),
         alignment_backbone=VGG('vgg16', out_indices=[2, 3, 4]),
         alignment_head=UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True),
         backbone_lr_factor=0.1, use_refign=True, adapt_to_ref=False, gamma=0.25, enable_fdist=True,
         color_jitter_p=1.0, blur=False, use_hrda=use_hrda, hrda_output_stride=4,
-        hrda_scale_attention=SegFormerHead(DIMS, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0))
+        hrda_scale_attention=SegFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0))
     closed_form_fill(model)
     return model.to(dev).train()
+
+
+def test_training_step_mit_b5_hrda_512_matches_reference(dev):
+    """G13-B5: one reference training_step with the BENCH's networks (MiT-B5 + DAFormer + HRDA scale attention, VGG-16 /
+    UAWarpC align) on a 512 x 512 (source, target, reference) triple -- K2/K3-sized token counts per view (256 x 256 views,
+    10 teacher views per image) -- in the fp32 parity mode, which runs on the hand-written kernels (split-bf16 products,
+    refign_amd/split32.py).  Three losses, per-group gradient norms, EMA / student checksums as in G13, plus strided
+    samples of two gradients (decode head's class weights, an fc1 of stage 3) and of two updated weights."""
+    from refign_amd import mfma
+    from refign_amd.trainer import Trainer
+    g = golden("step_hrda_b5_512x512")
+    model = build(True, dev, "mit_b5", [64, 128, 320, 512])
+    trainer = Trainer(model, fused_optimizer=False)
+    trainer.scheduler = torch.optim.lr_scheduler.LambdaLR(trainer.optimizer, lambda s: 1.0)
+    model._scheduler = trainer.scheduler
+    batch = make_batch(1, 512, 512, 64, dev)
+    random.seed(78); np.random.seed(78); torch.manual_seed(78)
+    model.global_step = 3
+    seen = {}
+    real_step = trainer.optimizer.step
+
+    def recording_step(*a, **k):
+        seen["norms"] = [float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in grp["params"])))
+                         for grp in trainer.optimizer.param_groups]
+        seen["conv_seg"] = model.head.conv_seg.weight.grad.detach().flatten()[::37].cpu().numpy()
+        seen["fc1"] = model.backbone.block3[20].mlp.fc1.weight.grad.detach().flatten()[::997].cpu().numpy()
+        return real_step(*a, **k)
+
+    trainer.optimizer.step = recording_step
+    mfma.LIBRARY_CALLS.clear()
+    model.training_step(batch, 0)
+    assert not mfma.LIBRARY_CALLS, mfma.library_summary()        # the whole fp32 step stayed on the hand-written kernels
+    losses = np.array([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+    np.testing.assert_allclose(np.array(seen["norms"]), g["grad_norms"], rtol=2e-2)
+    for key, ref in (("conv_seg", g["grad_conv_seg"]), ("fc1", g["grad_fc1"])):
+        assert np.abs(seen[key] - ref).max() <= 2e-2 * np.abs(ref).max(), key
+    ema = float(sum(p.double().abs().sum() for p in model.ema_parameters()))
+    live = float(sum(p.double().abs().sum() for p in model.live_parameters()))
+    assert abs(ema - float(g["ema_abs_sum"])) < 1e-5 * float(g["ema_abs_sum"])
+    assert abs(live - float(g["live_abs_sum"])) < 1e-5 * float(g["live_abs_sum"])
+    w_q = model.backbone.block1[0].attn.q.weight.detach().flatten()[::61].cpu().numpy()
+    w_fuse = model.head.fuse_layer.bottleneck.conv.weight.detach().flatten()[::9973].cpu().numpy()
+    assert np.abs(w_q - g["w_q"]).max() <= 1e-4 and np.abs(w_fuse - g["w_fuse"]).max() <= 1e-4
 
 
 @pytest.mark.parametrize("use_hrda,name,blk", [(False, "step_daformer_96x128", 32), (True, "step_hrda_128x128", 64)])
