@@ -301,7 +301,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # with the device, so it is taken HERE, with nothing of this step queued yet, not in the middle of the step
         # where it would drain the launch queue (same values: gt_src does not change during the step)
         nb_trg = batch['image_trg'].shape[0]
-        src_classes = torch.unique(gt_src[:nb_trg] if gt_src.shape[0] > nb_trg else gt_src)
+        src_classes = self._take_class_prefetch(gt_src, nb_trg)
+        if src_classes is None:
+            src_classes = torch.unique(gt_src[:nb_trg] if gt_src.shape[0] > nb_trg else gt_src)
+        self._prefetch_classes(batch.get("semantic_src_next"), nb_trg)
         self.update_momentum_encoder()
 
         # The teacher branch (teacher forward on target + reference, align, refine) depends on nothing the student does
@@ -436,6 +439,31 @@ class DomainAdaptationSegmentationModel(nn.Module):
                 feat = self._imnet_forward(images_src_next)[-1]
             done = self._side_stream.record_event()
         self._imnet_prefetch = (images_src_next, images_src_next._version, images_src_next.data_ptr(), feat, done)
+
+    # torch.unique synchronises the host with the device: at the start of a step it drains the whole previous step, and the
+    # device then idles while the host enqueues the new one (4.6 ms of every 181 ms step, profiles/r03_step_phases*.txt).
+    # With the NEXT batch known (Trainer.step(batch, next_batch=...)) the class set is taken a step ahead WITHOUT a
+    # synchronisation: a fixed-size histogram (no data-dependent shape), an asynchronous copy to pinned memory and an event
+    # that has long fired when the next step asks for it.  Same values as torch.unique (ascending class ids).
+    def _prefetch_classes(self, gt_next, nb):
+        self._class_prefetch = None
+        if gt_next is None or not gt_next.is_cuda or gt_next.dtype != torch.long:
+            return
+        g = gt_next[:nb] if gt_next.shape[0] > nb else gt_next
+        hist = torch.histc(g.to(torch.float32), bins=256, min=0, max=255)          # labels are 0 .. 18 and 255
+        host = getattr(self, "_class_hist_host", None)
+        if host is None:
+            host = self._class_hist_host = torch.empty(256, dtype=torch.float32).pin_memory()
+        host.copy_(hist, non_blocking=True)
+        self._class_prefetch = (gt_next, gt_next._version, gt_next.data_ptr(), nb, torch.cuda.current_stream().record_event())
+
+    def _take_class_prefetch(self, gt_src, nb):
+        pf, self._class_prefetch = getattr(self, "_class_prefetch", None), None
+        if pf is None or pf[0] is not gt_src or pf[1] != gt_src._version or pf[2] != gt_src.data_ptr() or pf[3] != nb:
+            return None
+        pf[4].synchronize()                                # recorded a whole step ago
+        ids = torch.nonzero(self._class_hist_host > 0).flatten()
+        return upload_async(ids, torch.long, gt_src.device)
 
     def _take_imnet_prefetch(self, images_src):
         pf, self._imnet_prefetch = getattr(self, "_imnet_prefetch", None), None

@@ -66,3 +66,19 @@ def test_dacs_draws_follow_the_reference_order(monkeypatch):
         M.get_dacs_mix(ns, trg, probs, src, gt)
         states.append((random.random(), float(np.random.rand()), float(torch.rand(()))))
     assert states[0] == states[1]
+
+
+def test_class_set_prefetch_equals_torch_unique():
+    """uda._prefetch_classes / _take_class_prefetch: the class set of the next batch from a fixed-size histogram + an
+    asynchronous copy (no host synchronisation in the step) == torch.unique of the labels, ignore label included."""
+    from refign_amd.uda import DomainAdaptationSegmentationModel as M
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(9)
+    gt = torch.tensor([0, 3, 7, 18, 255, 11])[torch.randint(0, 6, (3, 40, 56), generator=g)].to(dev)
+    ns = types.SimpleNamespace()
+    M._prefetch_classes(ns, gt, 2)
+    got = M._take_class_prefetch(ns, gt, 2)
+    assert got is not None and torch.equal(got.cpu(), torch.unique(gt[:2]).cpu())
+    assert M._take_class_prefetch(ns, gt, 2) is None                      # consumed
+    M._prefetch_classes(ns, gt, 2)
+    assert M._take_class_prefetch(ns, gt.clone(), 2) is None              # a different tensor: not this prefetch
