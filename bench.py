@@ -364,6 +364,9 @@ def cpu_baseline(wl, args):
     dt = time.perf_counter() - t0
     scale = (h * w) / float(args.height * args.width)
     return {"value": round(scale / dt, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind,
+            "kind_detail": ("restatement + reference correlation: the reference's compiled correlation.cpp, every other op "
+                            "the reference's algorithm restated on torch-CPU") if kind == "reference" else
+                           "restatement (oracle/corr_oracle.c + torch-CPU ops)",
             "sample": f"ONE full training step (same model/config, fp32) for 1 source image + 1 pair at {h}x{w} "
                       f"({scale:.4f} of the pixels of {args.height}x{args.width}) on the host with {cores} threads: {dt:.2f} s wall; value = "
                       f"(1 pair / {dt:.2f} s) x {scale:.4f} pixel ratio.  Correlation = "
@@ -384,7 +387,10 @@ def _ddp_guard(rank, world, progress):
     rehearsal instead of 192) -- unless those variables are set explicitly."""
     import threading
     explicit = "RFN_GRAPH_DDP" in os.environ or "RFN_RCCL_DIRECT" in os.environ
-    if not explicit and os.path.exists(DDP_STALL_MARKER):
+    # the marker only changes a later run's configuration when asked to (RFN_BENCH_STALL_MARKER=1): a leftover file in /tmp
+    # must not silently reconfigure a benchmark
+    use_marker = os.environ.get("RFN_BENCH_STALL_MARKER", "0") == "1"
+    if use_marker and not explicit and os.path.exists(DDP_STALL_MARKER):
         os.environ["RFN_GRAPH_DDP"] = os.environ["RFN_RCCL_DIRECT"] = "0"
         if rank == 0:
             print(f"bench.py: {DDP_STALL_MARKER} exists (an earlier multi-rank run stalled on this box): exchanges through "
@@ -399,7 +405,7 @@ def _ddp_guard(rank, world, progress):
                 conf = f"RFN_RCCL_DIRECT={os.environ.get('RFN_RCCL_DIRECT', '1')} RFN_GRAPH_DDP={os.environ.get('RFN_GRAPH_DDP', 'auto')}"
                 print(f"bench.py rank {rank}/{world}: no progress for {idle:.0f} s after '{progress[1]}' ({conf}); "
                       f"giving up", file=sys.stderr, flush=True)
-                if os.environ.get("RFN_RCCL_DIRECT", "1") != "0":
+                if use_marker and os.environ.get("RFN_RCCL_DIRECT", "1") != "0":
                     try:
                         with open(DDP_STALL_MARKER, "w") as f:
                             f.write(f"rank {rank}/{world} stalled after {progress[1]} ({conf})\n")
@@ -506,6 +512,7 @@ def main():
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(), "avg_launch_us": round(us, 2),
                 "avg_launch_us_back_to_back": round(us_b2b, 2),
+                "frac_back_to_back": round(wl.roofline_bytes() / (us_b2b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": wl.roofline_bytes(), "rocprofv3_in_step": rocprof_in_step_us()}
 
     cpu = None

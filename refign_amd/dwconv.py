@@ -107,11 +107,7 @@ def _dwconv_backward(ctx, x, w_tap, gy):
                                                        current_stream(x.device))
             _lib.check(rc, "dwconv3x3_nhwc_bwd_weight")
 
-        if direct:
-            from . import sidework                # parameter gradients: off the critical path (sidework.py)
-            sidework.fork(x.device, run, x, gy)
-        else:
-            run()
+        run()
         if not direct:
             gw = dw.t().reshape(ctx.wshape).to(ctx.wdtype)
             gb = db

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import mfma, sidework
+from . import mfma
 from .params import as_dtype, compute_dtype, grad_sink, linear_param_grads, sum_rows, transposed
 
 
@@ -90,11 +90,11 @@ class _LinearFn(torch.autograd.Function):
         sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
         part = None
         if need_w and sink_w is not None and (not need_b or sink_b is not None):
-            # hand-written split-T MFMA kernel accumulating straight into the flat gradient buffer (weight AND bias), on
-            # the side stream: nothing downstream of this layer waits for parameter gradients (refign_amd/sidework.py)
+            # hand-written split-T MFMA kernel accumulating straight into the flat gradient buffer (weight AND bias).
+            # (Forking it to a second stream inside the captured pass was measured and dropped in round 2: 449 vs 244 ms per
+            # step -- hipGraph replays cross-stream branches with a synchronisation per edge.)
             x2 = x.reshape(-1, K)
-            if sidework.fork(g2.device, lambda: mfma.gemm_tn(g2, x2, out=sink_w, bias_out=sink_b if need_b else None),
-                             g2, x2) is not None:
+            if mfma.gemm_tn(g2, x2, out=sink_w, bias_out=sink_b if need_b else None) is not None:
                 return gx, None, None, None, None, g_res, None
         if need_w:
             x2 = x.reshape(-1, K)

@@ -168,7 +168,8 @@ def conv2d_nhwc_wgrad(gy, x, KH, KW, Kpad, stride=1, pad=0, dil=1, bias_out=None
     return part
 
 
-_TN_WGS = int(os.environ.get("RFN_TN_WGS", "1024"))      # target workgroups of a weight-gradient launch (tools sweep)
+_TN_WGS = 1024      # target workgroups of a weight-gradient launch (swept in round 3: 1024 / 512 / 384 / 256 -> 185.4 / 185.2 /
+#                     186.4 / 189.6 ms per step)
 
 
 def slab_rows(T, tiles):

@@ -126,16 +126,8 @@ class Mlp(nn.Module):
         return y if res is None else _residual(res, y, rowscale)
 
 
-def _sdpa_backend():
-    name = os.environ.get("RFN_SDPA_BACKEND")
-    if not name:
-        return None
-    from torch.nn.attention import SDPBackend
-    return {"flash": SDPBackend.FLASH_ATTENTION, "efficient": SDPBackend.EFFICIENT_ATTENTION,
-            "math": SDPBackend.MATH}[name]
-
-
-_SDPA_BACKEND = _sdpa_backend()
+_SDPA_BACKEND = None          # (round 2's RFN_SDPA_BACKEND A/B knob is gone: attention never goes to the fused-SDPA library
+#                               on 16-bit or fp32 HIP tensors any more; the branch below is what CPU tensors take)
 _FUSED_UPCAT = os.environ.get("RFN_FUSED_UPCAT", "1") != "0"       # decode heads: up-sampling + concat in one kernel
 
 

@@ -31,7 +31,6 @@ import torch.nn.functional as F
 
 from . import align as align_mod
 from . import refine as refine_mod
-from . import sidework
 from ._tensor import const_tensor, upload_async
 from . import dacs as _dacs
 from . import f8 as _f8
@@ -286,7 +285,6 @@ class DomainAdaptationSegmentationModel(nn.Module):
             self._backward(loss, retain_graph, last)
         else:
             loss.backward(retain_graph=retain_graph)
-        sidework.join()          # parameter-gradient kernels forked to the side stream are complete from here on
 
     def log(self, name, value, **kw):
         self.logged[name] = value.detach() if torch.is_tensor(value) else value

@@ -85,7 +85,8 @@ def test_reference_yaml_builds_unmodified(path):
 
 def test_bench_stall_guard_exits_and_leaves_the_conservative_marker(tmp_path):
     """bench.py, N > 1: a run that stops making progress (the multi-rank step has only ever been rehearsed with one
-    rank on the development boxes) exits non-zero, says where it stopped and leaves a marker; the next run on the box that
+    rank on the development boxes) exits non-zero and says where it stopped; with RFN_BENCH_STALL_MARKER=1 (opt-in: a
+    leftover file must not silently reconfigure a benchmark) it also leaves a marker, and the next run on the box that
     finds the marker takes the conservative configuration (exchanges through torch.distributed, eager student) unless
     the switches are set explicitly."""
     import os
@@ -98,6 +99,9 @@ def test_bench_stall_guard_exits_and_leaves_the_conservative_marker(tmp_path):
             "time.sleep(30)\n" % root)
     env = {k: v for k, v in os.environ.items() if k not in ("RFN_GRAPH_DDP", "RFN_RCCL_DIRECT")}
     env.update(TMPDIR=str(tmp_path), RFN_BENCH_STALL_S="1")
+    r0 = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r0.returncode == 17 and not (tmp_path / "refign_amd_multi_rank_stalled").exists()      # no marker unless asked
+    env.update(RFN_BENCH_STALL_MARKER="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 17, r.stderr
     assert "no progress" in r.stderr and "warm-up step 1" in r.stderr and "rank 1/2" in r.stderr
