@@ -81,6 +81,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
   using E = Elem<DT>;
   using vec8 = typename E::vec8;
   static_assert(BK == 32 || BK == 64, "K-step of 32 or 64");
+  // profiling builds only (make FLAGS+=-DRFN_GEMM_PROFILE; tools/gemm_ablate.py): RFN_GEMM_ABLATE bit 1 no DMA, 2 no MFMA,
+  // 4 no stores -- which phases of a launch overlap (round 3: none do, profiles/r03_gemm_ablation.txt)
+#ifdef RFN_GEMM_PROFILE
+  const int ablate = epi.act >> 8;
+#else
+  constexpr int ablate = 0;
+#endif
   // NW waves as 2 (m) x NW / 2 (n); 8 waves (a 256 x 256 tile, wave tile 128 x 64) halve the LDS-DMA instructions a wave
   // issues per MFMA -- their issue cost, not the data volume, is what paces the 4-wave 128 x 128 tile (2 MFMAs per DMA)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
   auto issue = [&](int kt, int buf) {
     unsigned char* xs = smem + buf * STAGE;
     unsigned char* ws = xs + XBYTES;
+    if (ablate & 1) return;
     if constexpr (GATHER) {
       const unsigned j = (unsigned)(kt * PPR + dpiece);                     // 16-byte piece index along k
       const unsigned tap = cg.C8 == 1 ? j : __umulhi(j, cg.c8_magic), c8 = j - tap * cg.C8;
@@ -220,10 +228,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
       for (int i = 0; i < IB; ++i) wf[i] = *(const vec8*)(st + woff + i * 32 * ROWB + coff);
 #pragma unroll
       for (int j = 0; j < JB; ++j) xf[j] = *(const vec8*)(st + xoff + j * 32 * ROWB + coff);
+      if (!(ablate & 2)) {
 #pragma unroll
-      for (int i = 0; i < IB; ++i)
+        for (int i = 0; i < IB; ++i)
 #pragma unroll
-        for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(wf[i], xf[j], acc[i][j]);
+          for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(wf[i], xf[j], acc[i][j]);
+      }
     }
     if (++c_kt == nk) {
       // ---- epilogue.  Registers -> (bias, activation, 16-bit rounding) -> a per-wave LDS staging block -> row-contiguous
@@ -293,9 +303,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += b[e];
             }
-            if (epi.act != 0) {
+            if ((epi.act & 255) != 0) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], epi.act);
+              for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], epi.act & 255);
             }
             *(u32x2*)(stg + frow * PITCH + cl * 2) = pack4<DT>(v[0], v[1], v[2], v[3]);
           }
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
               const u32x2 hi = pack4<DT>(d[0] + rs * b[0], d[1] + rs * b[1], d[2] + rs * b[2], d[3] + rs * b[3]);
               o = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
-            *(u32x4*)(Y + (long)m * ldy + n) = o;
+            if (!(ablate & 4)) *(u32x4*)(Y + (long)m * ldy + n) = o;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next j block overwrites
@@ -876,6 +886,10 @@ int rfn_gemm_nt(const void* X, const void* W, const void* bias, const void* res,
                 int rows_per_sample, int act, void* Y, long M, long N, long K, long ldx, long ldw, long ldy, int dtype,
                 rfn_stream_t stream) {
   using namespace rfn;
+#ifdef RFN_GEMM_PROFILE
+  static const int prof = getenv("RFN_GEMM_ABLATE") ? atoi(getenv("RFN_GEMM_ABLATE")) : 0;
+  const int act_arg = act;
+#endif
   RFN_REQUIRE(X && W && Y, "gemm_nt: null operand");
   RFN_REQUIRE(dtype == 1 || dtype == 2, "gemm_nt: dtype %d (1 = bf16, 2 = f16)", dtype);
   RFN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0, "gemm_nt: M=%ld N=%ld K=%ld (K %% 64, N %% 8)", M, N, K);
@@ -885,6 +899,9 @@ int rfn_gemm_nt(const void* X, const void* W, const void* bias, const void* res,
   RFN_REQUIRE(rowscale == nullptr || rows_per_sample > 0, "gemm_nt: rowscale needs rows_per_sample");
   RFN_REQUIRE(act == 0 || act == 1 || act == 3, "gemm_nt: act (0 none, 1 ReLU, 3 LeakyReLU 0.1)");
   GemmEpi epi{(const uint16_t*)bias, (const uint16_t*)res, rowscale, rows_per_sample > 0 ? rows_per_sample : 1, act};
+#ifdef RFN_GEMM_PROFILE
+  epi.act = act_arg | (prof << 8);
+#endif
   hipStream_t s = (hipStream_t)stream;
   ConvGeom cg{};
   return dtype == 1 ? launch_nt<1, false>(X, W, Y, M, N, K, ldx, ldw, ldy, epi, cg, s)
