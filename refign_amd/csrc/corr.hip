@@ -419,11 +419,12 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_ker
 #pragma unroll UNR
     for (int c = 0; c < CC; ++c) {
       if constexpr (ILV) {
-        if (prefetch) {
-#pragma unroll
-          for (int k = 0; k < K; ++k)
-            if (k % CC == c) issue_one(next_ring, k);
-        }
+        // Round 3 experiment (variants 17-19 only): STAGGERED issue -- wave w issues all of its DMA instructions in front of
+        // channel (w mod CC) of the chunk instead of everybody right after the barrier, so that a quarter of the waves queue
+        // on the CU's address path while the others run their FMAs.  Hypothesis: the DMA-issue time (53 us with the FMAs
+        // ablated) and the product time (56 us) of a launch ADD because all waves stall on issue together.  Measured: 140.0
+        // vs 143.2 us (kbench, L1) -- 2 %: the phases do not add for that reason.  Not the default.
+        if (prefetch && c == ((int)(threadIdx.x >> 6) & (CC - 1))) issue(next_ring);
       }
       const float* cb = s2 + c * ROWS * PITCH;
       const float4 a = *reinterpret_cast<const float4*>(&cb[(R2 + row) * PITCH + 4 * strip]);

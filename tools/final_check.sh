@@ -14,3 +14,11 @@ grep '^{"metric"' /tmp/prof_bench.log > $O/bench_under_rocprof.json
 find /tmp/prof_bench -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_bench_kernel_stats.csv \;
 python tools/trace_window_stats.py $(find /tmp/prof_bench -name "*kernel_trace.csv") $O/bench_under_rocprof.json $O/rocprofv3_bench_kernel_stats_timed_region.csv > $O/trace_window.txt
 python tools/trace_queues.py $(find /tmp/prof_bench -name "*kernel_trace.csv") $O/bench_under_rocprof.json > $O/queues.txt 2>&1
+# round 3: K5 (fp8 teacher) bench line + micro-benchmark + MFMA-pipe counters, correlation kernels (incl. the experimental
+# matrix-pipe one and its ablation), DACS kernels
+timeout 600 python bench.py --precision k5 --no-cpu 2>/dev/null | tail -1 > $O/bench_k5_n1.json
+timeout 300 python tools/f8_bench.py 2>&1 | grep -v "amdgpu.ids" > $O/f8_bench.txt
+timeout 300 python tools/kbench.py --only L1,L2 2>&1 | grep -v "amdgpu.ids\|MIOpen" > $O/kbench_corr.txt
+for a in 1 2 4 6 7; do echo "RFN_CORR_ABLATE=$a"; RFN_CORR_ABLATE=$a timeout 200 python tools/kbench.py --only L1 2>&1 | grep -i "f16-split\|relu+l2norm"; done > $O/corr_f16_ablation.txt
+for t in f8gemm_fc1_s3:gemm_nt_f8 f8gemm_fc2_s3:gemm_nt_f8 f8attn_s3:attn_fwd_f8 gemm_fc1_s3:gemm_nt_kernel; do
+  echo "== ${t%%:*}"; bash tools/pmc_mfma.sh ${t%%:*} ${t##*:}; done > $O/pmc_f8_kernels.txt 2>&1

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/prof_mfma.py -- run ONE matrix-core kernel of the step a few times (for rocprofv3 --kernel-trace / --pmc).
-usage: prof_mfma.py [gemm_fc1_s3 | gemm_fc2_s3 | gemm_fc1_s1 | conv_bottleneck | attn_fwd_s3 | attn_bwd_s3 | wgrad_s3] [reps]
+usage: prof_mfma.py [gemm_fc1_s3 | gemm_fc2_s3 | gemm_fc1_s1 | f8gemm_fc1_s3 | f8gemm_fc2_s3 | f8attn_s3 | conv_bottleneck |
+                     attn_fwd_s3 | attn_bwd_s3 | wgrad_s3] [reps]
 Shapes: MiT-B5 stage shapes of the HRDA step (teacher batch 40 x 540x960 views; student batch 4)."""
 import os
 import sys
@@ -20,6 +21,19 @@ if what.startswith("gemm_"):
     x, w, b = r(M, K), r(N, K), r(N)
     fn = lambda: mfma.gemm_nt(x, w, b)  # noqa: E731
     print(f"{what}: M={M} N={N} K={K} flops={2.0 * M * N * K:.4g} bytes={2.0 * (M * K + N * K + M * N):.4g}")
+elif what.startswith("f8gemm_"):
+    from refign_amd import f8
+    M, N, K = {"f8gemm_fc1_s3": (81600, 1280, 320), "f8gemm_fc2_s3": (81600, 320, 1280)}[what]
+    x8, w8 = f8.quantize(r(M, K)), f8.quantize(r(N, K))
+    ws, b = torch.ones(N, device=dev), r(N)
+    fn = lambda: f8.gemm_nt(x8, w8, ws, bias=b, out_f8=what == "f8gemm_fc1_s3")  # noqa: E731
+    print(f"{what}: M={M} N={N} K={K} flops={2.0 * M * N * K:.4g} bytes={1.0 * (M * K + N * K) + (1.0 if 'fc1' in what else 2.0) * M * N:.4g}")
+elif what == "f8attn_s3":
+    from refign_amd import f8
+    B, h, Nq, Nkv = 40, 5, 2040, 510
+    q8, kv8 = f8.quantize(r(B, Nq, h * 64)), f8.quantize(r(B, Nkv, 2 * h * 64))
+    fn = lambda: f8.attention(q8, kv8, h, 0.125)  # noqa: E731
+    print(f"{what}: B={B} heads={h} Nq={Nq} Nkv={Nkv} fwd flops={4.0 * B * h * Nq * Nkv * 64:.4g}")
 elif what == "wgrad_s3":
     T, N, K = 8160, 1280, 320
     g, x = r(T, N), r(T, K)
