@@ -21,11 +21,11 @@ from .params import as_dtype, compute_dtype, grad_sink, linear_param_grads, sum_
 
 
 _FUSED_GRADS = os.environ.get("RFN_LINEAR_FUSED_GRADS", "1") != "0"      # A/B switch (tools)
-# residual + stochastic depth in the proj / fc2 GEMMs under autograd (the gradient-free passes always fuse).  OFF by default:
-# measured on the bench step it is neutral to slightly slower (239.0 / 241.5 vs 237.5 / 240.1 ms per step, same box) --
-# the 410 element-wise launches it removes per step cost what the scaled operand staging of the weight-gradient kernel
-# and the extra epilogue read add to 620 latency-bound GEMM launches.
-_FUSED_RESIDUAL = os.environ.get("RFN_FUSED_RESIDUAL", "0") == "1"
+# residual + stochastic depth in the proj / fc2 GEMMs under autograd (the gradient-free passes always fuse).  Round 2
+# measured it neutral (239.0 / 241.5 vs 237.5 / 240.1 ms per step); with the student passes replayed from graphs and the
+# library kernels gone, the 410 element-wise launches it removes are worth 1.0-1.2 ms per step (181.4 / 181.5 vs 182.4 /
+# 182.7 ms, round 3): ON by default, RFN_FUSED_RESIDUAL=0 switches it off.
+_FUSED_RESIDUAL = os.environ.get("RFN_FUSED_RESIDUAL", "1") != "0"
 
 
 def _split(T):

@@ -224,7 +224,7 @@ class Block(nn.Module):
             return self.mlp(self.norm2(x), H, W, res=x, rowscale=None if masks32 is None else masks32[1])
         if masks is not None:                       # pre-drawn stochastic-depth masks (MixVisionTransformer)
             if x.is_cuda and masks32 is not None and _linear._FUSED_RESIDUAL:
-                # training (opt-in, RFN_FUSED_RESIDUAL=1: measured neutral): the same fusion under autograd (linear._LinearFn: residual + per-sample scale in the proj /
+                # training (RFN_FUSED_RESIDUAL, on): the same fusion under autograd (linear._LinearFn: residual + per-sample scale in the proj /
                 # fc2 GEMM epilogue; in the backward the scale rides in the input- and weight-gradient kernels)
                 x = self.attn(self.norm1(x), H, W, res=x, rowscale=masks32[0])
                 return self.mlp(self.norm2(x), H, W, res=x, rowscale=masks32[1])
