@@ -190,6 +190,12 @@ unsigned long rfn_layernorm_bwd_workspace_bytes(int C);
 int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, const float* mean, const float* rstd,
                       void* grad_x, float* grad_gamma, float* grad_beta, void* workspace, long rows, int C,
                       int x_dtype, int gy_dtype, int accumulate, rfn_stream_t stream);
+/* rfn_layernorm_bwd with a second gradient of x folded in: grad_x = LayerNorm-backward(grad_y) + add (`add` has x's dtype and
+ * shape; NULL = plain backward).  The residual stream of a MiT block feeds the LayerNorm and the residual add
+ * (mix_transformer.py:203-207): this is the sum autograd would otherwise make in an element-wise kernel.  C % 8 == 0. */
+int rfn_layernorm_bwd_add(const void* x, const void* grad_y, const void* add, const float* gamma, const float* mean,
+                          const float* rstd, void* grad_x, float* grad_gamma, float* grad_beta, void* workspace, long rows, int C,
+                          int x_dtype, int gy_dtype, int accumulate, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Front end of the UAWarpC UncertaintyModule for search size 9 (models/modules.py:529-551, eval mode): every pixel's
@@ -281,7 +287,9 @@ int rfn_patchify_tokens(const void* src, void* dst, int B, int H, int W, int C, 
  * rfn_gemm_nt:  Y[M,N] = res + rowscale[m / rows_per_sample] * act( X[M,K] . W[N,K]^T + bias[N] )   (res, rowscale, bias: NULL = absent)
  *   forward: X = tokens, W = weight.  dgrad: X = grad_y [T,N], W = weight^T [K,N] (host keeps the transposed copy).
  *   bias / res / rowscale may be NULL (res NULL: Y = act(...); rowscale needs res: the stochastic-depth residual
- *   `x + drop_path(branch)` of mix_transformer.py:203-207 with per-sample keep masks).  act: 0 none, 1 ReLU, 3 LeakyReLU(0.1).
+ *   `x + drop_path(branch)` of mix_transformer.py:203-207 with per-sample keep masks).  act: 0 none, 1 ReLU, 3 LeakyReLU(0.1);
+ *   4: Y = (rowscale * (X W^T + b)) * gelu'(res) -- `res` is the pre-activation of an exact-erf GELU in front of this layer's
+ *   input, Y the gradient with respect to it (input-gradient GEMM of the Mix-FFN's fc2, mix_transformer.py:99-102).
  *   K % 64 == 0, N % 8 == 0, ldx / ldw / ldy % 8 == 0.
  * rfn_gemm_tn:  sum over rows t of slab s of rowscale[t / rows_per_sample] * G[t,n] * X[t,k] (rowscale may be NULL), S = ceil(T / rows_per_slab) slabs computed by separate
  *   workgroups (the reduction of a weight gradient is the TOKEN dimension: 8 160 ... 259 200 rows for a <= 2048 x 2048

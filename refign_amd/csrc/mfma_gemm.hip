@@ -37,6 +37,18 @@ struct GemmEpi {
   int act;                  // 0 none, 1 ReLU, 3 LeakyReLU(0.1)
 };
 
+// d/dz gelu(z) = Phi(z) + z phi(z), exact-erf GELU: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7) -- one v_rcp, one v_exp
+// (shared by the erf and the density term), a dozen FMAs; used by the act = 4 epilogue (a 16-bit result)
+__device__ __forceinline__ float gelu_grad(float z) {
+  const float x = fabsf(z) * 0.70710678118654752440f;
+  const float t = 1.0f / (1.0f + 0.3275911f * x);
+  const float e = __expf(-x * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  const float cdf = 0.5f * (1.0f + (z < 0.f ? -erf_abs : erf_abs));
+  return cdf + z * 0.3989422804014327f * e;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   // 1 = ReLU, 3 = LeakyReLU(0.1) (the matcher's decoders); GELU is NOT offered here: in the Mix-FFN it follows the
   // depthwise convolution (fused there, csrc/dwconv.hip), and its erf polynomial in this epilogue costs ~100 VGPRs
@@ -327,8 +339,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
               unpack4<DT>(u32x2{o[2], o[3]}, b);
               unpack4<DT>(u32x2{rr[0], rr[1]}, c);
               unpack4<DT>(u32x2{rr[2], rr[3]}, d);
-              const u32x2 lo = pack4<DT>(c[0] + rs * a[0], c[1] + rs * a[1], c[2] + rs * a[2], c[3] + rs * a[3]);
-              const u32x2 hi = pack4<DT>(d[0] + rs * b[0], d[1] + rs * b[1], d[2] + rs * b[2], d[3] + rs * b[3]);
+              u32x2 lo, hi;
+              if (epi.act == 4) {
+                // `res` carries the PRE-ACTIVATION z of an exact-erf GELU that sits in front of this layer's input: the result is
+                // the gradient with respect to z, (rs * branch) * gelu'(z) -- the Mix-FFN's fc2 input gradient handed straight to
+                // the depthwise backward (mix_transformer.py:99-102), no separate gelu_backward pass
+                lo = pack4<DT>(rs * a[0] * gelu_grad(c[0]), rs * a[1] * gelu_grad(c[1]), rs * a[2] * gelu_grad(c[2]),
+                               rs * a[3] * gelu_grad(c[3]));
+                hi = pack4<DT>(rs * b[0] * gelu_grad(d[0]), rs * b[1] * gelu_grad(d[1]), rs * b[2] * gelu_grad(d[2]),
+                               rs * b[3] * gelu_grad(d[3]));
+              } else {
+                lo = pack4<DT>(c[0] + rs * a[0], c[1] + rs * a[1], c[2] + rs * a[2], c[3] + rs * a[3]);
+                hi = pack4<DT>(d[0] + rs * b[0], d[1] + rs * b[1], d[2] + rs * b[2], d[3] + rs * b[3]);
+              }
               o = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
             if (!(ablate & 4)) *(u32x4*)(Y + (long)m * ldy + n) = o;
@@ -897,7 +920,8 @@ int rfn_gemm_nt(const void* X, const void* W, const void* bias, const void* res,
               "gemm_nt: leading dimensions must be multiples of 8 elements");
   RFN_REQUIRE(M < (1L << 31) && N < (1L << 31), "gemm_nt: extent");
   RFN_REQUIRE(rowscale == nullptr || rows_per_sample > 0, "gemm_nt: rowscale needs rows_per_sample");
-  RFN_REQUIRE(act == 0 || act == 1 || act == 3, "gemm_nt: act (0 none, 1 ReLU, 3 LeakyReLU 0.1)");
+  RFN_REQUIRE(act == 0 || act == 1 || act == 3 || (act == 4 && res != nullptr),
+              "gemm_nt: act (0 none, 1 ReLU, 3 LeakyReLU 0.1, 4 = times gelu'(res), needs res)");
   GemmEpi epi{(const uint16_t*)bias, (const uint16_t*)res, rowscale, rows_per_sample > 0 ? rows_per_sample : 1, act};
 #ifdef RFN_GEMM_PROFILE
   epi.act = act_arg | (prof << 8);

@@ -54,7 +54,7 @@ class _DWConv3x3Gelu(torch.autograd.Function):
     of the plain convolution."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, with_z=False):
         if x.dtype not in _DT:
             x = x.float()
         x = require_device_tensor(x.contiguous(), "x")
@@ -63,6 +63,8 @@ class _DWConv3x3Gelu(torch.autograd.Function):
                         lambda t: t.reshape(C, 9).t())
         b32 = None if bias is None else as_dtype(bias, torch.float32).detach().contiguous()
         need = any(ctx.needs_input_grad)
+        with_z = with_z and need
+        ctx.set_materialize_grads(False)          # the non-differentiable output's "gradient" must not become a zero tensor
         z = torch.empty_like(x) if need else None
         a = torch.empty_like(x)
         lib = _lib.load_library()
@@ -74,14 +76,26 @@ class _DWConv3x3Gelu(torch.autograd.Function):
             ctx.save_for_backward(x, w_tap, z)
             ctx.has_bias, ctx.wshape, ctx.wdtype = bias is not None, weight.shape, weight.dtype
             ctx.weight, ctx.bias, ctx.dilation = weight, bias, 1
+        if with_z:
+            # (a, z): the activation as a NON-differentiable tensor + the pre-activation that carries the gradient -- the
+            # consumer (linear._LinearFn with z=) returns d/dz directly, gelu' applied in its input-gradient GEMM's epilogue
+            ctx.mark_non_differentiable(a)
+            ctx.with_z = True
+            return a, z
+        ctx.with_z = False
         return a
 
     @staticmethod
-    def backward(ctx, ga):
+    def backward(ctx, *grads):
         x, w_tap, z = ctx.saved_tensors
-        gz = torch.ops.aten.gelu_backward(ga.to(z.dtype).contiguous(), z)
+        if ctx.with_z:
+            if grads[1] is None:
+                return None, None, None, None
+            gz = grads[1].to(z.dtype).contiguous()
+        else:
+            gz = torch.ops.aten.gelu_backward(grads[0].to(z.dtype).contiguous(), z)
         ctx.saved = (x, w_tap)
-        return _dwconv_backward(ctx, x, w_tap, gz)[:3]
+        return _dwconv_backward(ctx, x, w_tap, gz)[:3] + (None,)
 
 
 def _dwconv_backward(ctx, x, w_tap, gy):
@@ -114,10 +128,14 @@ def _dwconv_backward(ctx, x, w_tap, gy):
     return gx, gw, gb, None
 
 
-def dwconv3x3_gelu_tokens(x, weight, bias, H, W):
-    """gelu(DWConv(x)) on tokens (B, N=H*W, C) -> (B, N, C): mix_transformer.py:99-101 in one pass."""
+def dwconv3x3_gelu_tokens(x, weight, bias, H, W, with_z=False):
+    """gelu(DWConv(x)) on tokens (B, N=H*W, C) -> (B, N, C): mix_transformer.py:99-101 in one pass.  with_z (under autograd):
+    -> (a, z), a non-differentiable, z the pre-activation carrying the gradient (see _DWConv3x3Gelu); (a, None) otherwise."""
     B, N, C = x.shape
-    return _DWConv3x3Gelu.apply(x.reshape(B, H, W, C), weight, bias).reshape(B, N, C)
+    out = _DWConv3x3Gelu.apply(x.reshape(B, H, W, C), weight, bias, with_z)
+    if isinstance(out, tuple):
+        return out[0].reshape(B, N, C), out[1].reshape(B, N, C)
+    return (out.reshape(B, N, C), None) if with_z else out.reshape(B, N, C)
 
 
 def dwconv3x3_nhwc(x, weight, bias=None, dilation=1):

@@ -40,12 +40,20 @@ class _LayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        return _ln_backward(ctx, gy, None)
+
+
+def _ln_backward(ctx, gy, add):
         x2, w32, mean, rstd = ctx.saved_tensors
         rows, C = x2.shape
+        if gy is None:                                     # only the pass-through output was used
+            return (add, None, None, None, None)
         if gy.dtype not in _DT:
             gy = gy.float()
         gy2 = gy.contiguous().view(rows, C)
         dx = torch.empty_like(x2)
+        if add is not None:
+            add = add.to(x2.dtype).contiguous().view(rows, C)
         # parameter gradients: straight into the flat gradient buffer when the trainer provides one
         sg, sb = grad_sink(ctx.weight), grad_sink(ctx.bias)
         direct = sg is not None and sb is not None
@@ -54,13 +62,44 @@ class _LayerNormFn(torch.autograd.Function):
         lib = _lib.load_library()
         ws = workspace(_LN_WS_ROWS * 2 * C * 4, x2.device)     # == rfn_layernorm_bwd_workspace_bytes(C)
         with on_device(x2.device):
-            rc = lib.rfn_layernorm_bwd(ptr(x2), ptr(gy2), ptr(w32), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db),
-                                       ptr(ws), rows, C, _DT[x2.dtype], _DT[gy2.dtype], 1 if direct else 0,
-                                       current_stream(x2.device))
+            if add is not None and C % 8 == 0:
+                rc = lib.rfn_layernorm_bwd_add(ptr(x2), ptr(gy2), ptr(add), ptr(w32), ptr(mean), ptr(rstd), ptr(dx), ptr(dg),
+                                               ptr(db), ptr(ws), rows, C, _DT[x2.dtype], _DT[gy2.dtype], 1 if direct else 0,
+                                               current_stream(x2.device))
+                add = None
+            else:
+                rc = lib.rfn_layernorm_bwd(ptr(x2), ptr(gy2), ptr(w32), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db),
+                                           ptr(ws), rows, C, _DT[x2.dtype], _DT[gy2.dtype], 1 if direct else 0,
+                                           current_stream(x2.device))
         _lib.check(rc, "layernorm_bwd")
+        if add is not None:
+            dx = dx + add
         if direct:
             return dx.view(ctx.shape), None, None, None, None
         return dx.view(ctx.shape), dg.to(ctx.wdtype), db.to(ctx.wdtype), None, None
+
+
+class _LayerNormPassFn(torch.autograd.Function):
+    """(LayerNorm(x), x) -- the second output is x itself, to be used as the residual operand of the branch that follows
+    (mix_transformer.py:203-207: `x + drop_path(f(norm(x)))`).  Both gradients then arrive HERE and are summed inside the
+    LayerNorm-backward kernel (rfn_layernorm_bwd_add) instead of by an element-wise kernel of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        y = _LayerNormFn.forward(ctx, x, weight, bias, eps, out_dtype)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gx_res):
+        return _ln_backward(ctx, gy, gx_res)
+
+
+def layer_norm_pass(x, weight, bias, eps=1e-5):
+    """-> (LayerNorm(x), x) with the residual gradient folded into the LayerNorm backward (HIP tensors, C % 8 == 0)."""
+    out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    if out_dtype not in _DT:
+        out_dtype = x.dtype
+    return _LayerNormPassFn.apply(x, weight, bias, eps, out_dtype)
 
 
 def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):

@@ -40,16 +40,21 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, w_c, b_c, res=None, rowscale=None):
+    def forward(ctx, x, weight, bias, w_c, b_c, res=None, rowscale=None, z=None):
         """With `res` (same shape as the output, compute dtype) and optionally `rowscale` ((B,) fp32, one value per
         leading-dimension sample): y = res + rowscale[b] * (x W^T + b) in the GEMM epilogue -- the stochastic-depth
         residual of mix_transformer.py:203-207 under autograd.  Backward: the residual's gradient is the incoming one;
         the branch's gradient diag(rowscale) g is never materialised: the scale rides in the epilogue of the input-
         gradient GEMM and in the operand staging of the weight-gradient kernel."""
+        # z (optional): x = gelu(z) was produced by the depthwise + GELU kernel of the Mix-FFN (mix_transformer.py:99-102), which
+        # hands over x as a NON-differentiable tensor together with its pre-activation; the gradient this function returns
+        # is then the one with respect to z, (dy W) * gelu'(z), made in the epilogue of the input-gradient GEMM (act = 4) --
+        # no gelu_backward pass over the 4C-wide hidden tensor
         ctx.weight, ctx.bias = weight, bias
         N, K = w_c.shape
         x2 = x.reshape(-1, K)
         ctx.rps = x2.shape[0] // x.shape[0] if rowscale is not None else 0
+        ctx.z = z
         if res is not None:
             ctx.save_for_backward(x, w_c, rowscale)
             y = mfma.gemm_nt(x2, w_c, b_c, res=res.reshape(-1, N), rowscale=rowscale, rows_per_sample=ctx.rps)
@@ -68,24 +73,41 @@ class _LinearFn(torch.autograd.Function):
         x, w_c, rowscale = ctx.saved_tensors
         N, K = w_c.shape
         gx = gw = gb = None
+        z = ctx.z
+        want_x = ctx.needs_input_grad[0] or (z is not None and ctx.needs_input_grad[7])
         g_res = gy if ctx.needs_input_grad[5] else None
+
+        def route(t):          # (gx, gw, gb, None, None, g_res, None, gz): the input gradient belongs to z when z was given
+            return (None,) + t[1:5] + (g_res, None, t[0]) if z is not None else t[:5] + (g_res, None, None)
         if rowscale is not None:
-            out = _LinearFn._backward_scaled(ctx, gy, x, w_c, rowscale)
+            out = _LinearFn._backward_scaled(ctx, gy, x, w_c, rowscale, want_x)
             if out is not None:
-                return out + (g_res, None)
+                return route(out)
             gy = gy * rowscale.to(gy.dtype).view((-1,) + (1,) * (gy.dim() - 1))
         if gy.dtype != w_c.dtype:
             gy = gy.to(w_c.dtype)
         g2 = gy.reshape(-1, N)
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        if ctx.needs_input_grad[0]:
+        if want_x:
             # dx = dy W = dy (W^T)^T: the NT kernel on the cached transposed 16-bit copy of the weight
-            gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype)) if mfma.ENABLED and w_c.dtype != torch.float32 \
-                else None
+            gx = None
+            if mfma.ENABLED and w_c.dtype != torch.float32:
+                if z is not None:
+                    gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype), res=z.reshape(-1, K), act=4)
+                    if gx is not None:
+                        z = None                           # gelu' applied in the epilogue
+                else:
+                    gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype))
+            if gx is None:
+                gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype)) if mfma.ENABLED and w_c.dtype != torch.float32 \
+                    else None
             if gx is None:
                 mfma.note_library("linear.dgrad", g2, w_c)
             gx = (torch.mm(g2, w_c) if gx is None else gx).view(x.shape)
+            if z is not None:
+                gx = torch.ops.aten.gelu_backward(gx, z.to(gx.dtype))
+            z = ctx.z
         need_w, need_b = ctx.needs_input_grad[1], ctx.bias is not None and ctx.needs_input_grad[2]
         sink_w, sink_b = grad_sink(ctx.weight), grad_sink(ctx.bias)
         part = None
@@ -95,7 +117,7 @@ class _LinearFn(torch.autograd.Function):
             # step -- hipGraph replays cross-stream branches with a synchronisation per edge.)
             x2 = x.reshape(-1, K)
             if mfma.gemm_tn(g2, x2, out=sink_w, bias_out=sink_b if need_b else None) is not None:
-                return gx, None, None, None, None, g_res, None
+                return route((gx, None, None, None, None))
         if need_w:
             x2 = x.reshape(-1, K)
             T = x2.shape[0]
@@ -112,7 +134,7 @@ class _LinearFn(torch.autograd.Function):
         # both gradients straight into the flat gradient buffer in two launches
         if need_w and need_b and sink_w is not None and sink_b is not None and _FUSED_GRADS and \
                 part.dtype == g2.dtype and linear_param_grads(g2, part, sink_b, sink_w.view(-1)):
-            return gx, None, None, None, None, g_res, None
+            return route((gx, None, None, None, None))
         if need_w:
             if sink_w is not None:
                 sum_rows(part, out=sink_w.view(-1), accumulate=True)
@@ -123,10 +145,10 @@ class _LinearFn(torch.autograd.Function):
                 sum_rows(g2, out=sink_b, accumulate=True)
             else:
                 gb = sum_rows(g2).to(ctx.bias.dtype)
-        return gx, gw, gb, None, None, g_res, None
+        return route((gx, gw, gb, None, None))
 
     @staticmethod
-    def _backward_scaled(ctx, gy, x, w_c, rowscale):
+    def _backward_scaled(ctx, gy, x, w_c, rowscale, want_x):
         """Backward of the branch y = res + diag(rowscale) (x W^T + b) on the kernels that take the scale as an argument;
         None if one of them declines (the caller then scales the gradient and takes the general path)."""
         N, K = w_c.shape
@@ -142,8 +164,12 @@ class _LinearFn(torch.autograd.Function):
         if (need_w and sink_w is None) or (need_b and sink_b is None) or (need_b and not need_w):
             return None
         gx = None
-        if ctx.needs_input_grad[0]:
-            gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype), rowscale=rowscale, rows_per_sample=ctx.rps)
+        if want_x:
+            if ctx.z is not None:
+                gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype), res=ctx.z.reshape(-1, K), rowscale=rowscale,
+                                  rows_per_sample=ctx.rps, act=4)
+            else:
+                gx = mfma.gemm_nt(g2, transposed(ctx.weight, w_c.dtype), rowscale=rowscale, rows_per_sample=ctx.rps)
             if gx is None:
                 return None
             gx = gx.view(x.shape)
@@ -164,7 +190,7 @@ def linear_tokens(x2, weight, bias, cd):
     w_c = w_c.view(w_c.shape[0], -1)
     b_c = as_dtype(bias, cd)
     if torch.is_grad_enabled() and (weight.requires_grad or x2.requires_grad):
-        return _LinearFn.apply(x2, weight, bias, w_c, b_c, None, None)
+        return _LinearFn.apply(x2, weight, bias, w_c, b_c, None, None, None)
     y = mfma.gemm_nt(x2, w_c, b_c)
     if y is None:
         mfma.note_library("linear.fwd", x2, w_c)
@@ -172,8 +198,8 @@ def linear_tokens(x2, weight, bias, cd):
 
 
 class Linear(nn.Linear):
-    def forward(self, x, res=None, rowscale=None):
-        """y = x W^T + b.  Gradient-free callers may pass `res` (same shape as y) and a per-sample fp32 `rowscale`
+    def forward(self, x, res=None, rowscale=None, z=None):
+        """y = x W^T + b.  `z`: see _LinearFn (x = gelu(z), gradient routed to z).  Gradient-free callers may pass `res` (same shape as y) and a per-sample fp32 `rowscale`
         (B,): y = res + rowscale[b] * (x W^T + b), the stochastic-depth residual of mix_transformer.py:203-207 fused
         into the GEMM epilogue."""
         if not x.is_cuda:
@@ -192,8 +218,8 @@ class Linear(nn.Linear):
             if res is not None and _FUSED_RESIDUAL and mfma.ENABLED and cd != torch.float32 and res.dtype == cd and \
                     res.is_contiguous() and x.is_contiguous() and w_c.shape[1] % 64 == 0 and w_c.shape[0] % 64 == 0 and \
                     grad_sink(self.weight) is not None and (self.bias is None or grad_sink(self.bias) is not None):
-                return _LinearFn.apply(x, self.weight, self.bias, w_c, b_c, res, rowscale)
-            y = _LinearFn.apply(x, self.weight, self.bias, w_c, b_c, None, None)
+                return _LinearFn.apply(x, self.weight, self.bias, w_c, b_c, res, rowscale, z)
+            y = _LinearFn.apply(x, self.weight, self.bias, w_c, b_c, None, None, z)
             return y if res is None else _residual(res, y, rowscale)
         N, K = w_c.shape
         x2 = x.reshape(-1, K)

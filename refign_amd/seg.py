@@ -117,6 +117,16 @@ class Mlp(nn.Module):
                 and os.environ.get("RFN_FUSED_DWGELU", "1") != "0":
             from .dwconv import dwconv3x3_gelu_tokens           # depthwise conv + GELU in one pass (csrc/dwconv.hip)
             dw = self.dwconv.dwconv
+            if torch.is_grad_enabled() and x.requires_grad and self.drop.p == 0. and x.dtype in (torch.bfloat16, torch.float16) \
+                    and os.environ.get("RFN_FUSED_GELU_BWD", "0") == "1":
+                # opt-in (RFN_FUSED_GELU_BWD=1): the activation + its pre-activation; fc2's input-gradient GEMM applies gelu' in
+                # its epilogue instead of a gelu_backward pass over the 4C-wide hidden tensor.  Built, parity-tested
+                # (test_mix_ffn_gelu_backward_in_the_fc2_dgrad_epilogue), measured NEUTRAL on the step (182.4 / 183.0 vs 182.4 /
+                # 182.5 ms: what the 156 launches cost is what the erf in 156 GEMM epilogues costs)
+                a, z = dwconv3x3_gelu_tokens(x, dw.weight, dw.bias, H, W, with_z=True)
+                if res is not None:
+                    return self.fc2(a, res=res, rowscale=rowscale, z=z)
+                return self.fc2(a, z=z)
             x = self.drop(dwconv3x3_gelu_tokens(x, dw.weight, dw.bias, H, W))
         else:
             x = self.drop(self.act(self.dwconv(x, H, W)))
@@ -199,6 +209,20 @@ def _residual(res, y, rowscale):
     return torch.addcmul(res, y, rowscale.to(y.dtype).view((-1,) + (1,) * (y.dim() - 1)))
 
 
+_LN_PASS = os.environ.get("RFN_LN_PASS", "1") != "0"
+
+
+def _norm_pass(norm, x):
+    """(norm(x), x') where x' is x to be used as the residual operand of the branch: under autograd on the GPU the two
+    gradients of x (through the LayerNorm and through the residual add) are then summed inside the LayerNorm-backward kernel
+    (layernorm.layer_norm_pass) instead of by an element-wise launch of the autograd engine."""
+    if _LN_PASS and x.is_cuda and torch.is_grad_enabled() and x.requires_grad and type(norm) is LayerNorm and x.shape[-1] % 8 == 0 \
+            and x.shape[-1] <= 1024 and x.dtype in (torch.float32, torch.bfloat16) and len(norm.normalized_shape) == 1:
+        from .layernorm import layer_norm_pass
+        return layer_norm_pass(x, norm.weight, norm.bias, norm.eps)
+    return norm(x), x
+
+
 class Block(nn.Module):
     """Pre-norm transformer block with stochastic depth (mix_transformer.py:167-207)."""
 
@@ -226,14 +250,18 @@ class Block(nn.Module):
             if x.is_cuda and masks32 is not None and _linear._FUSED_RESIDUAL:
                 # training (RFN_FUSED_RESIDUAL, on): the same fusion under autograd (linear._LinearFn: residual + per-sample scale in the proj /
                 # fc2 GEMM epilogue; in the backward the scale rides in the input- and weight-gradient kernels)
-                x = self.attn(self.norm1(x), H, W, res=x, rowscale=masks32[0])
-                return self.mlp(self.norm2(x), H, W, res=x, rowscale=masks32[1])
+                n, xa = _norm_pass(self.norm1, x)
+                x = self.attn(n, H, W, res=xa, rowscale=masks32[0])
+                n, xa = _norm_pass(self.norm2, x)
+                return self.mlp(n, H, W, res=xa, rowscale=masks32[1])
             x = torch.addcmul(x, self.attn(self.norm1(x), H, W), masks[0])
             return torch.addcmul(x, self.mlp(self.norm2(x), H, W), masks[1])
         dp = self.drop_path
         if x.is_cuda and _linear._FUSED_RESIDUAL and not (self.training and isinstance(dp, DropPath) and dp.drop_prob > 0.):
-            x = self.attn(self.norm1(x), H, W, res=x)
-            return self.mlp(self.norm2(x), H, W, res=x)
+            n, xa = _norm_pass(self.norm1, x)
+            x = self.attn(n, H, W, res=xa)
+            n, xa = _norm_pass(self.norm2, x)
+            return self.mlp(n, H, W, res=xa)
         res = dp.residual if isinstance(dp, DropPath) else torch.add
         x = res(x, self.attn(self.norm1(x), H, W))
         return res(x, self.mlp(self.norm2(x), H, W))

@@ -62,3 +62,32 @@ def test_linear_split_weight_grad_matches_nn_linear(dev):
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-3, atol=1e-2)
     assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 320, 512])
+def test_layernorm_pass_through_sums_both_gradients(dev, dtype, C):
+    """layernorm.layer_norm_pass: (LayerNorm(x), x) whose backward sums the gradient through the norm and the gradient of the
+    pass-through output INSIDE the LayerNorm-backward kernel (rfn_layernorm_bwd_add) == autograd's own sum."""
+    from refign_amd.layernorm import LayerNorm, layer_norm_pass
+    torch.manual_seed(C)
+    ln = LayerNorm(C, eps=1e-6).to(dev)
+    x = torch.randn(3, 257, C, device=dev).to(dtype)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    g1, g2 = torch.randn_like(x), torch.randn_like(x)
+    y, xp = layer_norm_pass(xa, ln.weight, ln.bias, ln.eps)
+    assert xp.data_ptr() == xa.data_ptr()
+    torch.autograd.backward([y, xp], [g1, g2])
+    wg, bg = ln.weight.grad.clone(), ln.bias.grad.clone()
+    ln.zero_grad()
+    yb = ln(xb)
+    torch.autograd.backward([yb, xb * 1.0], [g1, g2])
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert torch.equal(y, yb)
+    assert float((xa.grad.float() - xb.grad.float()).abs().max()) <= tol * float(xb.grad.float().abs().max())
+    assert torch.allclose(wg, ln.weight.grad, rtol=1e-4, atol=1e-4) and torch.allclose(bg, ln.bias.grad, rtol=1e-4, atol=1e-4)
+    # only the pass-through output used: the gradient passes through untouched
+    xc = x.clone().requires_grad_()
+    _, xp = layer_norm_pass(xc, ln.weight, ln.bias, ln.eps)
+    xp.backward(g2)
+    assert torch.equal(xc.grad, g2)

@@ -354,3 +354,47 @@ def test_linear_fused_residual_and_drop_path_under_autograd(dev, dtype, B, T, K,
     if scaled:                                                        # dropped samples contribute nothing at all
         assert float(x.grad[0].abs().max()) == 0.0
     del buf
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 12, 20), (320, 9, 14)])
+@pytest.mark.parametrize("fused_res", [False, True])
+def test_mix_ffn_gelu_backward_in_the_fc2_dgrad_epilogue(dev, C, H, W, fused_res, monkeypatch):
+    """Mix-FFN (mix_transformer.py:79-103) under bf16 autocast with gelu' applied in the epilogue of fc2's input-gradient
+    GEMM (rfn_gemm_nt act = 4; erf by Abramowitz-Stegun 7.1.26) against the same module with the separate gelu_backward
+    pass and against an fp32 formulation: output, input gradient, every parameter gradient."""
+    import torch.nn.functional as F
+    from refign_amd import linear, seg
+    from refign_amd.trainer import FlatGradBuffer
+    monkeypatch.setattr(linear, "_FUSED_RESIDUAL", fused_res)
+    torch.manual_seed(C)
+    B = 3
+
+    def run(flag):
+        monkeypatch.setenv("RFN_FUSED_GELU_BWD", flag)
+        torch.manual_seed(C)
+        mlp = seg.Mlp(C, 4 * C).to(dev)
+        FlatGradBuffer(list(mlp.parameters()))
+        x = _rand((B, H * W, C), dev, torch.bfloat16, 60).requires_grad_(True)
+        res = _rand((B, H * W, C), dev, torch.bfloat16, 61).requires_grad_(True)
+        rs = torch.tensor([1.2, 0.0, 1.2], device=dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mlp(x, H, W, res=res, rowscale=rs)
+        y.backward(_rand(tuple(y.shape), dev, torch.bfloat16, 62))
+        return mlp, x, res, y
+
+    m1, x1, r1, y1 = run("1")
+    m0, x0, r0, y0 = run("0")
+    assert torch.equal(y1, y0)
+    for a, b in [(x1.grad, x0.grad), (r1.grad, r0.grad)] + [(p.grad, q.grad) for p, q in zip(m1.parameters(), m0.parameters())]:
+        assert float((a.float() - b.float()).abs().max()) <= 3e-2 * float(b.float().abs().max()) + 1e-6
+    # fp32 reference of the same function
+    xr = x1.detach().float().requires_grad_(True)
+    w = {k: v.detach().float().requires_grad_(True) for k, v in m1.named_parameters()}
+    h = F.linear(xr, w["fc1.weight"], w["fc1.bias"]).view(B, H, W, 4 * C).permute(0, 3, 1, 2)
+    h = F.gelu(F.conv2d(h, w["dwconv.dwconv.weight"], w["dwconv.dwconv.bias"], padding=1, groups=4 * C))
+    yr = r1.detach().float() + torch.tensor([1.2, 0.0, 1.2], device=dev).view(B, 1, 1) * \
+        F.linear(h.permute(0, 2, 3, 1).reshape(B, H * W, 4 * C), w["fc2.weight"], w["fc2.bias"])
+    yr.backward(_rand(tuple(yr.shape), dev, torch.bfloat16, 62).float())
+    assert float((x1.grad.float() - xr.grad).abs().max()) <= 4e-2 * float(xr.grad.abs().max())
+    for k, p in m1.named_parameters():
+        assert float((p.grad - w[k].grad).abs().max()) <= 4e-2 * float(w[k].grad.abs().max()) + 1e-4, k
