@@ -352,7 +352,8 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
  * teacher.  dtype 1 = bf16, 2 = f16; statistics, affine parameters and running buffers fp32; C % 8 == 0.
  * `relu`: activation after the affine map, 0 none, 1 ReLU, 3 LeakyReLU(0.1) (the codes of rfn_gemm_nt; the flow decoders
  * of the matcher use LeakyReLU, models/modules.py:395-477).
- * Statistics buffer `sums`: 2 C + 1 floats = (sum x, sum x^2, number of rows); the apply passes normalise with the row
+ * Statistics buffer `sums`: 2 C + 1 DOUBLES = (sum x, sum x^2, number of rows) -- fp64 from the first addition, so that the
+ * one-pass variance E[x^2] - mean^2 does not cancel (csrc/bn.hip header); the apply passes normalise with the row
  * count they find THERE, so a SUM all-reduce of the buffer between a stats pass and an apply pass turns batch statistics
  * into cross-replica ones -- SyncBatchNorm (torch/nn/modules/_functions.py:SyncBatchNorm; the reference trains with
  * `sync_batchnorm: True`).  `bwd_sums`: 2 C floats.
@@ -363,17 +364,17 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
  *   rfn_bn_apply_bwd  grad_x = gamma rstd (g' - (bwd_sums[0] + xhat bwd_sums[1]) / rows)
  *   rfn_bn_train_fwd / _bwd   one replica: the two passes back to back
  * ---------------------------------------------------------------------------------------------------------- */
-int rfn_bn_stats_fwd(const void* x, float* sums, long T, int C, int dtype, rfn_stream_t stream);
-int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* running_mean,
+int rfn_bn_stats_fwd(const void* x, double* sums, long T, int C, int dtype, rfn_stream_t stream);
+int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void* y, const double* sums, float* running_mean,
                      float* running_var, long T, int C, float eps, float momentum, int relu, int dtype, rfn_stream_t stream);
-int rfn_bn_stats_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
+int rfn_bn_stats_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* gamma, const float* beta,
                      float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
-int rfn_bn_apply_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* bwd_sums, const float* gamma,
+int rfn_bn_apply_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* bwd_sums, const float* gamma,
                      const float* beta, void* grad_x, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
-int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* sums, float* running_mean,
+int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, double* sums, float* running_mean,
                      float* running_var, long T, int C, float eps, float momentum, int relu, int dtype,
                      rfn_stream_t stream);
-int rfn_bn_train_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
+int rfn_bn_train_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* gamma, const float* beta,
                      void* grad_x, float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
 
 /* fp32-RESULT variants (split-bf16 parity mode, refign_amd/split32.py): bf16 operands whose reduction index carries the

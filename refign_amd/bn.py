@@ -125,7 +125,7 @@ class _BNActTrain(torch.autograd.Function):
         # xh: (B, H, W, C) contiguous, 16-bit
         C = xh.shape[-1]
         y = torch.empty_like(xh)
-        sums = torch.empty(2 * C + 1, dtype=torch.float32, device=xh.device)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=xh.device)     # fp64: csrc/bn.hip header
         _stats_fwd(xh, sums)
         comm = _exchange_comm(bn) if group is not None else None
         if group is not None:

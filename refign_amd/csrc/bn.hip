@@ -2,7 +2,7 @@
 // the norm + activation of every ConvBNReLU of the decode heads (models/modules.py:16-56; daformer.py:65-126,
 // segformer.py:62-70), which run with BATCH statistics in the student AND in the EMA teacher.
 //
-//   forward   stats pass : sums[0][c] = sum_t x[t,c], sums[1][c] = sum_t x[t,c]^2          (fp32 atomics, pre-zeroed)
+//   forward   stats pass : sums[0][c] = sum_t x[t,c], sums[1][c] = sum_t x[t,c]^2          (fp64, pre-zeroed)
 //             apply pass : y = relu?( (x - mean) * rstd * gamma + beta ), running statistics updated by block 0
 //   backward  stats pass : sums[0][c] = sum_t g'[t,c], sums[1][c] = sum_t g'[t,c] * xhat[t,c],  g' = g * (y > 0)
 //             apply pass : dx = gamma * rstd * ( g' - (sums[0] + xhat * sums[1]) / T )
@@ -10,13 +10,21 @@
 // implementation moves); what is fused away are the separate ReLU / ReLU-backward passes and the per-call
 // normalisation-constant kernels.  Lanes run along channels (16-byte vectors), rows are strided over lanes.
 //
+// The forward sums are DOUBLES from the first addition to the atomics: the variance is E[x^2] - mean^2, which cancels
+// catastrophically in fp32 once |mean| >> std over ~1e6 rows (torch's BatchNorm uses Welford / two passes for that
+// reason); in fp64 the one-pass formula has 29 more bits than the 16-bit inputs can use, and the order of the atomics no
+// longer shows in the fp32 constants derived from the sums.  The kernels stay HBM-bound (16 fp64 operations per 16-byte
+// load).  The backward sums have no cancellation and stay fp32.
+//
 // Data parallelism (SyncBatchNorm, torch/nn/modules/_functions.py: the reference trains with `sync_batchnorm: True`): the
-// statistics buffer is 2 C + 1 floats, the last one the number of rows the sums were taken over -- the stats pass adds
+// statistics buffer is 2 C + 1 doubles, the last one the number of rows the sums were taken over -- the stats pass adds
 // its own T there -- so that ONE all-reduce (SUM) of the buffer between the stats pass and the apply pass turns local
 // statistics into global ones; the apply passes normalise with the count they find in the buffer, never with T.  The
 // four phases are separate entry points for that (rfn_bn_stats_fwd / _apply_fwd / _stats_bwd / _apply_bwd); the
 // parameter gradients are the LOCAL backward sums (read before the exchange), as in SyncBatchNorm.
 #include <hip/hip_bf16.h>
+
+#include <type_traits>
 
 #include "common.h"
 #include "mfma.h"
@@ -40,23 +48,28 @@ template <int DT> __device__ __forceinline__ void store8(uint16_t* p, const floa
 }
 
 // per-channel constants from the forward sums
-__device__ __forceinline__ void norm_consts(const float* sums, int C, int c, float invT, float eps, float& mean, float& rstd) {
+__device__ __forceinline__ float batch_var(const double* sums, int C, int c, double invT, float& mean) {
   // invT = 1 / sums[2 C]: the (global) number of rows behind the sums
-  mean = sums[c] * invT;
-  const float var = fmaxf(sums[C + c] * invT - mean * mean, 0.f);
-  rstd = rsqrtf(var + eps);
+  const double m = sums[c] * invT;
+  mean = (float)m;
+  return (float)fmax(sums[C + c] * invT - m * m, 0.0);
+}
+__device__ __forceinline__ void norm_consts(const double* sums, int C, int c, double invT, float eps, float& mean, float& rstd) {
+  rstd = rsqrtf(batch_var(sums, C, c, invT, mean) + eps);
 }
 
 // BWD = false: sums of x and x^2.  BWD = true: sums of g' and g' * xhat (fwd_sums give mean / rstd, gamma / beta the sign of y)
 template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ g,
-                                                       const float* __restrict__ fwd_sums, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ sums, long T,
+                                                       const double* __restrict__ fwd_sums, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, void* __restrict__ sums_, long T,
                                                        int C, int cvb, float eps, int relu, float slope) {
-  __shared__ float red[2][256][8];
+  using ST = typename std::conditional<BWD, float, double>::type;      // forward sums: doubles (header)
+  ST* __restrict__ sums = (ST*)sums_;
+  __shared__ ST red[2][256][8];
   const int CV = C / 8, pl = 256 / cvb;
   const int cv = blockIdx.x * cvb + threadIdx.x % cvb, rl = threadIdx.x / cvb;
-  float s0[8] = {0}, s1[8] = {0};
+  ST s0[8] = {0}, s1[8] = {0};
   if (cv < CV) {
     const int c0 = cv * 8;
     float mean[8], a[8], b[8];
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float r;
-        norm_consts(fwd_sums, C, c0 + i, 1.f / fwd_sums[2 * C], eps, mean[i], r);
+        norm_consts(fwd_sums, C, c0 + i, 1.0 / fwd_sums[2 * C], eps, mean[i], r);
         a[i] = r;                                                       // xhat = (x - mean) * rstd
         b[i] = (gamma ? gamma[c0 + i] : 1.f);
       }
@@ -75,8 +88,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
       if (!BWD) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          s0[i] += xv[i];
-          s1[i] += xv[i] * xv[i];
+          s0[i] += (ST)xv[i];
+          s1[i] += (ST)xv[i] * (ST)xv[i];
         }
       } else {
         float gv[8];
@@ -103,31 +116,31 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
     const int which = idx / (cvb * 8), rem = idx % (cvb * 8), v = rem / 8, e = rem % 8;
     const int cvg = blockIdx.x * cvb + v;
     if (cvg >= CV) continue;
-    float sum = 0.f;
+    ST sum = 0;
     for (int r = 0; r < pl; ++r) sum += red[which][r * cvb + v][e];
     atomicAdd(sums + which * C + cvg * 8 + e, sum);
   }
-  if (!BWD && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(sums + 2 * C, (float)T);
+  if (!BWD && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(sums + 2 * C, (ST)T);
 }
 
 template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ g,
-                                                       const float* __restrict__ fwd_sums, const float* __restrict__ bwd_sums,
+                                                       const double* __restrict__ fwd_sums, const float* __restrict__ bwd_sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        uint16_t* __restrict__ out, float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, long T, int C, int cvb, float eps,
                                                        float momentum, int relu, float slope) {
   const int CV = C / 8, pl = 256 / cvb;
   const int cv = blockIdx.x * cvb + threadIdx.x % cvb, rl = threadIdx.x / cvb;
-  const float cnt = fwd_sums[2 * C];                   // rows behind the statistics (all ranks')
-  const float invT = 1.f / cnt;
+  const double invTd = 1.0 / fwd_sums[2 * C];          // rows behind the statistics (all ranks')
+  const float cnt = (float)fwd_sums[2 * C], invT = (float)invTd;
   if (!BWD && running_mean != nullptr && blockIdx.y == 0 && rl == 0 && cv < CV) {
     // running statistics: mean and UNBIASED variance of this batch, as nn.BatchNorm2d
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = cv * 8 + i;
-      const float mean = fwd_sums[c] * invT;
-      const float var = fmaxf(fwd_sums[C + c] * invT - mean * mean, 0.f);
+      float mean;
+      const float var = batch_var(fwd_sums, C, c, invTd, mean);
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (cnt / fmaxf(cnt - 1.f, 1.f));
     }
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
   float mean[8], rstd[8], gm[8], bt[8], k0[8], k1[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    norm_consts(fwd_sums, C, c0 + i, invT, eps, mean[i], rstd[i]);
+    norm_consts(fwd_sums, C, c0 + i, invTd, eps, mean[i], rstd[i]);
     gm[i] = gamma ? gamma[c0 + i] : 1.f;
     bt[i] = beta ? beta[c0 + i] : 0.f;
     if (BWD) {
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
 static inline int bn_cvb(int CV) { return CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV >= 16 ? 16 : 8)); }
 
 template <int DT>
-static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const float* fwd_sums, float* sums_or_bwd,
+static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const double* fwd_sums, void* sums_or_bwd,
                      const float* gamma, const float* beta, void* out, float* rmean, float* rvar, long T, int C, float eps,
                      float momentum, int relu, float slope, hipStream_t s) {
   const int CV = C / 8, cvb = bn_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
@@ -188,7 +201,7 @@ static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const f
   } else {
     if (bwd)
       hipLaunchKernelGGL((bn_apply_kernel<DT, true>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)g, fwd_sums,
-                         sums_or_bwd, gamma, beta, (uint16_t*)out, nullptr, nullptr, T, C, cvb, eps, momentum, relu, slope);
+                         (const float*)sums_or_bwd, gamma, beta, (uint16_t*)out, nullptr, nullptr, T, C, cvb, eps, momentum, relu, slope);
     else
       hipLaunchKernelGGL((bn_apply_kernel<DT, false>), grid, block, 0, s, (const uint16_t*)x, nullptr, fwd_sums, nullptr,
                          gamma, beta, (uint16_t*)out, rmean, rvar, T, C, cvb, eps, momentum, relu, slope);
@@ -212,15 +225,15 @@ static int bn_check(const char* what, long T, int C, int dtype) {
   return RFN_OK;
 }
 
-int rfn_bn_stats_fwd(const void* x, float* sums, long T, int C, int dtype, rfn_stream_t stream) {
+int rfn_bn_stats_fwd(const void* x, double* sums, long T, int C, int dtype, rfn_stream_t stream) {
   RFN_REQUIRE(x && sums, "bn_stats_fwd: null pointer");
   if (int rc = bn_check("bn_stats_fwd", T, C, dtype)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = zero_async(sums, (2 * (size_t)C + 1) * sizeof(float), s)) return rc;   // kernel, not a memset node (capi.hip)
+  if (int rc = zero_async(sums, (2 * (size_t)C + 1) * sizeof(double), s)) return rc;   // kernel, not a memset node (capi.hip)
   return RFN_BN_DISPATCH(false, false, x, nullptr, nullptr, sums, nullptr, nullptr, nullptr, nullptr, nullptr, T, C, 0.f, 0.f, 0, 0.f, s);
 }
 
-int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* running_mean,
+int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void* y, const double* sums, float* running_mean,
                      float* running_var, long T, int C, float eps, float momentum, int relu, int dtype, rfn_stream_t stream) {
   RFN_REQUIRE(x && y && sums, "bn_apply_fwd: null pointer");
   if (int rc = bn_check("bn_apply_fwd", T, C, dtype)) return rc;
@@ -228,7 +241,7 @@ int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void*
                          relu != 0, bn_slope(relu), (hipStream_t)stream);
 }
 
-int rfn_bn_stats_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
+int rfn_bn_stats_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* gamma, const float* beta,
                      float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream) {
   RFN_REQUIRE(x && grad_y && fwd_sums && bwd_sums, "bn_stats_bwd: null pointer");
   if (int rc = bn_check("bn_stats_bwd", T, C, dtype)) return rc;
@@ -237,16 +250,16 @@ int rfn_bn_stats_bwd(const void* x, const void* grad_y, const float* fwd_sums, c
   return RFN_BN_DISPATCH(true, false, x, grad_y, fwd_sums, bwd_sums, gamma, beta, nullptr, nullptr, nullptr, T, C, eps, 0.f, relu != 0, bn_slope(relu), s);
 }
 
-int rfn_bn_apply_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* bwd_sums, const float* gamma,
+int rfn_bn_apply_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* bwd_sums, const float* gamma,
                      const float* beta, void* grad_x, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream) {
   RFN_REQUIRE(x && grad_y && fwd_sums && bwd_sums && grad_x, "bn_apply_bwd: null pointer");
   if (int rc = bn_check("bn_apply_bwd", T, C, dtype)) return rc;
-  return RFN_BN_DISPATCH(true, true, x, grad_y, fwd_sums, const_cast<float*>(bwd_sums), gamma, beta, grad_x, nullptr, nullptr, T, C, eps,
+  return RFN_BN_DISPATCH(true, true, x, grad_y, fwd_sums, (void*)bwd_sums, gamma, beta, grad_x, nullptr, nullptr, T, C, eps,
                          0.f, relu != 0, bn_slope(relu), (hipStream_t)stream);
 }
 
-// one rank: stats + apply back to back (`sums`: 2 C + 1 floats)
-int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* sums, float* running_mean,
+// one rank: stats + apply back to back (`sums`: 2 C + 1 doubles)
+int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void* y, double* sums, float* running_mean,
                      float* running_var, long T, int C, float eps, float momentum, int relu, int dtype,
                      rfn_stream_t stream) {
   RFN_REQUIRE(T > 1, "bn_train_fwd: T=%ld", T);
@@ -254,7 +267,7 @@ int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void*
   return rfn_bn_apply_fwd(x, gamma, beta, y, sums, running_mean, running_var, T, C, eps, momentum, relu, dtype, stream);
 }
 
-int rfn_bn_train_bwd(const void* x, const void* grad_y, const float* fwd_sums, const float* gamma, const float* beta,
+int rfn_bn_train_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* gamma, const float* beta,
                      void* grad_x, float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream) {
   if (int rc = rfn_bn_stats_bwd(x, grad_y, fwd_sums, gamma, beta, bwd_sums, T, C, eps, relu, dtype, stream)) return rc;
   return rfn_bn_apply_bwd(x, grad_y, fwd_sums, bwd_sums, gamma, beta, grad_x, T, C, eps, relu, dtype, stream);

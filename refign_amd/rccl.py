@@ -24,7 +24,7 @@ import os
 import torch
 import torch.distributed as dist
 
-_NCCL_FLOAT32, _NCCL_SUM = 7, 0          # ncclDataType_t / ncclRedOp_t (nccl.h)
+_NCCL_DTYPE, _NCCL_SUM = {torch.float32: 7, torch.float64: 8}, 0          # ncclDataType_t / ncclRedOp_t (nccl.h)
 
 
 class _UniqueId(ctypes.Structure):
@@ -49,7 +49,7 @@ def _rccl():
         lib.ncclGetErrorString.restype = ctypes.c_char_p
         for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclCommDestroy):
             f.restype = ctypes.c_int
-        # ABI check: the enum values and the 128-byte id above are those of the NCCL 2.x API (nccl.h: ncclFloat32 = 7,
+        # ABI check: the enum values and the 128-byte id above are those of the NCCL 2.x API (nccl.h: ncclFloat32 = 7, ncclFloat64 = 8,
         # ncclSum = 0, NCCL_UNIQUE_ID_BYTES = 128, unchanged since 2.0); refuse anything else instead of guessing
         lib.ncclGetVersion.argtypes = [ctypes.POINTER(ctypes.c_int)]
         lib.ncclGetVersion.restype = ctypes.c_int
@@ -96,12 +96,12 @@ class DirectComm:
         _LIVE.append(self)
 
     def all_reduce_(self, t):
-        """in-place sum of a contiguous float32 tensor over the ranks, on the CURRENT stream of its device"""
-        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
-            raise RuntimeError("rccl.DirectComm.all_reduce_: contiguous float32 tensor on the communicator's device")
+        """in-place sum of a contiguous float32 / float64 tensor over the ranks, on the CURRENT stream of its device"""
+        if t.dtype not in _NCCL_DTYPE or not t.is_contiguous() or t.device != self.device:
+            raise RuntimeError("rccl.DirectComm.all_reduce_: contiguous float32/float64 tensor on the communicator's device")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            _check(_rccl().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _NCCL_FLOAT32, _NCCL_SUM, self._comm,
+            _check(_rccl().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _NCCL_DTYPE[t.dtype], _NCCL_SUM, self._comm,
                                          stream), "ncclAllReduce")
         return t
 

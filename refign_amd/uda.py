@@ -522,6 +522,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
                 and self._graphs["source_pass"].captured() and self._overlap_teacher(x)):
             return None
         if getattr(self, "_mix_stream", None) is None or self._mix_stream.device != x.device:
+            # default priority: a second high-priority stream lands on the side stream's hardware queue and the step
+            # goes from 181 to 246 ms (measured, round 3)
             self._mix_stream = torch.cuda.Stream(device=x.device)
         return self._mix_stream
 

@@ -1,11 +1,11 @@
 """Test infrastructure (NOT product code): torch restatements of the four passes of refign_amd/csrc/bn.hip, same buffer
-conventions (sums = (sum x, sum x^2, rows), bwd_sums = (sum g', sum g' xhat)), so that the statistics-exchange logic of
+conventions (sums = (sum x, sum x^2, rows) in fp64, bwd_sums = (sum g', sum g' xhat)), so that the statistics-exchange logic of
 refign_amd/bn.py can run on CPU tensors over gloo.  install() puts them in place of the kernel launchers."""
 import torch
 
 
 def stats_fwd(xh, sums):
-    x = xh.float().reshape(-1, xh.shape[-1])
+    x = xh.double().reshape(-1, xh.shape[-1])
     c = x.shape[1]
     sums[:c] = x.sum(0)
     sums[c:2 * c] = (x * x).sum(0)
@@ -15,8 +15,8 @@ def stats_fwd(xh, sums):
 def _consts(sums, c, eps):
     n = sums[2 * c]
     mean = sums[:c] / n
-    var = (sums[c:2 * c] / n - mean * mean).clamp_min(0)
-    return n, mean, var, torch.rsqrt(var + eps)
+    var = (sums[c:2 * c] / n - mean * mean).clamp_min(0).float()
+    return n.float(), mean.float(), var, torch.rsqrt(var + eps)
 
 
 def apply_fwd(xh, weight, bias, y, sums, bn, relu):

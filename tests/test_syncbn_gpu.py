@@ -58,7 +58,7 @@ def test_split_phase_kernels_with_added_buffers_equal_full_batch(dev, dtype, rel
     mods = [torch.nn.BatchNorm2d(C).to(dev) for _ in parts]
     xs = [full[a:b].contiguous() for a, b in parts]
     gs = [gfull[a:b].contiguous() for a, b in parts]
-    sums = [torch.empty(2 * C + 1, device=dev) for _ in parts]
+    sums = [torch.empty(2 * C + 1, device=dev, dtype=torch.float64) for _ in parts]
     for x, s in zip(xs, sums):
         bnk._stats_fwd(x, s)
     tot = sums[0] + sums[1]
@@ -84,6 +84,35 @@ def test_split_phase_kernels_with_added_buffers_equal_full_batch(dev, dtype, rel
     for m in mods:                                   # every replica tracks the statistics of the WHOLE batch
         assert torch.allclose(m.running_mean, ref.running_mean, atol=1e-4)
         assert torch.allclose(m.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+
+
+def test_statistics_of_a_far_off_centre_channel(dev):
+    """|mean| >> std over a million rows: the one-pass variance E[x^2] - mean^2 would lose every digit in fp32
+    (mean^2 = 1e6, var = 1/16: 7 decimal digits are gone before the subtraction).  The statistics buffer is fp64
+    (csrc/bn.hip header): batch and running statistics agree with an fp64 two-pass reference."""
+    from refign_amd import bn as bnk
+    torch.manual_seed(5)
+    C, T = 16, 1 << 20
+    x = (torch.randn(T, C, device=dev) * 0.25 + torch.linspace(-1000.0, 1000.0, C, device=dev)).to(torch.float16)
+    x = x.view(4, 512, 512, C)
+    xd = x.double().view(-1, C)
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    sums = torch.empty(2 * C + 1, device=dev, dtype=torch.float64)
+    bnk._stats_fwd(x, sums)
+    got_mean = sums[:C] / T
+    got_var = sums[C:2 * C] / T - got_mean * got_mean
+    assert float(sums[2 * C]) == T
+    assert float((got_mean - mean).abs().max()) < 1e-6
+    assert float(((got_var - var) / var).abs().max()) < 1e-6
+    mod = torch.nn.BatchNorm2d(C).to(dev)
+    y = torch.empty_like(x)
+    bnk._apply_fwd(x, mod.weight.detach(), mod.bias.detach(), y, sums, mod, False)
+    want = ((xd - mean) * torch.rsqrt(var + mod.eps)).view_as(x)
+    assert float((y.double() - want).abs().max()) < 2.0 ** -9 * float(want.abs().max())
+    assert torch.allclose(mod.running_var.double(), 0.9 + 0.1 * var * T / (T - 1), rtol=1e-5)
+    again = torch.empty_like(sums)
+    bnk._stats_fwd(x, again)
+    assert torch.equal((again[:2 * C] / T).float(), (sums[:2 * C] / T).float())     # atomic order does not show in fp32
 
 
 def _two_rank_worker(rank, world, port, out):
