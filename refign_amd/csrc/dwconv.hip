@@ -76,15 +76,7 @@ struct VecIO<__hip_bfloat16> {
       v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
   }
-  __device__ static unsigned pack(float lo, float hi) {
-    // round-to-nearest-even fp32 -> bf16 (matches torch's conversion)
-    auto rne = [](float f) -> unsigned {
-      unsigned u = __float_as_uint(f);
-      if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN
-      return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    };
-    return rne(lo) | (rne(hi) << 16);
-  }
+  __device__ static unsigned pack(float lo, float hi) { return bf16x2_bits(lo, hi); }   // common.h: one v_cvt_pk_bf16_f32
   __device__ static void store(__hip_bfloat16* p, const float (&v)[8]) {
     uint4 t;
     t.x = pack(v[0], v[1]); t.y = pack(v[2], v[3]); t.z = pack(v[4], v[5]); t.w = pack(v[6], v[7]);
@@ -225,7 +217,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
         if (!ACT || y != nullptr) VecIO<T>::store(y + obase + (size_t)(w0 + p * dil) * C, o);
         if (ACT) {
 #pragma unroll
-          for (int i = 0; i < V; ++i) o[i] = 0.5f * o[i] * (1.f + erff(o[i] * 0.70710678118654752440f)) * (F8 ? oq : 1.f);
+          for (int i = 0; i < V; ++i) {
+            // fp32 activations (parity mode): libm's erff; 16-bit / e4m3 results: mfma.h gelu_erf_fast
+            if constexpr (sizeof(T) == 4) o[i] = 0.5f * o[i] * (1.f + erff(o[i] * 0.70710678118654752440f));
+            else o[i] = gelu_erf_fast(o[i]) * (F8 ? oq : 1.f);
+          }
           VecIO<T>::store(ya + obase + (size_t)(w0 + p * dil) * C, o);
         }
       }

@@ -36,9 +36,7 @@ template <>
 __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <>
 __device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16* p, float v) {
-  unsigned u = __float_as_uint(v);
-  unsigned r = ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-  *reinterpret_cast<unsigned short*>(p) = (unsigned short)r;
+  *reinterpret_cast<unsigned short*>(p) = (unsigned short)bf16_bits(v);
 }
 
 template <>
@@ -170,10 +168,6 @@ __device__ __forceinline__ void ld8<__hip_bfloat16>(const __hip_bfloat16* p, flo
     v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
   }
 }
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-  const unsigned u = __float_as_uint(f);
-  return ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
 template <typename T>
 __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
 template <>
@@ -184,10 +178,10 @@ __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
 template <>
 __device__ __forceinline__ void st8<__hip_bfloat16>(__hip_bfloat16* p, const float (&v)[8]) {
   uint4 t;
-  t.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
-  t.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
-  t.z = bf16_rne(v[4]) | (bf16_rne(v[5]) << 16);
-  t.w = bf16_rne(v[6]) | (bf16_rne(v[7]) << 16);
+  t.x = bf16x2_bits(v[0], v[1]);
+  t.y = bf16x2_bits(v[2], v[3]);
+  t.z = bf16x2_bits(v[4], v[5]);
+  t.w = bf16x2_bits(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = t;
 }
 template <>

@@ -99,6 +99,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// exact-erf GELU for 16-bit / 8-bit results: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7 -- two orders below half an
+// ulp of a 16-bit result) -- one v_rcp, one v_exp, ten FMAs, no branches.  libm's erff is two branchy polynomials per
+// call (both executed by a wave whose lanes disagree): ~110 instructions per element, which made the GELU-fused
+// depthwise convolution VALU-bound (round 3: 197 us for 418 MB at the teacher's stage 3).
+__device__ __forceinline__ float gelu_erf_fast(float z) {
+  const float x = fabsf(z) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erf_abs = fmaf(-poly, e, 1.0f);
+  return 0.5f * z * (1.0f + copysignf(erf_abs, z));
+}
+
 // ---- fp8 (OCP e4m3) helpers of the K5 teacher path (csrc/f8.hip; producers in layernorm.hip / dwconv.hip) --------------
 struct f8e4m3 { unsigned char v; };          // storage tag: one e4m3 byte
 constexpr float kF8Max = 448.f;

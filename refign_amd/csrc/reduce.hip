@@ -263,11 +263,7 @@ struct CastChunk {
   long n;
 };
 
-__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) { return bf16_bits(f); }   // common.h
 
 __global__ __launch_bounds__(256) void multi_cast_f32_bf16_kernel(const CastChunk* __restrict__ table) {
   const CastChunk c = table[blockIdx.x];
@@ -277,8 +273,8 @@ __global__ __launch_bounds__(256) void multi_cast_f32_bf16_kernel(const CastChun
     for (; i + 3 < c.n; i += 256 * 4) {
       const float4 v = *reinterpret_cast<const float4*>(c.src + i);
       uint2 o;
-      o.x = f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16);
-      o.y = f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16);
+      o.x = bf16x2_bits(v.x, v.y);
+      o.y = bf16x2_bits(v.z, v.w);
       *reinterpret_cast<uint2*>(c.dst + i) = o;
     }
   }
@@ -309,8 +305,8 @@ __global__ __launch_bounds__(256) void multi_ema_kernel(const EmaChunk* __restri
       *reinterpret_cast<float4*>(c.ema + i) = e;
       if (c.dst16 != nullptr) {
         uint2 o;
-        o.x = f32_to_bf16_bits(e.x) | (f32_to_bf16_bits(e.y) << 16);
-        o.y = f32_to_bf16_bits(e.z) | (f32_to_bf16_bits(e.w) << 16);
+        o.x = bf16x2_bits(e.x, e.y);
+        o.y = bf16x2_bits(e.z, e.w);
         *reinterpret_cast<uint2*>(c.dst16 + i) = o;
       }
     }

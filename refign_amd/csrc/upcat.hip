@@ -31,10 +31,6 @@ __device__ __forceinline__ void unpack8(const uint4& t, float (&v)[8]) {
     v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
   }
 }
-__device__ __forceinline__ unsigned rne16(float f) {
-  const unsigned u = __float_as_uint(f);
-  return ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
 
 // one thread = one 8-channel vector of one output pixel (bf16: 16 bytes; fp32: 32 bytes)
 template <typename T>
@@ -92,10 +88,10 @@ __global__ __launch_bounds__(256) void upcat_nhwc_kernel(UpcatArgs a, T* __restr
   T* o = out + (((size_t)n * H + y) * W + x) * (size_t)CV * 8 + (size_t)cv * 8;
   if constexpr (sizeof(T) == 2) {
     uint4 t;
-    t.x = rne16(r[0]) | (rne16(r[1]) << 16);
-    t.y = rne16(r[2]) | (rne16(r[3]) << 16);
-    t.z = rne16(r[4]) | (rne16(r[5]) << 16);
-    t.w = rne16(r[6]) | (rne16(r[7]) << 16);
+    t.x = bf16x2_bits(r[0], r[1]);
+    t.y = bf16x2_bits(r[2], r[3]);
+    t.z = bf16x2_bits(r[4], r[5]);
+    t.w = bf16x2_bits(r[6], r[7]);
     *reinterpret_cast<uint4*>(o) = t;
   } else {
     *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
@@ -173,10 +169,10 @@ __global__ __launch_bounds__(256) void upcat_bwd_nhwc_kernel(UpcatBwdArgs a, con
   T* o = reinterpret_cast<T*>(a.dst[l]) + (((size_t)n * hl + ys) * wl + xs) * (size_t)CVl * 8 + (size_t)cl * 8;
   if constexpr (sizeof(T) == 2) {
     uint4 t;
-    t.x = rne16(acc[0]) | (rne16(acc[1]) << 16);
-    t.y = rne16(acc[2]) | (rne16(acc[3]) << 16);
-    t.z = rne16(acc[4]) | (rne16(acc[5]) << 16);
-    t.w = rne16(acc[6]) | (rne16(acc[7]) << 16);
+    t.x = bf16x2_bits(acc[0], acc[1]);
+    t.y = bf16x2_bits(acc[2], acc[3]);
+    t.z = bf16x2_bits(acc[4], acc[5]);
+    t.w = bf16x2_bits(acc[6], acc[7]);
     *reinterpret_cast<uint4*>(o) = t;
   } else {
     *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);

@@ -101,6 +101,18 @@ def main():
             y = dwconv3x3_nhwc(xg, wg, bb, dil)
             gy = torch.randn_like(y)
             add(f"dwconv fwd+bwd {B_}x{H}x{W}x{C} d{dil} {str(dt)[6:]}", timeit(lambda: torch.autograd.grad(dwconv3x3_nhwc(xg, wg, bb, dil), (xg, wg), gy), reps=5), 7 * x.numel() * es)
+    if not args.only or "dw" in args.only:
+        from refign_amd.dwconv import dwconv3x3_gelu_tokens
+        for (B_, H, W, C) in [(40, 34, 60, 1280), (40, 68, 120, 512), (40, 135, 240, 256), (4, 34, 60, 1280)]:
+            x = torch.randn(B_, H * W, C, device=dev).to(torch.bfloat16)
+            w = torch.randn(C, 1, 3, 3, device=dev)
+            bb = torch.randn(C, device=dev)
+            with torch.no_grad():
+                add(f"dwconv+gelu fwd (no z) {B_}x{H}x{W}x{C} bf16", timeit(lambda: dwconv3x3_gelu_tokens(x, w, bb, H, W)),
+                    2 * x.numel() * 2)
+            xg = x.clone().requires_grad_()
+            add(f"dwconv+gelu fwd (a, z) {B_}x{H}x{W}x{C} bf16", timeit(lambda: dwconv3x3_gelu_tokens(xg, w, bb, H, W, True)),
+                3 * x.numel() * 2)
     if not args.only or "unc" in args.only:
         from refign_amd import align as A
         um = A.UncertaintyModule(1, search_size=9, feed_in_previous=True).to(dev).eval()
