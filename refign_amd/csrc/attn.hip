@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 
   vec8 qf[4];
   load_row_frags<DT>(Q + (long)b * qsb + hd * 64, qsr, q, Nq, g, qf);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) pin_loaded(qf[kk]);       // mfma.h: no compiler wait inside the DMA loop
 
   // K / V packs are indexed (b, pack head): K and V of one kv tensor are packed together as 2 x heads "heads"
   const long pidx = (long)(b * pheads + hd) * nblk * kPackBlock;
@@ -280,6 +282,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
   }
   const float ls = (q < nqpad) ? lse2[(long)bh * nqpad + q] : 0.f;
   if (g == 0 && q < nqpad) delta[(long)bh * nqpad + q] = ok ? dl : 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {                        // mfma.h: no compiler wait inside the DMA loop
+    pin_loaded(qf[kk]);
+    pin_loaded(gf[kk]);
+  }
+  pin_loaded(ls);
 
   const long pbase = (long)(b * pheads + hd) * nblk * kPackBlock;
   const int nst = nblk / 2;
@@ -357,13 +365,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, dK / dV.  grid (key blocks of 256, query chunks, B * heads), 8 waves x 32 keys.  A lane owns one key: its K
-// and V rows sit in registers as B operands for the whole kernel; the query stream (R- and T-packs of Q and dO) goes
-// through a 2-deep LDS ring, 32 queries per stage, shared by the 8 waves.
+// and V rows sit in registers as B operands for the whole kernel; the query stream (R- and T-packs of Q and dO, and the
+// 32 + 32 softmax statistics of the block) goes through an NS-deep LDS ring, 32 queries per stage, shared by the 8 waves.
 //   S = Q K^T, P = exp2(c S - lse2), dP = dO V^T, dS = P o (dP - delta)
 //   dV^T += dO^T P,   dK^T += Q^T dS   (A operands from the T-packs, B operands = the P / dS register blocks)
 // Results are added (fp32 atomics, 128-byte coalesced) into accT[bh][2][64 d][nkpad keys].
+// EVERY global read of the loop is an LDS-DMA instruction of ours: the statistics used to be plain loads issued after the
+// next stage's DMA, and vmcnt retires in order -- the compiler's wait for them was a wait for that DMA, i.e. the ring
+// never ran ahead.  With the statistics in the stage and a counted wait, NS - 1 stages are in flight.  Measured (round 3,
+// tools/attn_bench.py, backward of the student's stage 3): 104 -> 94.5 us with the loop free of compiler waits, and NO
+// difference between rings of 2, 3, 4 and 6 stages: a workgroup's time is its fixed cost (K / V rows, first stage, atomics),
+// which is why the host keeps the grid within ONE round of 256 workgroups (mfma._chunk_blocks).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, int NS>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ K, const uint16_t* __restrict__ V,
                                                            long ksb, long ksr, const unsigned char* __restrict__ Qr,
                                                            const unsigned char* __restrict__ Qt,
@@ -374,8 +388,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __res
                                                            int nqpad, int nkpad, int blocks_per_chunk, float scale) {
   using E = Elem<DT>;
   using vec8 = typename E::vec8;
-  constexpr int STAGE = 4 * kPackBlock;                 // one query block: Q R, dO R, Q T, dO T
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  constexpr int STATS = 4 * kPackBlock;                 // offset of the statistics: 32 lse2, 32 delta
+  constexpr int STAGE = STATS + 256;                    // one query block: Q R, dO R, Q T, dO T, statistics
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, col = lane & 31;
   const int bh = blockIdx.z, b = bh / heads, hd = bh % heads;
   const int key = blockIdx.x * 256 + wave * 32 + col;
@@ -386,13 +401,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __res
   vec8 kf[4], vf[4];
   load_row_frags<DT>(K + (long)b * ksb + hd * 64, ksr, key, Nkv, g, kf);
   load_row_frags<DT>(V + (long)b * ksb + hd * 64, ksr, key, Nkv, g, vf);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {                        // mfma.h: no compiler wait inside the DMA loop
+    pin_loaded(kf[kk]);
+    pin_loaded(vf[kk]);
+  }
 
   const int qb0 = blockIdx.y * blocks_per_chunk;
-  const int qb1 = min(qb0 + blocks_per_chunk, nqblk);
+  const int nst = min(qb0 + blocks_per_chunk, nqblk) - qb0;
   const long pbase = (long)bh * nqblk * kPackBlock;
+  const float* stat_src = (g == 0 ? lse2 : delta) + (long)bh * nqpad + col;
   auto issue = [&](int qb, int buf) {
     unsigned char* dst = smem + buf * STAGE;
-    // 16 KB per stage = 16 DMA instructions, 2 per wave: wave w moves piece w of (Qr, dOr) and piece w of (Qt, dOt)
+    // 16 KB per stage = 16 DMA instructions, 2 per wave: wave w moves piece w of (Qr, dOr) and piece w of (Qt, dOt);
+    // wave 0 also moves the 256 bytes of statistics (one 4-byte instruction)
     const long off = pbase + (long)qb * kPackBlock + (wave & 3) * 1024 + lane * 16;
     if (wave < 4) {
       lds_dma16(Qr + off, dst + (wave & 3) * 1024);
@@ -401,30 +423,32 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __res
       lds_dma16(Qt + off, dst + 2 * kPackBlock + (wave & 3) * 1024);
       lds_dma16(Gt + off, dst + 3 * kPackBlock + (wave & 3) * 1024);
     }
+    if (wave == 0) lds_dma4(stat_src + qb * 32, dst + STATS);
   };
 
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f;
 
-  if (qb0 < qb1) {
-    issue(qb0, 0);
-    wait_dma_all();
-    wg_barrier();
-  }
-  for (int qb = qb0; qb < qb1; ++qb) {
-    const int buf = (qb - qb0) & 1;
-    if (qb + 1 < qb1) issue(qb + 1, buf ^ 1);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nst) issue(qb0 + s, s);
+  for (int i = 0; i < nst; ++i) {
+    // stage i has landed once at most the NS - 2 younger stages are outstanding (DMA retires in order; 2 instructions per
+    // stage and wave, 3 for wave 0)
+    if (NS == 2 || i + NS - 2 >= nst) wait_dma_all();
+    else if (wave == 0) wait_dma_upto<(NS - 2) * 3>();
+    else wait_dma_upto<(NS - 2) * 2>();
+    wg_barrier();                                        // ... everybody's part of it; everybody is done reading stage i - 1
+    if (i + NS - 1 < nst) issue(qb0 + i + NS - 1, (i + NS - 1) % NS);
     if (wave_live) {
-      const unsigned char* base = smem + buf * STAGE;
+      const unsigned char* base = smem + (i % NS) * STAGE;
       // statistics of the 16 query rows this lane's registers cover: rows 8 k + 4 g + 0..3
       f32x4 l4[4], d4[4];
-      const float* lp = lse2 + (long)bh * nqpad + qb * 32 + 4 * g;
-      const float* dp_ = delta + (long)bh * nqpad + qb * 32 + 4 * g;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        l4[k] = *(const f32x4*)(lp + 8 * k);
-        d4[k] = *(const f32x4*)(dp_ + 8 * k);
+        l4[k] = *(const f32x4*)(base + STATS + (8 * k + 4 * g) * 4);
+        d4[k] = *(const f32x4*)(base + STATS + 128 + (8 * k + 4 * g) * 4);
       }
       f32x16 s, dp;
 #pragma unroll
@@ -458,8 +482,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __res
           dk[db] = E::mma(qa, sb[m], dk[db]);
         }
     }
-    wait_dma_all();
-    wg_barrier();
   }
   if (kok) {
     float* ak = accT + (long)bh * 2 * 64 * nkpad + key;
@@ -576,13 +598,20 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
   // (a kernel, not a memset node, when the pass is captured into a hipGraph: capi.hip zero_async)
   if (int rc = zero_async(accT, (size_t)B * heads * 2 * 64 * nkpad * sizeof(float), s)) return rc;
   dim3 grid(cdiv(Nkv, 256), cdiv(nqblk, blocks_per_chunk), B * heads);
-#define RFN_DKV_LAUNCH(D)                                                                                               \
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, grid, dim3(512), 0, s, (const uint16_t*)K, (const uint16_t*)V,            \
+  static const int ring = getenv("RFN_ATTN_DKV_RING") ? atoi(getenv("RFN_ATTN_DKV_RING")) : 2;     // 2 or 4: no difference measured (round 3)
+#define RFN_DKV_LAUNCH_(D, R)                                                                                           \
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, R>), grid, dim3(512), 0, s, (const uint16_t*)K, (const uint16_t*)V,            \
                      kv_batch_stride, kv_row_stride, (const unsigned char*)q_rpack, (const unsigned char*)q_tpack,      \
                      (const unsigned char*)do_rpack, (const unsigned char*)do_tpack, lse2, delta, accT, heads, Nq, Nkv,  \
                      nqblk, nqpad, nkpad, blocks_per_chunk, scale)
-  if (dtype == 1) RFN_DKV_LAUNCH(1); else RFN_DKV_LAUNCH(2);
+#define RFN_DKV_LAUNCH(D)                                                                                               \
+  switch (ring) {                                                                                                       \
+    case 4: RFN_DKV_LAUNCH_(D, 4); break;                                                                               \
+    default: RFN_DKV_LAUNCH_(D, 2); break;                                                                              \
+  }
+  if (dtype == 1) { RFN_DKV_LAUNCH(1) } else { RFN_DKV_LAUNCH(2) }
 #undef RFN_DKV_LAUNCH
+#undef RFN_DKV_LAUNCH_
   int rc = check_launch("attn_bwd_dkv");
   if (rc != RFN_OK) return rc;
   const long total = (long)B * Nkv * 2 * heads * 64;

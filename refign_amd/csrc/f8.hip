@@ -398,6 +398,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f8_kernel(const unsigned char* _
     }
     qf = join32(lo, hi);
   }
+  pin_loaded(qf);                                          // mfma.h: no compiler wait inside the DMA loop
   const unsigned char* pbase = pack + (long)bh * nst * kStage8;
   auto issue = [&](int st, int buf) {
 #pragma unroll

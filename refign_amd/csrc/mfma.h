@@ -76,7 +76,27 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base)
 #pragma clang diagnostic pop
 }
 
+// 4 bytes per lane (lane i lands at lds_wave_base + 4 i): small per-stage side data riding in the same ring
+__device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_wave_base) {
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  const unsigned sbase = __builtin_amdgcn_readfirstlane(base);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(sbase) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+
 __device__ __forceinline__ void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Values the compiler loaded from global memory BEFORE a loop that issues LDS-DMA: make it wait for them here.  Otherwise
+// it places its own `s_waitcnt vmcnt(0)` at their first use INSIDE the loop -- it does not see our DMA instructions, and
+// the counter retires in order, so that wait drains the DMA just issued for the next stage, on every iteration: the ring
+// never runs ahead (found in round 3 in all three attention kernels).
+template <typename T> __device__ __forceinline__ void pin_loaded(const T& v) { asm volatile("" ::"v"(v)); }
+
+// counted hand-off: at most N of this wave's vector-memory instructions still outstanding (they retire in order)
+template <int N> __device__ __forceinline__ void wait_dma_upto() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 __device__ __forceinline__ void wg_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -82,9 +82,6 @@ struct ConvGeom {
 // counter and need not retire in order with the loads) the wait is vmcnt(0).  Measured on MI355X (profiles/): K-steps of
 // 64 (full 128-byte lines per row) with a 2-deep ring beat K-steps of 32 with a 4-deep ring by 1.3-1.6x on the K >= 512
 // shapes -- half-line requests double the L2 request count -- so BK = 64, NS = 2 is what the host launches.
-template <int N> __device__ __forceinline__ void wait_dma_upto() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <int DT, int BM, int BN, int BK, int NS, bool GATHER, int NW = 4, bool OUT32 = false>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,

@@ -276,12 +276,14 @@ def _fwd(q, kv, heads, scale, need_bwd):
 
 
 def _chunk_blocks(nqblk, Nkv, BH):
-    """32-query blocks per dK/dV workgroup: ~384 workgroups (512 threads each, one per CU at a time) over the chip, at
-    least 4 blocks each.  More, shorter chunks add fp32 atomics on the dK / dV image (every chunk adds its 256 x 64 x 2
-    partial) faster than they add parallelism: measured 199 / 189 / 159 / 260 us at 768 / 384 / 256 / 1536 target
-    workgroups on the stage-1 shape (B=4, 32 400 queries, 480 keys)."""
+    """32-query blocks per dK/dV workgroup: at most 256 workgroups (512 threads each, ONE per CU at a time), at least 4
+    blocks each.  A workgroup's time is mostly fixed cost (its keys' K / V rows, the first stage, 64 atomics per lane):
+    320 workgroups are two rounds over the 256 CUs and cost a whole second round -- measured on the student's shapes
+    (tools/attn_bench.py, backward of B=4: stage 1 / 2 / 3): 157 / 125 / 98 us at a target of 512, 156 / 116 / 95 at 384,
+    132 / 100 / 80 at 256, 175 / 144 / 125 at 768.  More, shorter chunks also add fp32 atomics on the dK / dV image (every
+    chunk adds its 256 x 64 x 2 partial)."""
     kblocks = -(-Nkv // 256)
-    chunks = max(1, int(os.environ.get("RFN_ATTN_DKV_WGS", "384")) // max(1, kblocks * BH))
+    chunks = max(1, int(os.environ.get("RFN_ATTN_DKV_WGS", "256")) // max(1, kblocks * BH))
     return max(4, -(-nqblk // chunks))
 
 
