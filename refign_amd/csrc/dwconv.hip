@@ -138,15 +138,36 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ bias, T* __restrict__ y, int B,
                                                             int H, int W, int C, int dil, int cvb,
                                                             T* __restrict__ ya = nullptr, float xs = 1.f,
-                                                            float oq = 1.f) {
+                                                            float oq = 1.f, int sliced = 0) {
   // xs / oq (e4m3 activations only): stored input bytes mean xs * value -- folded into the weights; outputs are stored as
   // value * oq
   constexpr bool F8 = std::is_same<T, f8e4m3>::value;
   constexpr int V = VecIO<T>::N, V2 = V / 2;
   const int CV = C / V, WQ = quads_per_row(W, dil);
-  const int pl = 256 / cvb;
-  const int cv = blockIdx.x * cvb + threadIdx.x % cvb;
-  if (cv >= CV) return;
+  // Two launch geometries.
+  //  * grid (channel blocks, quad chunks), rows in image order: the first-generation mapping.
+  //  * SLICED (gridDim.y == 1, sliced != 0): a 1-D grid of 8 j blocks; block id runs on XCD id % 8 (the dispatcher's
+  //    round-robin) and owns channel slice id % 8 (cvb = CV / 8 vectors) -- so the three uses of an input row (output
+  //    rows h - d, h, h + d) are made by ONE XCD and the second and third find the row in that XCD's L2 -- provided they
+  //    come soon enough: the blocks of an XCD walk the rows in lockstep (the grid is exactly the resident blocks), and
+  //    for a dilated convolution in residue-class order r, r + d, r + 2 d, ... (h_slots = d ceil(H / d) slots per image),
+  //    so the uses are 1 and 2 rows apart whatever the dilation.  With the first mapping a row's uses land on different
+  //    XCDs / megabytes apart: each is a fabric read (measured round 3: tools/kbench.py --only dw).
+  int pl, cv, qfirst, qstride;
+  if (sliced) {
+    pl = blockDim.x / cvb;
+    if ((int)threadIdx.x >= cvb * pl) return;
+    cv = (blockIdx.x & 7) * cvb + threadIdx.x % cvb;
+    qfirst = (blockIdx.x >> 3) * pl + threadIdx.x / cvb;
+    qstride = (gridDim.x >> 3) * pl;
+  } else {
+    pl = 256 / cvb;
+    cv = blockIdx.x * cvb + threadIdx.x % cvb;
+    if (cv >= CV) return;
+    qfirst = blockIdx.y * pl + threadIdx.x / cvb;
+    qstride = gridDim.y * pl;
+  }
+  const int Hd = (H + dil - 1) / dil, h_slots = sliced ? dil * Hd : H;
   const int c0 = cv * V;
   // weights, bias and accumulators live as adjacent-channel PAIRS: every multiply-add below is one v_pk_fma_f32
   f32x2 wr[9][V2];   // tap-major weights (9, C): one contiguous fp32 vector per tap
@@ -168,10 +189,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
 #pragma unroll
   for (int i = 0; i < V2; ++i)
     bs[i] = (bias != nullptr) ? f32x2{bias[c0 + 2 * i], bias[c0 + 2 * i + 1]} : f32x2{0.0f, 0.0f};
-  const long nquads = (long)B * H * WQ;
-  for (long quad = (long)blockIdx.y * pl + threadIdx.x / cvb; quad < nquads; quad += (long)gridDim.y * pl) {
+  const long nquads = (long)B * h_slots * WQ;
+  for (long quad = qfirst; quad < nquads; quad += qstride) {
     int b, h, w0;
-    quad_coords(quad, WQ, H, dil, b, h, w0);
+    quad_coords(quad, WQ, h_slots, dil, b, h, w0);
+    if (sliced && dil > 1) {                            // slot -> row of residue class slot / Hd
+      h = h / Hd + (h % Hd) * dil;
+      if (h >= H) continue;
+    }
     f32x2 acc[kPX][V2];
 #pragma unroll
     for (int p = 0; p < kPX; ++p)
@@ -350,14 +375,41 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_reduce_kernel(const 
 }
 
 static inline int pick_cvb(int CV) { return CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV >= 16 ? 16 : 8)); }
+
+// the SLICED geometry of dwconv3x3_fwd_kernel: one channel slice of CV / 8 vectors per XCD (at least 8 vectors = 128-byte
+// runs per pixel), and exactly the blocks that are resident at once -- 2 per CU (216 VGPRs: 2 waves per SIMD), 64 per XCD
+// (or twice that: no difference measured) -- so that an XCD's blocks advance through the rows together.
+// RFN_DWCONV_SLICED=0: first-generation grid everywhere.
+struct SlicedGeom {
+  bool on;
+  int cvb, grid;
+};
+// Measured (round 3, tools/kbench.py --only dw, first-generation grid -> sliced): ASPP 40 x 135 x 240 x 1024, dilation 6:
+// 1884 -> 1451 us (1422 with 128 blocks per XCD, 1706 with 32); fp32, dilation 12: 361 -> 272 us; 4 x 34 x 60 x 1280: 19.1 ->
+// 14.4 us; Mix-FFN + GELU 40 x 34 x 60 x 1280: 160 -> 149 us.  NOT for slices under 16 vectors (512 channels: 128-byte runs
+// per pixel, 214 -> 240 us).
+static inline SlicedGeom sliced_geom(int CV, long nslots) {
+  static const int enabled = getenv("RFN_DWCONV_SLICED") ? atoi(getenv("RFN_DWCONV_SLICED")) : 1;
+  static const int per_xcd = getenv("RFN_DWCONV_SLICED_BLOCKS") ? atoi(getenv("RFN_DWCONV_SLICED_BLOCKS")) : 128;
+  if (!enabled || CV % 8 != 0 || CV / 8 < 16 || CV / 8 > 64) return SlicedGeom{false, 0, 0};
+  const int cvb = CV / 8, pl = 256 / cvb;
+  const int j = (int)std::max<long>(1, std::min<long>(cdiv(nslots, pl), per_xcd));
+  return SlicedGeom{true, cvb, 8 * j};
+}
 constexpr int kMaxStripes = 128;
 
 template <typename T>
 static int launch_fwd_gelu(const void* x, const float* w, const float* bias, void* y, void* ya, int B, int H, int W,
                            int C, hipStream_t st, float xs = 1.f, float oq = 1.f) {
   constexpr int V = VecIO<T>::N;
-  const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
+  const int CV = C / V;
   const long nquads = (long)B * H * ((W + kPX - 1) / kPX);
+  if (SlicedGeom sg = sliced_geom(CV, nquads); sg.on) {
+    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, true>), dim3(sg.grid), dim3(256), 0, st, (const T*)x, w, bias,
+                       (T*)y, B, H, W, C, 1, sg.cvb, (T*)ya, xs, oq, 1);
+    return check_launch("dwconv3x3_fwd_kernel<gelu, sliced>");
+  }
+  const int cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(nquads, pl), (256L * 16) / gx));
   hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, true>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias,
                      (T*)y, B, H, W, C, 1, cvb, (T*)ya, xs, oq);
@@ -368,8 +420,19 @@ template <typename T>
 static int launch_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,
                       int flip, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
-  const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
-  const long nquads = (long)B * H * (dil * (((W + dil - 1) / dil + kPX - 1) / kPX));
+  const int CV = C / V;
+  const int WQ = dil * (((W + dil - 1) / dil + kPX - 1) / kPX);
+  if (SlicedGeom sg = sliced_geom(CV, (long)B * dil * ((H + dil - 1) / dil) * WQ); sg.on) {
+    if (flip)
+      hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, true>), dim3(sg.grid), dim3(256), 0, st, (const T*)x, w, bias, (T*)y, B,
+                         H, W, C, dil, sg.cvb, (T*)nullptr, 1.f, 1.f, 1);
+    else
+      hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false>), dim3(sg.grid), dim3(256), 0, st, (const T*)x, w, bias, (T*)y,
+                         B, H, W, C, dil, sg.cvb, (T*)nullptr, 1.f, 1.f, 1);
+    return check_launch("dwconv3x3_fwd_kernel<sliced>");
+  }
+  const int cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
+  const long nquads = (long)B * H * WQ;
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(nquads, pl), (256L * 16) / gx));
   if (flip)
     hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, true>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias, (T*)y, B,

@@ -8,7 +8,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,H,W,C,dil", [(2, 7, 9, 32, 1), (1, 17, 30, 256, 1), (2, 33, 41, 64, 6), (1, 5, 3, 8, 1),
-                                        (1, 40, 64, 1024, 12)])
+                                        (1, 40, 64, 1024, 12),
+                                        # the XCD-sliced geometry (csrc/dwconv.hip sliced_geom): slices of 20 / 40 vectors
+                                        # (idle threads in the block), rows in residue-class order with H % dilation != 0
+                                        (2, 9, 13, 1280, 1), (1, 23, 31, 1024, 6), (3, 5, 4, 2048, 18)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_dwconv_matches_conv2d(dev, B, H, W, C, dil, dtype):
     from refign_amd.dwconv import dwconv3x3_nhwc
@@ -42,3 +45,27 @@ def test_mix_ffn_dwconv_tokens_equals_reference_formulation(dev):
     x = torch.randn(2, 12 * 20, 64, device=dev)
     want = m.dwconv(x.transpose(1, 2).reshape(2, 64, 12, 20)).flatten(2).transpose(1, 2)
     assert torch.allclose(m(x, 12, 20), want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 13, 64), (2, 9, 13, 1280), (1, 34, 60, 512)])
+def test_fused_dwconv_gelu_matches_conv_then_exact_gelu(dev, B, H, W, C):
+    """gelu(DWConv(x)) in one pass (mix_transformer.py:99-101) on bf16 tokens: the activation of the 16-bit path is the
+    branch-free erf of csrc/mfma.h (A&S 7.1.26, |error| < 1.5e-7) -- compared with the exact-erf GELU of an fp32
+    convolution, to the rounding of the bf16 result; the pre-activation z (with_z) is the plain convolution."""
+    from refign_amd.dwconv import dwconv3x3_gelu_tokens
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, H * W, C, generator=g) * 1.5).to(dev).to(torch.bfloat16)
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.4).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    z_ref = torch.nn.functional.conv2d(x.float().view(B, H, W, C).permute(0, 3, 1, 2), w, b, padding=1, groups=C)
+    z_ref = z_ref.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    a_ref = torch.nn.functional.gelu(z_ref)
+    with torch.no_grad():
+        a = dwconv3x3_gelu_tokens(x, w, b, H, W)
+    assert a.dtype == torch.bfloat16
+    tol = 2.0 ** -8 * a_ref.abs() + 2e-3
+    assert bool(((a.float() - a_ref).abs() <= tol).all())
+    xg = x.clone().requires_grad_()
+    a2, z = dwconv3x3_gelu_tokens(xg, w, b, H, W, with_z=True)
+    assert torch.equal(a2, a)
+    assert bool(((z.float() - z_ref).abs() <= 2.0 ** -8 * z_ref.abs() + 2e-3).all())
