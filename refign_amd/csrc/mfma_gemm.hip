@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
                                                       float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
                                                       int R, int tiles_k, int accumulate, float* __restrict__ gbias,
                                                       const float* __restrict__ rowscale, int rows_per_sample,
-                                                      WgradGeom wg = WgradGeom{}) {
+                                                      WgradGeom wg, int xcd) {
   using E = Elem<DT>;
   constexpr int BT = 32;                   // rows of the reduction per stage (two 16-slot k-steps)
   constexpr int IB = BN / 64, JB = BK / 64;
@@ -395,7 +395,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles = (N / BN) * tiles_k;
-  const int slab = blockIdx.x / tiles, tile = blockIdx.x % tiles;   // slabs of one tile are far apart, tiles of one slab adjacent
+  // slab-major logical order, XCD-aware (mfma.h xcd_remap: consecutive logical ids on ONE XCD): the tiles of a slab share
+  // its rows of G and X (a slab of both operands fits the XCD's 4 MB L2), so each operand byte crosses the fabric once instead
+  // of once per XCD.  xcd = 0 (RFN_GEMM_TN_XCD=0): dispatch order, as in the first two rounds.
+  const int lid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int slab = lid / tiles, tile = lid % tiles;
   const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
   const long t0 = (long)slab * R;          // slab = R rows (R % 32 == 0), the last one may run past T: masked loads
 
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(const uint16_t* __restric
                                                        float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
                                                        int R, int tiles_k, int accumulate, float* __restrict__ gbias,
                                                        const float* __restrict__ rowscale, int rows_per_sample,
-                                                       WgradGeom wg) {
+                                                       WgradGeom wg, int xcd) {
   using E = Elem<DT>;
   constexpr int IB = BN / 64, JB = BK / 64;
   constexpr int NQ = BT / 4;                                     // row quads per stage
@@ -617,7 +621,11 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(const uint16_t* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles = (N / BN) * tiles_k;
-  const int slab = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  // slab-major logical order, XCD-aware (mfma.h xcd_remap: consecutive logical ids on ONE XCD): the tiles of a slab share
+  // its rows of G and X (a slab of both operands fits the XCD's 4 MB L2), so each operand byte crosses the fabric once instead
+  // of once per XCD.  xcd = 0 (RFN_GEMM_TN_XCD=0): dispatch order, as in the first two rounds.
+  const int lid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int slab = lid / tiles, tile = lid % tiles;
   const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
   const long t0 = (long)slab * R;
 
@@ -805,12 +813,19 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
       return fail(RFN_ELAUNCH, "conv2d_nhwc: zero page symbol");
     cg.zero = zero_page;
   }
-  // tile: the widest n the problem fills; m 128, or 64 when the problem would not give every CU a tile otherwise
-  int bn = (N % 128 == 0) ? 128 : 64;
-  int bm = ((long)cdiv(M, 128) * cdiv(N, bn) >= 256) ? 128 : 64;
+  // tile: the largest of 128 x 128 (N % 128 == 0), 128 x 64, 64 x 64 that still gives ~1000 tiles (2-4 workgroups per CU
+  // are resident; a launch of 300-600 big tiles is one and a bit rounds of a latency chain -- swept on replayed graphs in
+  // round 3, profiles/r03_gemm_sweep.txt: 8160 x 320 -> 1280: 21.6 -> 18.1 us, 8160 x 1280 -> 320: 19.5 -> 17.5,
+  // 2040 x 512 -> 2048: 13.7 -> 11.1)
+  int bn = (N % 128 == 0) ? 128 : 64, bm = 128;
+  if ((long)cdiv(M, 128) * cdiv(N, bn) < 1000) {
+    bn = 64;
+    if ((long)cdiv(M, 128) * cdiv(N, 64) < 1000) bm = 64;
+  }
   int ns = 2;
-  // big problems whose n extent fills 256-wide tiles: 8 waves on a 256 x 256 tile (1 workgroup per CU)
-  if (N % 256 == 0 && (long)cdiv(M, 256) * (N / 256) >= 256) bm = bn = 256;
+  // big problems whose n extent fills 256-wide tiles: 8 waves on a 256 x 256 tile (1 workgroup per CU); with a long
+  // reduction (K >= 1024) already from 128 tiles on (20400 x 2048 -> 512: 74.8 -> 59.7 us)
+  if (N % 256 == 0 && (long)cdiv(M, 256) * (N / 256) >= (K >= 1024 ? 128 : 256)) bm = bn = 256;
   static const char* cfg_env = getenv("RFN_GEMM_CFG");          // "bm,bn,ns": tile sweep of tools/mfma_bench.py
   if (cfg_env != nullptr) sscanf(cfg_env, "%d,%d,%d", &bm, &bn, &ns);
   const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
@@ -871,6 +886,7 @@ static int launch_tn(const void* G, const void* X, float* P, long T, long N, lon
                      WgradGeom wg = WgradGeom{}) {
   const int S = cdiv(T, R);
   dim3 block(256);
+  static const int tn_xcd = getenv("RFN_GEMM_TN_XCD") ? atoi(getenv("RFN_GEMM_TN_XCD")) : 1;
   // (first-generation kernel = the fall-back for operands that are not 16-byte aligned; measured on the step: 189.2 ms with
   // it everywhere, 185.8 ms with the second generation)
   const bool vec = (GATHER ? wg.C % 8 == 0 : (ldx % 8 == 0 && ((size_t)X & 15) == 0)) && ldg % 8 == 0 && ((size_t)G & 15) == 0;
@@ -878,22 +894,22 @@ static int launch_tn(const void* G, const void* X, float* P, long T, long N, lon
     if (N % 128 == 0 && K % 128 == 0) {
       dim3 grid((unsigned)((N / 128) * (K / 128) * S));
       hipLaunchKernelGGL((gemm_tn2_kernel<DT, 128, 128, 32, GATHER>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X,
-                         P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps, wg);
+                         P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps, wg, tn_xcd);
     } else {
       dim3 grid((unsigned)((N / 64) * (K / 64) * S));
       hipLaunchKernelGGL((gemm_tn2_kernel<DT, 64, 64, 64, GATHER>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X,
-                         P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps, wg);
+                         P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps, wg, tn_xcd);
     }
     return check_launch("gemm_tn2");
   }
   if (N % 128 == 0 && K % 128 == 0) {
     dim3 grid((unsigned)((N / 128) * (K / 128) * S));
     hipLaunchKernelGGL((gemm_tn_kernel<DT, 128, 128, GATHER>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps, wg);
+                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps, wg, tn_xcd);
   } else {
     dim3 grid((unsigned)((N / 64) * (K / 64) * S));
     hipLaunchKernelGGL((gemm_tn_kernel<DT, 64, 64, GATHER>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps, wg);
+                       (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps, wg, tn_xcd);
   }
   return check_launch("gemm_tn");
 }
