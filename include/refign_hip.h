@@ -377,6 +377,18 @@ int rfn_bn_train_fwd(const void* x, const float* gamma, const float* beta, void*
 int rfn_bn_train_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* gamma, const float* beta,
                      void* grad_x, float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Segmentation loss of the student passes in one kernel (csrc/loss.hip): bilinear up-sampling (align_corners = False) of
+ * the class logits (B, C, h, w) to the label size (H, W) + pixel-weighted cross-entropy with ignore_index, summed over all
+ * pixels -- models/segmentation_model.py:163-179, :226-250 (F.interpolate) + models/losses.py:10-22
+ * (PixelWeightedCrossEntropyLoss).  loss_sum[0] <- the sum (the host divides by B H W: the reference's mean over ALL
+ * pixels); grad_lo (B, C, h, w) fp32 <- d loss_sum / d logits.  Both are zeroed inside.  dtype of logits: 0 fp32, 1 bf16,
+ * 2 f16; target int64 (B, H, W); weight fp32 (B, H, W) or NULL; round16: round the interpolated logits to `dtype` (what an
+ * unfused 16-bit F.interpolate stores).  C <= 19, H >= 2 h, W >= 2 w.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_upsample_ce(const void* logits, const long* target, const float* weight, float* grad_lo, double* loss_sum, int B,
+                    int C, int h, int w, int H, int W, int ignore_index, int dtype, int round16, rfn_stream_t stream);
+
 /* fp32-RESULT variants (split-bf16 parity mode, refign_amd/split32.py): bf16 operands whose reduction index carries the
  * three split products side by side, fp32 accumulate, fp32 bias / residual / result (leading dimension ldy in floats).
  * rfn_conv2d_nhwc_o32: (B, H, W, C) = the convolution's input side, N output channels; transposed = 0: Y (B, OH, OW, N) from

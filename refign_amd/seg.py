@@ -712,7 +712,7 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
                 up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
                 up_att = F.interpolate(att, scale_factor=2, mode='bilinear', align_corners=False)
                 inserted = box.insert(hr_seg, up_lr.shape[2:], head_os)
-                return up_att * inserted + up_lr, _up_logits(hr_seg, (box.h, box.w)), box
+                return up_att * inserted + up_lr, defer_logits(hr_seg, (box.h, box.w)), box
             if self.training and not is_teacher:
                 box = boxes[0]
                 crop_size = (box[1] - box[0], box[3] - box[2])
@@ -725,7 +725,7 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
                 inserted = torch.zeros_like(up_lr)
                 sy, sx = hr_crop_slice(box, head_os)
                 inserted[:, :, sy, sx] = hr_seg
-                hr_logits = _up_logits(hr_seg, crop_size)
+                hr_logits = defer_logits(hr_seg, crop_size)
                 return up_att * inserted + up_lr, hr_logits, box
             up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
             # overlap-average the sliding crops (the reference rescales `hr_boxes` in place, hrda.py:207-208)
@@ -746,6 +746,72 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
 # ---------------------------------------------------------------------------------------------------------------------
 # loss
 # ---------------------------------------------------------------------------------------------------------------------
+_FUSED_CE = os.environ.get("RFN_FUSED_CE", "1") != "0"
+# set by the training model once it knows that the consumer of the training logits is PixelWeightedCrossEntropyLoss (the
+# only thing that understands a DeferredUpsample); heads used on their own keep returning tensors
+FUSED_CE_CONSUMER = False
+_CE_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+class DeferredUpsample:
+    """Class logits that are still to be up-sampled (bilinear, align_corners=False) to `size` -- what the decode head /
+    the training step hand to the loss instead of the up-sampled tensor, so that PixelWeightedCrossEntropyLoss can do
+    up-sampling, cross-entropy and their backward in ONE kernel (csrc/loss.hip).  `materialize()` is the tensor the
+    reference would have passed (hrda.py:176, segmentation_model.py:163)."""
+
+    def __init__(self, logits, size):
+        self.logits, self.size = logits, (int(size[0]), int(size[1]))
+
+    def materialize(self):
+        return _up_logits(self.logits, self.size)
+
+    @property
+    def shape(self):
+        return torch.Size((*self.logits.shape[:2], *self.size))
+
+
+def defer_logits(logits, size):
+    """-> DeferredUpsample when the fused loss kernel covers the case (HIP tensor, <= 19 classes, scale factors >= 2,
+    gradients wanted), else the up-sampled logits themselves."""
+    if _FUSED_CE and FUSED_CE_CONSUMER and logits.is_cuda and logits.dim() == 4 and logits.dtype in _CE_DT and logits.shape[1] <= 19 \
+            and size[0] >= 2 * logits.shape[2] and size[1] >= 2 * logits.shape[3] and torch.is_grad_enabled():
+        return DeferredUpsample(logits, size)
+    return _up_logits(logits, size)
+
+
+class _UpsampleCEFn(torch.autograd.Function):
+    """mean over all pixels of weight * CE(bilinear_up(logits), target); the gradient w.r.t. the low-resolution logits
+    comes out of the forward kernel (rfn_upsample_ce) and is scaled by the upstream gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight, size, ignore_index):
+        from . import _lib
+        from ._tensor import current_stream, on_device, ptr
+        B, C, h, w = logits.shape
+        H, W = size
+        lg = logits.contiguous()
+        tg = target.contiguous()
+        wt = None if weight is None else weight.to(torch.float32).contiguous()
+        if tg.dtype != torch.int64 or tuple(tg.shape) != (B, H, W) or (wt is not None and tuple(wt.shape) != (B, H, W)):
+            raise RuntimeError("upsample_ce: target (B, H, W) int64 / weight (B, H, W) expected")
+        grad = torch.empty((B, C, h, w), dtype=torch.float32, device=lg.device)
+        total = torch.empty(1, dtype=torch.float64, device=lg.device)
+        # 16-bit logits: the unfused path stores the up-sampled logits in that dtype before the fp32 softmax
+        rc = None
+        with on_device(lg.device):
+            rc = _lib.load_library().rfn_upsample_ce(ptr(lg), ptr(tg), ptr(wt), ptr(grad), ptr(total), B, C, h, w, H, W,
+                                                     int(ignore_index), _CE_DT[lg.dtype], 1, current_stream(lg.device))
+        _lib.check(rc, "upsample_ce")
+        ctx.save_for_backward(grad)
+        ctx.npix, ctx.dtype = float(B * H * W), logits.dtype
+        return (total[0] / ctx.npix).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * (g.to(torch.float32) / ctx.npix)).to(ctx.dtype), None, None, None, None
+
+
 class PixelWeightedCrossEntropyLoss(nn.Module):
     """models/losses.py:10-22: CE(ignore_index, reduction none) x optional pixel weight, mean over ALL pixels."""
 
@@ -754,6 +820,10 @@ class PixelWeightedCrossEntropyLoss(nn.Module):
         self.ignore_index = ignore_index
 
     def forward(self, input, target, pixel_weight=None):
+        if isinstance(input, DeferredUpsample):
+            if pixel_weight is not None:
+                assert pixel_weight.dim() == target.dim()
+            return _UpsampleCEFn.apply(input.logits, target, pixel_weight, input.size, self.ignore_index)
         loss = F.cross_entropy(input, target, ignore_index=self.ignore_index, reduction='none')
         if pixel_weight is not None:
             assert pixel_weight.dim() == loss.dim()

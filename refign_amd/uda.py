@@ -37,7 +37,8 @@ from . import f8 as _f8
 from .graphs import GraphedNoGrad, GraphedStep
 from .params import ema_update
 from .config import instantiate_class
-from .seg import DeviceBox, draw_crop_offsets, hrda_backbone, hrda_head, predraw_crop, push_device_crop
+from . import seg as _seg
+from .seg import DeviceBox, defer_logits, draw_crop_offsets, hrda_backbone, hrda_head, predraw_crop, push_device_crop
 
 IMNET_MEAN = (0.485, 0.456, 0.406)
 IMNET_STD = (0.229, 0.224, 0.225)
@@ -163,6 +164,12 @@ def _upsample_logits(logits, size):
     return F.interpolate(logits, size, mode='bilinear', align_corners=False)
 
 
+def _logits_for_loss(logits, size):
+    """_upsample_logits for logits that only the loss consumes: deferred, so that up-sampling + cross-entropy + backward
+    run as one kernel (seg.DeferredUpsample / csrc/loss.hip); the up-sampled tensor where that does not apply."""
+    return defer_logits(logits, size)
+
+
 class DomainAdaptationSegmentationModel(nn.Module):
     """models/segmentation_model.py:25-701.  Constructor keywords are the reference's."""
 
@@ -219,6 +226,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
             self.imnet_backbone = copy.deepcopy(self.backbone)
             self.imnet_backbone.requires_grad_(False)
         self.loss = loss
+        # up-sampling + cross-entropy + backward of the student passes as one kernel (seg.DeferredUpsample)
+        _seg.FUSED_CE_CONSUMER = isinstance(loss, _seg.PixelWeightedCrossEntropyLoss)
         self.metrics_cfg = metrics
         from .metrics import build_collections
         self.valid_metrics, self.test_metrics = build_collections(metrics, instantiate_class)
@@ -322,11 +331,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if self.use_hrda:
             feats_src = feats_src[0]                                     # low-resolution features
             logits_src, hr_logits_src, crop_box_src = logits_src
-            logits_src = _upsample_logits(logits_src, images_src.shape[-2:])
+            logits_src = _logits_for_loss(logits_src, images_src.shape[-2:])
             loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
                 self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
         else:
-            logits_src = _upsample_logits(logits_src, images_src.shape[-2:])
+            logits_src = _logits_for_loss(logits_src, images_src.shape[-2:])
             loss_src = self.loss(logits_src, gt_src)
         self.log("train_loss_src", loss_src)
         self.manual_backward(loss_src, retain_graph=self.enable_fdist)
@@ -361,12 +370,12 @@ class DomainAdaptationSegmentationModel(nn.Module):
         mixed_pred = self.head(self.backbone(mixed_img))
         if self.use_hrda:
             mixed_pred, hr_mixed_pred, box = mixed_pred
-            mixed_pred = _upsample_logits(mixed_pred, mixed_img.shape[-2:])
+            mixed_pred = _logits_for_loss(mixed_pred, mixed_img.shape[-2:])
             mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
                 self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box),
                                                 pixel_weight=crop(mixed_weight, box))
         else:
-            mixed_pred = _upsample_logits(mixed_pred, mixed_img.shape[-2:])
+            mixed_pred = _logits_for_loss(mixed_pred, mixed_img.shape[-2:])
             mixed_loss = self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight)
         self.log("train_loss_uda_trg", mixed_loss)
         self.manual_backward(mixed_loss, last=True)
@@ -407,7 +416,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         feats_src = self.backbone(images_src)
         logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
         feats_src = feats_src[0]
-        logits_src = _upsample_logits(logits_src, images_src.shape[-2:])
+        logits_src = _logits_for_loss(logits_src, images_src.shape[-2:])
         loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
             self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
         self.manual_backward(loss_src, retain_graph=self.enable_fdist)
@@ -475,7 +484,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         """MIXED (:226-250), forward and backward."""
         push_device_crop(off, self.hrda_output_stride * 2.0)
         mixed_pred, hr_mixed_pred, box = self.head(self.backbone(mixed_img))
-        mixed_pred = _upsample_logits(mixed_pred, mixed_img.shape[-2:])
+        mixed_pred = _logits_for_loss(mixed_pred, mixed_img.shape[-2:])
         mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
             self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
         self.manual_backward(mixed_loss)
