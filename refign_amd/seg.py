@@ -695,6 +695,30 @@ def hrda_backbone(self, head_os: int, is_teacher: bool = False) -> Callable:
     return deco
 
 
+_REJOIN = os.environ.get("RFN_HRDA_REJOIN", "1") != "0"
+
+
+def _rejoin(a, b):
+    """torch.cat((a, b)) for the two halves torch.split made of ONE tensor along dim 0 (hrda_backbone splits the backbone's
+    batch into LR views and HR crops, hrda_head runs the decode head on both again, hrda.py:139-150): when they are still
+    adjacent views of one dense buffer and nothing is to be differentiated, the joined batch is a view of that buffer
+    -- no copy (the teacher's stage-1 features are 174 MB per step).  Anything else: torch.cat."""
+    if _REJOIN and (not torch.is_grad_enabled() or not (a.requires_grad or b.requires_grad)) and a.dim() >= 2 \
+            and a.dtype == b.dtype \
+            and a.shape[1:] == b.shape[1:] and a.stride() == b.stride() and a.device == b.device \
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() \
+            and b.storage_offset() == a.storage_offset() + a.shape[0] * a.stride(0):
+        dense = sorted(zip(a.stride()[1:], a.shape[1:]))        # inner dims tile the sample without gaps, in any order
+        run = 1
+        for st, n in dense:
+            if n != 1 and st != run:
+                return torch.cat((a, b))
+            run *= n
+        if a.stride(0) == run:
+            return a.as_strided((a.shape[0] + b.shape[0], *a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat((a, b))
+
+
 def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: bool = False) -> Callable:
     """Decorator for head.forward (hrda.py:139-235): scale attention from the LR features, fusion of LR logits and
     HR crop logits.  Student/train returns (logits, hr_logits, crop_box); teacher/eval returns logits."""
@@ -704,7 +728,7 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
             lr_feats, hr_feats, boxes = inp
             att = torch.sigmoid(hrda_scale_attention(lr_feats))
             nl, nh = lr_feats[0].shape[0], hr_feats[0].shape[0]
-            seg = fn([torch.cat(p) for p in zip(lr_feats, hr_feats)], *args, **kwargs)
+            seg = fn([_rejoin(*p) for p in zip(lr_feats, hr_feats)], *args, **kwargs)
             lr_seg, hr_seg = torch.split(seg, [nl, nh])
             if self.training and not is_teacher and isinstance(boxes[0], DeviceBox):
                 box = boxes[0]

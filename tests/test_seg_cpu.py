@@ -194,3 +194,24 @@ def test_predrawn_hrda_crop_keeps_the_python_random_stream_order():
     assert seg.extract_crop(x, (96, 160), div) == (0, 96, 0, 160)
     random.seed(5)
     assert random.random() == c1
+
+
+def test_rejoin_is_a_view_of_the_split_batch_and_a_copy_otherwise():
+    """seg._rejoin (hrda_head): halves of one tensor split along dim 0 come back as a view of it -- contiguous and
+    channels-last -- when no gradient is wanted; torch.cat in every other case."""
+    import torch
+    from refign_amd.seg import _rejoin
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        x = torch.randn(5, 6, 4, 3).contiguous(memory_format=fmt)
+        a, b = torch.split(x, [2, 3])
+        j = _rejoin(a, b)
+        assert torch.equal(j, x) and j.data_ptr() == x.data_ptr() and j.stride() == x.stride()
+    x = torch.randn(5, 6, 4, 3)
+    a, b = torch.split(x, [2, 3])
+    assert _rejoin(b, a).data_ptr() != x.data_ptr() and torch.equal(_rejoin(b, a), torch.cat((b, a)))      # wrong order
+    assert _rejoin(a, b.clone()).data_ptr() != x.data_ptr()                                               # other buffer
+    assert _rejoin(x[:2, :3], x[2:, :3]).data_ptr() != x.data_ptr()                                       # gaps inside
+    xg = x.clone().requires_grad_()
+    ag, bg = torch.split(xg * 1.0, [2, 3])
+    j = _rejoin(ag, bg)
+    assert j.grad_fn is not None and "Cat" in type(j.grad_fn).__name__                                    # differentiated: cat
