@@ -367,6 +367,11 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
 int rfn_bn_stats_fwd(const void* x, double* sums, long T, int C, int dtype, rfn_stream_t stream);
 int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void* y, const double* sums, float* running_mean,
                      float* running_var, long T, int C, float eps, float momentum, int relu, int dtype, rfn_stream_t stream);
+/* rfn_bn_apply_fwd with y at a row pitch of ld_y elements: y = a channel slice of a wider channels-last tensor (the ASPP
+ * branches write into their concatenation, daformer.py:110-118) */
+int rfn_bn_apply_fwd_ld(const void* x, const float* gamma, const float* beta, void* y, long ld_y, const double* sums,
+                        float* running_mean, float* running_var, long T, int C, float eps, float momentum, int relu, int dtype,
+                        rfn_stream_t stream);
 int rfn_bn_stats_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* gamma, const float* beta,
                      float* bwd_sums, long T, int C, float eps, int relu, int dtype, rfn_stream_t stream);
 int rfn_bn_apply_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* bwd_sums, const float* gamma,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "rfn_upsample_ce": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     "rfn_bn_stats_fwd": (c_int, [c_void_p] * 2 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "rfn_bn_apply_fwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_float, c_int, c_int, c_void_p]),
+    "rfn_bn_apply_fwd_ld": (c_int, [c_void_p] * 4 + [ctypes.c_long] + [c_void_p] * 3 + [ctypes.c_long, c_int, c_float, c_float, c_int, c_int, c_void_p]),
     "rfn_bn_stats_bwd": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
     "rfn_bn_apply_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
     "rfn_bn_train_fwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_float, c_int, c_int, c_void_p]),

@@ -96,6 +96,13 @@ def _stats_fwd(xh, sums):
 
 def _apply_fwd(xh, weight, bias, y, sums, bn, relu):
     T, C = xh.numel() // xh.shape[-1], xh.shape[-1]
+    if y.stride(-2) != C:                                  # a channel slice of a wider channels-last tensor
+        with on_device(xh.device):
+            _lib.check(_lib.load_library().rfn_bn_apply_fwd_ld(ptr(xh), ptr(weight), ptr(bias), ptr(y), y.stride(-2), ptr(sums),
+                                                               ptr(bn.running_mean), ptr(bn.running_var), T, C,
+                                                               float(bn.eps), float(bn.momentum), int(relu),
+                                                               _DT16[xh.dtype], current_stream(xh.device)), "bn_apply_fwd_ld")
+        return
     with on_device(xh.device):
         _lib.check(_lib.load_library().rfn_bn_apply_fwd(ptr(xh), ptr(weight), ptr(bias), ptr(y), ptr(sums),
                                                         ptr(bn.running_mean), ptr(bn.running_var), T, C, float(bn.eps),
@@ -121,10 +128,11 @@ def _apply_bwd(xh, gy, sums, bsums, weight, bias, gx, eps, relu):
 
 class _BNActTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xh, weight, bias, bn, relu, group):
-        # xh: (B, H, W, C) contiguous, 16-bit
+    def forward(ctx, xh, weight, bias, bn, relu, group, out=None):
+        # xh: (B, H, W, C) contiguous, 16-bit; out (gradient-free callers): where the result goes -- (B, H, W, C) with the
+        # strides of a channel slice of a contiguous (B, H, W, C') tensor
         C = xh.shape[-1]
-        y = torch.empty_like(xh)
+        y = torch.empty_like(xh) if out is None else out
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=xh.device)     # fp64: csrc/bn.hip header
         _stats_fwd(xh, sums)
         comm = _exchange_comm(bn) if group is not None else None
@@ -166,10 +174,20 @@ class _BNActTrain(torch.autograd.Function):
                 sink.add_(local[0])
             else:
                 gb = local[0].to(bias.dtype)
-        return (gx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None
+        return (gx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None
 
 
-def bn_act_train(x, bn, relu, dtype):
+def slice_out_ok(out, xshape):
+    """`out` can receive a (B, C, H, W)-shaped result directly: an NCHW-shaped view whose memory is a channel slice of a
+    contiguous channels-last tensor (16-byte aligned, pitch a multiple of 8)."""
+    B, C, H, W = xshape
+    if tuple(out.shape) != (B, C, H, W) or out.stride(1) != 1 or out.stride(3) % 8 or out.stride(3) < C:
+        return False
+    p = out.stride(3)
+    return out.stride(2) == W * p and out.stride(0) == H * W * p and out.data_ptr() % 16 == 0
+
+
+def bn_act_train(x, bn, relu, dtype, out=None):
     """act(bn(x)) with batch statistics, `relu`: False / 0 none, True / 1 ReLU, 3 LeakyReLU(0.1) (the activation codes of
     the GEMM entry points); x NCHW-shaped (any memory format, converted to channels-last 16-bit if it is
     not already); returns an NCHW-shaped channels-last tensor."""
@@ -180,4 +198,10 @@ def bn_act_train(x, bn, relu, dtype):
         xh = xh.contiguous()
     w = bn.weight if bn.weight.dtype == torch.float32 else bn.weight.float()
     b = bn.bias if bn.bias.dtype == torch.float32 else bn.bias.float()
+    if out is not None:
+        if torch.is_grad_enabled() and (xh.requires_grad or w.requires_grad) or out.dtype != dtype \
+                or not slice_out_ok(out, x.shape):
+            raise RuntimeError("bn_act_train(out=...): gradient-free calls into a channels-last channel slice only")
+        _BNActTrain.apply(xh, w, b, bn, relu, sync_group(bn), out.permute(0, 2, 3, 1))
+        return out
     return _BNActTrain.apply(xh, w, b, bn, relu, sync_group(bn)).permute(0, 3, 1, 2)

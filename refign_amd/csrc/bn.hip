@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        uint16_t* __restrict__ out, float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, long T, int C, int cvb, float eps,
-                                                       float momentum, int relu, float slope) {
+                                                       float momentum, int relu, float slope, long ldo) {
+  // ldo: row pitch of `out` in elements (C for a dense result; larger when the result is a channel slice of a wider
+  // channels-last tensor -- the branches of the ASPP write straight into their concatenation, daformer.py:110-118)
   const int CV = C / 8, pl = 256 / cvb;
   const int cv = blockIdx.x * cvb + threadIdx.x % cvb, rl = threadIdx.x / cvb;
   const double invTd = 1.0 / fwd_sums[2 * C];          // rows behind the statistics (all ranks')
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
         o[i] = gm[i] * rstd[i] * (gp - k0[i] - xh * k1[i]);
       }
     }
-    store8<DT>(out + t * C + c0, o);
+    store8<DT>(out + t * ldo + c0, o);
   }
 }
 
@@ -187,7 +189,8 @@ static inline int bn_cvb(int CV) { return CV >= 64 ? 64 : (CV >= 32 ? 32 : (CV >
 template <int DT>
 static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const double* fwd_sums, void* sums_or_bwd,
                      const float* gamma, const float* beta, void* out, float* rmean, float* rvar, long T, int C, float eps,
-                     float momentum, int relu, float slope, hipStream_t s) {
+                     float momentum, int relu, float slope, hipStream_t s, long ldo = 0) {
+  if (ldo == 0) ldo = C;
   const int CV = C / 8, cvb = bn_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(T, (long)pl * 4), (256L * 8) / gx));
   dim3 grid(gx, gy), block(256);
@@ -201,10 +204,10 @@ static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const d
   } else {
     if (bwd)
       hipLaunchKernelGGL((bn_apply_kernel<DT, true>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)g, fwd_sums,
-                         (const float*)sums_or_bwd, gamma, beta, (uint16_t*)out, nullptr, nullptr, T, C, cvb, eps, momentum, relu, slope);
+                         (const float*)sums_or_bwd, gamma, beta, (uint16_t*)out, nullptr, nullptr, T, C, cvb, eps, momentum, relu, slope, ldo);
     else
       hipLaunchKernelGGL((bn_apply_kernel<DT, false>), grid, block, 0, s, (const uint16_t*)x, nullptr, fwd_sums, nullptr,
-                         gamma, beta, (uint16_t*)out, rmean, rvar, T, C, cvb, eps, momentum, relu, slope);
+                         gamma, beta, (uint16_t*)out, rmean, rvar, T, C, cvb, eps, momentum, relu, slope, ldo);
   }
   return check_launch("bn kernel");
 }
@@ -239,6 +242,18 @@ int rfn_bn_apply_fwd(const void* x, const float* gamma, const float* beta, void*
   if (int rc = bn_check("bn_apply_fwd", T, C, dtype)) return rc;
   return RFN_BN_DISPATCH(false, true, x, nullptr, sums, nullptr, gamma, beta, y, running_mean, running_var, T, C, eps, momentum,
                          relu != 0, bn_slope(relu), (hipStream_t)stream);
+}
+
+// rfn_bn_apply_fwd with the result written at a row pitch of ld_y elements (>= C, multiple of 8): y is a channel slice of a
+// wider channels-last tensor
+int rfn_bn_apply_fwd_ld(const void* x, const float* gamma, const float* beta, void* y, long ld_y, const double* sums,
+                        float* running_mean, float* running_var, long T, int C, float eps, float momentum, int relu, int dtype,
+                        rfn_stream_t stream) {
+  RFN_REQUIRE(x && y && sums, "bn_apply_fwd_ld: null pointer");
+  RFN_REQUIRE(ld_y >= C && ld_y % 8 == 0 && ((size_t)y & 15) == 0, "bn_apply_fwd_ld: pitch %ld (>= C = %d, %% 8, 16-byte base)", ld_y, C);
+  if (int rc = bn_check("bn_apply_fwd_ld", T, C, dtype)) return rc;
+  return RFN_BN_DISPATCH(false, true, x, nullptr, sums, nullptr, gamma, beta, y, running_mean, running_var, T, C, eps, momentum,
+                         relu != 0, bn_slope(relu), (hipStream_t)stream, ld_y);
 }
 
 int rfn_bn_stats_bwd(const void* x, const void* grad_y, const double* fwd_sums, const float* gamma, const float* beta,

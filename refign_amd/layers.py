@@ -128,10 +128,26 @@ class ConvBNReLU(nn.Module):
                 return y
         return self._conv2d(x, c.weight, c.bias)
 
-    def forward(self, x):
+    def fused_out_ok(self, x):
+        """forward(x, out=...) is available: gradient-free, training-mode BatchNorm on the fused kernel (the EMA teacher's
+        decode head) -- the block's result can be written straight into a channel slice of a wider tensor."""
+        m = self.pointwise_conv if self.depthwise_separable else self
+        if not (x.is_cuda and not torch.is_grad_enabled() and m.use_norm and m.training and m.act in (None, 'relu')
+                and os.environ.get("RFN_BN_KERNEL", "1") != "0"):
+            return False
+        from . import bn as bnk
+        from .params import compute_dtype
+        return bnk.usable(x, m.bn, compute_dtype(x))
+
+    def forward(self, x, out=None):
         if self.depthwise_separable:
-            return self.pointwise_conv(self.depthwise_conv(x))
+            return self.pointwise_conv(self.depthwise_conv(x), out=out)
         c = self.conv
+        if out is not None:
+            from . import bn as bnk
+            from .params import compute_dtype
+            cd = compute_dtype(x)
+            return bnk.bn_act_train(self._conv_train(x, cd), self.bn, {None: 0, 'relu': 1, 'leaky': 3}[self.act], cd, out=out)
         if x.is_cuda and c.groups == 1 and not torch.is_grad_enabled() and (not self.use_norm or not self.training) \
                 and self.act_slope in (0.0, LEAKY_SLOPE):
             # gradient-free, BatchNorm in eval mode (the frozen matcher): ONE launch of the hand-written implicit-GEMM

@@ -70,3 +70,26 @@ def test_upsample_concat_fused_matches_interpolate_cat(dev, dt, sizes, chans, bw
     want.backward(go)
     for a, b in zip(toks, refs):
         assert torch.allclose(a.grad.float(), b.grad.float(), **tol)
+
+
+def test_aspp_branches_write_into_the_concatenation(monkeypatch):
+    """Gradient-free ASPP in training mode (the EMA teacher's decode head): every branch's BatchNorm + ReLU
+    writes its channels straight into the concatenated channels-last tensor (rfn_bn_apply_fwd_ld) -- same result and same
+    running statistics as the torch.cat formulation (daformer.py:110-118)."""
+    import copy
+    from refign_amd import seg
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    a = seg.ASPPWrapper(64, 32, True, (1, 6, 12, 18), False, torch.nn.BatchNorm2d, torch.nn.ReLU).to(dev).train()
+    b = copy.deepcopy(a)
+    x = torch.randn(3, 64, 20, 28, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        monkeypatch.setattr(seg, "_ASPP_NOCAT", True)
+        ya = a(x)
+        monkeypatch.setattr(seg, "_ASPP_NOCAT", False)
+        yb = b(x)
+    assert torch.equal(ya, yb)
+    for (na, ba), (nb, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(ba, bb), na
