@@ -165,6 +165,10 @@ int rfn_align_tail_f32(const float* logits_ref, const float* flow_q, const float
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W,
                            int C, int dilation, int dtype, int flip, rfn_stream_t stream);
+/* the same (bf16 only) + the BatchNorm statistics of the result in `sums` (2 C + 1 doubles: the buffer of rfn_bn_stats_fwd,
+ * zeroed inside): depthwise 3x3 -> BN of the DAFormer ASPP branches (daformer.py:10-62) without the statistics pass */
+int rfn_dwconv3x3_nhwc_fwd_stats(const void* x, const float* weight, const float* bias, void* y, double* sums, int B, int H,
+                                 int W, int C, int dilation, int dtype, rfn_stream_t stream);
 /* The same convolution (dilation 1) followed by GELU (exact erf) -- the DWConv + act of the Mix-FFN
  * (mix_transformer.py:99-101) in one pass: y_act = gelu(conv(x) + bias); y_pre (may be NULL) = the pre-activation,
  * which the backward of GELU needs and a gradient-free pass does not. */

@@ -128,13 +128,14 @@ def _apply_bwd(xh, gy, sums, bsums, weight, bias, gx, eps, relu):
 
 class _BNActTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xh, weight, bias, bn, relu, group, out=None):
+    def forward(ctx, xh, weight, bias, bn, relu, group, out=None, sums=None):
         # xh: (B, H, W, C) contiguous, 16-bit; out (gradient-free callers): where the result goes -- (B, H, W, C) with the
         # strides of a channel slice of a contiguous (B, H, W, C') tensor
         C = xh.shape[-1]
         y = torch.empty_like(xh) if out is None else out
-        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=xh.device)     # fp64: csrc/bn.hip header
-        _stats_fwd(xh, sums)
+        if sums is None:                                    # (else: the producer of xh left them, csrc/dwconv.hip STATS)
+            sums = torch.empty(2 * C + 1, dtype=torch.float64, device=xh.device)     # fp64: csrc/bn.hip header
+            _stats_fwd(xh, sums)
         comm = _exchange_comm(bn) if group is not None else None
         if group is not None:
             _all_reduce(sums, group, comm)
@@ -174,7 +175,7 @@ class _BNActTrain(torch.autograd.Function):
                 sink.add_(local[0])
             else:
                 gb = local[0].to(bias.dtype)
-        return (gx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None
+        return (gx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None, None
 
 
 def slice_out_ok(out, xshape):
@@ -187,7 +188,7 @@ def slice_out_ok(out, xshape):
     return out.stride(2) == W * p and out.stride(0) == H * W * p and out.data_ptr() % 16 == 0
 
 
-def bn_act_train(x, bn, relu, dtype, out=None):
+def bn_act_train(x, bn, relu, dtype, out=None, sums=None):
     """act(bn(x)) with batch statistics, `relu`: False / 0 none, True / 1 ReLU, 3 LeakyReLU(0.1) (the activation codes of
     the GEMM entry points); x NCHW-shaped (any memory format, converted to channels-last 16-bit if it is
     not already); returns an NCHW-shaped channels-last tensor."""
@@ -202,6 +203,6 @@ def bn_act_train(x, bn, relu, dtype, out=None):
         if torch.is_grad_enabled() and (xh.requires_grad or w.requires_grad) or out.dtype != dtype \
                 or not slice_out_ok(out, x.shape):
             raise RuntimeError("bn_act_train(out=...): gradient-free calls into a channels-last channel slice only")
-        _BNActTrain.apply(xh, w, b, bn, relu, sync_group(bn), out.permute(0, 2, 3, 1))
+        _BNActTrain.apply(xh, w, b, bn, relu, sync_group(bn), out.permute(0, 2, 3, 1), sums)
         return out
-    return _BNActTrain.apply(xh, w, b, bn, relu, sync_group(bn)).permute(0, 3, 1, 2)
+    return _BNActTrain.apply(xh, w, b, bn, relu, sync_group(bn), None, sums).permute(0, 3, 1, 2)

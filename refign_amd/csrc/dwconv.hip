@@ -133,12 +133,18 @@ __device__ __forceinline__ uint2 mask_raw(const uint2& t, bool ok) { return ok ?
 // activation is computed on the fp32 accumulators and written to `ya`; the pre-activation goes to `y` only if that
 // pointer is given (the backward needs it, a gradient-free pass does not) -- the separate GELU kernel (one more read
 // and write of the 4C-wide hidden tensor) disappears.
-template <typename T, bool FLIP, bool ACT = false>
+// STATS: the BatchNorm that follows a depthwise convolution of the decode heads (daformer.py:10-62: DepthwiseSeparable ASPP
+// branch = depthwise 3x3 -> BN -> ReLU -> 1x1 -> BN -> ReLU) needs the per-channel sum and sum of squares of THIS kernel's
+// result: a thread owns one channel vector for its whole life, so it adds up what it stores (the ROUNDED values: what the
+// statistics pass of csrc/bn.hip would have read back -- 2.65 GB for the teacher's 42 maps, 0.5 ms, per branch), the block
+// folds its pixel lanes in LDS and adds to the fp64 buffer of csrc/bn.hip (sum x, sum x^2, rows).
+template <typename T, bool FLIP, bool ACT = false, bool STATS = false>
 __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, T* __restrict__ y, int B,
                                                             int H, int W, int C, int dil, int cvb,
                                                             T* __restrict__ ya = nullptr, float xs = 1.f,
-                                                            float oq = 1.f, int sliced = 0) {
+                                                            float oq = 1.f, int sliced = 0,
+                                                            double* __restrict__ sums = nullptr) {
   // xs / oq (e4m3 activations only): stored input bytes mean xs * value -- folded into the weights; outputs are stored as
   // value * oq
   constexpr bool F8 = std::is_same<T, f8e4m3>::value;
@@ -154,21 +160,29 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
   //    so the uses are 1 and 2 rows apart whatever the dilation.  With the first mapping a row's uses land on different
   //    XCDs / megabytes apart: each is a fabric read (measured round 3: tools/kbench.py --only dw).
   int pl, cv, qfirst, qstride;
+  bool active;
   if (sliced) {
     pl = blockDim.x / cvb;
-    if ((int)threadIdx.x >= cvb * pl) return;
+    active = (int)threadIdx.x < cvb * pl;
     cv = (blockIdx.x & 7) * cvb + threadIdx.x % cvb;
     qfirst = (blockIdx.x >> 3) * pl + threadIdx.x / cvb;
     qstride = (gridDim.x >> 3) * pl;
   } else {
     pl = 256 / cvb;
     cv = blockIdx.x * cvb + threadIdx.x % cvb;
-    if (cv >= CV) return;
+    active = cv < CV;
     qfirst = blockIdx.y * pl + threadIdx.x / cvb;
     qstride = gridDim.y * pl;
   }
+  if (!STATS && !active) return;
+  if (!active) cv = 0;                                   // (STATS: idle threads stay for the block reduction)
   const int Hd = (H + dil - 1) / dil, h_slots = sliced ? dil * Hd : H;
   const int c0 = cv * V;
+  float st0[STATS ? V : 1], st1[STATS ? V : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) st0[i] = st1[i] = 0.f;
+  }
   // weights, bias and accumulators live as adjacent-channel PAIRS: every multiply-add below is one v_pk_fma_f32
   f32x2 wr[9][V2];   // tap-major weights (9, C): one contiguous fp32 vector per tap
 #pragma unroll
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
 #pragma unroll
   for (int i = 0; i < V2; ++i)
     bs[i] = (bias != nullptr) ? f32x2{bias[c0 + 2 * i], bias[c0 + 2 * i + 1]} : f32x2{0.0f, 0.0f};
-  const long nquads = (long)B * h_slots * WQ;
+  const long nquads = active ? (long)B * h_slots * WQ : 0;
   for (long quad = qfirst; quad < nquads; quad += qstride) {
     int b, h, w0;
     quad_coords(quad, WQ, h_slots, dil, b, h, w0);
@@ -240,6 +254,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
 #pragma unroll
         for (int i = 0; i < V2; ++i) { o[2 * i] = acc[p][i].x; o[2 * i + 1] = acc[p][i].y; }
         if (!ACT || y != nullptr) VecIO<T>::store(y + obase + (size_t)(w0 + p * dil) * C, o);
+        if constexpr (STATS) {
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float r = sizeof(T) == 2 ? __uint_as_float(bf16_bits(o[i]) << 16) : o[i];
+            st0[i] += r;
+            st1[i] = fmaf(r, r, st1[i]);
+          }
+        }
         if (ACT) {
 #pragma unroll
           for (int i = 0; i < V; ++i) {
@@ -250,6 +272,25 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
           VecIO<T>::store(ya + obase + (size_t)(w0 + p * dil) * C, o);
         }
       }
+  }
+  if constexpr (STATS) {
+    __shared__ float sred[2][256][V + 1];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      sred[0][threadIdx.x][i] = active ? st0[i] : 0.f;
+      sred[1][threadIdx.x][i] = active ? st1[i] : 0.f;
+    }
+    __syncthreads();
+    // thread (which, channel vector of the block, element): fold the pixel lanes, one fp64 atomic per channel and block
+    const int cvbase = sliced ? (blockIdx.x & 7) * cvb : blockIdx.x * cvb;
+    for (int idx = threadIdx.x; idx < 2 * cvb * V; idx += blockDim.x) {
+      const int which = idx / (cvb * V), rem = idx % (cvb * V), v = rem / V, e = rem % V;
+      if (cvbase + v >= CV) continue;
+      float sum = 0.f;
+      for (int r = 0; r < pl; ++r) sum += sred[which][r * cvb + v][e];
+      atomicAdd(sums + which * C + (cvbase + v) * V + e, (double)sum);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(sums + 2 * C, (double)B * H * W);
   }
 }
 
@@ -417,6 +458,25 @@ static int launch_fwd_gelu(const void* x, const float* w, const float* bias, voi
 }
 
 template <typename T>
+static int launch_fwd_stats(const void* x, const float* w, const float* bias, void* y, double* sums, int B, int H, int W, int C,
+                            int dil, hipStream_t st) {
+  constexpr int V = VecIO<T>::N;
+  const int CV = C / V;
+  const int WQ = dil * (((W + dil - 1) / dil + kPX - 1) / kPX);
+  if (SlicedGeom sg = sliced_geom(CV, (long)B * dil * ((H + dil - 1) / dil) * WQ); sg.on) {
+    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, false, true>), dim3(sg.grid), dim3(256), 0, st, (const T*)x, w, bias,
+                       (T*)y, B, H, W, C, dil, sg.cvb, (T*)nullptr, 1.f, 1.f, 1, sums);
+    return check_launch("dwconv3x3_fwd_kernel<sliced, stats>");
+  }
+  const int cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
+  const long nquads = (long)B * H * WQ;
+  const int gy = (int)std::max<long>(1, std::min<long>(cdiv(nquads, pl), (256L * 16) / gx));
+  hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, false, true>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias, (T*)y,
+                     B, H, W, C, dil, cvb, (T*)nullptr, 1.f, 1.f, 0, sums);
+  return check_launch("dwconv3x3_fwd_kernel<stats>");
+}
+
+template <typename T>
 static int launch_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int dil,
                       int flip, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
@@ -478,6 +538,18 @@ int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias
     return launch_fwd<__hip_bfloat16>(x, weight, bias, y, B, H, W, C, dilation, flip, (hipStream_t)stream);
   }
   return fail(RFN_EINVAL, "rfn_dwconv3x3_nhwc_fwd: dtype must be 0 (f32) or 1 (bf16)");
+}
+
+// rfn_dwconv3x3_nhwc_fwd (bf16) that also leaves the BatchNorm statistics of its result in `sums` (2 C + 1 doubles: sum,
+// sum of squares, rows -- the buffer of rfn_bn_stats_fwd, zeroed here): the statistics pass over the result is not needed
+int rfn_dwconv3x3_nhwc_fwd_stats(const void* x, const float* weight, const float* bias, void* y, double* sums, int B, int H,
+                                 int W, int C, int dilation, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && weight && y && sums, "rfn_dwconv3x3_nhwc_fwd_stats: null pointer");
+  RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "rfn_dwconv3x3_nhwc_fwd_stats: bad size");
+  RFN_REQUIRE(dtype == 1 && C % 8 == 0, "rfn_dwconv3x3_nhwc_fwd_stats: bf16 (dtype 1), C %% 8 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = zero_async(sums, (2 * (size_t)C + 1) * sizeof(double), st)) return rc;
+  return launch_fwd_stats<__hip_bfloat16>(x, weight, bias, y, sums, B, H, W, C, dilation, st);
 }
 
 int rfn_dwconv3x3_gelu_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y_pre, void* y_act, int B,

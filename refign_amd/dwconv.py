@@ -15,10 +15,16 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 _DW_WS_STRIPES = 128       # kMaxStripes in csrc/dwconv.hip (checked against the ABI in the GPU tests)
 
 
-def _fwd(x, w_tap, bias, dilation, flip):
+def _fwd(x, w_tap, bias, dilation, flip, stats=None):
     B, H, W, C = x.shape
     y = torch.empty_like(x)
     lib = _lib.load_library()
+    if stats is not None:                                   # + the BatchNorm statistics of the result (csrc/dwconv.hip STATS)
+        with on_device(x.device):
+            rc = lib.rfn_dwconv3x3_nhwc_fwd_stats(ptr(x), ptr(w_tap), ptr(bias), ptr(y), ptr(stats), B, H, W, C, dilation,
+                                                  _DT[x.dtype], current_stream(x.device))
+        _lib.check(rc, "dwconv3x3_nhwc_fwd_stats")
+        return y
     with on_device(x.device):
         rc = lib.rfn_dwconv3x3_nhwc_fwd(ptr(x), ptr(w_tap), ptr(bias), ptr(y), B, H, W, C, dilation, _DT[x.dtype],
                                         1 if flip else 0, current_stream(x.device))
@@ -28,7 +34,7 @@ def _fwd(x, w_tap, bias, dilation, flip):
 
 class _DWConv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, dilation):
+    def forward(ctx, x, weight, bias, dilation, stats=None):
         if x.dtype not in _DT:
             x = x.float()
         x = require_device_tensor(x.contiguous(), "x")
@@ -41,12 +47,12 @@ class _DWConv3x3(torch.autograd.Function):
         ctx.dilation, ctx.has_bias = dilation, bias is not None
         ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
         ctx.weight, ctx.bias = weight, bias
-        return _fwd(x, w_tap, b32, dilation, False)
+        return _fwd(x, w_tap, b32, dilation, False, stats)
 
     @staticmethod
     def backward(ctx, gy):
         x, w_tap = ctx.saved_tensors
-        return _dwconv_backward(ctx, x, w_tap, gy.to(x.dtype).contiguous())
+        return _dwconv_backward(ctx, x, w_tap, gy.to(x.dtype).contiguous()) + (None,)
 
 
 class _DWConv3x3Gelu(torch.autograd.Function):
@@ -138,11 +144,16 @@ def dwconv3x3_gelu_tokens(x, weight, bias, H, W, with_z=False):
     return (out.reshape(B, N, C), None) if with_z else out.reshape(B, N, C)
 
 
-def dwconv3x3_nhwc(x, weight, bias=None, dilation=1):
-    """x: (B,H,W,C) fp32/bf16; weight: (C,1,3,3); bias: (C) or None; same-size output (padding = dilation)."""
+def dwconv3x3_nhwc(x, weight, bias=None, dilation=1, stats=None):
+    """x: (B,H,W,C) fp32/bf16; weight: (C,1,3,3); bias: (C) or None; same-size output (padding = dilation).
+    `stats` (bf16 x, C % 8 == 0): a float64 tensor of 2 C + 1 elements that receives the BatchNorm statistics of the result
+    (sum, sum of squares, rows: the buffer of bn._stats_fwd)."""
     if x.dim() != 4 or weight.shape[0] != x.shape[-1]:
         raise RuntimeError("dwconv3x3_nhwc: x must be (B,H,W,C) and weight (C,1,3,3)")
-    return _DWConv3x3.apply(x, weight, bias, int(dilation))
+    if stats is not None and not (x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0 and stats.dtype == torch.float64
+                                  and stats.is_contiguous() and stats.numel() == 2 * x.shape[-1] + 1):
+        raise RuntimeError("dwconv3x3_nhwc(stats=...): bf16 input with C % 8 == 0 and a float64 buffer of 2 C + 1 elements")
+    return _DWConv3x3.apply(x, weight, bias, int(dilation), stats)
 
 
 def dwconv3x3_tokens(x, weight, bias, H, W):

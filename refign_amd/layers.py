@@ -14,6 +14,9 @@ import torch.nn.functional as F
 LEAKY_SLOPE = 0.1   # activation_layer = partial(nn.LeakyReLU, negative_slope=0.1)  (modules.py:407,459,498)
 
 
+_DW_BN_STATS = os.environ.get("RFN_DW_BN_STATS", "1") != "0"
+
+
 class ConvBNReLU(nn.Module):
     """Constructor semantics and parameter names of models/modules.py:16-56, including the depthwise-separable form
     (a depthwise ConvBNReLU followed by a 1x1 pointwise ConvBNReLU, each with its own norm + activation)."""
@@ -76,7 +79,7 @@ class ConvBNReLU(nn.Module):
         self._folded = None
         return super()._apply(fn, *a, **k)
 
-    def _conv2d(self, x, w, b):
+    def _conv2d(self, x, w, b, stats=None):
         """The convolution itself.  Depthwise 3x3 (the DAFormer ASPP branches) goes to the hand-written channels-last
         HIP kernel on the GPU -- the library's grouped-conv path for group size 1 is ~50x off the HBM roofline; every
         other shape is a dense conv on the ROCm library."""
@@ -86,8 +89,10 @@ class ConvBNReLU(nn.Module):
                 and c.in_channels % 8 == 0):
             from .dwconv import dwconv3x3_nhwc
             xh = x.permute(0, 2, 3, 1)                       # free for channels_last inputs
-            y = dwconv3x3_nhwc(xh if xh.is_contiguous() else xh.contiguous(), w, b, c.dilation[0])
+            y = dwconv3x3_nhwc(xh if xh.is_contiguous() else xh.contiguous(), w, b, c.dilation[0], stats=stats)
             return y.permute(0, 3, 1, 2)                     # NCHW-shaped, channels_last strides
+        if stats is not None:
+            raise RuntimeError("ConvBNReLU._conv2d(stats=...): depthwise 3x3 on the HIP kernel only")
         if x.is_cuda:
             from . import mfma, split32
             if c.groups == 1 and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and split32.usable(x):
@@ -139,15 +144,30 @@ class ConvBNReLU(nn.Module):
         from .params import compute_dtype
         return bnk.usable(x, m.bn, compute_dtype(x))
 
+    def _dw_stats_ok(self, x, cd):
+        """depthwise 3x3 -> BatchNorm(train): the convolution kernel leaves the batch statistics of its result behind
+        (csrc/dwconv.hip STATS), the BatchNorm skips its statistics pass.  RFN_DW_BN_STATS=0: two passes, as before."""
+        c = self.conv
+        return (_DW_BN_STATS and x.is_cuda and x.dtype == torch.bfloat16 and cd == torch.bfloat16
+                and c.groups == c.in_channels == c.out_channels and c.kernel_size == (3, 3) and c.stride == (1, 1)
+                and c.padding == c.dilation and c.dilation[0] == c.dilation[1] and c.in_channels % 8 == 0)
+
+    def _bn_train(self, x, cd, out=None):
+        from . import bn as bnk
+        act = {None: 0, 'relu': 1, 'leaky': 3}[self.act]
+        if self._dw_stats_ok(x, cd):
+            c = self.conv
+            sums = torch.empty(2 * c.out_channels + 1, dtype=torch.float64, device=x.device)
+            return bnk.bn_act_train(self._conv2d(x, c.weight, c.bias, stats=sums), self.bn, act, cd, out=out, sums=sums)
+        return bnk.bn_act_train(self._conv_train(x, cd), self.bn, act, cd, out=out)
+
     def forward(self, x, out=None):
         if self.depthwise_separable:
             return self.pointwise_conv(self.depthwise_conv(x), out=out)
         c = self.conv
         if out is not None:
-            from . import bn as bnk
             from .params import compute_dtype
-            cd = compute_dtype(x)
-            return bnk.bn_act_train(self._conv_train(x, cd), self.bn, {None: 0, 'relu': 1, 'leaky': 3}[self.act], cd, out=out)
+            return self._bn_train(x, compute_dtype(x), out=out)
         if x.is_cuda and c.groups == 1 and not torch.is_grad_enabled() and (not self.use_norm or not self.training) \
                 and self.act_slope in (0.0, LEAKY_SLOPE):
             # gradient-free, BatchNorm in eval mode (the frozen matcher): ONE launch of the hand-written implicit-GEMM
@@ -170,7 +190,7 @@ class ConvBNReLU(nn.Module):
                 from .params import compute_dtype
                 cd = compute_dtype(x)
                 if bnk.usable(x, self.bn, cd):
-                    return bnk.bn_act_train(self._conv_train(x, cd), self.bn, {None: 0, 'relu': 1, 'leaky': 3}[self.act], cd)
+                    return self._bn_train(x, cd)
             x = self._conv2d(x, c.weight, c.bias)
             if self.use_norm:
                 x = self.bn(x)

@@ -69,3 +69,27 @@ def test_fused_dwconv_gelu_matches_conv_then_exact_gelu(dev, B, H, W, C):
     a2, z = dwconv3x3_gelu_tokens(xg, w, b, H, W, with_z=True)
     assert torch.equal(a2, a)
     assert bool(((z.float() - z_ref).abs() <= 2.0 ** -8 * z_ref.abs() + 2e-3).all())
+
+
+@pytest.mark.parametrize("B,H,W,C,dil", [(2, 20, 28, 1024, 6), (3, 9, 13, 1280, 1), (2, 17, 30, 64, 1), (1, 23, 31, 256, 12)])
+def test_dwconv_leaves_the_batchnorm_statistics_of_its_result(dev, B, H, W, C, dil):
+    """rfn_dwconv3x3_nhwc_fwd_stats (depthwise 3x3 -> BatchNorm of the ASPP branches, daformer.py:10-62): same result as the
+    plain kernel, and the (sum, sum of squares, rows) buffer equals what bn._stats_fwd reads back from that result --
+    both geometries of the kernel (first-generation grid, XCD-sliced with idle threads)."""
+    from refign_amd import bn as bnk
+    from refign_amd.dwconv import dwconv3x3_nhwc
+    g = torch.Generator().manual_seed(C + H + dil)
+    x = (torch.randn(B, H, W, C, generator=g) + 0.3).to(dev).to(torch.bfloat16)
+    w = torch.randn(C, 1, 3, 3, generator=g).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    with torch.no_grad():
+        want = dwconv3x3_nhwc(x, w, b, dil)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        got = dwconv3x3_nhwc(x, w, b, dil, stats=sums)
+    assert torch.equal(got, want)
+    ref = torch.empty_like(sums)
+    bnk._stats_fwd(want, ref)
+    assert float(sums[2 * C]) == float(ref[2 * C]) == B * H * W
+    scale = ref[C:2 * C].abs().max()
+    assert float((sums[:C] - ref[:C]).abs().max()) <= 1e-5 * float(ref[:C].abs().max() + scale.sqrt())
+    assert float((sums[C:2 * C] - ref[C:2 * C]).abs().max()) <= 1e-5 * float(scale)
