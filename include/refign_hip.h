@@ -169,6 +169,14 @@ int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias
  * zeroed inside): depthwise 3x3 -> BN of the DAFormer ASPP branches (daformer.py:10-62) without the statistics pass */
 int rfn_dwconv3x3_nhwc_fwd_stats(const void* x, const float* weight, const float* bias, void* y, double* sums, int B, int H,
                                  int W, int C, int dilation, int dtype, rfn_stream_t stream);
+/* gradient-free depthwise 3x3 -> BatchNorm(batch statistics) -> ReLU (the EMA teacher's ASPP branches) in two
+ * passes over the INPUT: statistics of the (rounded) convolution result without storing it, then convolution + normalisation
+ * + activation in one pass -- 3 tensor passes instead of 5.  A SyncBatchNorm all-reduces `sums` in between. */
+int rfn_dwconv3x3_nhwc_stats(const void* x, const float* weight, const float* bias, double* sums, int B, int H, int W, int C,
+                             int dilation, int dtype, rfn_stream_t stream);
+int rfn_dwconv3x3_bn_act_nhwc_fwd(const void* x, const float* weight, const float* bias, const float* gamma, const float* beta,
+                                  const double* sums, float* running_mean, float* running_var, void* y, int B, int H, int W,
+                                  int C, int dilation, float eps, float momentum, int relu, int dtype, rfn_stream_t stream);
 /* The same convolution (dilation 1) followed by GELU (exact erf) -- the DWConv + act of the Mix-FFN
  * (mix_transformer.py:99-101) in one pass: y_act = gelu(conv(x) + bias); y_pre (may be NULL) = the pre-activation,
  * which the backward of GELU needs and a gradient-free pass does not. */

@@ -138,13 +138,27 @@ __device__ __forceinline__ uint2 mask_raw(const uint2& t, bool ok) { return ok ?
 // result: a thread owns one channel vector for its whole life, so it adds up what it stores (the ROUNDED values: what the
 // statistics pass of csrc/bn.hip would have read back -- 2.65 GB for the teacher's 42 maps, 0.5 ms, per branch), the block
 // folds its pixel lanes in LDS and adds to the fp64 buffer of csrc/bn.hip (sum x, sum x^2, rows).
-template <typename T, bool FLIP, bool ACT = false, bool STATS = false>
+// STATS = 2: statistics only, nothing is stored; BNE: the result is BatchNorm(batch statistics from `sums`) + ReLU of the
+// convolution -- the two passes of the gradient-free form (the EMA teacher's decode head): statistics pass, then convolution
+// + normalisation + activation in one pass; 3 tensor passes (read, read, write) instead of the 5 of convolution (read,
+// write), statistics (read), BatchNorm (read, write).  BnEpi: gamma / beta (may be null), eps, relu, and the running buffers
+// the blocks of the first row of the grid update (momentum), as csrc/bn.hip's apply pass does.
+struct BnEpi {
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float eps, momentum;
+  int relu;
+};
+
+template <typename T, bool FLIP, bool ACT = false, int STATS = 0, bool BNE = false>
 __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, T* __restrict__ y, int B,
                                                             int H, int W, int C, int dil, int cvb,
                                                             T* __restrict__ ya = nullptr, float xs = 1.f,
                                                             float oq = 1.f, int sliced = 0,
-                                                            double* __restrict__ sums = nullptr) {
+                                                            double* __restrict__ sums = nullptr, BnEpi bn = BnEpi{}) {
   // xs / oq (e4m3 activations only): stored input bytes mean xs * value -- folded into the weights; outputs are stored as
   // value * oq
   constexpr bool F8 = std::is_same<T, f8e4m3>::value;
@@ -174,14 +188,33 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
     qfirst = blockIdx.y * pl + threadIdx.x / cvb;
     qstride = gridDim.y * pl;
   }
-  if (!STATS && !active) return;
+  if (STATS == 0 && !active) return;
   if (!active) cv = 0;                                   // (STATS: idle threads stay for the block reduction)
   const int Hd = (H + dil - 1) / dil, h_slots = sliced ? dil * Hd : H;
   const int c0 = cv * V;
   float st0[STATS ? V : 1], st1[STATS ? V : 1];
-  if constexpr (STATS) {
+  if constexpr (STATS != 0) {
 #pragma unroll
     for (int i = 0; i < V; ++i) st0[i] = st1[i] = 0.f;
+  }
+  float bsc[BNE ? V : 1], bsh[BNE ? V : 1];              // y = relu(conv * bsc + bsh)
+  if constexpr (BNE) {
+    const double cnt = sums[2 * C], inv = 1.0 / cnt;
+    const bool first = sliced ? (blockIdx.x >> 3) == 0 : blockIdx.y == 0;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = c0 + i;
+      const double m = sums[c] * inv;
+      const float var = (float)fmax(sums[C + c] * inv - m * m, 0.0), mean = (float)m;
+      const float g = bn.gamma != nullptr ? bn.gamma[c] : 1.f, be = bn.beta != nullptr ? bn.beta[c] : 0.f;
+      bsc[i] = rsqrtf(var + bn.eps) * g;
+      bsh[i] = be - mean * bsc[i];
+      if (first && active && threadIdx.x / cvb == 0 && bn.running_mean != nullptr) {
+        const float n = (float)cnt;
+        bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * mean;
+        bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * var * (n / fmaxf(n - 1.f, 1.f));
+      }
+    }
   }
   // weights, bias and accumulators live as adjacent-channel PAIRS: every multiply-add below is one v_pk_fma_f32
   f32x2 wr[9][V2];   // tap-major weights (9, C): one contiguous fp32 vector per tap
@@ -253,8 +286,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
         float o[V];
 #pragma unroll
         for (int i = 0; i < V2; ++i) { o[2 * i] = acc[p][i].x; o[2 * i + 1] = acc[p][i].y; }
-        if (!ACT || y != nullptr) VecIO<T>::store(y + obase + (size_t)(w0 + p * dil) * C, o);
-        if constexpr (STATS) {
+        if constexpr (BNE) {
+          // the statistics were taken of the ROUNDED convolution result (what the unfused path stores and reads back)
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float r = sizeof(T) == 2 ? __uint_as_float(bf16_bits(o[i]) << 16) : o[i];
+            const float z = fmaf(r, bsc[i], bsh[i]);
+            o[i] = (bn.relu && z <= 0.f) ? 0.f : z;
+          }
+        }
+        if (STATS != 2 && (!ACT || y != nullptr)) VecIO<T>::store(y + obase + (size_t)(w0 + p * dil) * C, o);
+        if constexpr (STATS != 0) {
 #pragma unroll
           for (int i = 0; i < V; ++i) {
             const float r = sizeof(T) == 2 ? __uint_as_float(bf16_bits(o[i]) << 16) : o[i];
@@ -273,7 +315,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
         }
       }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS != 0) {
     __shared__ float sred[2][256][V + 1];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -457,23 +499,24 @@ static int launch_fwd_gelu(const void* x, const float* w, const float* bias, voi
   return check_launch("dwconv3x3_fwd_kernel<gelu>");
 }
 
-template <typename T>
+// STATS 1: convolution + statistics; 2: statistics only; BNE: convolution + BatchNorm + activation from complete statistics
+template <typename T, int STATS, bool BNE>
 static int launch_fwd_stats(const void* x, const float* w, const float* bias, void* y, double* sums, int B, int H, int W, int C,
-                            int dil, hipStream_t st) {
+                            int dil, hipStream_t st, BnEpi bn = BnEpi{}) {
   constexpr int V = VecIO<T>::N;
   const int CV = C / V;
   const int WQ = dil * (((W + dil - 1) / dil + kPX - 1) / kPX);
   if (SlicedGeom sg = sliced_geom(CV, (long)B * dil * ((H + dil - 1) / dil) * WQ); sg.on) {
-    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, false, true>), dim3(sg.grid), dim3(256), 0, st, (const T*)x, w, bias,
-                       (T*)y, B, H, W, C, dil, sg.cvb, (T*)nullptr, 1.f, 1.f, 1, sums);
-    return check_launch("dwconv3x3_fwd_kernel<sliced, stats>");
+    hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, false, STATS, BNE>), dim3(sg.grid), dim3(256), 0, st, (const T*)x, w, bias,
+                       (T*)y, B, H, W, C, dil, sg.cvb, (T*)nullptr, 1.f, 1.f, 1, sums, bn);
+    return check_launch("dwconv3x3_fwd_kernel<sliced, stats / bn>");
   }
   const int cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
   const long nquads = (long)B * H * WQ;
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(nquads, pl), (256L * 16) / gx));
-  hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, false, true>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias, (T*)y,
-                     B, H, W, C, dil, cvb, (T*)nullptr, 1.f, 1.f, 0, sums);
-  return check_launch("dwconv3x3_fwd_kernel<stats>");
+  hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T, false, false, STATS, BNE>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, w, bias,
+                     (T*)y, B, H, W, C, dil, cvb, (T*)nullptr, 1.f, 1.f, 0, sums, bn);
+  return check_launch("dwconv3x3_fwd_kernel<stats / bn>");
 }
 
 template <typename T>
@@ -549,7 +592,32 @@ int rfn_dwconv3x3_nhwc_fwd_stats(const void* x, const float* weight, const float
   RFN_REQUIRE(dtype == 1 && C % 8 == 0, "rfn_dwconv3x3_nhwc_fwd_stats: bf16 (dtype 1), C %% 8 == 0");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = zero_async(sums, (2 * (size_t)C + 1) * sizeof(double), st)) return rc;
-  return launch_fwd_stats<__hip_bfloat16>(x, weight, bias, y, sums, B, H, W, C, dilation, st);
+  return launch_fwd_stats<__hip_bfloat16, 1, false>(x, weight, bias, y, sums, B, H, W, C, dilation, st);
+}
+
+// Gradient-free depthwise 3x3 -> BatchNorm(batch statistics) -> ReLU in two passes over the INPUT (bf16):
+//   rfn_dwconv3x3_nhwc_stats        sums <- (sum, sum of squares, rows) of the rounded convolution result, nothing stored;
+//   rfn_dwconv3x3_bn_act_nhwc_fwd   y = act(bn(conv(x))) with the statistics in `sums` (between the two a SyncBatchNorm
+//                                   all-reduces `sums`); running_mean / running_var (may be NULL) updated as rfn_bn_apply_fwd.
+int rfn_dwconv3x3_nhwc_stats(const void* x, const float* weight, const float* bias, double* sums, int B, int H, int W, int C,
+                             int dilation, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && weight && sums, "rfn_dwconv3x3_nhwc_stats: null pointer");
+  RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "rfn_dwconv3x3_nhwc_stats: bad size");
+  RFN_REQUIRE(dtype == 1 && C % 8 == 0, "rfn_dwconv3x3_nhwc_stats: bf16 (dtype 1), C %% 8 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = zero_async(sums, (2 * (size_t)C + 1) * sizeof(double), st)) return rc;
+  return launch_fwd_stats<__hip_bfloat16, 2, false>(x, weight, bias, nullptr, sums, B, H, W, C, dilation, st);
+}
+
+int rfn_dwconv3x3_bn_act_nhwc_fwd(const void* x, const float* weight, const float* bias, const float* gamma, const float* beta,
+                                  const double* sums, float* running_mean, float* running_var, void* y, int B, int H, int W,
+                                  int C, int dilation, float eps, float momentum, int relu, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && weight && sums && y, "rfn_dwconv3x3_bn_act_nhwc_fwd: null pointer");
+  RFN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "rfn_dwconv3x3_bn_act_nhwc_fwd: bad size");
+  RFN_REQUIRE(dtype == 1 && C % 8 == 0 && (relu == 0 || relu == 1), "rfn_dwconv3x3_bn_act_nhwc_fwd: bf16, C %% 8 == 0, relu 0 / 1");
+  BnEpi bn{gamma, beta, running_mean, running_var, eps, momentum, relu};
+  return launch_fwd_stats<__hip_bfloat16, 0, true>(x, weight, bias, y, const_cast<double*>(sums), B, H, W, C, dilation,
+                                                   (hipStream_t)stream, bn);
 }
 
 int rfn_dwconv3x3_gelu_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y_pre, void* y_act, int B,

@@ -156,6 +156,38 @@ def dwconv3x3_nhwc(x, weight, bias=None, dilation=1, stats=None):
     return _DWConv3x3.apply(x, weight, bias, int(dilation), stats)
 
 
+@torch.no_grad()
+def dwconv3x3_bn_act_nhwc(x, weight, bias, dilation, bn, relu):
+    """act(bn(dwconv3x3(x))) with BATCH statistics, gradient-free (the EMA teacher's ASPP branches run their BatchNorms in
+    training mode; daformer.py:10-62): two passes over x -- statistics of the convolution result without storing
+    it, then convolution + normalisation + ReLU -- instead of convolution, statistics pass and BatchNorm pass over the
+    result.  x: (B, H, W, C) bf16 contiguous; bn: the (Sync)BatchNorm2d module (running buffers updated as in training)."""
+    from . import bn as bnk
+    B, H, W, C = x.shape
+    w_tap = derived(weight, "tap_major_f32", lambda t: t.float().reshape(C, 9).t().contiguous(),
+                    lambda t: t.reshape(C, 9).t())
+    b32 = None if bias is None else as_dtype(bias, torch.float32).detach().contiguous()
+    g = None if bn.weight is None else as_dtype(bn.weight, torch.float32).detach().contiguous()
+    be = None if bn.bias is None else as_dtype(bn.bias, torch.float32).detach().contiguous()
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+    y = torch.empty_like(x)
+    lib = _lib.load_library()
+    with on_device(x.device):
+        rc = lib.rfn_dwconv3x3_nhwc_stats(ptr(x), ptr(w_tap), ptr(b32), ptr(sums), B, H, W, C, int(dilation), _DT[x.dtype],
+                                          current_stream(x.device))
+    _lib.check(rc, "dwconv3x3_nhwc_stats")
+    group = bnk.sync_group(bn)
+    if group is not None:
+        bnk._all_reduce(sums, group, bnk._exchange_comm(bn))
+    with on_device(x.device):
+        rc = lib.rfn_dwconv3x3_bn_act_nhwc_fwd(ptr(x), ptr(w_tap), ptr(b32), ptr(g), ptr(be), ptr(sums), ptr(bn.running_mean),
+                                               ptr(bn.running_var), ptr(y), B, H, W, C, int(dilation), float(bn.eps),
+                                               float(bn.momentum), 1 if relu else 0, _DT[x.dtype], current_stream(x.device))
+    _lib.check(rc, "dwconv3x3_bn_act_nhwc_fwd")
+    bn.num_batches_tracked.add_(1)
+    return y
+
+
 def dwconv3x3_tokens(x, weight, bias, H, W):
     """x: (B, N=H*W, C) tokens -> (B, N, C)."""
     B, N, C = x.shape

@@ -15,6 +15,7 @@ LEAKY_SLOPE = 0.1   # activation_layer = partial(nn.LeakyReLU, negative_slope=0.
 
 
 _DW_BN_STATS = os.environ.get("RFN_DW_BN_STATS", "1") != "0"
+_DW_BN_FUSED = os.environ.get("RFN_DW_BN_FUSED", "1") != "0"
 
 
 class ConvBNReLU(nn.Module):
@@ -155,6 +156,15 @@ class ConvBNReLU(nn.Module):
     def _bn_train(self, x, cd, out=None):
         from . import bn as bnk
         act = {None: 0, 'relu': 1, 'leaky': 3}[self.act]
+        if self._dw_stats_ok(x, cd) and not torch.is_grad_enabled() and out is None and act in (0, 1) and _DW_BN_FUSED \
+                and self.bn.momentum is not None:
+            # gradient-free (EMA teacher): statistics pass without a store, then convolution + BatchNorm + ReLU in one pass
+            from .dwconv import dwconv3x3_bn_act_nhwc
+            c = self.conv
+            xh = x.permute(0, 2, 3, 1)
+            y = dwconv3x3_bn_act_nhwc(xh if xh.is_contiguous() else xh.contiguous(), c.weight, c.bias, c.dilation[0], self.bn,
+                                      act == 1)
+            return y.permute(0, 3, 1, 2)
         if self._dw_stats_ok(x, cd):
             c = self.conv
             sums = torch.empty(2 * c.out_channels + 1, dtype=torch.float64, device=x.device)

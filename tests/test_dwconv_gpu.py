@@ -93,3 +93,32 @@ def test_dwconv_leaves_the_batchnorm_statistics_of_its_result(dev, B, H, W, C, d
     scale = ref[C:2 * C].abs().max()
     assert float((sums[:C] - ref[:C]).abs().max()) <= 1e-5 * float(ref[:C].abs().max() + scale.sqrt())
     assert float((sums[C:2 * C] - ref[C:2 * C]).abs().max()) <= 1e-5 * float(scale)
+
+
+@pytest.mark.parametrize("B,H,W,C,dil,relu", [(2, 20, 28, 1024, 6, True), (3, 9, 13, 1280, 1, True), (2, 17, 30, 64, 18, False)])
+def test_gradient_free_dwconv_batchnorm_relu_in_two_input_passes(dev, B, H, W, C, dil, relu):
+    """dwconv3x3_bn_act_nhwc (statistics without a store, then convolution + BatchNorm(batch statistics) + ReLU) == the
+    chain depthwise kernel -> csrc/bn.hip statistics -> apply, result and running buffers (same rounded values enter the
+    statistics; the fp64 sums differ only in summation order)."""
+    import copy
+    from refign_amd import bn as bnk
+    from refign_amd.dwconv import dwconv3x3_bn_act_nhwc, dwconv3x3_nhwc
+    g = torch.Generator().manual_seed(C + H + dil)
+    x = (torch.randn(B, H, W, C, generator=g) + 0.2).to(dev).to(torch.bfloat16)
+    w = torch.randn(C, 1, 3, 3, generator=g).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    bn_a = torch.nn.BatchNorm2d(C).to(dev).train()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(C, generator=g).to(dev) + 0.5)
+        bn_a.bias.copy_(torch.randn(C, generator=g).to(dev))
+    bn_b = copy.deepcopy(bn_a)
+    with torch.no_grad():
+        got = dwconv3x3_bn_act_nhwc(x, w, b, dil, bn_a, relu)
+        conv = dwconv3x3_nhwc(x, w, b, dil)
+        want = bnk.bn_act_train(conv.permute(0, 3, 1, 2), bn_b, 1 if relu else 0, torch.bfloat16).permute(0, 2, 3, 1)
+    err = (got.float() - want.float()).abs()
+    assert float(err.max()) <= 2.0 ** -7 * float(want.float().abs().max())          # at most a rounding step apart ...
+    assert float((err > 0).float().mean()) < 1e-3                                    # ... and almost everywhere equal
+    assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-6, atol=1e-7)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
