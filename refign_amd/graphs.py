@@ -21,6 +21,8 @@ anyway is recoverable -- the thread is put back on its original stream and the r
 (tests/test_step_gpu.py::test_failed_graph_capture_falls_back_to_eager).  Exercised on the GPU with a 1-rank RCCL
 process group (same module tree as N > 1: SyncBatchNorm everywhere); not with several ranks (one-GPU boxes).
 """
+import contextlib
+import gc
 import os
 import warnings
 
@@ -29,6 +31,22 @@ import torch
 
 def enabled():
     return os.environ.get("RFN_HIP_GRAPH", "1") != "0"
+
+
+@contextlib.contextmanager
+def _no_cyclic_gc():
+    """No cyclic garbage collection while a capture is open: a collection that happens to run inside the captured region
+    finalises whatever cyclic garbage exists -- graphs, events, tensors with recorded streams of an earlier model -- and
+    some of their destructors make runtime calls that are illegal during a capture; the process aborts (seen in round 3 in
+    the test suite, on the ninth model of a process).  torch.cuda.graph collects BEFORE it begins; reference counting
+    keeps freeing everything that is not a cycle."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _fresh_containers(out):
@@ -91,7 +109,7 @@ class GraphedNoGrad:
         # thread_local: calls made by other host threads during the capture (the RCCL watchdog of torch.distributed
         # polls its events) must not invalidate it
         try:
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with _no_cyclic_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 outputs = self.fn(*inputs)
         except BaseException:
             # torch.cuda.graph.__exit__ raises from capture_end() BEFORE it restores the stream: the thread would stay
@@ -200,7 +218,7 @@ class GraphedStep:
         import contextlib
         ctx = self.capture_context() if self.capture_context is not None else contextlib.nullcontext()
         try:
-            with ctx:
+            with ctx, _no_cyclic_gc():
                 with torch.cuda.graph(g, pool=self.shared.get("pool"), capture_error_mode="thread_local"):
                     outputs = self.fn(*inputs)
         except BaseException:
