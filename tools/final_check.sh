@@ -22,3 +22,13 @@ timeout 300 python tools/kbench.py --only L1,L2 2>&1 | grep -v "amdgpu.ids\|MIOp
 for a in 1 2 4 6 7; do echo "RFN_CORR_ABLATE=$a"; RFN_CORR_ABLATE=$a timeout 200 python tools/kbench.py --only L1 2>&1 | grep -i "f16-split\|relu+l2norm"; done > $O/corr_f16_ablation.txt
 for t in f8gemm_fc1_s3:gemm_nt_f8 f8gemm_fc2_s3:gemm_nt_f8 f8attn_s3:attn_fwd_f8 gemm_fc1_s3:gemm_nt_kernel; do
   echo "== ${t%%:*}"; bash tools/pmc_mfma.sh ${t%%:*} ${t##*:}; done > $O/pmc_f8_kernels.txt 2>&1
+# round 3, second half: per-entry-point census of the step, what is left in ATen, attention / depthwise / GEMM sweeps on replayed
+# graphs, per-CU fetch rates (L2 / MALL / HBM), cost of a node in a linear graph
+timeout 300 python tools/abi_census.py --top 60 2>&1 | grep -v "amdgpu.ids" > $O/abi_census.txt
+timeout 300 python tools/aten_census.py 2>&1 | grep -v "amdgpu.ids\|Warn\|_warn" > $O/aten_census.txt
+timeout 300 python tools/attn_bench.py 2>&1 | grep -v "amdgpu.ids" > $O/attn_bench.txt
+timeout 300 python tools/kbench.py --only dw 2>&1 | grep -v "amdgpu.ids\|MIOpen" > $O/kbench_dwconv.txt
+SWEEP_CFGS=";128,128,2;128,64,2;64,64,2;256,256,2" SWEEP_PERSIST=0 timeout 600 python tools/gemm_sweep.py 2>&1 | grep -v "amdgpu.ids" > $O/gemm_sweep.txt
+timeout 120 python tools/micro/graph_chain.py 2>&1 | grep -v "amdgpu.ids" > $O/graph_chain.txt
+if [ ! -x refign_amd/lib/ab/cu_fetch_rate ]; then mkdir -p refign_amd/lib/ab && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/cu_fetch_rate.hip -o refign_amd/lib/ab/cu_fetch_rate 2>/dev/null; fi
+timeout 120 refign_amd/lib/ab/cu_fetch_rate > $O/cu_fetch_rate.txt 2>&1
