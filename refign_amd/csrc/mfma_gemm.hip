@@ -802,6 +802,191 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(const uint16_t* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TN kernel, third generation (round 3): LDS-DMA staging + hardware transpose reads.
+// The weight gradient needs both operands with the reduction index t as the slot index of the MFMA operands, i.e.
+// "transposed" against their row-major storage; generations 1 and 2 transposed in registers on the way to LDS (16 v_perm,
+// 4 ds_write_b128 per thread and stage) and were bound by exactly that -- per CU one workgroup-step per ~0.45 us whatever
+// the number of slabs, the prefetch depth or the occupancy (PMC: 9 % MFMA, 53 % waiting; VALU and LDS pipe each about half
+// of the step).  gfx950's `ds_read_b64_tr_b16` does the transpose in the LDS read: within a 16-lane group lane p supplies
+// the address of 4 contiguous 16-bit elements and lane i receives element i % 4 of lanes i / 4 + 4 j, j = 0..3 (probed:
+// tools/micro/tr_probe.hip).  With lane p pointing at row p / 4, columns 4 (p % 4) .. + 3 of a [4 rows][16 columns] block
+// lane i gets rows 0..3 of column i: 4 consecutive t of ONE column -- half an MFMA operand.  So the tiles go to LDS ROW-MAJOR,
+// as they lie in memory, by LDS-DMA (no registers, no VALU), and a fragment is two transpose reads.
+// LDS image of an operand tile: [BT rows][cols], 16-byte pieces; piece c of row r at slot c ^ swz(r), swz(r) = 4 ((r >> 1) & 1)
+// for 128-byte rows (64 columns), 4 (r & 3) for 256-byte rows (128 columns): the 16 pieces a 32-lane half of a transpose read
+// touches (4 rows x 64 bytes) are 16 distinct slots of the 256-byte bank row.
+// Rows past the end of the slab / of T are DMA'd from the zero page.  rowscale (stochastic depth): the 8 rows of a lane's
+// fragment belong to one sample (rows_per_sample % 8 == 0, the host checks), the fragment is scaled in fp32 and rounded back
+// as the eager g * mask -- the slab's scales are put in LDS before the loop (no global load inside the DMA loop: mfma.h
+// pin_loaded).  Bias gradient: column sums of the (scaled) G fragments, by the waves with wk == 0 of the tiles with k0 == 0.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x2 lds_read_tr16(unsigned addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+
+template <int DT, int BN, int BK, int BT>
+__global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
+                                                       float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
+                                                       int R, int tiles_k, int accumulate, float* __restrict__ gbias,
+                                                       const float* __restrict__ rowscale, int rows_per_sample,
+                                                       const void* zero, int xcd) {
+  using E = Elem<DT>;
+  constexpr int IB = BN / 64, JB = BK / 64;
+  constexpr int GROW = BN * 2, XROW = BK * 2;                      // bytes per LDS row
+  constexpr int GBYTES = BT * GROW, XBYTES = BT * XROW, STAGE = GBYTES + XBYTES;
+  constexpr int GPPR = BN / 8, XPPR = BK / 8;                      // 16-byte pieces per row
+  constexpr int GI = BT * GPPR / 256, XI = BT * XPPR / 256;        // DMA instructions per wave and stage
+  static_assert(GI >= 1 && XI >= 1 && (BN == 64 || BN == 128) && (BK == 64 || BK == 128), "tile");
+  constexpr int kMaxScales = 64;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  __shared__ float sscale[kMaxScales];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles = (N / BN) * tiles_k;
+  const int lid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int slab = lid / tiles, tile = lid % tiles;
+  const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
+  const long t0 = (long)slab * R;
+  const long tend = min((long)T, t0 + R);
+  const int nit = (int)((tend - t0 + BT - 1) / BT);
+  auto gswz = [](int r) { return BN == 64 ? ((r >> 1) & 1) << 2 : (r & 3) << 2; };
+  auto xswz = [](int r) { return BK == 64 ? ((r >> 1) & 1) << 2 : (r & 3) << 2; };
+
+  // the slab's stochastic-depth scales: sample of row t0 + 8 m is s0 + ...; sscale[i] = rowscale[s0 + i]
+  const long s0 = rowscale != nullptr ? t0 / rows_per_sample : 0;
+  if (rowscale != nullptr) {
+    const long s1 = (tend - 1) / rows_per_sample;
+    if ((int)threadIdx.x <= (int)(s1 - s0) && threadIdx.x < kMaxScales) sscale[threadIdx.x] = rowscale[s0 + threadIdx.x];
+  }
+  // ---- DMA: instruction u of this wave moves 64 pieces = 64 / PPR rows of the tile; lane = (row, LDS piece slot), it fetches
+  // source piece slot ^ swz(row)
+  auto issue = [&](int it, int buf) {
+    unsigned char* gs = smem + buf * STAGE;
+    unsigned char* xs = gs + GBYTES;
+    const long tb = t0 + (long)it * BT;
+#pragma unroll
+    for (int u = 0; u < GI; ++u) {
+      const int q = GI * wave + u, r = q * (64 / GPPR) + lane / GPPR, c = lane % GPPR;
+      const long t = tb + r;
+      const void* src = t < tend ? (const void*)(G + t * ldg + n0 + 8 * (c ^ gswz(r))) : zero;
+      lds_dma16(src, gs + q * 1024);
+    }
+#pragma unroll
+    for (int u = 0; u < XI; ++u) {
+      const int q = XI * wave + u, r = q * (64 / XPPR) + lane / XPPR, c = lane % XPPR;
+      const long t = tb + r;
+      const void* src = t < tend ? (const void*)(X + t * ldx + k0 + 8 * (c ^ xswz(r))) : zero;
+      lds_dma16(src, xs + q * 1024);
+    }
+  };
+
+  f32x16 acc[IB][JB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[IB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i) bsum[i] = 0.f;
+  const bool do_bias = gbias != nullptr && k0 == 0 && wk == 0;
+
+  // ---- fragment addressing: lane = (16-lane group q16, p); group: column half (q16 & 1), k-slot half g = q16 >> 1
+  const int g = lane >> 5, col = lane & 31, p = lane & 15, q16 = lane >> 4;
+  const int frow = 8 * g + (p >> 2);                               // + 16 ks + 4 h
+  const int fcol = 16 * (q16 & 1) + 4 * (p & 3);                   // + block offset; multiple of 4 -> byte offset 0 / 8 in a piece
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto gaddr = [&](int buf, int row, int c) {                      // byte address of element (row, c) of the G tile
+    return lds0 + buf * STAGE + row * GROW + 16 * ((c >> 3) ^ gswz(row)) + 2 * (c & 7);
+  };
+  auto xaddr = [&](int buf, int row, int c) {
+    return lds0 + buf * STAGE + GBYTES + row * XROW + 16 * ((c >> 3) ^ xswz(row)) + 2 * (c & 7);
+  };
+
+  issue(0, 0);
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    wait_dma_all();
+    wg_barrier();                                  // stage `it` has landed everywhere; everybody is done reading stage it - 1
+    if (it + 1 < nit) issue(it + 1, buf ^ 1);
+#pragma unroll
+    for (int ks = 0; ks < BT / 16; ++ks) {
+      const int row = 16 * ks + frow;
+      typename E::vec8 af[IB], bf[JB];
+      u32x2 a0[IB], a1[IB], b0[JB], b1[JB];
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        const int c = wn * (BN / 2) + i * 32 + fcol;
+        a0[i] = lds_read_tr16(gaddr(buf, row, c));
+        a1[i] = lds_read_tr16(gaddr(buf, row + 4, c));
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) {
+        const int c = wk * (BK / 2) + j * 32 + fcol;
+        b0[j] = lds_read_tr16(xaddr(buf, row, c));
+        b1[j] = lds_read_tr16(xaddr(buf, row + 4, c));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float sc = 1.f;
+      if (rowscale != nullptr) {
+        const long tr = t0 + (long)it * BT + 16 * ks + 8 * g;      // the lane's 8 rows: one sample (rows_per_sample % 8 == 0)
+        sc = tr < tend ? sscale[min((long)(kMaxScales - 1), tr / rows_per_sample - s0)] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        if (rowscale != nullptr || do_bias) {
+          float f[8];
+          unpack4<DT>(a0[i], *(float(*)[4])&f[0]);
+          unpack4<DT>(a1[i], *(float(*)[4])&f[4]);
+          if (rowscale != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= sc;
+            a0[i] = pack4<DT>(f[0], f[1], f[2], f[3]);
+            a1[i] = pack4<DT>(f[4], f[5], f[6], f[7]);
+            unpack4<DT>(a0[i], *(float(*)[4])&f[0]);               // the bias gradient sums the ROUNDED scaled values
+            unpack4<DT>(a1[i], *(float(*)[4])&f[4]);
+          }
+          if (do_bias) bsum[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+        }
+        af[i] = join8<DT>(a0[i], a1[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < JB; ++j) bf[j] = join8<DT>(b0[j], b1[j]);
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(af[i], bf[j], acc[i][j]);
+    }
+  }
+
+  float* out = accumulate ? P : P + (long)slab * N * K;
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int kk = k0 + wk * (BK / 2) + j * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * (BN / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (accumulate) atomicAdd(out + (long)n * K + kk, acc[i][j][r]);
+        else out[(long)n * K + kk] = acc[i][j][r];
+      }
+    }
+  if (do_bias) {                                  // lanes (col, g = 0 / 1) hold the two k-slot halves of column col
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const float sum = half_sum(bsum[i]);
+      if (g == 0) atomicAdd(gbias + n0 + wn * (BN / 2) + i * 32 + col, sum);
+    }
+  }
+}
+
 __device__ uint4 g_zero_page[4];          // zero-initialised: DMA source of out-of-image / padding pieces
 
 template <int DT, bool GATHER>
@@ -890,6 +1075,29 @@ static int launch_tn(const void* G, const void* X, float* P, long T, long N, lon
   // (first-generation kernel = the fall-back for operands that are not 16-byte aligned; measured on the step: 189.2 ms with
   // it everywhere, 185.8 ms with the second generation)
   const bool vec = (GATHER ? wg.C % 8 == 0 : (ldx % 8 == 0 && ((size_t)X & 15) == 0)) && ldg % 8 == 0 && ((size_t)G & 15) == 0;
+  static const int tn3 = getenv("RFN_GEMM_TN3") ? atoi(getenv("RFN_GEMM_TN3")) : 1;
+  if (!GATHER && vec && tn3) {
+    // third generation (LDS-DMA + transpose reads); the stochastic-depth scale needs whole samples per 8-row fragment and the
+    // slab's scales in 64 LDS floats
+    const long span = rowscale != nullptr ? ((long)R + rps - 1) / rps + 1 : 0;
+    if (rowscale == nullptr || (rps % 8 == 0 && span <= 64)) {
+      static void* zero_page = nullptr;
+      if (zero_page == nullptr && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero_page)) != hipSuccess)
+        return fail(RFN_ELAUNCH, "gemm_tn: zero page symbol");
+      if (N % 128 == 0 && K % 128 == 0) {
+        dim3 grid((unsigned)((N / 128) * (K / 128) * S));
+        hipLaunchKernelGGL((gemm_tn3_kernel<DT, 128, 128, 32>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
+                           (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps, zero_page,
+                           tn_xcd);
+      } else {
+        dim3 grid((unsigned)((N / 64) * (K / 64) * S));
+        hipLaunchKernelGGL((gemm_tn3_kernel<DT, 64, 64, 64>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
+                           (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps, zero_page,
+                           tn_xcd);
+      }
+      return check_launch("gemm_tn3");
+    }
+  }
   if (vec) {
     if (N % 128 == 0 && K % 128 == 0) {
       dim3 grid((unsigned)((N / 128) * (K / 128) * S));

@@ -172,10 +172,14 @@ _TN_WGS = 1024      # target workgroups of a weight-gradient launch (swept in ro
 #                     186.4 / 189.6 ms per step)
 
 
-def slab_rows(T, tiles):
+def slab_rows(T, tiles, nk=0):
     """Rows per slab of the split-T weight-gradient GEMM: enough slabs to fill the chip (~1024 workgroups with the
-    output tiles), slabs of at least 256 rows, multiples of 32."""
+    output tiles), slabs of at least 256 rows, multiples of 32 -- and not more slabs than ~2.5 M fp32 atomics in all: every
+    slab ADDS a whole N x K partial, and the L2 retires ~0.6 T atomic adds per second (tools: a 320 x 320 gradient of 8160
+    rows takes 16.2 us in 32 slabs, 12.1 us in 10; 27 % of a 320 x 1280 launch is its atomics)."""
     want = max(1, min(64, _TN_WGS // max(tiles, 1)))
+    if nk > 0:
+        want = min(want, max(4, 2_500_000 // nk, -(-512 // max(tiles, 1))))     # ... but at least ~512 workgroups
     rows = -(-T // want)
     rows = max(256, -(-rows // 32) * 32)
     return rows
@@ -200,7 +204,7 @@ def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None, rowscale=None, ro
         return None
     if rows_per_slab is None:
         tile = 128 if (N % 128 == 0 and K % 128 == 0) else 64
-        rows_per_slab = slab_rows(T, (N // tile) * (K // tile))
+        rows_per_slab = slab_rows(T, (N // tile) * (K // tile), N * K)
     S = -(-T // rows_per_slab)
     if out is not None:
         if not (out.dtype == torch.float32 and out.is_contiguous() and out.numel() == N * K and
