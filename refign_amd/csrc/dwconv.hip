@@ -403,23 +403,28 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_weight_kernel(const T* __re
       }
     }
   }
-  __shared__ float red[256 * 8];
+  // fold the block's pixel lanes: two passes of 5 of the 10 rows (9 taps + bias) through 40 KB of LDS, every thread sums
+  // (10 one-row passes with two barriers each and only the first pixel lane summing were a 3-5 us tail)
+  __shared__ float red[5][256][V];
   float* wrow = ws + (size_t)blockIdx.y * 10 * C;
-  for (int k = 0; k < 10; ++k) {
+  for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const f32x2 t = (k < 9) ? aw[k][i / 2] : ab[i / 2];
-      red[threadIdx.x * V + i] = (i & 1) ? t.y : t.x;
-    }
-    __syncthreads();
-    if (pli == 0 && active) {
+    for (int kk = 0; kk < 5; ++kk) {
+      const int k = pass * 5 + kk;
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        float s = 0.0f;
-        for (int p = 0; p < pl; ++p) s += red[(p * cvb + cvi) * V + i];
-        wrow[(size_t)k * C + c0 + i] = s;
+        const f32x2 t = (k < 9) ? aw[k < 9 ? k : 0][i / 2] : ab[i / 2];
+        red[kk][threadIdx.x][i] = (i & 1) ? t.y : t.x;
       }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 5 * cvb * V; o += 256) {
+      const int kk = o / (cvb * V), rem = o - kk * cvb * V, cvj = rem / V, i = rem - cvj * V;
+      if (blockIdx.x * cvb + cvj >= CV) continue;
+      float sum = 0.0f;
+      for (int p = 0; p < pl; ++p) sum += red[kk][p * cvb + cvj][i];
+      wrow[(size_t)(pass * 5 + kk) * C + (blockIdx.x * cvb + cvj) * V + i] = sum;
     }
   }
 }
@@ -550,8 +555,16 @@ template <typename T>
 static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db, float* ws, int B, int H, int W, int C,
                              int dil, int flags, hipStream_t st) {
   constexpr int V = VecIO<T>::N;
-  const int CV = C / V, cvb = pick_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
+  // narrow channel blocks on LARGE maps: with 16 vectors (256 contiguous bytes per pixel) a block has 16 pixel lanes instead
+  // of 4 -- four times the workgroups for the same partial-sum volume (the workspace row of a stripe is 10 C floats however
+  // the channels are split).  Measured (tools/kbench.py --only dw, forward + backward): 40 x 135 x 240 x 256: 1 393 -> 1 070 us;
+  // the student's small maps (4 x 34 x 60 x 1280: 130 -> 173 us) keep the wide blocks.  RFN_DWCONV_WGRAD_CVB forces a width.
+  static const int force_cvb = getenv("RFN_DWCONV_WGRAD_CVB") ? atoi(getenv("RFN_DWCONV_WGRAD_CVB")) : 0;
+  const int CV = C / V;
   const long nquads = (long)B * H * (dil * (((W + dil - 1) / dil + kPX - 1) / kPX));
+  const int want_cvb = force_cvb ? force_cvb : (nquads >= 65536 ? 16 : 0);
+  const int cvb = (want_cvb >= 8 && want_cvb <= 64 && (want_cvb & (want_cvb - 1)) == 0 && CV >= want_cvb) ? want_cvb : pick_cvb(CV);
+  const int gx = cdiv(CV, cvb), pl = 256 / cvb;
   const int stripes = (int)std::max<long>(1, std::min<long>(std::min<long>(kMaxStripes, cdiv(nquads, pl)),
                                                             std::max<long>(1, (256L * 8) / gx)));
   hipLaunchKernelGGL((dwconv3x3_bwd_weight_kernel<T>), dim3(gx, stripes), dim3(256), 0, st, (const T*)x, (const T*)gy,
