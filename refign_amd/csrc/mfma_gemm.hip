@@ -828,12 +828,15 @@ __device__ __forceinline__ u32x2 lds_read_tr16(unsigned addr) {
   return r;
 }
 
-template <int DT, int BN, int BK, int BT>
+// GATHER: the weight gradient of a convolution -- row t of the X operand is the im2col row of output pixel t = (b, oy, ox),
+// a 16-byte piece is 8 channels of ONE tap (C % 8 == 0): the DMA source of (row, piece) is x[b, oy s - p + ky d, ox s - p + kx d,
+// c .. c + 7] or the zero page; a lane's pieces (tap, channel) are fixed, its rows advance by BT per stage.
+template <int DT, int BN, int BK, int BT, bool GATHER = false>
 __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
                                                        float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
                                                        int R, int tiles_k, int accumulate, float* __restrict__ gbias,
                                                        const float* __restrict__ rowscale, int rows_per_sample,
-                                                       const void* zero, int xcd) {
+                                                       const void* zero, int xcd, WgradGeom wg = WgradGeom{}) {
   using E = Elem<DT>;
   constexpr int IB = BN / 64, JB = BK / 64;
   constexpr int GROW = BN * 2, XROW = BK * 2;                      // bytes per LDS row
@@ -863,6 +866,29 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
     const long s1 = (tend - 1) / rows_per_sample;
     if ((int)threadIdx.x <= (int)(s1 - s0) && threadIdx.x < kMaxScales) sscale[threadIdx.x] = rowscale[s0 + threadIdx.x];
   }
+  // GATHER: per X instruction u of this lane: (dy, dx, channel) of its piece, (image, oy, ox) of its row in stage 0
+  int gdy[GATHER ? XI : 1], gdx[GATHER ? XI : 1], gch[GATHER ? XI : 1], gb[GATHER ? XI : 1], goy[GATHER ? XI : 1],
+      gox[GATHER ? XI : 1];
+  bool gok[GATHER ? XI : 1];
+  if constexpr (GATHER) {
+    const long ohw = (long)wg.OH * wg.OW;
+#pragma unroll
+    for (int u = 0; u < XI; ++u) {
+      const int q = XI * wave + u, r = q * (64 / XPPR) + lane / XPPR, c = lane % XPPR;
+      const unsigned k = (unsigned)(k0 + 8 * (c ^ xswz(r)));
+      const unsigned tap = __umulhi(k, wg.c_magic);
+      gch[u] = (int)(k - tap * wg.C);
+      const unsigned ky = wg.KW == 1 ? tap : __umulhi(tap, wg.kw_magic), kx = tap - ky * wg.KW;
+      gok[u] = (int)ky < wg.KH;
+      gdy[u] = (int)ky * wg.dil - wg.pad;
+      gdx[u] = (int)kx * wg.dil - wg.pad;
+      const long t = t0 + r;
+      gb[u] = (int)(t / ohw);
+      const int rem = (int)(t - gb[u] * ohw);
+      goy[u] = rem / wg.OW;
+      gox[u] = rem - goy[u] * wg.OW;
+    }
+  }
   // ---- DMA: instruction u of this wave moves 64 pieces = 64 / PPR rows of the tile; lane = (row, LDS piece slot), it fetches
   // source piece slot ^ swz(row)
   auto issue = [&](int it, int buf) {
@@ -880,7 +906,22 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
     for (int u = 0; u < XI; ++u) {
       const int q = XI * wave + u, r = q * (64 / XPPR) + lane / XPPR, c = lane % XPPR;
       const long t = tb + r;
-      const void* src = t < tend ? (const void*)(X + t * ldx + k0 + 8 * (c ^ xswz(r))) : zero;
+      const void* src;
+      if constexpr (GATHER) {
+        const int iy = goy[u] * wg.stride + gdy[u], ix = gox[u] * wg.stride + gdx[u];
+        const bool ok = t < tend && gok[u] && (unsigned)iy < (unsigned)wg.H && (unsigned)ix < (unsigned)wg.W;
+        src = ok ? (const void*)(X + (((long)gb[u] * wg.H + iy) * wg.W + ix) * wg.C + gch[u]) : zero;
+        gox[u] += BT;                                  // the stage after this one (stages are issued in order)
+        while (gox[u] >= wg.OW) {
+          gox[u] -= wg.OW;
+          if (++goy[u] == wg.OH) {
+            goy[u] = 0;
+            ++gb[u];
+          }
+        }
+      } else {
+        src = t < tend ? (const void*)(X + t * ldx + k0 + 8 * (c ^ xswz(r))) : zero;
+      }
       lds_dma16(src, xs + q * 1024);
     }
   };
@@ -1074,9 +1115,9 @@ static int launch_tn(const void* G, const void* X, float* P, long T, long N, lon
   static const int tn_xcd = getenv("RFN_GEMM_TN_XCD") ? atoi(getenv("RFN_GEMM_TN_XCD")) : 1;
   // (first-generation kernel = the fall-back for operands that are not 16-byte aligned; measured on the step: 189.2 ms with
   // it everywhere, 185.8 ms with the second generation)
-  const bool vec = (GATHER ? wg.C % 8 == 0 : (ldx % 8 == 0 && ((size_t)X & 15) == 0)) && ldg % 8 == 0 && ((size_t)G & 15) == 0;
+  const bool vec = (GATHER ? wg.C % 8 == 0 : ldx % 8 == 0) && ((size_t)X & 15) == 0 && ldg % 8 == 0 && ((size_t)G & 15) == 0;
   static const int tn3 = getenv("RFN_GEMM_TN3") ? atoi(getenv("RFN_GEMM_TN3")) : 1;
-  if (!GATHER && vec && tn3) {
+  if (vec && tn3) {
     // third generation (LDS-DMA + transpose reads); the stochastic-depth scale needs whole samples per 8-row fragment and the
     // slab's scales in 64 LDS floats
     const long span = rowscale != nullptr ? ((long)R + rps - 1) / rps + 1 : 0;
@@ -1086,14 +1127,14 @@ static int launch_tn(const void* G, const void* X, float* P, long T, long N, lon
         return fail(RFN_ELAUNCH, "gemm_tn: zero page symbol");
       if (N % 128 == 0 && K % 128 == 0) {
         dim3 grid((unsigned)((N / 128) * (K / 128) * S));
-        hipLaunchKernelGGL((gemm_tn3_kernel<DT, 128, 128, 32>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                           (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias, rowscale, rps, zero_page,
-                           tn_xcd);
+        hipLaunchKernelGGL((gemm_tn3_kernel<DT, 128, 128, 32, GATHER>), grid, block, 0, s, (const uint16_t*)G,
+                           (const uint16_t*)X, P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias,
+                           rowscale, rps, zero_page, tn_xcd, wg);
       } else {
         dim3 grid((unsigned)((N / 64) * (K / 64) * S));
-        hipLaunchKernelGGL((gemm_tn3_kernel<DT, 64, 64, 64>), grid, block, 0, s, (const uint16_t*)G, (const uint16_t*)X, P,
-                           (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias, rowscale, rps, zero_page,
-                           tn_xcd);
+        hipLaunchKernelGGL((gemm_tn3_kernel<DT, 64, 64, 64, GATHER>), grid, block, 0, s, (const uint16_t*)G,
+                           (const uint16_t*)X, P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias,
+                           rowscale, rps, zero_page, tn_xcd, wg);
       }
       return check_launch("gemm_tn3");
     }
