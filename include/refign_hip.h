@@ -398,8 +398,8 @@ int rfn_bn_train_bwd(const void* x, const void* grad_y, const double* fwd_sums, 
  * Segmentation loss of the student passes in one kernel (csrc/loss.hip): bilinear up-sampling (align_corners = False) of
  * the class logits (B, C, h, w) to the label size (H, W) + pixel-weighted cross-entropy with ignore_index, summed over all
  * pixels -- models/segmentation_model.py:163-179, :226-250 (F.interpolate) + models/losses.py:10-22
- * (PixelWeightedCrossEntropyLoss).  loss_sum[0] <- the sum (the host divides by B H W: the reference's mean over ALL
- * pixels); grad_lo (B, C, h, w) fp32 <- d loss_sum / d logits.  Both are zeroed inside.  dtype of logits: 0 fp32, 1 bf16,
+ * (PixelWeightedCrossEntropyLoss).  loss_sum[0..63] <- 64 partial sums (the host adds them and divides by B H W: the
+ * reference's mean over ALL pixels; one address for 8 000 workgroups would serialise in the L2); grad_lo (B, C, h, w) fp32 <- d loss_sum / d logits.  Both are zeroed inside.  dtype of logits: 0 fp32, 1 bf16,
  * 2 f16; target int64 (B, H, W); weight fp32 (B, H, W) or NULL; round16: round the interpolated logits to `dtype` (what an
  * unfused 16-bit F.interpolate stores).  C <= 19, H >= 2 h, W >= 2 w.
  * ---------------------------------------------------------------------------------------------------------- */

@@ -6,8 +6,8 @@
 // mean over ALL pixels of weight * CE(ignore_index).  Unfused, the (B, 19, 1080, 1920) tensor (158 MB in fp32) is written
 // by the up-sampling, read and written by log_softmax, read by nll_loss, and the same again backwards -- 1.3 ms per
 // student pass in six ATen kernels, between the forward and the backward of the pass (round 3, tools/aten_census.py).
-// Here a workgroup owns a 16 x 32 tile of label pixels:
-//   1. the low-resolution logits under the tile (its bilinear footprint, <= 10 x 18 cells x C) go to LDS;
+// Here a workgroup owns a 16 x 16 tile of label pixels (32 KB of LDS: 4-5 workgroups per CU):
+//   1. the low-resolution logits under the tile (its bilinear footprint, <= 10 x 10 cells x C) go to LDS;
 //   2. every pixel interpolates its C logits (ATen's formula and operand order, optionally rounded to the 16-bit dtype
 //      the unfused path would have stored), takes the log-sum-exp, adds weight * (lse - z[target]) to the loss and leaves
 //      weight * (softmax - onehot) -- its gradient with respect to the up-sampled logits -- in LDS;
@@ -23,8 +23,9 @@
 
 namespace rfn {
 
-constexpr int kLossTH = 16, kLossTW = 32, kLossPX = kLossTH * kLossTW;     // label pixels per workgroup
+constexpr int kLossTH = 16, kLossTW = 16, kLossPX = kLossTH * kLossTW;     // label pixels per workgroup (one per thread)
 constexpr int kLossFY = kLossTH / 2 + 2, kLossFX = kLossTW / 2 + 2;         // footprint bound at scale 2
+constexpr int kLossSlots = 64;                                              // partial loss sums
 constexpr int kLossMaxC = 19;                                               // classes (Cityscapes); LDS is sized for it
 
 template <int DT> struct LossElem;
@@ -52,19 +53,21 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in, int& i0,
   l1 = s - (float)i0;
 }
 
-template <int DT>
+// FULLC: C == kLossMaxC, no per-class guards (with a run-time class count every class of every loop is a branch)
+template <int DT, bool FULLC>
 __global__ __launch_bounds__(256) void upsample_ce_kernel(const void* __restrict__ logits, const long* __restrict__ target,
                                                           const float* __restrict__ weight, float* __restrict__ grad_lo,
                                                           double* __restrict__ loss_sum, int C, int h, int w, int H, int W,
                                                           float sy, float sx, int ignore_index, int round16) {
   using E = LossElem<DT>;
-  // 60.8 KB of the 64 KB a kernel may declare: the footprint logits (steps 1-2) and the x-reduced gradient (step 3) share
+  // the footprint logits (steps 1-2) and the x-reduced gradient (step 3) share their LDS
   __shared__ float tmp[kLossMaxC * kLossTH * kLossFX];         // [c][ty][fx]
   float* const lo = tmp;                                       // [c][fy][fx], dead before step 3a writes tmp
   __shared__ float pr[kLossMaxC * kLossPX];                    // [c][ty * 32 + tx]: gradient w.r.t. the up-sampled logits
   __shared__ int ry0[kLossTH], ry1[kLossTH], cx0[kLossTW], cx1[kLossTW];
   __shared__ float rl[kLossTH], cl[kLossTW];
   __shared__ float red[4];
+  __shared__ int txlo[kLossFX], txhi[kLossFX], tylo[kLossFY], tyhi[kLossFY];
   const int tid = threadIdx.x, b = blockIdx.z;
   const int Y0 = blockIdx.y * kLossTH, X0 = blockIdx.x * kLossTW;
   const int YN = min(kLossTH, H - Y0), XN = min(kLossTW, W - X0);       // live rows / columns of the tile
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const void* __restrict
     const float ly = rl[ty], hy = 1.f - ly, lx = cl[tx], hx = 1.f - lx;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c) {
-      if (c < C) {
+      if (FULLC || c < C) {
         const float* p = lo + c * kLossFY * kLossFX;
         float v = hy * (hx * p[a0 + b0] + lx * p[a0 + b1]) + ly * (hx * p[a1 + b0] + lx * p[a1 + b1]);
         if (round16) v = E::round(v);
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const void* __restrict
     float S = 0.f, zt = 0.f;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c) {
-      if (c < C) {
+      if (FULLC || c < C) {
         if (valid && c == (int)t) zt = z[c];
         z[c] = __expf(z[c] - m);
         S += z[c];
@@ -134,14 +137,36 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const void* __restrict
     const float inv = valid ? wt / S : 0.f;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c) {
-      if (c < C) pr[c * kLossPX + px] = z[c] * inv - ((valid && c == (int)t) ? wt : 0.f);
+      if (FULLC || c < C) pr[c * kLossPX + px] = z[c] * inv - ((valid && c == (int)t) ? wt : 0.f);
     }
     if (valid) lsum += wt * (m + __logf(S) - zt);                  // weight * (lse - z[target])
   }
   lsum = wave_sum(lsum);
   if ((tid & 63) == 0) red[tid >> 6] = lsum;
   __syncthreads();
-  if (tid == 0) atomicAdd(loss_sum, (double)((red[0] + red[1]) + (red[2] + red[3])));
+  // kLossSlots partial sums (the host adds them): 8 160 tiles adding to ONE address were serialised in the L2 -- 435 us of
+  // same-address atomics around 70 us of work
+  if (tid == 0)
+    atomicAdd(loss_sum + (blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) % kLossSlots,
+              (double)((red[0] + red[1]) + (red[2] + red[3])));
+  // the tile columns / rows whose footprint contains a cell are a contiguous run (the source index is monotone): its ends,
+  // so that the sums below walk ~2 x scale pixels instead of the whole tile edge
+  if (tid < nfx) {
+    const int cell = fx0 + tid;
+    int lo_ = XN, hi_ = -1;
+    for (int tx = 0; tx < XN; ++tx)
+      if (cx0[tx] == cell || cx1[tx] == cell) { lo_ = min(lo_, tx); hi_ = tx; }
+    txlo[tid] = lo_;
+    txhi[tid] = hi_;
+  } else if (tid >= 64 && tid < 64 + nfy) {
+    const int f = tid - 64, cell = fy0 + f;
+    int lo_ = YN, hi_ = -1;
+    for (int ty = 0; ty < YN; ++ty)
+      if (ry0[ty] == cell || ry1[ty] == cell) { lo_ = min(lo_, ty); hi_ = ty; }
+    tylo[f] = lo_;
+    tyhi[f] = hi_;
+  }
+  __syncthreads();
   // ---- 3a. transpose of the interpolation along x: tmp[c][ty][fx] = sum_tx wx(tx, fx) pr[c][ty][tx]
   for (int i = tid; i < C * kLossTH * nfx; i += 256) {
     const int c = i / (kLossTH * nfx), r = i - c * kLossTH * nfx, ty = r / nfx, fx = r - ty * nfx;
@@ -149,7 +174,7 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const void* __restrict
     if (ty < YN) {
       const float* p = pr + c * kLossPX + ty * kLossTW;
       const int cell = fx0 + fx;
-      for (int tx = 0; tx < XN; ++tx) {
+      for (int tx = txlo[fx]; tx <= txhi[fx]; ++tx) {
         const float l = cl[tx];
         const float wgt = (cx0[tx] == cell ? 1.f - l : 0.f) + (cx1[tx] == cell ? l : 0.f);
         acc = fmaf(wgt, p[tx], acc);
@@ -163,7 +188,7 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const void* __restrict
     const int c = i / (nfy * nfx), r = i - c * nfy * nfx, fy = r / nfx, fx = r - fy * nfx;
     const int cell = fy0 + fy;
     float acc = 0.f;
-    for (int ty = 0; ty < YN; ++ty) {
+    for (int ty = tylo[fy]; ty <= tyhi[fy]; ++ty) {
       const float l = rl[ty];
       const float wgt = (ry0[ty] == cell ? 1.f - l : 0.f) + (ry1[ty] == cell ? l : 0.f);
       acc = fmaf(wgt, tmp[(c * kLossTH + ty) * kLossFX + fx], acc);
@@ -177,7 +202,7 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const void* __restrict
 extern "C" {
 using namespace rfn;
 
-// loss_sum[0] <- sum over all (b, y, x) of weight * CE(bilinear(logits)[b, :, y, x], target), grad_lo (B, C, h, w) fp32 <- the
+// loss_sum[0..63] <- 64 partial sums (their sum is the result) over all (b, y, x) of weight * CE(bilinear(logits)[b, :, y, x], target), grad_lo (B, C, h, w) fp32 <- the
 // gradient of that sum with respect to the low-resolution logits; both are zeroed here.  logits: (B, C, h, w) contiguous,
 // dtype 0 fp32 / 1 bf16 / 2 f16; target: (B, H, W) int64; weight: (B, H, W) fp32 or NULL.  round16: round the interpolated
 // logits to `dtype` first (what an unfused 16-bit up-sampling stores).
@@ -189,12 +214,16 @@ int rfn_upsample_ce(const void* logits, const long* target, const float* weight,
   RFN_REQUIRE(dtype >= 0 && dtype <= 2, "upsample_ce: dtype %d (0 = f32, 1 = bf16, 2 = f16)", dtype);
   hipStream_t s = (hipStream_t)stream;
   if (int rc = zero_async(grad_lo, (size_t)B * C * h * w * sizeof(float), s)) return rc;
-  if (int rc = zero_async(loss_sum, sizeof(double), s)) return rc;
+  if (int rc = zero_async(loss_sum, kLossSlots * sizeof(double), s)) return rc;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;      // ATen: area_pixel_compute_scale with size=
   dim3 grid(cdiv(W, kLossTW), cdiv(H, kLossTH), B);
 #define RFN_UCE(D)                                                                                                     \
-  hipLaunchKernelGGL(upsample_ce_kernel<D>, grid, dim3(256), 0, s, logits, target, weight, grad_lo, loss_sum, C, h, w, \
-                     H, W, sy, sx, ignore_index, round16 && D != 0)
+  if (C == kLossMaxC)                                                                                                  \
+    hipLaunchKernelGGL((upsample_ce_kernel<D, true>), grid, dim3(256), 0, s, logits, target, weight, grad_lo, loss_sum, \
+                       C, h, w, H, W, sy, sx, ignore_index, round16 && D != 0);                                         \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((upsample_ce_kernel<D, false>), grid, dim3(256), 0, s, logits, target, weight, grad_lo, loss_sum, \
+                       C, h, w, H, W, sy, sx, ignore_index, round16 && D != 0)
   if (dtype == 0) RFN_UCE(0);
   else if (dtype == 1) RFN_UCE(1);
   else RFN_UCE(2);

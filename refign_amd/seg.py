@@ -836,7 +836,7 @@ class _UpsampleCEFn(torch.autograd.Function):
         if tg.dtype != torch.int64 or tuple(tg.shape) != (B, H, W) or (wt is not None and tuple(wt.shape) != (B, H, W)):
             raise RuntimeError("upsample_ce: target (B, H, W) int64 / weight (B, H, W) expected")
         grad = torch.empty((B, C, h, w), dtype=torch.float32, device=lg.device)
-        total = torch.empty(1, dtype=torch.float64, device=lg.device)
+        total = torch.empty(64, dtype=torch.float64, device=lg.device)          # kLossSlots partial sums
         # 16-bit logits: the unfused path stores the up-sampled logits in that dtype before the fp32 softmax
         rc = None
         with on_device(lg.device):
@@ -845,7 +845,7 @@ class _UpsampleCEFn(torch.autograd.Function):
         _lib.check(rc, "upsample_ce")
         ctx.save_for_backward(grad)
         ctx.npix, ctx.dtype = float(B * H * W), logits.dtype
-        return (total[0] / ctx.npix).to(torch.float32)
+        return (total.sum() / ctx.npix).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
