@@ -122,6 +122,9 @@ int rfn_l2norm_channels_f32(const float* x, float* out, int B, int C, int HW, rf
  * are widened exactly, the norm and the division are fp32 -- what `.float()` -> NCHW copy -> rfn_l2norm_channels_f32
  * computes, in one pass.  C a multiple of 8, <= 2048. */
 int rfn_l2norm_channels_nhwc16_f32(const void* x, float* out, int B, int C, int HW, int dtype, rfn_stream_t stream);
+/* 2 x 2 / stride 2 max-pool (floor mode) of a channels-last 16-bit map: the pools of the VGG-16 pyramid
+ * (models/backbones/vgg.py:33-60: nn.MaxPool2d(2, 2)).  x (B, H, W, C) -> y (B, H / 2, W / 2, C); C % 8 == 0; dtype 1 bf16, 2 f16 */
+int rfn_maxpool2x2_nhwc16(const void* x, void* y, int B, int H, int W, int C, int dtype, rfn_stream_t stream);
 
 /* refine() + eta() (segmentation_model.py:438-491), gamma = trust-score exponent.
  * logits_trg, logits_ref: (B,19,H,W); warp_mask (nullable): (B,H,W) uint8; certs (nullable): (B,1,H,W);

@@ -212,6 +212,33 @@ _VGG_CFG = {
 }
 
 
+_POOL_KERNEL = os.environ.get("RFN_POOL_KERNEL", "1") != "0"
+
+
+def _maxpool2x2(x, m):
+    """nn.MaxPool2d(2, 2) (floor mode) of an NCHW-shaped tensor with channels-last 16-bit memory on the HIP kernel
+    (csrc/warp.hip rfn_maxpool2x2_nhwc16); None outside that domain."""
+    def two(v):
+        return v == 2 or tuple(v) == (2, 2) if not isinstance(v, int) else v == 2
+    if not (two(m.kernel_size) and two(m.stride) and m.padding in (0, (0, 0)) and m.dilation in (1, (1, 1))
+            and not m.ceil_mode and not m.return_indices):
+        return None
+    if x.dim() != 4 or x.dtype not in (torch.bfloat16, torch.float16) or x.shape[1] % 8 or x.shape[2] < 2 or x.shape[3] < 2:
+        return None
+    xh = x.permute(0, 2, 3, 1)
+    if not xh.is_contiguous():
+        return None
+    from . import _lib
+    from ._tensor import current_stream, on_device, ptr
+    B, H, W, C = xh.shape
+    y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    with on_device(x.device):
+        rc = _lib.load_library().rfn_maxpool2x2_nhwc16(ptr(xh), ptr(y), B, H, W, C, 1 if x.dtype == torch.bfloat16 else 2,
+                                                       current_stream(x.device))
+    _lib.check(rc, "maxpool2x2_nhwc16")
+    return y.permute(0, 3, 1, 2)
+
+
 class VGG(nn.Module):
     """models/backbones/vgg.py:33-149.  `features` is an nn.Sequential with the torchvision layout (so
     `features.N.weight` keys match); tap points are after the first ReLU and after every max-pool; `out_indices`
@@ -274,6 +301,12 @@ class VGG(nn.Module):
                 if y is not None:
                     x = y
                     i += 2
+                    continue
+            if isinstance(m, nn.MaxPool2d) and x.is_cuda and not torch.is_grad_enabled() and _POOL_KERNEL:
+                y = _maxpool2x2(x, m)
+                if y is not None:
+                    x = y
+                    i += 1
                     continue
             if fused and isinstance(m, nn.Conv2d) and i + 1 < hi and isinstance(self.features[i + 1], nn.ReLU):
                 x = torch.ops.aten.miopen_convolution_relu(x, m.weight, m.bias, m.stride, m.padding, m.dilation,

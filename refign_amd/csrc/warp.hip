@@ -357,6 +357,47 @@ __global__ __launch_bounds__(256) void area_resize_kernel(const float* __restric
   out[idx] = s / (float)((y1 - y0) * (x1 - x0));
 }
 
+
+// 2 x 2 / stride 2 max-pool of a channels-last 16-bit map (the pools of the VGG-16 pyramid, models/backbones/vgg.py:33-60:
+// nn.MaxPool2d(2, 2), floor mode): a thread owns 8 channels of 2 adjacent output pixels -- 8 independent 16-byte loads in
+// flight (ATen's channels-last pool: 0.54 ms for 4 x 1080 x 1920 x 64 = 2.4 TB/s).  Max of representable values: exact.
+template <typename S>
+__global__ __launch_bounds__(256) void maxpool2x2_nhwc16_kernel(const S* __restrict__ x, S* __restrict__ y, int H, int W,
+                                                                int OH, int OW, int CV, long total) {
+  typedef S V8 __attribute__((ext_vector_type(8)));
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;                                // total = B * OH * ceil(OW / 2) * CV
+  const int OWP = (OW + 1) / 2;
+  const int cv = (int)(idx % CV);
+  long t = idx / CV;
+  const int xp = (int)(t % OWP);
+  t /= OWP;
+  const int oy = (int)(t % OH), b = (int)(t / OH);
+  const long rs = (long)W * CV * 8;
+  const S* p = x + ((long)b * H + 2 * oy) * rs + (long)cv * 8;
+  V8 v[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ix = min(4 * xp + c, W - 1);
+      v[r][c] = *(const V8*)(p + r * rs + (long)ix * CV * 8);
+    }
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int ox = 2 * xp + o;
+    if (ox >= OW) break;
+    V8 m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = fmaxf((float)v[0][2 * o][e], (float)v[0][2 * o + 1][e]);
+      const float c = fmaxf((float)v[1][2 * o][e], (float)v[1][2 * o + 1][e]);
+      m[e] = (S)fmaxf(a, c);
+    }
+    *(V8*)(y + (((long)b * OH + oy) * OW + ox) * CV * 8 + (long)cv * 8) = m;
+  }
+}
+
 }  // namespace rfn
 
 using namespace rfn;
@@ -459,6 +500,25 @@ int rfn_l2norm_channels_nhwc16_f32(const void* x, float* out, int B, int C, int 
                        HW);
   }
   return check_launch("l2norm_nhwc16_to_nchw_kernel");
+}
+
+// y (B, H / 2, W / 2, C) = 2 x 2 / stride 2 max-pool (floor mode) of the channels-last 16-bit x (B, H, W, C), C % 8 == 0; dtype 1
+// bf16, 2 f16
+int rfn_maxpool2x2_nhwc16(const void* x, void* y, int B, int H, int W, int C, int dtype, rfn_stream_t stream) {
+  RFN_REQUIRE(x && y, "maxpool2x2_nhwc16: null pointer");
+  RFN_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0, "maxpool2x2_nhwc16: B=%d H=%d W=%d C=%d (C %% 8)", B, H, W, C);
+  RFN_REQUIRE(dtype == 1 || dtype == 2, "maxpool2x2_nhwc16: dtype %d (1 = bf16, 2 = f16)", dtype);
+  const int OH = H / 2, OW = W / 2, CV = C / 8;
+  const long total = (long)B * OH * ((OW + 1) / 2) * CV;
+  RFN_REQUIRE(total / 256 < 0x7fffffffL, "maxpool2x2_nhwc16: too large");
+  const int grid = cdiv(total, 256);
+  if (dtype == 1)
+    hipLaunchKernelGGL(maxpool2x2_nhwc16_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x,
+                       (__bf16*)y, H, W, OH, OW, CV, total);
+  else
+    hipLaunchKernelGGL(maxpool2x2_nhwc16_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,
+                       (_Float16*)y, H, W, OH, OW, CV, total);
+  return check_launch("maxpool2x2_nhwc16");
 }
 
 }  // extern "C"

@@ -394,3 +394,20 @@ def test_label_majority_kernel_matches_one_hot_pooling(H, W, scale, minr):
     got = M.downscale_label_ratio(gt.to(dev), scale, minr, 19, out_size=(oh, ow))
     assert got.device.type == "cuda" and tuple(got.shape) == (2, 1, oh, ow)
     assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 18, 22), (1, 128, 17, 19), (3, 8, 2, 2), (1, 256, 33, 62)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_maxpool2x2_kernel_equals_max_pool2d(B, C, H, W, dtype):
+    """csrc/warp.hip rfn_maxpool2x2_nhwc16 (the VGG pyramid's nn.MaxPool2d(2, 2), floor mode) on channels-last 16-bit maps,
+    odd extents included: bit-equal to F.max_pool2d."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from refign_amd.align import _maxpool2x2
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, C, H, W, generator=g).to("cuda:0").to(dtype).contiguous(memory_format=torch.channels_last)
+    m = torch.nn.MaxPool2d(kernel_size=2, stride=2)
+    with torch.no_grad():
+        got = _maxpool2x2(x, m)
+    assert got is not None and torch.equal(got, torch.nn.functional.max_pool2d(x, 2, 2))
+    assert _maxpool2x2(x.float(), m) is None and _maxpool2x2(x, torch.nn.MaxPool2d(3, 2)) is None
