@@ -253,6 +253,12 @@ int rfn_linear_param_grads(const void* grad_y, float* grad_bias, void* workspace
  * rfn_multi_cast_chunk_elems() elements; the host splits every tensor into such chunks once per parameter set.
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_multi_cast_chunk_elems(void);
+/* layout-changing refresh of cached weight copies in one launch: every row of `table` (12 int64: src fp32 pointer, dst
+ * pointer, extents of dst dims 1..3, source strides of dims 0..3 in elements, first dst element and element count of the
+ * chunk, dst dtype 0 fp32 / 1 bf16 / 2 f16) copies <= rfn_multi_permute_chunk_elems() consecutive elements of a contiguous
+ * <= 4-D dst from a strided view of an fp32 parameter (autocast's / the kernels' permuted weight forms after an optimiser step) */
+int rfn_multi_permute_chunk_elems(void);
+int rfn_multi_permute_cast_f32(const void* table, int nchunks, rfn_stream_t stream);
 int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream);
 /* EMA-teacher update of a whole parameter set in ONE launch (models/segmentation_model.py:676-689):
  * ema <- momentum * ema + (1 - momentum) * live, fp32 in place; table = nchunks x {float* ema, const float* live,

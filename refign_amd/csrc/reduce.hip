@@ -283,6 +283,32 @@ __global__ __launch_bounds__(256) void multi_cast_f32_bf16_kernel(const CastChun
     c.dst[j] = (unsigned short)f32_to_bf16_bits(c.src[j]);
 }
 
+// Layout-changing copies of a parameter set in one launch: dst (contiguous, up to 4-D, fp32 / bf16 / f16) <- a strided fp32 view
+// of a parameter (the (Co, r, r, C) patch-GEMM form of a convolution weight, the tap-major depthwise weights, W^T of the patch
+// GEMMs ...: torch._foreach_copy_ runs one tiny strided-copy kernel per tensor -- 240 of them after every optimiser / EMA
+// step, on the serial tail of the training step).  A chunk = kPermChunk consecutive dst elements of one tensor.
+struct PermChunk {
+  const float* src;
+  void* dst;
+  long n1, n2, n3;             // extents of dims 1..3 of dst (dim 0 is implied)
+  long s0, s1, s2, s3;         // strides of the source view, in elements
+  long off, cnt;               // first dst element of the chunk, elements in it
+  long dtype;                  // of dst: 0 fp32, 1 bf16, 2 f16
+};
+constexpr int kPermChunk = 8192;
+
+__global__ __launch_bounds__(256) void multi_permute_cast_kernel(const PermChunk* __restrict__ table) {
+  const PermChunk c = table[blockIdx.x];
+  for (long j = threadIdx.x; j < c.cnt; j += 256) {
+    const long i = c.off + j;
+    const long i3 = i % c.n3, r3 = i / c.n3, i2 = r3 % c.n2, r2 = r3 / c.n2, i1 = r2 % c.n1, i0 = r2 / c.n1;
+    const float v = c.src[i0 * c.s0 + i1 * c.s1 + i2 * c.s2 + i3 * c.s3];
+    if (c.dtype == 0) ((float*)c.dst)[i] = v;
+    else if (c.dtype == 1) ((unsigned short*)c.dst)[i] = (unsigned short)bf16_bits(v);
+    else ((_Float16*)c.dst)[i] = (_Float16)v;
+  }
+}
+
 // EMA of a whole parameter set in one launch (models/segmentation_model.py:676-689: teacher <- m teacher + (1 - m) student)
 // with the bf16 copy of the updated teacher weight written in the same pass where the chunk has one (dst16 != null).
 struct EmaChunk {
@@ -422,6 +448,16 @@ int rfn_multi_ema_f32(const void* table, int nchunks, float momentum, rfn_stream
 }
 
 int rfn_multi_cast_chunk_elems(void) { return 16384; }
+
+int rfn_multi_permute_chunk_elems(void) { return rfn::kPermChunk; }
+
+// table: nchunks rows of 12 int64 {src, dst, n1, n2, n3, s0, s1, s2, s3, off, cnt, dtype} (struct PermChunk above)
+int rfn_multi_permute_cast_f32(const void* table, int nchunks, rfn_stream_t stream) {
+  RFN_REQUIRE(table && nchunks > 0, "rfn_multi_permute_cast_f32: empty table");
+  hipLaunchKernelGGL(rfn::multi_permute_cast_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                     (const rfn::PermChunk*)table);
+  return rfn::check_launch("multi_permute_cast_kernel");
+}
 
 int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream) {
   RFN_REQUIRE(table && nchunks > 0, "rfn_multi_cast_f32_bf16: empty table");

@@ -89,13 +89,45 @@ def _build_plan(params):
             transposes.append(_transpose_table([dst[i] for i in idx], [src[i] for i in idx], dev) +
                               (dev, [dst[i] for i in idx], [src[i] for i in idx]))
         skip = skip | set(tr)
-    return {"entries": entries, "transposes": transposes,
+    # every other layout-changing copy of an fp32 parameter view into a contiguous <= 4-D tensor: one launch
+    # (csrc/reduce.hip multi_permute_cast_kernel) instead of one strided-copy kernel per tensor
+    rest = [i for i in range(len(dst)) if i not in skip]
+    pm = [i for i in rest if dst[i].is_cuda and dst[i].is_contiguous() and dst[i].dtype in _PERM_DT
+          and src[i].dtype == torch.float32 and 1 <= dst[i].dim() <= 4 and dst[i].numel() > 0
+          and src[i].shape == dst[i].shape]
+    permutes = []
+    if len(pm) >= 4 and os.environ.get("RFN_PERMUTE_REFRESH", "1") != "0":
+        by_dev = {}
+        for i in pm:
+            by_dev.setdefault(dst[i].device, []).append(i)
+        for dev, idx in by_dev.items():
+            permutes.append(_permute_table([dst[i] for i in idx], [src[i] for i in idx], dev) +
+                            (dev, [dst[i] for i in idx], [src[i] for i in idx]))
+        skip = skip | set(pm)
+    return {"entries": entries, "transposes": transposes, "permutes": permutes,
             # (the tensors are kept next to the table: they own the memory the table points into)
             "casts": [_cast_table([dst[i] for i in idx], [src[i] for i in idx], dev) + (dev, [dst[i] for i in idx],
                                                                                          [src[i] for i in idx])
                       for dev, idx in casts.items()],
             "rest": ([d for i, d in enumerate(dst) if i not in skip], [s_ for i, s_ in enumerate(src) if i not in skip]),
             "gen": _GENERATION[0]}
+
+
+_PERM_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def _permute_table(dst, src, dev):
+    """Chunk table of the multi-tensor layout-changing copy: 12 int64 per chunk (csrc/reduce.hip PermChunk), built once."""
+    import numpy as np
+    chunk = _lib.load_library().rfn_multi_permute_chunk_elems()
+    rows = []
+    for d, s_ in zip(dst, src):
+        shape = [1] * (4 - d.dim()) + list(d.shape)
+        strides = [0] * (4 - d.dim()) + list(s_.stride())
+        n = d.numel()
+        rows += [(s_.data_ptr(), d.data_ptr(), shape[1], shape[2], shape[3], strides[0], strides[1], strides[2], strides[3],
+                  off, min(chunk, n - off), _PERM_DT[d.dtype]) for off in range(0, n, chunk)]
+    return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows)
 
 
 def _cast_table(dst, src, dev):
@@ -172,6 +204,10 @@ def refresh(params, plan_key=None):
             with on_device(dev):
                 rc = _lib.load_library().rfn_multi_transpose_cast_f32_bf16(ptr(table), ntiles, current_stream(dev))
             _lib.check(rc, "multi_transpose_cast")
+        for table, nrows, dev, _, _ in plan["permutes"]:
+            with on_device(dev):
+                rc = _lib.load_library().rfn_multi_permute_cast_f32(ptr(table), nrows, current_stream(dev))
+            _lib.check(rc, "multi_permute_cast")
         if plan["rest"][0]:
             torch._foreach_copy_(*plan["rest"])
 
