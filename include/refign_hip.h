@@ -300,6 +300,12 @@ int rfn_upsample_concat_nhwc_bwd(const void* grad_out, void* grad0, void* grad1,
 int rfn_patchify_tokens(const void* src, void* dst, int B, int H, int W, int C, int r, int dtype, int inverse,
                         rfn_stream_t stream);
 
+/* The same with the patch row in (c, ry, rx) order -- the (C, r, r) layout of one output channel of the convolution weight
+ * (mix_transformer.py:85 `self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)`): the patch GEMM multiplies
+ * by the parameter's own (Co, C r r) matrix and its weight gradient lands in the parameter's layout.  r in {2, 4, 8}. */
+int rfn_patchify_tokens_cmajor(const void* src, void* dst, int B, int H, int W, int C, int r, int dtype, int inverse,
+                               rfn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Hand-written matrix-core (MFMA 32x32x16) GEMMs of a token-wise nn.Linear -- q / kv / proj / fc1 / fc2 / sr-as-Linear
  * of MiT (mix_transformer.py:96-103,137-164) and the MLP embeds of the decode heads (daformer.py:129-149).

@@ -58,6 +58,7 @@ SIGNATURES = {
                                  + [c_void_p]),
     "rfn_upsample_concat_nhwc_bwd": (c_int, [c_void_p] * 5 + [ctypes.POINTER(c_int)] * 3 + [c_int] * 5 + [c_void_p]),
     "rfn_patchify_tokens": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "rfn_patchify_tokens_cmajor": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rfn_multi_cast_chunk_elems": (c_int, []),
     "rfn_multi_permute_chunk_elems": (c_int, []),
     "rfn_multi_permute_cast_f32": (c_int, [c_void_p, c_int, c_void_p]),

@@ -299,10 +299,13 @@ constexpr int kPermChunk = 8192;
 
 __global__ __launch_bounds__(256) void multi_permute_cast_kernel(const PermChunk* __restrict__ table) {
   const PermChunk c = table[blockIdx.x];
-  for (long j = threadIdx.x; j < c.cnt; j += 256) {
-    const long i = c.off + j;
-    const long i3 = i % c.n3, r3 = i / c.n3, i2 = r3 % c.n2, r2 = r3 / c.n2, i1 = r2 % c.n1, i0 = r2 / c.n1;
-    const float v = c.src[i0 * c.s0 + i1 * c.s1 + i2 * c.s2 + i3 * c.s3];
+  // 32-bit index arithmetic (a parameter tensor has < 2^31 elements): three 64-bit divisions per element were the whole
+  // cost of this kernel (177 us per launch for ~100 MB)
+  const unsigned n1 = (unsigned)c.n1, n2 = (unsigned)c.n2, n3 = (unsigned)c.n3, cnt = (unsigned)c.cnt;
+  for (unsigned j = threadIdx.x; j < cnt; j += 256) {
+    const unsigned i = (unsigned)c.off + j;
+    const unsigned i3 = i % n3, r3 = i / n3, i2 = r3 % n2, r2 = r3 / n2, i1 = r2 % n1, i0 = r2 / n1;
+    const float v = c.src[(long)i0 * c.s0 + (long)i1 * c.s1 + (long)i2 * c.s2 + (long)i3 * c.s3];
     if (c.dtype == 0) ((float*)c.dst)[i] = v;
     else if (c.dtype == 1) ((unsigned short*)c.dst)[i] = (unsigned short)bf16_bits(v);
     else ((_Float16*)c.dst)[i] = (_Float16)v;

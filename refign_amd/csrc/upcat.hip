@@ -321,9 +321,116 @@ __global__ __launch_bounds__(256) void patchify_kernel(const char* __restrict__ 
   }
 }
 
+// The same gather with the patch row in (c, ry, rx) order -- the (C, r, r) layout of one output channel of the convolution
+// weight: the patch GEMM then multiplies by the parameter's own (Co, C r r) matrix and its weight gradient is ADDED
+// straight into the parameter's .grad (coalesced atomics of the TN kernel) -- no permuted weight copy to refresh, no
+// partial-sum + permuted-add passes (5 launches per spatial-reduction convolution and backward pass).
+// Both sides of the move are 16-byte vectors that are contiguous across the lanes of a wave; the element transposition
+// happens in LDS, which holds `np` patches in TOKEN order [p][ry][rx][c] (a first version with each thread writing its 8
+// channels' runs of r elements straight to memory -- 4-byte stores 64 bytes apart -- ran at a quarter of the speed).
+template <typename E, int R>
+__global__ __launch_bounds__(256) void patchify_cmajor_kernel(const E* __restrict__ src, E* __restrict__ dst, int H, int W,
+                                                              int C, int Hr, int Wr, int npatch, int np, int inverse,
+                                                              unsigned magic_kv, unsigned magic_cve) {
+  extern __shared__ uint4 patch_lds[];
+  constexpr int VE = 16 / sizeof(E);
+  const int K = R * R * C, KV = K / VE, CVE = C / VE;
+  const int p0 = blockIdx.x * np;
+  const int n = min(np, npatch - p0);
+  const int nvec = n * KV;
+  E* sm = reinterpret_cast<E*>(patch_lds);
+  long* pbase = reinterpret_cast<long*>(sm + (size_t)np * K);     // token address of pixel (0, 0), channel 0 of each patch
+  if ((int)threadIdx.x < n) {
+    const int patch = p0 + threadIdx.x, j = patch % Wr, t = patch / Wr, i = t % Hr, b = t / Hr;
+    pbase[threadIdx.x] = (((long)b * H + (long)i * R) * W + (long)j * R) * C;
+  }
+  // neighbouring lanes of the patch side are VE elements of a patch row apart: for R R > 8 that is the same channel at pixel
+  // index rr + 8, C elements further -- the same bank.  XOR the pixel's 16-byte vector index with rr / 8.
+  constexpr int SWM = (R * R >= 16) ? (R * R / 8 - 1) : 0;
+  const int swm = (CVE % (SWM + 1) == 0) ? SWM : 0;
+  // the two run-time divisors (vectors per patch, vectors per pixel) by multiplication: magic = 2^32 / d + 1, exact for
+  // dividends < 2^32 / d (a workgroup's vector count; integer divisions were most of the first version's instructions)
+  struct Tok { int lds; long addr; };
+  auto token_side = [&](int v) -> Tok {          // v = (p, ry, rx, cv): LDS vector p KV + rr CVE + (cv ^ swizzle(rr))
+    const int p = (int)__umulhi((unsigned)v, magic_kv), rem = v - p * KV;
+    const int rr = (int)__umulhi((unsigned)rem, magic_cve), cv = rem - rr * CVE;
+    const int ry = rr / R, rx = rr - ry * R;
+    return Tok{p * KV + rr * CVE + (cv ^ ((rr >> 3) & swm)), pbase[p] + ((long)ry * W + rx) * C + cv * VE};
+  };
+  auto lds_elem = [&](int p, int k) -> int {     // patch-side element k = (c, ry, rx) of local patch p
+    const int c = k / (R * R), rr = k - c * (R * R);
+    const int cv = c / VE;
+    return p * K + rr * C + ((cv ^ ((rr >> 3) & swm)) * VE) + (c - cv * VE);
+  };
+  __syncthreads();
+  if (!inverse) {
+    for (int v = threadIdx.x; v < nvec; v += 256) {
+      const Tok t = token_side(v);
+      patch_lds[t.lds] = *reinterpret_cast<const uint4*>(src + t.addr);
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < nvec; u += 256) {
+      const int p = (int)__umulhi((unsigned)u, magic_kv), kv = u - p * KV;
+      alignas(16) E o[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] = sm[lds_elem(p, kv * VE + e)];
+      *reinterpret_cast<uint4*>(dst + (long)(p0 + p) * K + (long)kv * VE) = *reinterpret_cast<const uint4*>(o);
+    }
+  } else {
+    for (int u = threadIdx.x; u < nvec; u += 256) {
+      const int p = (int)__umulhi((unsigned)u, magic_kv), kv = u - p * KV;
+      alignas(16) E o[VE];
+      *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(src + (long)(p0 + p) * K + (long)kv * VE);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) sm[lds_elem(p, kv * VE + e)] = o[e];
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < nvec; v += 256) {
+      const Tok t = token_side(v);
+      *reinterpret_cast<uint4*>(dst + t.addr) = patch_lds[t.lds];
+    }
+  }
+}
+
+template <typename E>
+static int launch_patchify_cmajor(const void* src, void* dst, int B, int H, int W, int C, int r, int inverse, hipStream_t st) {
+  const int Hr = H / r, Wr = W / r;
+  const long npatch = (long)B * Hr * Wr;
+  const long pbytes = (long)r * r * C * sizeof(E);
+  if (C < 16) return fail(RFN_EINVAL, "rfn_patchify_tokens_cmajor: C >= 16 (got %d)", C);
+  if (pbytes > 65536 - 8 || npatch >= (1L << 31) / (r * r * C))
+    return fail(RFN_EINVAL, "rfn_patchify_tokens_cmajor: a patch has to fit 64 KB of LDS (r r C = %ld bytes)", pbytes);
+  // ~16 KB of patches per workgroup, fewer while that leaves the grid under two workgroups per CU
+  long np = std::min<long>(256, std::max<long>(1, 16384 / pbytes));
+  while (np > 1 && cdiv(npatch, np) < 512) np >>= 1;
+  const int grid = (int)cdiv(npatch, np);
+  const size_t lds = (size_t)np * pbytes + (size_t)np * sizeof(long);
+  constexpr int VE = 16 / sizeof(E);
+  const unsigned magic_kv = (unsigned)((1ull << 32) / (unsigned)(r * r * C / VE) + 1);
+  const unsigned magic_cve = (unsigned)((1ull << 32) / (unsigned)(C / VE) + 1);
+#define RFN_PCM(R)                                                                                                     \
+  hipLaunchKernelGGL((patchify_cmajor_kernel<E, R>), dim3(grid), dim3(256), lds, st, (const E*)src, (E*)dst, H, W, C, \
+                     Hr, Wr, (int)npatch, (int)np, inverse, magic_kv, magic_cve)
+  if (r == 2) RFN_PCM(2);
+  else if (r == 4) RFN_PCM(4);
+  else RFN_PCM(8);
+#undef RFN_PCM
+  return check_launch("patchify_cmajor_kernel");
+}
+
 }  // namespace rfn
 
 extern "C" {
+
+// patch rows in (c, ry, rx) order (see patchify_cmajor_kernel); r in {2, 4, 8} (the MiT spatial-reduction ratios)
+int rfn_patchify_tokens_cmajor(const void* src, void* dst, int B, int H, int W, int C, int r, int dtype, int inverse,
+                               rfn_stream_t stream) {
+  RFN_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && (r == 2 || r == 4 || r == 8) && r <= H && r <= W,
+              "rfn_patchify_tokens_cmajor: bad arguments (C %% 8 == 0, r in {2, 4, 8})");
+  RFN_REQUIRE(dtype == 0 || dtype == 1, "rfn_patchify_tokens_cmajor: dtype must be 0 (f32) or 1 (bf16 / f16)");
+  if (dtype == 1) return rfn::launch_patchify_cmajor<unsigned short>(src, dst, B, H, W, C, r, inverse, (hipStream_t)stream);
+  return rfn::launch_patchify_cmajor<unsigned int>(src, dst, B, H, W, C, r, inverse, (hipStream_t)stream);
+}
 
 int rfn_patchify_tokens(const void* src, void* dst, int B, int H, int W, int C, int r, int dtype, int inverse,
                         rfn_stream_t stream) {

@@ -125,6 +125,7 @@ def _permute_table(dst, src, dev):
         shape = [1] * (4 - d.dim()) + list(d.shape)
         strides = [0] * (4 - d.dim()) + list(s_.stride())
         n = d.numel()
+        assert n < 2 ** 31, "the permute kernel indexes one tensor with 32 bits"
         rows += [(s_.data_ptr(), d.data_ptr(), shape[1], shape[2], shape[3], strides[0], strides[1], strides[2], strides[3],
                   off, min(chunk, n - off), _PERM_DT[d.dtype]) for off in range(0, n, chunk)]
     return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows)

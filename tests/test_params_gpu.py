@@ -184,18 +184,48 @@ def test_spatial_reduction_conv_as_patch_linear(dev, H, W, r, sink):
         assert torch.allclose(patch_conv_tokens(x, H, W, a), yb, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("H,W,r", [(16, 24, 2), (34, 60, 4), (64, 72, 8), (17, 31, 2)])
+def test_spatial_reduction_conv_bf16_gradients_land_in_the_flat_buffer(dev, H, W, r):
+    """under the bf16 autocast of the training step, with the flat gradient buffer: channel-major patches, the TN kernel adds
+    the weight AND bias gradient straight into the (Co, C, r, r) / (Co,) views (one launch), twice (accumulation)"""
+    from refign_amd.conv import Conv2d, patch_conv_tokens
+    from refign_amd.trainer import FlatGradBuffer
+    torch.manual_seed(H + r)
+    C, B = 64, 2
+    a, b = Conv2d(C, C, r, stride=r).to(dev), nn.Conv2d(C, C, r, stride=r).to(dev)
+    b.load_state_dict(a.state_dict())
+    FlatGradBuffer(a.parameters())
+    x = torch.randn(B, H * W, C, device=dev)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    for rep in range(2):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ya = patch_conv_tokens(xa, H, W, a)
+            yb = b(xb.transpose(1, 2).reshape(B, C, H, W)).flatten(2).transpose(1, 2)
+        assert ya.shape == yb.shape and ya.dtype == torch.bfloat16
+        assert torch.allclose(ya.float(), yb.float(), rtol=2e-2, atol=2e-2)
+        g = torch.randn_like(yb)
+        ya.backward(g)
+        yb.backward(g)
+    for got, want in ((xa.grad, xb.grad), (a.weight.grad, b.weight.grad), (a.bias.grad, b.bias.grad)):
+        scale = float(want.abs().max())
+        assert torch.allclose(got / scale, want / scale, rtol=3e-2, atol=1e-2), float((got - want).abs().max()) / scale
+
+
+@pytest.mark.parametrize("cmajor", [False, True])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,C,r", [(2, 16, 24, 64, 2), (1, 135, 50, 32, 8), (3, 17, 30, 320, 2), (2, 34, 61, 128, 4)])
-def test_patchify_tokens_kernel(dev, dt, B, H, W, C, r):
-    """csrc/upcat.hip patchify_kernel: gather to r x r patches and scatter back == the view/permute formulation."""
+def test_patchify_tokens_kernel(dev, dt, B, H, W, C, r, cmajor):
+    """csrc/upcat.hip patchify_kernel / patchify_cmajor_kernel: gather to r x r patches -- (ry, rx, c) rows, or (c, ry, rx)
+    rows, the layout of the convolution weight -- and scatter back == the view/permute formulation."""
     from refign_amd import conv
     x = torch.randn(B, H * W, C, device=dev).to(dt)
     Hr, Wr = H // r, W // r
-    want = x.view(B, H, W, C)[:, :Hr * r, :Wr * r].reshape(B, Hr, r, Wr, r, C).permute(0, 1, 3, 2, 4, 5) \
+    order = (0, 1, 3, 5, 2, 4) if cmajor else (0, 1, 3, 2, 4, 5)
+    want = x.view(B, H, W, C)[:, :Hr * r, :Wr * r].reshape(B, Hr, r, Wr, r, C).permute(*order) \
         .reshape(B * Hr * Wr, r * r * C)
-    got, hr, wr = conv._to_patches(x, H, W, r)
+    got, hr, wr = conv._to_patches(x, H, W, r, cmajor)
     assert (hr, wr) == (Hr, Wr) and torch.equal(got, want)
-    back = conv._from_patches(got, B, H, W, C, r, Hr, Wr)
+    back = conv._from_patches(got, B, H, W, C, r, Hr, Wr, cmajor)
     ref = torch.zeros(B, H, W, C, device=dev, dtype=dt)
     ref[:, :Hr * r, :Wr * r] = x.view(B, H, W, C)[:, :Hr * r, :Wr * r]
     assert torch.equal(back, ref.view(B, H * W, C))
