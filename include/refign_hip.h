@@ -296,12 +296,12 @@ int rfn_upsample_concat_nhwc_bwd(const void* grad_out, void* grad0, void* grad1,
 
 /* Token map (B, H*W, C) -> non-overlapping r x r patches (B*(H/r)*(W/r), r*r*C) with (ry, rx, c) fastest (inverse = 0),
  * or back (inverse = 1; a ragged border of the token map is NOT written -- zero it first): gather / scatter around the
- * spatial-reduction convolution of the MiT attention run as a Linear (mix_transformer.py:128-134).  C % 8 == 0. */
+ * spatial-reduction convolution of the MiT attention run as a Linear (mix_transformer.py:133-146).  C % 8 == 0. */
 int rfn_patchify_tokens(const void* src, void* dst, int B, int H, int W, int C, int r, int dtype, int inverse,
                         rfn_stream_t stream);
 
 /* The same with the patch row in (c, ry, rx) order -- the (C, r, r) layout of one output channel of the convolution weight
- * (mix_transformer.py:85 `self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)`): the patch GEMM multiplies
+ * (mix_transformer.py:133-136 `self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)`): the patch GEMM multiplies
  * by the parameter's own (Co, C r r) matrix and its weight gradient lands in the parameter's layout.  r in {2, 4, 8}. */
 int rfn_patchify_tokens_cmajor(const void* src, void* dst, int B, int H, int W, int C, int r, int dtype, int inverse,
                                rfn_stream_t stream);

@@ -90,7 +90,7 @@ class Conv2d(nn.Conv2d):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Spatial-reduction convolution of the MiT attention (kernel = stride = sr_ratio, no padding: mix_transformer.py:128-134)
+# Spatial-reduction convolution of the MiT attention (kernel = stride = sr_ratio, no padding: mix_transformer.py:133-146)
 # as what it is -- a Linear over non-overlapping r x r patches -- on the token layout, without the NCHW round trip.
 # Forward: one gather copy (tokens -> patches) + one GEMM with bias, output directly as (B, N', C) tokens for the
 # LayerNorm that follows.  Backward: the Linear's three GEMM-shaped ops (split-T weight gradient, parameter gradients
