@@ -817,10 +817,9 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(const uint16_t* __restric
 // LDS image of an operand tile: [BT rows][cols], 16-byte pieces; piece c of row r at slot c ^ swz(r), swz(r) = 4 ((r >> 1) & 1)
 // for 128-byte rows (64 columns), 4 (r & 3) for 256-byte rows (128 columns): the 16 pieces a 32-lane half of a transpose read
 // touches (4 rows x 64 bytes) are 16 distinct slots of the 256-byte bank row.
-// Rows past the end of the slab / of T are DMA'd from the zero page.  rowscale (stochastic depth): the 8 rows of a lane's
-// fragment belong to one sample (rows_per_sample % 8 == 0, the host checks), the fragment is scaled in fp32 and rounded back
-// as the eager g * mask -- the slab's scales are put in LDS before the loop (no global load inside the DMA loop: mfma.h
-// pin_loaded).  Bias gradient: column sums of the (scaled) G fragments, by the waves with wk == 0 of the tiles with k0 == 0.
+// Rows past the end of the slab / of T are DMA'd from the zero page.  rowscale (stochastic depth): see SEG below -- the slab's
+// scales are put in LDS before the loop (no global load inside the DMA loop: mfma.h pin_loaded).  Bias gradient: column sums
+// of the G fragments (per sample, scaled like the products), by the waves with wk == 0 of the tiles with k0 == 0.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32x2 lds_read_tr16(unsigned addr) {
   u32x2 r;
@@ -831,7 +830,12 @@ __device__ __forceinline__ u32x2 lds_read_tr16(unsigned addr) {
 // GATHER: the weight gradient of a convolution -- row t of the X operand is the im2col row of output pixel t = (b, oy, ox),
 // a 16-byte piece is 8 channels of ONE tap (C % 8 == 0): the DMA source of (row, piece) is x[b, oy s - p + ky d, ox s - p + kx d,
 // c .. c + 7] or the zero page; a lane's pieces (tap, channel) are fixed, its rows advance by BT per stage.
-template <int DT, int BN, int BK, int BT, bool GATHER = false>
+// SEG (rowscale given): the slab's rows are walked sample by sample -- a stage never crosses a sample boundary (its rows
+// past the end of the sample come from the zero page), the products of a sample go to a second accumulator block and are
+// folded into the result with the sample's scale when the sample ends: sum_s scale_s (G_s^T X_s) in fp32.  (The first
+// version scaled the G FRAGMENTS -- unpack, multiply, round, repack, 40 VALU instructions per 16-row step in every one of
+// the K / 64 tiles that share a G panel: 8 160 x 320 x 1 280 took 42 us against 25 us without a scale.)
+template <int DT, int BN, int BK, int BT, bool GATHER = false, bool SEG = false>
 __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
                                                        float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
                                                        int R, int tiles_k, int accumulate, float* __restrict__ gbias,
@@ -856,15 +860,25 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
   const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
   const long t0 = (long)slab * R;
   const long tend = min((long)T, t0 + R);
-  const int nit = (int)((tend - t0 + BT - 1) / BT);
+  static_assert(!(SEG && GATHER), "sample segments: plain operands only");
   auto gswz = [](int r) { return BN == 64 ? ((r >> 1) & 1) << 2 : (r & 3) << 2; };
   auto xswz = [](int r) { return BK == 64 ? ((r >> 1) & 1) << 2 : (r & 3) << 2; };
 
-  // the slab's stochastic-depth scales: sample of row t0 + 8 m is s0 + ...; sscale[i] = rowscale[s0 + i]
-  const long s0 = rowscale != nullptr ? t0 / rows_per_sample : 0;
-  if (rowscale != nullptr) {
+  // the slab's stochastic-depth scales: sscale[i] = rowscale[s0 + i], s0 = sample of the slab's first row
+  const long s0 = SEG ? t0 / rows_per_sample : 0;
+  // end of the sample segment that starts at row a (a = t0 or a multiple of rows_per_sample)
+  auto seg_end = [&](long a) { return SEG ? min(tend, (a / rows_per_sample + 1) * rows_per_sample) : tend; };
+  int nit = 0;
+  if constexpr (SEG) {
     const long s1 = (tend - 1) / rows_per_sample;
     if ((int)threadIdx.x <= (int)(s1 - s0) && threadIdx.x < kMaxScales) sscale[threadIdx.x] = rowscale[s0 + threadIdx.x];
+    for (long a = t0; a < tend;) {
+      const long e = seg_end(a);
+      nit += (int)((e - a + BT - 1) / BT);
+      a = e;
+    }
+  } else {
+    nit = (int)((tend - t0 + BT - 1) / BT);
   }
   // GATHER: per X instruction u of this lane: (dy, dx, channel) of its piece, (image, oy, ox) of its row in stage 0
   int gdy[GATHER ? XI : 1], gdx[GATHER ? XI : 1], gch[GATHER ? XI : 1], gb[GATHER ? XI : 1], goy[GATHER ? XI : 1],
@@ -891,15 +905,24 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
   }
   // ---- DMA: instruction u of this wave moves 64 pieces = 64 / PPR rows of the tile; lane = (row, LDS piece slot), it fetches
   // source piece slot ^ swz(row)
+  long itb = t0, iend = seg_end(t0);                 // issue cursor: first row of the next stage, end of its sample segment
   auto issue = [&](int it, int buf) {
     unsigned char* gs = smem + buf * STAGE;
     unsigned char* xs = gs + GBYTES;
-    const long tb = t0 + (long)it * BT;
+    const long tb = SEG ? itb : t0 + (long)it * BT;
+    const long tlim = SEG ? iend : tend;
+    if constexpr (SEG) {                               // (stages are issued in order)
+      itb += BT;
+      if (itb >= iend) {
+        itb = iend;
+        iend = seg_end(iend);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < GI; ++u) {
       const int q = GI * wave + u, r = q * (64 / GPPR) + lane / GPPR, c = lane % GPPR;
       const long t = tb + r;
-      const void* src = t < tend ? (const void*)(G + t * ldg + n0 + 8 * (c ^ gswz(r))) : zero;
+      const void* src = t < tlim ? (const void*)(G + t * ldg + n0 + 8 * (c ^ gswz(r))) : zero;
       lds_dma16(src, gs + q * 1024);
     }
 #pragma unroll
@@ -920,7 +943,7 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
           }
         }
       } else {
-        src = t < tend ? (const void*)(X + t * ldx + k0 + 8 * (c ^ xswz(r))) : zero;
+        src = t < tlim ? (const void*)(X + t * ldx + k0 + 8 * (c ^ xswz(r))) : zero;
       }
       lds_dma16(src, xs + q * 1024);
     }
@@ -937,6 +960,20 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
 #pragma unroll
   for (int i = 0; i < IB; ++i) bsum[i] = 0.f;
   const bool do_bias = gbias != nullptr && k0 == 0 && wk == 0;
+  // SEG: result so far (finished samples, scaled); acc / bsum hold the running sample
+  f32x16 tot[SEG ? IB : 1][SEG ? JB : 1];
+  float btot[SEG ? IB : 1];
+  if constexpr (SEG) {
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      btot[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    }
+  }
+  long ctb = t0, cend = seg_end(t0);                   // compute cursor
 
   // ---- fragment addressing: lane = (16-lane group q16, p); group: column half (q16 & 1), k-slot half g = q16 >> 1
   const int g = lane >> 5, col = lane & 31, p = lane & 15, q16 = lane >> 4;
@@ -974,26 +1011,20 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
         b1[j] = lds_read_tr16(xaddr(buf, row + 4, c));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      float sc = 1.f;
-      if (rowscale != nullptr) {
-        const long tr = t0 + (long)it * BT + 16 * ks + 8 * g;      // the lane's 8 rows: one sample (rows_per_sample % 8 == 0)
-        sc = tr < tend ? sscale[min((long)(kMaxScales - 1), tr / rows_per_sample - s0)] : 0.f;
-      }
+      // the transpose reads are inline asm: the compiler does not know that their results arrive asynchronously, and nothing
+      // ties the MFMAs below to the wait above -- it scheduled the first of them in front of it (found when the run-time
+      // rowscale branch that used to sit here went away).  Volatile asms keep their order; these give the users a dependency.
+#pragma unroll
+      for (int i = 0; i < IB; ++i) asm volatile("" : "+v"(a0[i]), "+v"(a1[i]));
+#pragma unroll
+      for (int j = 0; j < JB; ++j) asm volatile("" : "+v"(b0[j]), "+v"(b1[j]));
 #pragma unroll
       for (int i = 0; i < IB; ++i) {
-        if (rowscale != nullptr || do_bias) {
+        if (do_bias) {
           float f[8];
           unpack4<DT>(a0[i], *(float(*)[4])&f[0]);
           unpack4<DT>(a1[i], *(float(*)[4])&f[4]);
-          if (rowscale != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] *= sc;
-            a0[i] = pack4<DT>(f[0], f[1], f[2], f[3]);
-            a1[i] = pack4<DT>(f[4], f[5], f[6], f[7]);
-            unpack4<DT>(a0[i], *(float(*)[4])&f[0]);               // the bias gradient sums the ROUNDED scaled values
-            unpack4<DT>(a1[i], *(float(*)[4])&f[4]);
-          }
-          if (do_bias) bsum[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+          bsum[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         }
         af[i] = join8<DT>(a0[i], a1[i]);
       }
@@ -1003,6 +1034,34 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
       for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(af[i], bf[j], acc[i][j]);
+    }
+    if constexpr (SEG) {
+      ctb += BT;
+      if (ctb >= cend) {                               // the sample is complete: fold it in with its scale
+        const float sc = sscale[min((long)(kMaxScales - 1), (cend - 1) / rows_per_sample - s0)];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+          btot[i] = fmaf(sc, bsum[i], btot[i]);
+          bsum[i] = 0.f;
+#pragma unroll
+          for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              tot[i][j][r] = fmaf(sc, acc[i][j][r], tot[i][j][r]);
+              acc[i][j][r] = 0.f;
+            }
+        }
+        ctb = cend;
+        cend = seg_end(cend);
+      }
+    }
+  }
+  if constexpr (SEG) {
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      bsum[i] = btot[i];
+#pragma unroll
+      for (int j = 0; j < JB; ++j) acc[i][j] = tot[i][j];
     }
   }
 
@@ -1121,21 +1180,24 @@ static int launch_tn(const void* G, const void* X, float* P, long T, long N, lon
     // third generation (LDS-DMA + transpose reads); the stochastic-depth scale needs whole samples per 8-row fragment and the
     // slab's scales in 64 LDS floats
     const long span = rowscale != nullptr ? ((long)R + rps - 1) / rps + 1 : 0;
-    if (rowscale == nullptr || (rps % 8 == 0 && span <= 64)) {
+    if (rowscale == nullptr || (!GATHER && span <= 64)) {
       static void* zero_page = nullptr;
       if (zero_page == nullptr && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero_page)) != hipSuccess)
         return fail(RFN_ELAUNCH, "gemm_tn: zero page symbol");
-      if (N % 128 == 0 && K % 128 == 0) {
-        dim3 grid((unsigned)((N / 128) * (K / 128) * S));
-        hipLaunchKernelGGL((gemm_tn3_kernel<DT, 128, 128, 32, GATHER>), grid, block, 0, s, (const uint16_t*)G,
-                           (const uint16_t*)X, P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 128), accumulate, gbias,
-                           rowscale, rps, zero_page, tn_xcd, wg);
+      const bool big = N % 128 == 0 && K % 128 == 0;
+      dim3 grid((unsigned)(big ? (N / 128) * (K / 128) * S : (N / 64) * (K / 64) * S));
+#define RFN_TN3(BN_, BK_, BT_, SEG_)                                                                                      \
+  hipLaunchKernelGGL((gemm_tn3_kernel<DT, BN_, BK_, BT_, GATHER && !SEG_, SEG_>), grid, block, 0, s, (const uint16_t*)G, \
+                     (const uint16_t*)X, P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / BK_), accumulate, gbias,      \
+                     rowscale, rps, zero_page, tn_xcd, wg)
+      if (rowscale != nullptr) {
+        if (big) RFN_TN3(128, 128, 32, true);
+        else RFN_TN3(64, 64, 64, true);
       } else {
-        dim3 grid((unsigned)((N / 64) * (K / 64) * S));
-        hipLaunchKernelGGL((gemm_tn3_kernel<DT, 64, 64, 64, GATHER>), grid, block, 0, s, (const uint16_t*)G,
-                           (const uint16_t*)X, P, (int)T, (int)N, (int)K, ldg, ldx, R, (int)(K / 64), accumulate, gbias,
-                           rowscale, rps, zero_page, tn_xcd, wg);
+        if (big) RFN_TN3(128, 128, 32, false);
+        else RFN_TN3(64, 64, 64, false);
       }
+#undef RFN_TN3
       return check_launch("gemm_tn3");
     }
   }
