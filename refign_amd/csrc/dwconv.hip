@@ -558,11 +558,12 @@ static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db
   // narrow channel blocks on LARGE maps: with 16 vectors (256 contiguous bytes per pixel) a block has 16 pixel lanes instead
   // of 4 -- four times the workgroups for the same partial-sum volume (the workspace row of a stripe is 10 C floats however
   // the channels are split).  Measured (tools/kbench.py --only dw, forward + backward): 40 x 135 x 240 x 256: 1 393 -> 1 070 us;
-  // the student's small maps (4 x 34 x 60 x 1280: 130 -> 173 us) keep the wide blocks.  RFN_DWCONV_WGRAD_CVB forces a width.
+  // per-call census of the step (tools/abi_census.py): 4 x 68 x 120 x 512: 47 -> 24 us, 4 x 135 x 240 x 256: 78 -> 48 us; the
+  // student's stage 3 / 4 maps (4 x 34 x 60 x 1280: 27 vs 26 us) keep the wide blocks.  RFN_DWCONV_WGRAD_CVB forces a width.
   static const int force_cvb = getenv("RFN_DWCONV_WGRAD_CVB") ? atoi(getenv("RFN_DWCONV_WGRAD_CVB")) : 0;
   const int CV = C / V;
   const long nquads = (long)B * H * (dil * (((W + dil - 1) / dil + kPX - 1) / kPX));
-  const int want_cvb = force_cvb ? force_cvb : (nquads >= 65536 ? 16 : 0);
+  const int want_cvb = force_cvb ? force_cvb : (nquads >= 8000 ? 16 : 0);
   const int cvb = (want_cvb >= 8 && want_cvb <= 64 && (want_cvb & (want_cvb - 1)) == 0 && CV >= want_cvb) ? want_cvb : pick_cvb(CV);
   const int gx = cdiv(CV, cvb), pl = 256 / cvb;
   const int stripes = (int)std::max<long>(1, std::min<long>(std::min<long>(kMaxStripes, cdiv(nquads, pl)),
