@@ -8,6 +8,9 @@ timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_n1.json
 timeout 300 python tools/opt_phase_debug.py 2>&1 | grep "^step" > $O/step_phases_events.txt
 timeout 300 python tools/overlap_debug.py 2>&1 | grep "step\|host" >> $O/step_phases_events.txt
+# the serial tail (end of the mixed pass -> start of the next source pass) WITHOUT a host synchronisation between the two steps
+# (opt_phase_debug synchronises after every step: its boundary figure includes the host's enqueue time)
+timeout 300 python tools/tail_debug.py 2>&1 | grep -v "amdgpu.ids" > $O/step_tail_events.txt
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench --output-format csv -- python $R/bench.py --no-cpu --steps 6 --warmup 3 > /tmp/prof_bench.log 2>&1
 cd $R
 grep '^{"metric"' /tmp/prof_bench.log > $O/bench_under_rocprof.json

@@ -67,6 +67,6 @@ for it in range(4):
     msg += f" | device: S {ev['S0'].elapsed_time(ev['S1']):.1f}  M {ev['M0'].elapsed_time(ev['M1']):.1f}  opt {ev['opt0'].elapsed_time(ev['opt1']):.1f}  ema {ev['ema0'].elapsed_time(ev['ema1']):.1f}"
     msg += f"  S-end -> M-start {ev['S1'].elapsed_time(ev['M0']):.1f}"
     if prev_m1 is not None:
-        msg += f"  | previous M-end -> this S-start {prev_m1.elapsed_time(ev['S0']):.1f} ms"
+        msg += f"  | previous M-end -> this S-start {prev_m1.elapsed_time(ev['S0']):.1f} ms (host-bound here: this tool synchronises every step; tools/tail_debug.py)"
     print(msg)
     prev_m1 = ev["M1"]
