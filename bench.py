@@ -573,8 +573,9 @@ def main():
                                                 "in stream order after the source pass")
         if isinstance(wl, RefignStep) and type(wl) is not RefignAlignRefine:
             line["config"]["next_batch_prefetch"] = (
-                "frozen ImageNet-encoder features of the next step's source images computed during this step's mixed pass "
-                "(same work per step; RFN_PREFETCH_NEXT=0 computes them inside the source pass)") if PIPELINE_NEXT_BATCH \
+                "frozen ImageNet-encoder features of the next step's source images and the frozen matcher's flow of the next "
+                "(reference, target) pair computed during this step's mixed pass (same work per step, same numbers; "
+                "RFN_PREFETCH_NEXT=0 computes both inside the step, RFN_ALIGN_PREFETCH=0 the flow only)") if PIPELINE_NEXT_BATCH \
                 else "off"
         print(json.dumps(line))
 

@@ -527,6 +527,23 @@ def align(alignment_backbone, alignment_head, logits_ref, images_ref, images_trg
         return matching.align_tail(logits_ref, flow_q.float(), logvar_q.float())
 
 
+def align_flow(alignment_backbone, alignment_head, images_ref, images_trg):
+    """The image-only part of align(): quarter-resolution flow and log-variance of the mixture density (fp32).  It depends on
+    the two images and on the frozen matcher, on nothing that training changes -- uda.prefetch_align_flow computes it for
+    the NEXT batch while this step's mixed pass has the device mostly to itself."""
+    h, w = images_trg.shape[-2:]
+    dt = align_compute_dtype()
+    with torch.autocast("cuda", enabled=dt != torch.float32, dtype=dt if dt != torch.float32 else None):
+        pyr = extract_pyramids(alignment_backbone, images_ref.float(), images_trg.float())
+        flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
+    return flow_q.float(), logvar_q.float()
+
+
+def align_from_flow(logits_ref, flow_q, logvar_q):
+    """The rest of align(): (warped_ref_logits, mask, certainty) from the reference logits and align_flow()'s result."""
+    return matching.align_tail(logits_ref, flow_q, logvar_q)
+
+
 _ALIGN_DTYPES = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
 
 

@@ -262,7 +262,8 @@ class Trainer:
         what depends on its inputs only (the frozen ImageNet encoder's features of the next source images) while this
         step's mixed pass runs (uda.prefetch_imnet_features)."""
         if next_batch is not None:
-            batch = dict(batch, image_src_next=next_batch["image_src"], semantic_src_next=next_batch.get("semantic_src"))
+            batch = dict(batch, image_src_next=next_batch["image_src"], semantic_src_next=next_batch.get("semantic_src"),
+                         image_trg_next=next_batch.get("image_trg"), image_ref_next=next_batch.get("image_ref"))
         # Python's cyclic collector fires on allocation counts; a step allocates ~10^5 autograd / tensor wrapper objects
         # and a generation-2 pass in the middle of a step stalls the launch thread for ~100 ms (seen as one slow step in
         # ten).  Collect at a step boundary every `gc_interval` steps instead, with the automatic collector off.

@@ -170,6 +170,9 @@ def _logits_for_loss(logits, size):
     return defer_logits(logits, size)
 
 
+_ALIGN_PREFETCH = os.environ.get("RFN_ALIGN_PREFETCH", "1") != "0"
+
+
 class DomainAdaptationSegmentationModel(nn.Module):
     """models/segmentation_model.py:25-701.  Constructor keywords are the reference's."""
 
@@ -263,7 +266,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
         self.logged = {}
         # hipGraph replay of the gradient-free halves (eager until warmed up; eager for good if capture fails)
         self._graphs = {"teacher_backbone": GraphedNoGrad(self._teacher_backbone, "teacher backbone"),
-                        "align_refine": GraphedNoGrad(self._align_refine, "align + refine")}
+                        "align_refine": GraphedNoGrad(self._align_refine, "align + refine"),
+                        # the same in two pieces: the image-only part can be computed a step ahead (prefetch_align_flow)
+                        "align_flow": GraphedNoGrad(self._align_flow, "align (images -> flow)"),
+                        "tail_refine": GraphedNoGrad(self._tail_refine, "warp + refine")}
         if self.enable_fdist:
             self._graphs["imnet_features"] = GraphedNoGrad(self._imnet_features, "ImageNet features")
         # forward + backward of the student passes (single process; eager under DDP: SyncBatchNorm collectives)
@@ -592,8 +598,13 @@ class DomainAdaptationSegmentationModel(nn.Module):
             cur.wait_stream(mix)                         # both passes done before the optimiser merges their gradients
             mixed_loss.record_stream(cur)
         nxt = batch.get("image_src_next")
+        branch_done = self._side_stream.record_event() if early is not None else None
         if nxt is not None:                              # after the teacher branch the side stream is idle: fill it
             self.prefetch_imnet_features(nxt, after=prefetch_free)
+        if batch.get("image_trg_next") is not None and batch.get("image_ref_next") is not None and early is not None:
+            # (after this step's warp + refine, which reads the flow buffers the prefetch re-fills)
+            with torch.no_grad():
+                self.prefetch_align_flow(batch["image_ref_next"], batch["image_trg_next"], after=branch_done)
         self.log("train_loss_uda_trg", mixed_loss)
         opt.step()
         sch.step()
@@ -653,6 +664,13 @@ class DomainAdaptationSegmentationModel(nn.Module):
         m_logits = _upsample_logits(m_logits, m_input.shape[-2:])
         m_logits_trg, m_logits_ref = torch.split(m_logits, [b, b], dim=0)
         if self.use_align:
+            if self._align_split(images_trg):
+                # two pieces, so that the image-only one can come from the previous step (prefetch_align_flow); the same two
+                # graphs either way: a run with and one without the prefetch compute the same numbers
+                flow = self._take_align_prefetch(images_ref, images_trg)
+                if flow is None:
+                    flow = self._graphs["align_flow"](images_ref, images_trg)
+                return self._graphs["tail_refine"](m_logits_trg.contiguous(), m_logits_ref.contiguous(), *flow)
             return self._graphs["align_refine"](m_logits_trg.contiguous(), m_logits_ref.contiguous(), images_ref,
                                                 images_trg)
         return self.refine(m_logits_trg, m_logits_ref, None, None)
@@ -660,6 +678,53 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def _align_refine(self, logits_trg, logits_ref, images_ref, images_trg):
         warped, warp_mask, warp_certs = self.align(logits_ref, images_ref, images_trg)
         return self.refine(logits_trg, warped, warp_mask, warp_certs)
+
+    def _align_flow(self, images_ref, images_trg):
+        return align_mod.align_flow(self.alignment_backbone, self.alignment_head, images_ref, images_trg)
+
+    def _tail_refine(self, logits_trg, logits_ref, flow_q, logvar_q):
+        warped, warp_mask, warp_certs = align_mod.align_from_flow(logits_ref, flow_q, logvar_q)
+        return self.refine(logits_trg, warped, warp_mask, warp_certs)
+
+    def _align_split(self, x):
+        """align() as flow + (warp, refine): whenever the flow of the next batch may be computed ahead, i.e. the target
+        branch always aligns (no adapt_to_ref coin) and runs on the side stream.  RFN_ALIGN_PREFETCH=0: one piece."""
+        return (_ALIGN_PREFETCH and self.use_refign and self.use_align and not self.adapt_to_ref and x.is_cuda
+                and self._overlap_teacher(x))
+
+    def prefetch_align_flow(self, images_ref_next, images_trg_next, after=None):
+        """Software pipelining across steps, like prefetch_imnet_features: the matcher (frozen VGG-16 + flow decoders,
+        ~16 ms of the teacher branch at 1080 x 1920) sees the two images only, so the flow of the NEXT batch is computed on the
+        side stream while this step's mixed pass runs -- the teacher branch, the head of the critical
+        path teacher -> mixed pass, gets that much shorter.  Same work per step, same numbers (same two graphs).
+        `after`: event the stream waits for (this step's warp + refine has consumed the previous result)."""
+        if not self._align_split(images_trg_next):
+            return
+        # the side stream itself (behind the teacher branch and the ImageNet-feature prefetch): a fourth stream of the
+        # process shares a hardware queue with one of the other three and the step goes from 157 to 301 ms (measured)
+        self._ensure_side_stream(images_trg_next.device)
+        st = self._side_stream
+        if after is not None:
+            st.wait_event(after)
+        with torch.cuda.stream(st):
+            flow = self._graphs["align_flow"](images_ref_next, images_trg_next)
+            done = st.record_event()
+        key = tuple((t, t._version, t.data_ptr()) for t in (images_ref_next, images_trg_next))
+        self._align_prefetch = (key, flow, done)
+
+    def _take_align_prefetch(self, images_ref, images_trg):
+        pf, self._align_prefetch = getattr(self, "_align_prefetch", None), None
+        if pf is None:
+            return None
+        key, flow, done = pf
+        for (t, ver, ptr_), cur in zip(key, (images_ref, images_trg)):
+            if t is not cur or t._version != ver or t.data_ptr() != ptr_:
+                return None
+        torch.cuda.current_stream().wait_event(done)
+        for f in flow:
+            f.record_stream(torch.cuda.current_stream())
+        self.__dict__["_align_prefetch_used"] = self.__dict__.get("_align_prefetch_used", 0) + 1      # diagnostics
+        return flow
 
     def _teacher_backbone(self, x):
         # K5 (RFN_TEACHER_F8=1 / bench.py --precision k5): the EMA teacher's MiT blocks on the fp8 matrix-core kernels

@@ -221,10 +221,13 @@ def test_hipgraph_replay_equals_eager(dev, use_hrda, monkeypatch):
             for a, b in zip(f_got, f_want):
                 assert float((a.float() - b.float()).abs().max()) <= 2e-2 * max(1.0, float(b.float().abs().max()))
     from refign_amd.graphs import GraphedNoGrad
+    unused = ("align_refine",) if model._align_split(trg) else ("align_flow", "tail_refine")
     for name, graphed in model._graphs.items():
         if not isinstance(graphed, GraphedNoGrad):
             continue                                     # student passes: test_student_passes_graph_replay_equals_eager
         st = [s for s in graphed.states.values()]
+        if not st and name in unused:
+            continue                                     # align() runs in one piece OR as flow + (warp, refine)
         assert len(st) == 1 and st[0]["graph"] is not None and not st[0]["failed"], f"{name}: capture did not happen"
     # train()/eval() (folded-BN caches are re-made) drops the captures
     model.train()
@@ -347,7 +350,7 @@ def test_prefetched_imnet_features_give_the_same_trajectory(dev, monkeypatch):
     as computing them inside the source pass (5 steps, different source images every step, graphs on)."""
     from refign_amd.trainer import Trainer
     monkeypatch.setenv("RFN_GRAPH_STUDENT", "1")
-    traj = {}
+    traj, used_align = {}, {}
     for mode in (True, False):
         model = build(True, dev)
         trainer = Trainer(model, fused_optimizer=False)
@@ -364,7 +367,10 @@ def test_prefetched_imnet_features_give_the_same_trajectory(dev, monkeypatch):
             trainer.step(batches[it], it, next_batch=batches[it + 1] if mode else None)
             rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
         traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), used)
+        used_align[mode] = model.__dict__.get("_align_prefetch_used", 0)
     assert traj[True][2] == 4, "the prefetched features were not picked up"
+    if model.use_align and not model.adapt_to_ref:      # the matcher's flow of the next batch is pipelined the same way
+        assert used_align[True] == 4 and used_align[False] == 0, used_align
     np.testing.assert_allclose(traj[True][0], traj[False][0], rtol=2e-3)
     assert abs(traj[True][1] - traj[False][1]) < 1e-5 * traj[False][1]
 
