@@ -720,9 +720,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         for (t, ver, ptr_), cur in zip(key, (images_ref, images_trg)):
             if t is not cur or t._version != ver or t.data_ptr() != ptr_:
                 return None
-        torch.cuda.current_stream().wait_event(done)
-        for f in flow:
-            f.record_stream(torch.cuda.current_stream())
+        torch.cuda.current_stream().wait_event(done)       # (the flow tensors are the graph's own output buffers)
         self.__dict__["_align_prefetch_used"] = self.__dict__.get("_align_prefetch_used", 0) + 1      # diagnostics
         return flow
 
