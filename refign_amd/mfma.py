@@ -172,6 +172,10 @@ _TN_WGS = 1024      # target workgroups of a weight-gradient launch (swept in ro
 #                     186.4 / 189.6 ms per step)
 
 
+_TN_ATOMICS = int(os.environ.get("RFN_GEMM_TN_ATOMICS", "2500000"))     # atomic adds per launch (see slab_rows)
+_TN_MIN_WGS = int(os.environ.get("RFN_GEMM_TN_MIN_WGS", "512"))
+
+
 def slab_rows(T, tiles, nk=0):
     """Rows per slab of the split-T weight-gradient GEMM: enough slabs to fill the chip (~1024 workgroups with the
     output tiles), slabs of at least 256 rows, multiples of 32 -- and not more slabs than ~2.5 M fp32 atomics in all: every
@@ -179,7 +183,7 @@ def slab_rows(T, tiles, nk=0):
     rows takes 16.2 us in 32 slabs, 12.1 us in 10; 27 % of a 320 x 1280 launch is its atomics)."""
     want = max(1, min(64, _TN_WGS // max(tiles, 1)))
     if nk > 0:
-        want = min(want, max(4, 2_500_000 // nk, -(-512 // max(tiles, 1))))     # ... but at least ~512 workgroups
+        want = min(want, max(4, _TN_ATOMICS // nk, -(-_TN_MIN_WGS // max(tiles, 1))))     # ... but at least ~512 workgroups
     rows = -(-T // want)
     rows = max(256, -(-rows // 32) * 32)
     return rows
@@ -285,9 +289,11 @@ def _chunk_blocks(nqblk, Nkv, BH):
     320 workgroups are two rounds over the 256 CUs and cost a whole second round -- measured on the student's shapes
     (tools/attn_bench.py, backward of B=4: stage 1 / 2 / 3): 157 / 125 / 98 us at a target of 512, 156 / 116 / 95 at 384,
     132 / 100 / 80 at 256, 175 / 144 / 125 at 768.  More, shorter chunks also add fp32 atomics on the dK / dV image (every
-    chunk adds its 256 x 64 x 2 partial)."""
+    chunk adds its 256 x 64 x 2 partial).  Those numbers are from isolated launches; INSIDE the step, where three streams share the
+    device and the L2 atomic units, fewer and longer chunks win: step 154.1 / 153.6 / 153.0 ms at targets of 256 / 192 / 128,
+    155.8 at 384; 151.4 / 151.4 / 152.6 / 153.1 at 128 / 96 / 64 / 48 (another box) -- 128 is the default since."""
     kblocks = -(-Nkv // 256)
-    chunks = max(1, int(os.environ.get("RFN_ATTN_DKV_WGS", "256")) // max(1, kblocks * BH))
+    chunks = max(1, int(os.environ.get("RFN_ATTN_DKV_WGS", "128")) // max(1, kblocks * BH))
     return max(4, -(-nqblk // chunks))
 
 
