@@ -1102,10 +1102,11 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   // are resident; a launch of 300-600 big tiles is one and a bit rounds of a latency chain -- swept on replayed graphs in
   // round 3, profiles/r03_gemm_sweep.txt: 8160 x 320 -> 1280: 21.6 -> 18.1 us, 8160 x 1280 -> 320: 19.5 -> 17.5,
   // 2040 x 512 -> 2048: 13.7 -> 11.1)
+  static const long min_tiles = getenv("RFN_GEMM_NT_MIN_TILES") ? atol(getenv("RFN_GEMM_NT_MIN_TILES")) : 1000;
   int bn = (N % 128 == 0) ? 128 : 64, bm = 128;
-  if ((long)cdiv(M, 128) * cdiv(N, bn) < 1000) {
+  if ((long)cdiv(M, 128) * cdiv(N, bn) < min_tiles) {
     bn = 64;
-    if ((long)cdiv(M, 128) * cdiv(N, 64) < 1000) bm = 64;
+    if ((long)cdiv(M, 128) * cdiv(N, 64) < min_tiles) bm = 64;
   }
   int ns = 2;
   // big problems whose n extent fills 256-wide tiles: 8 waves on a 256 x 256 tile (1 workgroup per CU); with a long
