@@ -529,7 +529,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
         memory pool), so it starts when the pseudo-labels are there and runs next to the last ~40 ms of the source pass
         (the feature-distance backward, which otherwise has the device to itself at 10-25 us per latency-bound kernel).
         What the two passes still share are the BatchNorm running statistics of the decode head, updated by both
-        forwards: the mixed pass's head forward comes a whole teacher branch (>= 90 ms here) after the source pass's,
+        forwards: the mixed pass's head forward comes a whole teacher branch plus its own backbone forward (~88 + ~15 ms here;
+        the source pass's head forward is over after ~45 ms) after the source pass's,
         which is why this is limited to the Refign configuration (teacher + align + refine before the mix)."""
         if not (self.use_refign and self.use_align):
             return None
