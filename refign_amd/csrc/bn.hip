@@ -82,9 +82,10 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
         b[i] = (gamma ? gamma[c0 + i] : 1.f);
       }
     }
-    for (long t = (long)blockIdx.y * pl + rl; t < T; t += (long)gridDim.y * pl) {
-      float xv[8];
-      load8<DT>(x + t * C + c0, xv);
+    float bt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bt[i] = (BWD && beta) ? beta[c0 + i] : 0.f;
+    auto accumulate = [&](const float (&xv)[8], const float (&gv)[8]) {
       if (!BWD) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -92,17 +93,35 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const uint16_t* __restric
           s1[i] += (ST)xv[i] * (ST)xv[i];
         }
       } else {
-        float gv[8];
-        load8<DT>(g + t * C + c0, gv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float xh = (xv[i] - mean[i]) * a[i];
-          const float z = xh * b[i] + (beta ? beta[c0 + i] : 0.f);
+          const float z = xh * b[i] + bt[i];
           const float gp = (relu && z <= 0.f) ? slope * gv[i] : gv[i];
           s0[i] += gp;
           s1[i] += gp * xh;
         }
       }
+    };
+    // four rows per iteration, their loads issued together: one row at a time (two 16-byte loads in flight per thread) ran at
+    // 1.5-2.1 TB/s on the decode head's backward statistics (section 4.5 of DESIGN.md: memory-level parallelism per thread)
+    const long stride = (long)gridDim.y * pl;
+    long t = (long)blockIdx.y * pl + rl;
+    for (; t + 3 * stride < T; t += 4 * stride) {
+      float xv[4][8], gv[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        load8<DT>(x + (t + u * stride) * C + c0, xv[u]);
+        if (BWD) load8<DT>(g + (t + u * stride) * C + c0, gv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accumulate(xv[u], gv[u]);
+    }
+    for (; t < T; t += stride) {
+      float xv[8], gv[8];
+      load8<DT>(x + t * C + c0, xv);
+      if (BWD) load8<DT>(g + t * C + c0, gv);
+      accumulate(xv, gv);
     }
   }
 #pragma unroll
