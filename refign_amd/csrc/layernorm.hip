@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TX* __rest
     const long r = r0 + grp;
     const bool valid = r < rows;
     const float mu = valid ? mean[r] : 0.0f, rs = valid ? rstd[r] : 0.0f;
-    float xh[NV][8], gg[NV][8];
+    float xh[NV][8], gg[NV][8], av[NV][8];
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -292,6 +292,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TX* __rest
       if (valid && act[j]) {
         ld8<TX>(x + r * C + (sub + LPR * j) * 8, xv);
         ld8<TG>(gy + r * C + (sub + LPR * j) * 8, gv);
+        // the residual gradient is requested WITH the row, not after the two row reductions (a second exposed load latency
+        // per row: the launch is a chain of <= 8 row iterations per wave)
+        if (add != nullptr) ld8<TX>(add + r * C + (sub + LPR * j) * 8, av[j]);
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { xv[i] = mu; gv[i] = 0.0f; }
@@ -315,10 +318,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TX* __rest
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = rs * (gg[j][i] - s1 - xh[j][i] * s2);
         if (add != nullptr) {
-          float a[8];
-          ld8<TX>(add + r * C + (sub + LPR * j) * 8, a);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] += a[i];
+          for (int i = 0; i < 8; ++i) o[i] += av[j][i];
         }
         st8<TX>(dx + r * C + (sub + LPR * j) * 8, o);
       }
