@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm2.h"
 #include "mfma.h"
 
 namespace rfn {
@@ -1097,6 +1098,34 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
     if (zero_page == nullptr && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero_page)) != hipSuccess)
       return fail(RFN_ELAUNCH, "conv2d_nhwc: zero page symbol");
     cg.zero = zero_page;
+  }
+  // second-generation kernel (gemm2.h: software-pipelined K loop, stores dripped under the next tile's MFMAs) for the big
+  // Linear layers whose column count is a multiple of 320 -- every GEMM of MiT-B5's stage 3 on the teacher's 40 views:
+  // 1.2-1.5x on those shapes (profiles/r04_gemm2_v3_probe.txt); bit-identical results.  RFN_GEMM2=0: the first generation.
+  if constexpr (!GATHER && DT == 1) {
+    static const int g2 = getenv("RFN_GEMM2") ? atoi(getenv("RFN_GEMM2")) : 1;
+    static const long g2_min = getenv("RFN_GEMM2_MIN_TILES") ? atol(getenv("RFN_GEMM2_MIN_TILES")) : 200;
+    const long t2 = (long)cdiv(M, 192) * (N / 320);
+    const bool res2 = epi.res != nullptr || epi.rowscale != nullptr;
+    if (g2 && !out32 && N % 320 == 0 && K >= 192 && (epi.act & 255) == 0 && t2 >= g2_min &&
+        (M + 192) * ldy * 2 < (1L << 32) && ldx < (1L << 22) && ldw < (1L << 22) && (((size_t)X | (size_t)W | (size_t)Y) & 15) == 0 &&
+        (epi.res == nullptr || ((size_t)epi.res & 15) == 0)) {
+      Gemm2Epi e2{epi.bias, epi.res, epi.rowscale, epi.rows_per_sample, nullptr};
+      const int tn = (int)(N / 320);
+      dim3 grid((unsigned)std::min<long>(t2, 256)), block(256);
+#define RFN_G2(BIAS_, RES_)                                                                                              \
+  hipLaunchKernelGGL((gemm_nt2_kernel<1, 192, 320, 2, 2, BIAS_, RES_, 0, 3, 4, 4, 8>), grid, block, 0, s, (const uint16_t*)X, \
+                     (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tn, (int)t2, e2)
+      if (epi.bias != nullptr) {
+        if (res2) RFN_G2(true, true);
+        else RFN_G2(true, false);
+      } else {
+        if (res2) RFN_G2(false, true);
+        else RFN_G2(false, false);
+      }
+#undef RFN_G2
+      return check_launch("gemm_nt2");
+    }
   }
   // tile: the largest of 128 x 128 (N % 128 == 0), 128 x 64, 64 x 64 that still gives ~1000 tiles (2-4 workgroups per CU
   // are resident; a launch of 300-600 big tiles is one and a bit rounds of a latency chain -- swept on replayed graphs in

@@ -63,6 +63,61 @@ def test_gemm_nt_epilogues(dev, act):
     assert torch.equal(got[:T], res[:T])                       # dropped sample: the residual passes through exactly
 
 
+@pytest.mark.parametrize("M,N,K,bias,res,scale", [
+    (40001, 320, 320, True, False, False),     # ragged bottom edge (40001 = 208 * 192 + 65), one column tile
+    (20400, 640, 320, False, False, False),    # the teacher's kv projection, no bias
+    (12100, 1280, 192, True, False, False),    # minimum K (three K-steps carry the previous tile's stores)
+    (39000, 320, 1280, True, True, True),      # fc2 with the stochastic-depth residual
+    (38500, 320, 320, False, True, False),     # residual without bias / scale
+    (38500, 320, 128 + 64, True, False, True), # per-sample scale without residual
+])
+def test_gemm_nt_second_generation_kernel(dev, M, N, K, bias, res, scale):
+    """Big-M, N % 320 == 0 problems run the software-pipelined kernel of csrc/gemm2.h (192 x 320 tiles, stores issued under
+    the next tile's MFMAs, counted s_waitcnt hand-off).  Checked two ways: against the fp32 reference (bound: one 16-bit
+    rounding of the result, two with a residual -- the kernel rounds before the residual add like the first generation), and
+    BITWISE against the same product computed in row chunks that are too small for the new kernel (< 200 tiles: they
+    run gemm_nt_kernel) -- every output row depends on its own row of x only, both kernels walk k in the same order with
+    the same MFMA, so the results must be identical; a stale LDS stage, a lost store or a tile mix-up cannot pass."""
+    from refign_amd.mfma import gemm_nt
+    dtype = torch.bfloat16
+    x = _rand((M, K), dev, dtype, 11)
+    w = _rand((N, K), dev, dtype, 12, K ** -0.5)
+    b = _rand((N,), dev, dtype, 13) if bias else None
+    r = _rand((M, N), dev, dtype, 14) if res else None
+    rps = 2040
+    rs = (0.5 + torch.rand((M + rps - 1) // rps, device=dev)).float() if scale else None
+    if rs is not None:
+        rs[1] = 0.0                                                   # a dropped sample
+    got = gemm_nt(x, w, b, res=r, rowscale=rs, rows_per_sample=rps if scale else 0)
+    assert got is not None
+    z = x.float() @ w.float().t()
+    if b is not None:
+        z = z + b.float()
+    want = z
+    if rs is not None:
+        want = rs.repeat_interleave(rps)[:M, None] * want
+    if r is not None:
+        want = r.float() + want
+    tol = (3 if (res or scale) else 2) * EPS[dtype] * float(want.abs().max())
+    assert float((got.float() - want).abs().max()) <= tol
+    # row chunks of 190 * 192 / (N / 320) rows at most: below the tile threshold of the new kernel; chunk boundaries are
+    # multiples of rows_per_sample so that the scale index restarts correctly
+    step = rps * max(1, (150 * 192 // (N // 320)) // rps)
+    parts = []
+    for m0 in range(0, M, step):
+        m1 = min(M, m0 + step)
+        parts.append(gemm_nt(x[m0:m1], w, b, res=None if r is None else r[m0:m1],
+                             rowscale=None if rs is None else rs[m0 // rps:].contiguous(), rows_per_sample=rps if scale else 0))
+    chunked = torch.cat(parts)
+    diff = (got.float() - chunked.float()).abs()
+    if res or scale:
+        # the residual add is `r + s * v` in both kernels, contracted to an fma by the compiler in one of them: a handful
+        # of last-bit differences are legitimate; anything structural would be O(1) wrong on O(tile) entries
+        assert int((diff > 0).sum()) <= M * N // 100000 + 8 and float(diff.max()) <= 2 * EPS[dtype] * float(want.abs().max())
+    else:
+        assert torch.equal(got, chunked)
+
+
 CONV_CASES = [  # B, H, W, C, N, k, stride, pad, dil
     (2, 17, 23, 64, 64, 3, 1, 1, 1),        # VGG-style 3x3
     (1, 33, 40, 8, 64, 7, 4, 3, 1),         # MiT patch_embed1 (RGB padded to 8 channels): K = 392 -> padded 448
