@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="ONLY time the CPU baseline at the full image size (minutes) and print it as one JSON line")
     return ap.parse_args()
 
 
@@ -339,10 +341,9 @@ def cpu_baseline(wl, args):
         return {"value": round(1.0 / dt, 5), "unit": "image-pairs/s", "cores": cores, "kind": kind,
                 "sample": f"1 pair through the align+refine kernel stage on the host, {dt:.2f} s wall"}
     import copy
+    import math
     from refign_amd import config
     from refign_amd.trainer import Trainer
-    # ~1/16 of the pixels, rounded to multiples of 32 (HRDA crop boxes need H/2 and W/2 divisible by 16)
-    h, w = max(64, args.height // 4 // 32 * 32), max(64, args.width // 4 // 32 * 32)
     cfg = copy.deepcopy(REF_CFG)
     cfg["model"]["init_args"]["use_hrda"] = wl.use_hrda
     if not wl.use_hrda:
@@ -353,25 +354,57 @@ def cpu_baseline(wl, args):
     model.align = lambda lr, ir, it: cpu_align.align(model.alignment_backbone, model.alignment_head, lr, ir, it, corr_fn)
     model.refine = lambda lt, lr, m, c: cpu_align.refine(lt, lr, m, c, gamma=model.gamma)
     trainer = Trainer(model, fused_optimizer=False)
-    g = torch.Generator().manual_seed(99)
-    lbl = torch.randint(0, 19, (1, (h + 31) // 32, (w + 31) // 32), generator=g)
-    lbl = lbl.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :h, :w].contiguous()
-    trg = torch.randn(1, 3, h, w, generator=g)
-    batch = {"image_src": torch.randn(1, 3, h, w, generator=g), "semantic_src": lbl, "image_trg": trg,
-             "image_ref": 0.8 * torch.roll(trg, (1, -1), (2, 3)) + 0.2 * torch.randn(1, 3, h, w, generator=g)}
-    t0 = time.perf_counter()
-    trainer.step(batch)
-    dt = time.perf_counter() - t0
-    scale = (h * w) / float(args.height * args.width)
-    return {"value": round(scale / dt, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind,
-            "kind_detail": ("restatement + reference correlation: the reference's compiled correlation.cpp, every other op "
-                            "the reference's algorithm restated on torch-CPU") if kind == "reference" else
-                           "restatement (oracle/corr_oracle.c + torch-CPU ops)",
-            "sample": f"ONE full training step (same model/config, fp32) for 1 source image + 1 pair at {h}x{w} "
-                      f"({scale:.4f} of the pixels of {args.height}x{args.width}) on the host with {cores} threads: {dt:.2f} s wall; value = "
-                      f"(1 pair / {dt:.2f} s) x {scale:.4f} pixel ratio.  Correlation = "
-                      f"{'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'}"
-                      f" + OpenMP, all other ops torch-CPU ATen (what the reference's CPU path calls)"}
+
+    def one_step(h, w):
+        g = torch.Generator().manual_seed(99)
+        lbl = torch.randint(0, 19, (1, (h + 31) // 32, (w + 31) // 32), generator=g)
+        lbl = lbl.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :h, :w].contiguous()
+        trg = torch.randn(1, 3, h, w, generator=g)
+        batch = {"image_src": torch.randn(1, 3, h, w, generator=g), "semantic_src": lbl, "image_trg": trg,
+                 "image_ref": 0.8 * torch.roll(trg, (1, -1), (2, 3)) + 0.2 * torch.randn(1, 3, h, w, generator=g)}
+        t0 = time.perf_counter()
+        trainer.step(batch)
+        return time.perf_counter() - t0
+
+    full_px = float(args.height * args.width)
+    detail = ("restatement + reference correlation: the reference's compiled correlation.cpp, every other op the reference's "
+              "algorithm restated on torch-CPU") if kind == "reference" else "restatement (oracle/corr_oracle.c + torch-CPU ops)"
+    kind_out = "restatement+reference-correlation" if kind == "reference" else "port"
+    if getattr(args, "cpu_baseline_full", False):
+        # the full-size sample, measured once per round (minutes): tools/final_check.sh -> profiles/rNN_cpu_baseline_full.json
+        dt = one_step(args.height, args.width)
+        return {"value": round(1.0 / dt, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind_out, "kind_detail": detail,
+                "sample": f"ONE full training step (same model/config, fp32) for 1 source image + 1 pair at the FULL "
+                          f"{args.height}x{args.width} on the host with {cores} threads: {dt:.1f} s wall"}
+    # bounded default: two reduced sizes (multiples of 32: HRDA crop boxes need H/2 and W/2 divisible by 16), the exponent
+    # of time against pixels fitted from them, the larger one extrapolated to the full size with that exponent
+    sizes = [(max(64, args.height // 4 // 32 * 32), max(64, args.width // 4 // 32 * 32)),
+             (max(96, args.height * 3 // 8 // 32 * 32), max(96, args.width * 3 // 8 // 32 * 32))]
+    one_step(64, 64)                                     # warm the allocator / thread pool: not part of either sample
+    times = [one_step(h, w) for h, w in sizes]
+    px = [float(h * w) for h, w in sizes]
+    expo = math.log(times[1] / times[0]) / math.log(px[1] / px[0]) if px[1] > px[0] and times[0] > 0 else 1.0
+    t_full = times[1] * (full_px / px[1]) ** expo
+    out = {"value": round(1.0 / t_full, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind_out, "kind_detail": detail,
+           "fitted_exponent": round(expo, 3),
+           "samples": [{"size": f"{h}x{w}", "pixel_fraction": round(p_ / full_px, 4), "seconds": round(t, 2)}
+                       for (h, w), p_, t in zip(sizes, px, times)],
+           "sample": f"ONE full training step (same model/config, fp32) for 1 source image + 1 pair on the host with {cores} "
+                     f"threads at {sizes[0][0]}x{sizes[0][1]} ({times[0]:.2f} s) and {sizes[1][0]}x{sizes[1][1]} ({times[1]:.2f} s): "
+                     f"time ~ pixels^{expo:.2f}; value = 1 pair / ({times[1]:.2f} s x ({full_px / px[1]:.2f})^{expo:.2f}).  "
+                     f"Correlation = {'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'}"
+                     f" + OpenMP, all other ops torch-CPU ATen (what the reference's CPU path calls)"}
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_full.json")), reverse=True):
+        try:
+            with open(path) as f:
+                full = json.load(f)
+            out["measured_full_size"] = {"value": full["value"], "cores": full["cores"], "sample": full["sample"],
+                                         "source": os.path.relpath(path, ROOT)}
+            break
+        except Exception:
+            continue
+    return out
 
 
 DDP_STALL_MARKER = os.path.join(os.environ.get("TMPDIR", "/tmp"), "refign_amd_multi_rank_stalled")
@@ -423,6 +456,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.cpu_baseline_full:                  # host cores only: one full-size CPU step, one JSON line, done
+        import types
+        wl = types.SimpleNamespace(use_hrda=WORKLOADS[args.workload].use_hrda)
+        print(json.dumps(cpu_baseline(wl, args)), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
