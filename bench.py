@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", default="full", choices=["full", "small"],
+                    help="cpu_baseline leg: one step at the full image size (default, ~1 min) or two reduced sizes + extrapolation")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="ONLY time the CPU baseline at the full image size (minutes) and print it as one JSON line")
     return ap.parse_args()
@@ -370,14 +372,19 @@ def cpu_baseline(wl, args):
     detail = ("restatement + reference correlation: the reference's compiled correlation.cpp, every other op the reference's "
               "algorithm restated on torch-CPU") if kind == "reference" else "restatement (oracle/corr_oracle.c + torch-CPU ops)"
     kind_out = "restatement+reference-correlation" if kind == "reference" else "port"
-    if getattr(args, "cpu_baseline_full", False):
-        # the full-size sample, measured once per round (minutes): tools/final_check.sh -> profiles/rNN_cpu_baseline_full.json
+    if getattr(args, "cpu_baseline_full", False) or getattr(args, "cpu_sample", "full") == "full":
+        # the metric's own unit of work, measured: one pair at the full image size (55 s on the 32 host threads of the MI355X
+        # box in round 4 -- VERDICT r3 asked for the measurement instead of an extrapolation from 6 % of the pixels)
         dt = one_step(args.height, args.width)
         return {"value": round(1.0 / dt, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind_out, "kind_detail": detail,
                 "sample": f"ONE full training step (same model/config, fp32) for 1 source image + 1 pair at the FULL "
-                          f"{args.height}x{args.width} on the host with {cores} threads: {dt:.1f} s wall"}
-    # bounded default: two reduced sizes (multiples of 32: HRDA crop boxes need H/2 and W/2 divisible by 16), the exponent
-    # of time against pixels fitted from them, the larger one extrapolated to the full size with that exponent
+                          f"{args.height}x{args.width} on the host with {cores} threads: {dt:.1f} s wall.  Correlation = "
+                          f"{'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'}"
+                          f" + OpenMP, all other ops torch-CPU ATen (what the reference's CPU path calls)"}
+    # --cpu-sample small: two reduced sizes (multiples of 32: HRDA crop boxes need H/2 and W/2 divisible by 16), the exponent
+    # of time against pixels fitted from them, the larger one extrapolated to the full size with that exponent.  (Round 4:
+    # exponent 0.78 between 6 % and 13 % of the pixels -- fixed per-op costs still weigh at those sizes -- and the
+    # extrapolation is then 47 % too fast against the measured full size: hence the full size is the default.)
     sizes = [(max(64, args.height // 4 // 32 * 32), max(64, args.width // 4 // 32 * 32)),
              (max(96, args.height * 3 // 8 // 32 * 32), max(96, args.width * 3 // 8 // 32 * 32))]
     one_step(64, 64)                                     # warm the allocator / thread pool: not part of either sample
@@ -385,26 +392,13 @@ def cpu_baseline(wl, args):
     px = [float(h * w) for h, w in sizes]
     expo = math.log(times[1] / times[0]) / math.log(px[1] / px[0]) if px[1] > px[0] and times[0] > 0 else 1.0
     t_full = times[1] * (full_px / px[1]) ** expo
-    out = {"value": round(1.0 / t_full, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind_out, "kind_detail": detail,
-           "fitted_exponent": round(expo, 3),
-           "samples": [{"size": f"{h}x{w}", "pixel_fraction": round(p_ / full_px, 4), "seconds": round(t, 2)}
-                       for (h, w), p_, t in zip(sizes, px, times)],
-           "sample": f"ONE full training step (same model/config, fp32) for 1 source image + 1 pair on the host with {cores} "
-                     f"threads at {sizes[0][0]}x{sizes[0][1]} ({times[0]:.2f} s) and {sizes[1][0]}x{sizes[1][1]} ({times[1]:.2f} s): "
-                     f"time ~ pixels^{expo:.2f}; value = 1 pair / ({times[1]:.2f} s x ({full_px / px[1]:.2f})^{expo:.2f}).  "
-                     f"Correlation = {'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'}"
-                     f" + OpenMP, all other ops torch-CPU ATen (what the reference's CPU path calls)"}
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_full.json")), reverse=True):
-        try:
-            with open(path) as f:
-                full = json.load(f)
-            out["measured_full_size"] = {"value": full["value"], "cores": full["cores"], "sample": full["sample"],
-                                         "source": os.path.relpath(path, ROOT)}
-            break
-        except Exception:
-            continue
-    return out
+    return {"value": round(1.0 / t_full, 6), "unit": "image-pairs/s", "cores": cores, "kind": kind_out, "kind_detail": detail,
+            "fitted_exponent": round(expo, 3),
+            "samples": [{"size": f"{h}x{w}", "pixel_fraction": round(p_ / full_px, 4), "seconds": round(t, 2)}
+                        for (h, w), p_, t in zip(sizes, px, times)],
+            "sample": f"EXTRAPOLATED: one full training step for 1 source image + 1 pair on the host with {cores} threads at "
+                      f"{sizes[0][0]}x{sizes[0][1]} ({times[0]:.2f} s) and {sizes[1][0]}x{sizes[1][1]} ({times[1]:.2f} s): time ~ "
+                      f"pixels^{expo:.2f}; value = 1 pair / ({times[1]:.2f} s x ({full_px / px[1]:.2f})^{expo:.2f})"}
 
 
 DDP_STALL_MARKER = os.path.join(os.environ.get("TMPDIR", "/tmp"), "refign_amd_multi_rank_stalled")

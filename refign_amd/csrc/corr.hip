@@ -280,6 +280,15 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(sbase) : "memory", "m0");
 #pragma clang diagnostic pop
 }
+// the same with the non-temporal hint (experiment: RFN_CORR_ABLATE bit 3)
+__device__ __forceinline__ void lds_dma16_nt(const float* gsrc, float* lds_wave_base) {
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base;
+  const unsigned sbase = __builtin_amdgcn_readfirstlane(base);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "s"(sbase) : "memory", "m0");
+#pragma clang diagnostic pop
+}
 
 // NTILE = 2: the workgroup is two independent halves, each owning its own tile (ids 2b, 2b+1 of the launch's tile
 // order), its own LDS region and its own DMA stream; only the per-chunk barrier is shared.  This doubles the waves per
@@ -395,7 +404,11 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_ker
       const int wi = wave + k * NW;
       if (wi < NINSTR) {                               // wave-uniform
         float* ldst = ring + wi * 256;                 // wave-uniform LDS base; lane lands at +lane*16 B
-        if (gok[k]) lds_dma16(gsrc[k], ldst);
+        if (ablate & 8) {
+          if (gok[k]) lds_dma16_nt(gsrc[k], ldst);
+        } else {
+          if (gok[k]) lds_dma16(gsrc[k], ldst);
+        }
         gsrc[k] += (size_t)CC * plane;
       }
     }
@@ -793,6 +806,10 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
                        (int)ntiles, xcd_remap);                                                                   \
     return check_launch("corr9_pipe_kernel");                                                                     \
   }
+      // Round 4: at K4 level 1 the 4-stage ring with counted waits (two-channel chunks, three chunks in flight) is the
+      // default -- 102 us against 111 us for the 2-stage kernel on the step's kind of operands (profiles/r04_corr_try.txt);
+      // identical results (same products, same order).
+      if (variant == 0 && ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2 >= 192) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 20) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 21) RFN_LAUNCH_PIPE(16, 64, 3, 1)
       if (variant == 22) RFN_LAUNCH_PIPE(8, 64, 3, 1)

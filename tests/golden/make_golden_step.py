@@ -148,4 +148,39 @@ def g13_b5():
     torch.set_grad_enabled(False)
 
 
-GROUPS = {"G13": g13, "G13B5": g13_b5}
+def g13_k3():
+    """G13-K3: BASELINE config 3 -- one reference training_step of the DAFormer model (no HRDA) with MiT-B5 on a b = 2 batch
+    of 512 x 1024 crops (cityscapes_acdc/refign_daformer.yaml:11-41 uses these networks; the crop is the K3 size of
+    SURVEY section 8), closed-form weights, augmentation off.  Same capture as G13-B5."""
+    torch.set_grad_enabled(True)
+    dims = [64, 128, 320, 512]
+    model = run_reference(False, "mit_b5", dims)
+    H, W = 512, 1024
+    batch = make_batch(2, H, W, 64)
+    random.seed(79); np.random.seed(79); torch.manual_seed(79)
+    model.global_step = 3
+    grads = {}
+    real = model._rec.step
+
+    def step():
+        grads["conv_seg"] = model.head.conv_seg.weight.grad.detach().flatten()[::37].clone().numpy()
+        grads["fc1"] = model.backbone.block3[20].mlp.fc1.weight.grad.detach().flatten()[::997].clone().numpy()
+        real()
+    model._rec.step = step
+    import time
+    t0 = time.perf_counter()
+    model.training_step(batch, 0)
+    print(f"    reference step: {time.perf_counter() - t0:.1f} s")
+    ema = float(sum(p.double().abs().sum() for p in model.ema_parameters()))
+    live = float(sum(p.double().abs().sum() for p in model.live_parameters()))
+    save("step_daformer_b5_512x1024", losses=np.array([model.logged["train_loss_src"], model.logged["train_loss_featdist_src"],
+                                                       model.logged["train_loss_uda_trg"]]),
+         grad_norms=np.array(model._rec.norms), ema_abs_sum=ema, live_abs_sum=live, size=np.array([H, W]),
+         grad_conv_seg=grads["conv_seg"], grad_fc1=grads["fc1"],
+         w_q=model.backbone.block1[0].attn.q.weight.detach().flatten()[::61].numpy(),
+         w_fuse=model.head.fuse_layer.bottleneck.conv.weight.detach().flatten()[::9973].numpy())
+    print("   ", model.logged, model._rec.norms)
+    torch.set_grad_enabled(False)
+
+
+GROUPS = {"G13": g13, "G13B5": g13_b5, "G13K3": g13_k3}

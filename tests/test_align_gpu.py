@@ -201,6 +201,65 @@ def test_align_end_to_end_smooth_golden_north_star(dev):
 
 
 @torch.no_grad()
+def test_align_k4_golden_north_star_at_1080x1920(dev):
+    """G7-K4: the same statement as G7s at the size the metric is quoted on -- one 1080 x 1920 pair through VGG-16, the
+    UAWarpC head, confidence and the logits warp, against the reference CPU path's output captured by
+    tests/golden/make_golden_k4.py (strided samples + fp64 checksums of the 158 MB of outputs).  Stage by stage (feature
+    pyramids, the four (flow, log-variance) levels, confidence, mask) and the north star: warped logits within 1e-3 inside
+    the validity mask, argmax exact where the reference's own top-2 margin exceeds 10x that tolerance."""
+    from refign_amd.align import VGG, UAWarpCHead, align, extract_pyramids
+    g = golden("align_smooth_1080x1920")
+    H, W = [int(v) for v in g["size"]]
+    assert (H, W) == (1080, 1920)
+    vgg = closed_form_fill(VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone.").to(dev).eval()
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select',
+                                        estimate_uncertainty=True)).to(dev).eval()
+    img_trg = (hashed_uniform((1, 3, H, W), "g7k4/trg") * 4 - 2).astype(np.float32)
+    img_ref = (0.8 * np.roll(img_trg, (2, -3), (2, 3)) + 0.2 * (hashed_uniform((1, 3, H, W), "g7k4/ref") * 4 - 2)).astype(np.float32)
+    logits = smooth_logits(19, H, W, "g7k4/logits")
+    pt, pr, pt256, pr256 = extract_pyramids(vgg, T(img_ref, dev), T(img_trg, dev))
+    report = []
+    for name, fs in (("pyr", [torch.cat([a, b]) for a, b in zip(pr, pt)]),
+                     ("pyr256", [torch.cat([a, b]) for a, b in zip(pr256, pt256)])):
+        for i, f in enumerate(fs):
+            want = g[f"{name}{i}_sample"]
+            got = f[:, ::16, ::8, ::8].cpu().numpy()
+            err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)
+            report.append((f"{name}{i}", err))
+            assert err < 1e-4, (name, i, err)
+            cs = float(f.double().abs().sum())
+            assert abs(cs - float(g[f"{name}{i}_abs_checksum"])) < 1e-5 * float(g[f"{name}{i}_abs_checksum"])
+    levels = head(pt, pr, pt256, pr256, (H, W))
+    for lvl, (fl, un) in zip((4, 3, 2, 1), levels):
+        st = 4 if lvl <= 2 else 1
+        ef = float(np.abs(fl[:, :, ::st, ::st].cpu().numpy() - g[f"flow{lvl}_sample"]).max())
+        eu = float(np.abs(un[:, :, ::st, ::st].cpu().numpy() - g[f"uncert{lvl}_sample"]).max())
+        report.append((f"flow{lvl} [px]", ef))
+        report.append((f"logvar{lvl}", eu))
+        assert ef < 2e-2 and eu < 5e-3, (lvl, ef, eu)
+    print("\nalign @1080x1920 per-stage max abs error vs reference CPU path:", ", ".join(f"{k}={v:.2e}" for k, v in report))
+    warped, mask, cert = align(vgg, head, T(logits, dev), T(img_ref, dev), T(img_trg, dev))
+    m = mask.cpu().numpy()
+    want_mask = np.unpackbits(g["mask_bits"])[: H * W].reshape(1, H, W).astype(bool)
+    assert int(g["mask_count"]) == int(want_mask.sum())
+    np.testing.assert_array_equal(m, want_mask)
+    c = cert.cpu().numpy()
+    np.testing.assert_allclose(c[:, :, ::8, ::8], g["cert_sample"], atol=1e-3)
+    # (measured on MI355X: flow1 3.3e-3 px, log-variance 1.2e-3 max abs; the confidence sum over 2 M pixels then differs by
+    # 1.9e-4 relative -- a mean per-pixel difference of 5e-6)
+    assert abs(float(cert.double().sum()) - float(g["cert_checksum"])) < 5e-4 * abs(float(g["cert_checksum"]))
+    ws = warped[:, :, ::16, ::16].cpu().numpy()
+    inside = want_mask[:, None, ::16, ::16]
+    err = np.abs(ws - g["warped_sample"]) * inside
+    assert err.max() <= 1e-3, f"warped logits differ by {err.max():.2e} (north star 1e-3)"
+    assert abs(float(warped.double().sum()) - float(g["warped_checksum"])) < 1e-5 * float(g["warped_abs_checksum"])
+    am = warped.argmax(1)[:, ::4, ::4].cpu().numpy()
+    decided = (g["warped_margin"].astype(np.float32) > 1e-2) & want_mask[:, ::4, ::4]
+    assert decided.mean() > 0.9
+    assert (am == g["warped_argmax"])[decided].all(), "argmax mask not pixel-exact"
+
+
+@torch.no_grad()
 def test_align_amp_precision_map(dev, monkeypatch):
     """Inside a reduced-precision autocast region align() runs its convolutions in fp16 -- the reference's AMP dtype
     (README.md:262) -- with correlation / warp / L2 norm / uncertainty kernels in fp32: close to the fp32 golden (G7),
