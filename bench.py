@@ -568,12 +568,17 @@ def main():
             "value": round(pairs / dt, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if (args.workload == AlignRefineKernels.name or args.precision == "fp32") else
+            "dtype": ("f32 (3 x bf16 split products)" if args.precision == "fp32" and args.workload != AlignRefineKernels.name
+                      and os.environ.get("RFN_FP32_SPLIT", "1") != "0" else "f32")
+                     if (args.workload == AlignRefineKernels.name or args.precision == "fp32") else
                      ("bf16+fp8(e4m3) teacher" if args.precision == "k5" else "bf16"),
             "data": "synthetic",
             "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": f"{args.height}x{args.width}",
                        "networks": "HRDA MiT-B5 + DAFormer head + VGG-16/UAWarpC align (random init)",
-                       "precision_map": ("fp32 everywhere" if args.precision == "fp32" else
+                       "precision_map": (("fp32 storage everywhere; Linear / convolution / attention products as three bf16 "
+                                          "products on the MFMA kernels (refign_amd/split32.py, ~2^-16 relative)"
+                                          if os.environ.get("RFN_FP32_SPLIT", "1") != "0" else "fp32 everywhere (library GEMMs)")
+                                         if args.precision == "fp32" else
                                          ("K5: as the bf16 map, plus the EMA teacher's MiT blocks (Linear layers and "
                                           "attention core, 40 views) on fp8 e4m3 MFMA kernels; " if args.precision == "k5"
                                           else "") +

@@ -380,20 +380,42 @@ class _ConvMfmaFn(torch.autograd.Function):
         Np = -(-N // 64) * 64
         gh = _nhwc16(gy, dtype, Np)                                  # (B, OH, OW, Np), zero in the padded channels
         gx = gw = gb = None
+        need_w = ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
+
+        def library_backward(want_x, want_w, want_b):
+            """a shape outside a backward kernel's domain (conv2d_mfma_grad pre-checks the Python-side limits only): the
+            library's convolution_backward for the missing gradients, recorded like every other library call"""
+            _mfma.note_library("convolution_backward", gy, weight)
+            xn = xh[..., :C].permute(0, 3, 1, 2)
+            return torch.ops.aten.convolution_backward(
+                gy.to(dtype), xn, weight.to(dtype), [N] if bias is not None else None, [s, s], [p, p], [d, d], False, [0, 0], 1,
+                [want_x, want_w, want_b])
+
         if ctx.needs_input_grad[0]:
             dx = _mfma.conv2d_nhwc_dgrad(gh, _packed_t(weight, dtype, 64), H, W, Cp, KH, KW, s, p, d)
             if dx is None:
-                raise RuntimeError("conv2d dgrad (MFMA): operands outside the kernel's domain")
-            gx = (dx[..., :C] if Cp != C else dx).permute(0, 3, 1, 2)
-        need_w = ctx.needs_input_grad[1]
-        need_b = bias is not None and ctx.needs_input_grad[2]
+                gx = library_backward(True, False, False)[0]
+            else:
+                gx = (dx[..., :C] if Cp != C else dx).permute(0, 3, 1, 2)
         if need_w or need_b:
             sw, sb = grad_sink(weight), grad_sink(bias)
             Kp = -(-(KH * KW * Cp) // 64) * 64
             bsum = torch.zeros(Np, dtype=torch.float32, device=gh.device) if need_b else None
             part = _mfma.conv2d_nhwc_wgrad(gh, xh, KH, KW, Kp, s, p, d, bias_out=bsum)
             if part is None:
-                raise RuntimeError("conv2d wgrad (MFMA): operands outside the kernel's domain")
+                _, lw, lb = library_backward(False, need_w, need_b)
+                if need_w:
+                    if sw is not None:
+                        sw.add_(lw.to(sw.dtype))
+                    else:
+                        gw = lw.to(weight.dtype)
+                if need_b:
+                    if sb is not None:
+                        sb.add_(lb.to(sb.dtype))
+                    else:
+                        gb = lb.to(bias.dtype)
+                return gx, gw, gb, None, None, None, None, None
             if need_w:
                 S = part.shape[0]
                 g2 = sum_rows(part.view(S, Np * Kp)).view(Np, Kp)[:N, :KH * KW * Cp].view(N, KH, KW, Cp)[..., :C]

@@ -25,8 +25,10 @@ _YIQ_INV = np.linalg.inv(_YIQ)
 MAX_BATCH = 8
 
 
-def usable(images_src, images_trg, gt_src):
-    return (images_src.is_cuda and images_src.dtype == torch.float32 and images_trg.dtype == torch.float32
+def usable(images_src, images_trg, gt_src, num_classes=19):
+    """num_classes: labels are 0 .. num_classes - 1 and 255.  The kernels carry a sample's chosen classes as a 32-bit set
+    (bit c = class c for c <= 30, bit 31 = the ignore label 255): label sets with more than 31 classes take the torch path."""
+    return (num_classes <= 31 and images_src.is_cuda and images_src.dtype == torch.float32 and images_trg.dtype == torch.float32
             and images_src.dim() == 4 and images_src.shape[1] == 3 and images_trg.shape == images_src.shape
             and images_src.shape[0] <= MAX_BATCH and (images_src.shape[2] * images_src.shape[3]) % 4 == 0
             and min(images_src.shape[2:]) > 16 and gt_src.dtype == torch.long)
@@ -39,7 +41,11 @@ def draw_class_bits(classes, nb):
     idx = np.stack([np.random.choice(n, int((n + n % 2) / 2), replace=False) for _ in range(nb)])
     chosen = classes[upload_async(idx, torch.long, classes.device)]                  # (nb, k) class values
     chosen = torch.where(chosen == 255, torch.full_like(chosen, 31), chosen).clamp_(0, 31)
-    return torch.bitwise_left_shift(torch.ones_like(chosen), chosen).sum(1)
+    bits = torch.bitwise_left_shift(torch.ones_like(chosen), chosen)
+    out = bits[:, 0]
+    for j in range(1, bits.shape[1]):                   # OR, not sum: a repeated (clamped) class must not carry into the next bit
+        out = torch.bitwise_or(out, bits[:, j])
+    return out
 
 
 def draw_jitter(s):

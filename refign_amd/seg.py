@@ -753,7 +753,7 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
                 up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
                 up_att = F.interpolate(att, scale_factor=2, mode='bilinear', align_corners=False)
                 inserted = box.insert(hr_seg, up_lr.shape[2:], head_os)
-                return up_att * inserted + up_lr, defer_logits(hr_seg, (box.h, box.w)), box
+                return up_att * inserted + up_lr, defer_logits(hr_seg, (box.h, box.w), fused_ce_consumer(self)), box
             if self.training and not is_teacher:
                 box = boxes[0]
                 crop_size = (box[1] - box[0], box[3] - box[2])
@@ -766,7 +766,7 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
                 inserted = torch.zeros_like(up_lr)
                 sy, sx = hr_crop_slice(box, head_os)
                 inserted[:, :, sy, sx] = hr_seg
-                hr_logits = defer_logits(hr_seg, crop_size)
+                hr_logits = defer_logits(hr_seg, crop_size, fused_ce_consumer(self))
                 return up_att * inserted + up_lr, hr_logits, box
             up_lr = F.interpolate((1 - att) * lr_seg, scale_factor=2, mode='bilinear', align_corners=False)
             # overlap-average the sliding crops (the reference rescales `hr_boxes` in place, hrda.py:207-208)
@@ -788,9 +788,21 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
 # loss
 # ---------------------------------------------------------------------------------------------------------------------
 _FUSED_CE = os.environ.get("RFN_FUSED_CE", "1") != "0"
-# set by the training model once it knows that the consumer of the training logits is PixelWeightedCrossEntropyLoss (the
-# only thing that understands a DeferredUpsample); heads used on their own keep returning tensors
-FUSED_CE_CONSUMER = False
+# Whether the consumer of a head's / model's training logits is PixelWeightedCrossEntropyLoss itself (the only thing that
+# runs a DeferredUpsample as one kernel) is a property of the OWNING MODEL, carried as an attribute on the module
+# (`mark_fused_ce_consumer`): heads used on their own, models with another loss or a subclass that overrides `forward` keep
+# getting tensors.  (Round 3 had a module-level flag here: the last model constructed won for every head of the process.)
+
+
+def mark_fused_ce_consumer(module, loss):
+    module._rfn_fused_ce_consumer = type(loss) is PixelWeightedCrossEntropyLoss
+    return module._rfn_fused_ce_consumer
+
+
+def fused_ce_consumer(module):
+    return bool(getattr(module, "_rfn_fused_ce_consumer", False))
+
+
 _CE_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 
@@ -810,11 +822,18 @@ class DeferredUpsample:
     def shape(self):
         return torch.Size((*self.logits.shape[:2], *self.size))
 
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        """Any torch function other than the fused loss (F.cross_entropy in a user's own loss, an interpolate, a metric ...)
+        gets the tensor the reference would have passed: materialise and go on."""
+        conv = lambda a: a.materialize() if isinstance(a, DeferredUpsample) else a  # noqa: E731
+        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
 
-def defer_logits(logits, size):
-    """-> DeferredUpsample when the fused loss kernel covers the case (HIP tensor, <= 19 classes, scale factors >= 2,
-    gradients wanted), else the up-sampled logits themselves."""
-    if _FUSED_CE and FUSED_CE_CONSUMER and logits.is_cuda and logits.dim() == 4 and logits.dtype in _CE_DT and logits.shape[1] <= 19 \
+
+def defer_logits(logits, size, consumer_is_fused_ce=False):
+    """-> DeferredUpsample when the consumer is the fused loss and its kernel covers the case (HIP tensor, <= 19 classes,
+    scale factors >= 2, gradients wanted), else the up-sampled logits themselves."""
+    if _FUSED_CE and consumer_is_fused_ce and logits.is_cuda and logits.dim() == 4 and logits.dtype in _CE_DT and logits.shape[1] <= 19 \
             and size[0] >= 2 * logits.shape[2] and size[1] >= 2 * logits.shape[3] and torch.is_grad_enabled():
         return DeferredUpsample(logits, size)
     return _up_logits(logits, size)

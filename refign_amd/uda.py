@@ -164,10 +164,11 @@ def _upsample_logits(logits, size):
     return F.interpolate(logits, size, mode='bilinear', align_corners=False)
 
 
-def _logits_for_loss(logits, size):
-    """_upsample_logits for logits that only the loss consumes: deferred, so that up-sampling + cross-entropy + backward
-    run as one kernel (seg.DeferredUpsample / csrc/loss.hip); the up-sampled tensor where that does not apply."""
-    return defer_logits(logits, size)
+def _logits_for_loss(model, logits, size):
+    """_upsample_logits for logits that only `model.loss` consumes: deferred when that loss is the fused one, so that
+    up-sampling + cross-entropy + backward run as one kernel (seg.DeferredUpsample / csrc/loss.hip); the up-sampled tensor
+    where that does not apply."""
+    return defer_logits(logits, size, _seg.fused_ce_consumer(model))
 
 
 _ALIGN_PREFETCH = os.environ.get("RFN_ALIGN_PREFETCH", "1") != "0"
@@ -230,7 +231,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
             self.imnet_backbone.requires_grad_(False)
         self.loss = loss
         # up-sampling + cross-entropy + backward of the student passes as one kernel (seg.DeferredUpsample)
-        _seg.FUSED_CE_CONSUMER = isinstance(loss, _seg.PixelWeightedCrossEntropyLoss)
+        _seg.mark_fused_ce_consumer(self, loss)
+        _seg.mark_fused_ce_consumer(self.head, loss)
         self.metrics_cfg = metrics
         from .metrics import build_collections
         self.valid_metrics, self.test_metrics = build_collections(metrics, instantiate_class)
@@ -337,11 +339,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if self.use_hrda:
             feats_src = feats_src[0]                                     # low-resolution features
             logits_src, hr_logits_src, crop_box_src = logits_src
-            logits_src = _logits_for_loss(logits_src, images_src.shape[-2:])
+            logits_src = _logits_for_loss(self, logits_src, images_src.shape[-2:])
             loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
                 self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
         else:
-            logits_src = _logits_for_loss(logits_src, images_src.shape[-2:])
+            logits_src = _logits_for_loss(self, logits_src, images_src.shape[-2:])
             loss_src = self.loss(logits_src, gt_src)
         self.log("train_loss_src", loss_src)
         self.manual_backward(loss_src, retain_graph=self.enable_fdist)
@@ -376,12 +378,12 @@ class DomainAdaptationSegmentationModel(nn.Module):
         mixed_pred = self.head(self.backbone(mixed_img))
         if self.use_hrda:
             mixed_pred, hr_mixed_pred, box = mixed_pred
-            mixed_pred = _logits_for_loss(mixed_pred, mixed_img.shape[-2:])
+            mixed_pred = _logits_for_loss(self, mixed_pred, mixed_img.shape[-2:])
             mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
                 self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box),
                                                 pixel_weight=crop(mixed_weight, box))
         else:
-            mixed_pred = _logits_for_loss(mixed_pred, mixed_img.shape[-2:])
+            mixed_pred = _logits_for_loss(self, mixed_pred, mixed_img.shape[-2:])
             mixed_loss = self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight)
         self.log("train_loss_uda_trg", mixed_loss)
         self.manual_backward(mixed_loss, last=True)
@@ -422,7 +424,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         feats_src = self.backbone(images_src)
         logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
         feats_src = feats_src[0]
-        logits_src = _logits_for_loss(logits_src, images_src.shape[-2:])
+        logits_src = _logits_for_loss(self, logits_src, images_src.shape[-2:])
         loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
             self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
         self.manual_backward(loss_src, retain_graph=self.enable_fdist)
@@ -463,18 +465,24 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if gt_next is None or not gt_next.is_cuda or gt_next.dtype != torch.long:
             return
         g = gt_next[:nb] if gt_next.shape[0] > nb else gt_next
-        hist = torch.histc(g.to(torch.float32), bins=256, min=0, max=255)          # labels are 0 .. 18 and 255
+        # labels are 0 .. 18 and 255; histc drops values outside [0, 255] (another ignore convention, -1 ...): the bin total
+        # then falls short of the pixel count and _take_class_prefetch declines (torch.unique keeps such labels, and the host's
+        # random stream depends on the size of the class set)
+        hist = torch.histc(g.to(torch.float32), bins=256, min=0, max=255)
         host = getattr(self, "_class_hist_host", None)
         if host is None:
             host = self._class_hist_host = torch.empty(256, dtype=torch.float32).pin_memory()
         host.copy_(hist, non_blocking=True)
-        self._class_prefetch = (gt_next, gt_next._version, gt_next.data_ptr(), nb, torch.cuda.current_stream().record_event())
+        self._class_prefetch = (gt_next, gt_next._version, gt_next.data_ptr(), nb, torch.cuda.current_stream().record_event(),
+                                g.numel())
 
     def _take_class_prefetch(self, gt_src, nb):
         pf, self._class_prefetch = getattr(self, "_class_prefetch", None), None
         if pf is None or pf[0] is not gt_src or pf[1] != gt_src._version or pf[2] != gt_src.data_ptr() or pf[3] != nb:
             return None
         pf[4].synchronize()                                # recorded a whole step ago
+        if int(round(float(self._class_hist_host.sum()))) != pf[5]:
+            return None                                    # labels outside 0 .. 255: the caller takes torch.unique
         ids = torch.nonzero(self._class_hist_host > 0).flatten()
         return upload_async(ids, torch.long, gt_src.device)
 
@@ -490,7 +498,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         """MIXED (:226-250), forward and backward."""
         push_device_crop(off, self.hrda_output_stride * 2.0)
         mixed_pred, hr_mixed_pred, box = self.head(self.backbone(mixed_img))
-        mixed_pred = _logits_for_loss(mixed_pred, mixed_img.shape[-2:])
+        mixed_pred = _logits_for_loss(self, mixed_pred, mixed_img.shape[-2:])
         mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
             self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
         self.manual_backward(mixed_loss)
@@ -906,7 +914,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
             pseudo_weight[:, :self.psweight_ignore_top, :] = 0
         if self.psweight_ignore_bottom > 0:
             pseudo_weight[:, -self.psweight_ignore_bottom:, :] = 0
-        if os.environ.get("RFN_DACS_KERNEL", "1") != "0" and _dacs.usable(images_src, images_trg, gt_src):
+        if os.environ.get("RFN_DACS_KERNEL", "1") != "0" and _dacs.usable(images_src, images_trg, gt_src,
+                                                                              getattr(self.head, "num_classes", 19)):
             # N4: the pixel work of the mix / jitter / blur as HIP kernels (refign_amd/dacs.py); the draws below are made in
             # the order the per-sample loop further down makes them
             classes = torch.unique(gt_src) if src_classes is None else src_classes

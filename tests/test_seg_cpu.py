@@ -215,3 +215,44 @@ def test_rejoin_is_a_view_of_the_split_batch_and_a_copy_otherwise():
     ag, bg = torch.split(xg * 1.0, [2, 3])
     j = _rejoin(ag, bg)
     assert j.grad_fn is not None and "Cat" in type(j.grad_fn).__name__                                    # differentiated: cat
+
+
+def test_deferred_upsample_materialises_for_any_other_consumer_and_flag_is_per_model():
+    """the 'consumer is the fused loss' switch is an attribute of the owning model / head (not a module global: the
+    last model constructed used to win for every head of the process), and a DeferredUpsample that reaches anything but the
+    fused loss -- a user's own F.cross_entropy, a subclass overriding forward -- behaves as the tensor the reference passes."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from refign_amd import seg
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 19, 6, 8, generator=g)
+    target = torch.randint(0, 19, (2, 24, 32), generator=g)
+    d = seg.DeferredUpsample(logits, (24, 32))
+    want = F.cross_entropy(F.interpolate(logits, (24, 32), mode="bilinear", align_corners=False), target)
+    assert torch.allclose(F.cross_entropy(d, target), want)
+    assert tuple(d.shape) == (2, 19, 24, 32)
+
+    class Sub(seg.PixelWeightedCrossEntropyLoss):
+        def forward(self, input, target, pixel_weight=None):
+            return F.cross_entropy(input, target)
+
+    a, b = nn.Module(), nn.Module()
+    assert seg.mark_fused_ce_consumer(a, seg.PixelWeightedCrossEntropyLoss()) is True
+    assert seg.mark_fused_ce_consumer(b, Sub()) is False          # a subclass may not understand a DeferredUpsample
+    assert seg.fused_ce_consumer(a) and not seg.fused_ce_consumer(b) and not seg.fused_ce_consumer(nn.Module())
+    assert not hasattr(seg, "FUSED_CE_CONSUMER")
+
+
+def test_dacs_class_bits_are_a_set_not_a_sum():
+    """class ids >= 31 clamp onto bit 31; duplicates must OR (a sum carries into bit 32 and truncates), and label
+    sets of more than 31 classes do not take the kernel path at all."""
+    import numpy as np
+    from refign_amd import dacs
+    np.random.seed(0)
+    classes = torch.tensor([0, 3, 31, 40, 255, 77])
+    bits = dacs.draw_class_bits(classes, 4)
+    assert int(bits.max()) < (1 << 32) and int(bits.min()) >= 0
+    for v in bits.tolist():
+        assert v & ~((1 << 0) | (1 << 3) | (1 << 31)) == 0
+    img = torch.zeros(2, 3, 32, 32)
+    assert not dacs.usable(img, img, torch.zeros(2, 32, 32, dtype=torch.long), num_classes=40)
