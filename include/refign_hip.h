@@ -447,19 +447,6 @@ int rfn_conv2d_nhwc_wgrad(const void* GY, const void* X, float* P, float* grad_b
                           int dtype, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Local correlation layer on the matrix pipe (round 3, csrc/corr_f16.hip): same result as rfn_local_corr_layer_f32
- * (LocalFeatureCorrelationLayer.forward, models/modules.py:266-274 over the sampler of correlation.cpp:80-129) from
- * operands in the "split-fp16, chunk-major" format  [b][c / 32][part][y][x][c % 32] fp16, part 0 = fp16(v), part 1 =
- * fp16(v - part 0) -- 4 bytes per feature like fp32, 22 significand bits; products th.sh + th.sl + tl.sh, fp32 accumulate.
- *   rfn_split_f16                  fp32 NCHW features -> that format; with `flow` (B, 2, H, W) the features are bilinearly
- *                                  warped on the way (warp() of helpers/matching_utils.py:11-49; uawarpc.py:149-152).  C % 32.
- *   rfn_local_corr_layer_f16split  out (B, 81, H, W) fp32; fuse = 1: + ReLU + L2 norm over the 81 shifts, 0: raw sums.
- * ---------------------------------------------------------------------------------------------------------- */
-int rfn_split_f16(const float* x, const float* flow, void* out, int B, int C, int H, int W, rfn_stream_t stream);
-int rfn_local_corr_layer_f16split(const void* target_split, const void* source_split, float* out, int B, int C, int H, int W,
-                                  int fuse, rfn_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------------------------
  * N4 -- GPU-side data step of the UDA iteration (csrc/dacs.hip): DACS class-mix + colour jitter + Gaussian blur of
  * helpers/dacs_transforms.py:14-24,43-78,81-112 as called per sample by models/segmentation_model.py:525-582.  Images
  * (B, 3, H, W) fp32 ImageNet-normalised, labels (B, H, W) int64, weights (B, H, W) fp32; B <= 8, H*W % 4 == 0.

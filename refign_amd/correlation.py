@@ -152,43 +152,6 @@ def local_correlation_layer(feature_source, feature_target, flow=None, single_ke
     return out
 
 
-def split_f16(features, flow=None):
-    """fp32 (B, C, H, W) features -> the split-fp16 chunk-major operand of `local_correlation_layer_split`
-    ((B, C/32, 2, H, W, 32) fp16: hi = fp16(v), lo = fp16(v - hi)); with `flow` the features are bilinearly warped on the
-    way (warp(feature_source, flow), uawarpc.py:149-152) without materialising the warped fp32 map."""
-    require_device_tensor(features, "features", torch.float32)
-    B, C, H, W = features.shape
-    if C % 32:
-        raise RuntimeError("split_f16: C must be a multiple of 32")
-    if flow is not None:
-        require_device_tensor(flow, "flow", torch.float32)
-        if tuple(flow.shape) != (B, 2, H, W):
-            raise RuntimeError("split_f16: flow must be (B,2,H,W)")
-    out = torch.empty((B, C // 32, 2, H, W, 32), dtype=torch.float16, device=features.device)
-    with on_device(features.device):
-        rc = _lib.load_library().rfn_split_f16(ptr(features), ptr(flow), ptr(out), B, C, H, W,
-                                               current_stream(features.device))
-    _lib.check(rc, "split_f16")
-    return out
-
-
-def local_correlation_layer_split(source_split, target_split, fuse=True):
-    """LocalFeatureCorrelationLayer.forward (modules.py:266-274) on the matrix pipe (csrc/corr_f16.hip) from operands made
-    by `split_f16`: (B, 81, H, W) fp32 = patch-9 correlation (+ ReLU + L2 norm over the shifts when `fuse`)."""
-    for t, name in ((source_split, "source_split"), (target_split, "target_split")):
-        require_device_tensor(t, name, torch.float16)
-    if source_split.shape != target_split.shape or source_split.dim() != 6 or source_split.shape[2] != 2 \
-            or source_split.shape[5] != 32:
-        raise RuntimeError("local_correlation_layer_split: operands must both be (B, C/32, 2, H, W, 32)")
-    B, NC, _, H, W, _ = source_split.shape
-    out = torch.empty((B, 81, H, W), dtype=torch.float32, device=source_split.device)
-    with on_device(out.device):
-        rc = _lib.load_library().rfn_local_corr_layer_f16split(ptr(target_split), ptr(source_split), ptr(out), B, NC * 32, H, W,
-                                                               1 if fuse else 0, current_stream(out.device))
-    _lib.check(rc, "local_corr_layer_f16split")
-    return out
-
-
 def _channel_splits(B, C, H, W):
     """How many channel chunks the patch-9 kernel of a TINY map is split into (csrc/corr.hip launch_corr9_split): the
     tiled kernel walks the channels of a tile serially, so a map of a few 8x64 tiles (2 x 256 x 32 x 32: 8 workgroups on

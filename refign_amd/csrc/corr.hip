@@ -767,9 +767,8 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe_ke
   }
 }
 
-// corr_mfma.hip: the same forward on the fp32 matrix pipe; > 0 = shape not taken
-int launch_corr9_mfma(const float* in1, const float* in2, float* out, int B, int C, int H, int W, bool fuse,
-                      hipStream_t st);
+// (The fp32-matrix-pipe formulation of this forward -- exact, measured slower: 166-171 vs 139 us, profiles/r02_corr_mfma_*.txt,
+// r03_corr_f16_ablation.txt -- lives in tools/experiments/matrix_pipe_corr/, outside the product library.)
 
 template <bool FUSE, bool WARP>
 static int launch_corr9(const float* in1, const float* in2, const float* flow, float* out, int B, int C, int H,
@@ -780,10 +779,6 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
       static const int xcd_remap = getenv("RFN_CORR_XCD") ? atoi(getenv("RFN_CORR_XCD")) : 0;
       // profiling only: bit0 no DMA, bit1 no FMAs, bit2 no stores (results are then meaningless)
       static const int ablate = getenv("RFN_CORR_ABLATE") ? atoi(getenv("RFN_CORR_ABLATE")) : 0;
-      if (variant == 30) {
-        const int rc = launch_corr9_mfma(in1, in2, out, B, C, H, W, FUSE, st);
-        if (rc <= 0) return rc;
-      }
 #define RFN_LAUNCH_DMA(TH_, TW_, CC_, MINW_, UNR_, NTILE_, ILV_)                                                      \
   {                                                                                                               \
     const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \

@@ -74,54 +74,6 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
   for (int c = 0; c < cend; ++c) dst[(size_t)c * HW] = tap_sample(src + (size_t)c * HW, t);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// fp32 NCHW features -> "split-fp16, chunk-major" operands of the matrix-core correlation kernel (csrc/corr_f16.hip):
-//   out[b][chunk = c / 32][part][y][x][c % 32]   fp16,  part 0 = hi = fp16(v), part 1 = lo = fp16(v - hi)
-// (hi + lo carries 22 significand bits of v: the three products hi.hi' + hi.lo' + lo.hi' reproduce an fp32 product to
-// ~2^-21).  With `flow` the source is bilinearly warped on the way (warp(feature_source, flow) of uawarpc.py:149-152) --
-// the warped fp32 map is never written.  One thread = one pixel x one 32-channel chunk: channel-plane reads are contiguous
-// along x across the wave, the thread's 2 x 64 output bytes are contiguous.   grid (ceil(HW / 256), C / 32, B)
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, const float* __restrict__ flow,
-                                                        _Float16* __restrict__ out, int C, int H, int W) {
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  const int HW = H * W;
-  if (pix >= HW) return;
-  const int n = blockIdx.z, chunk = blockIdx.y, NC = C / 32;
-  const float* src = x + ((size_t)n * C + (size_t)chunk * 32) * HW;
-  Tap t;
-  if (flow != nullptr) {
-    const int gy = pix / W, gx = pix - gy * W;
-    const float* fl = flow + (size_t)n * 2 * HW;
-    t = bilinear_tap((float)gx, (float)gy, fl[pix], fl[HW + pix], H, W);
-  }
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  unsigned hi[16], lo[16];
-#pragma unroll
-  for (int c = 0; c < 32; c += 2) {
-    float v0, v1;
-    if (flow != nullptr) {
-      v0 = tap_sample(src + (size_t)c * HW, t);
-      v1 = tap_sample(src + (size_t)(c + 1) * HW, t);
-    } else {
-      v0 = src[(size_t)c * HW + pix];
-      v1 = src[(size_t)(c + 1) * HW + pix];
-    }
-    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-    const h2 hh = {h0, h1};
-    const h2 ll = {(_Float16)(v0 - (float)h0), (_Float16)(v1 - (float)h1)};
-    hi[c / 2] = __builtin_bit_cast(unsigned, hh);
-    lo[c / 2] = __builtin_bit_cast(unsigned, ll);
-  }
-  _Float16* ph = out + ((((size_t)n * NC + chunk) * 2 + 0) * HW + pix) * 32;
-  _Float16* pl = out + ((((size_t)n * NC + chunk) * 2 + 1) * HW + pix) * 32;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    *reinterpret_cast<uint4*>(ph + 8 * q) = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
-    *reinterpret_cast<uint4*>(pl + 8 * q) = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
-  }
-}
-
 // Backward of warp() = backward of grid_sample(bilinear, align_corners=True, zeros) composed with the flow -> grid map
 // (ATen grid_sampler_2d_backward: gix = sum_c g [ (ne - nw) (1 - ty) + (se - sw) ty ], giy likewise; taps outside the
 // image contribute zero).  d ix / d flow_x = ((W - 1) / 2) (2 / max(W - 1, 1)): 1 for W > 1, 0 for a one-pixel axis.
@@ -422,15 +374,6 @@ int rfn_warp_f32(const float* x, const float* flow, float* out, unsigned char* m
   dim3 grid(cdiv((long)H * W, 256), cdiv(C, CG), B);
   hipLaunchKernelGGL((warp_kernel<CG>), grid, dim3(256), 0, (hipStream_t)stream, x, flow, out, mask, C, H, W);
   return check_launch("warp_kernel");
-}
-
-int rfn_split_f16(const float* x, const float* flow, void* out, int B, int C, int H, int W, rfn_stream_t stream) {
-  RFN_REQUIRE(x && out, "rfn_split_f16: null pointer");
-  RFN_REQUIRE(B > 0 && C > 0 && C % 32 == 0 && H > 0 && W > 0, "rfn_split_f16: sizes (C %% 32)");
-  RFN_REQUIRE((long)H * W < 0x7fffffffL && B <= 65535, "rfn_split_f16: tensor too large");
-  dim3 grid(cdiv((long)H * W, 256), C / 32, B);
-  hipLaunchKernelGGL(split_f16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, flow, (_Float16*)out, C, H, W);
-  return check_launch("split_f16_kernel");
 }
 
 int rfn_warp_bwd_f32(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow, int B,

@@ -360,22 +360,6 @@ def test_upsample_concat_full_size(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["0", "2"])
-def test_corr9_matrix_pipe_variants_match_fp64_formulation(cfg):
-    """The opt-in fp32-MFMA correlation kernels (corr_mfma.hip: wave-private rings = cfg 0, workgroup-shared tiles =
-    cfg 2) against a plain fp64 torch formulation on ragged / tiny / multi-tile shapes, raw and with the fused ReLU +
-    L2 norm (1e-5 relative; the kernel is selected once per process, hence the subprocess)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RFN_CORR_VARIANT="30", RFN_CORR_MFMA_CFG=cfg, RFN_CORR_CHECK_ONLY="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "corr_variant_check.py")], env=env,
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "worst" in r.stdout and " OK" in r.stdout, r.stdout + r.stderr
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("H,W,scale,minr", [(64, 96, 32, 0.75), (1080 // 4, 1920 // 4, 32, 0.75), (40, 56, 8, 0.5),
                                             (33, 47, 16, 0.3)])
 def test_label_majority_kernel_matches_one_hot_pooling(H, W, scale, minr):

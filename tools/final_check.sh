@@ -22,7 +22,6 @@ python tools/trace_queues.py $(find /tmp/prof_bench -name "*kernel_trace.csv") $
 timeout 600 python bench.py --precision k5 --no-cpu 2>/dev/null | tail -1 > $O/bench_k5_n1.json
 timeout 300 python tools/f8_bench.py 2>&1 | grep -v "amdgpu.ids" > $O/f8_bench.txt
 timeout 300 python tools/kbench.py --only L1,L2 2>&1 | grep -v "amdgpu.ids\|MIOpen" > $O/kbench_corr.txt
-for a in 1 2 4 6 7; do echo "RFN_CORR_ABLATE=$a"; RFN_CORR_ABLATE=$a timeout 200 python tools/kbench.py --only L1 2>&1 | grep -i "f16-split\|relu+l2norm"; done > $O/corr_f16_ablation.txt
 for t in f8gemm_fc1_s3:gemm_nt_f8 f8gemm_fc2_s3:gemm_nt_f8 f8attn_s3:attn_fwd_f8 gemm_fc1_s3:gemm_nt_kernel; do
   echo "== ${t%%:*}"; bash tools/pmc_mfma.sh ${t%%:*} ${t##*:}; done > $O/pmc_f8_kernels.txt 2>&1
 # round 3, second half: per-entry-point census of the step, what is left in ATen, attention / depthwise / GEMM sweeps on replayed

@@ -52,11 +52,6 @@ def main():
         fp = 2.0 * 81 * C * b * H * W
         add(f"corr9 raw            {lvl} C={C} {H}x{W}", timeit(lambda: correlation.forward(f1, f2, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)), nb, fp)
         add(f"corr9 +relu+l2norm   {lvl} C={C} {H}x{W}", timeit(lambda: correlation.local_correlation_layer(f2, f1)), nb, fp)
-        if C % 32 == 0:
-            s1, s2 = correlation.split_f16(f1), correlation.split_f16(f2)
-            add(f"corr9 f16-split MFMA {lvl} C={C} {H}x{W}", timeit(lambda: correlation.local_correlation_layer_split(s2, s1)), nb, fp)
-            add(f"split_f16            {lvl} C={C} {H}x{W}", timeit(lambda: correlation.split_f16(f2)), 8 * b * H * W * C)
-            add(f"split_f16 + warp     {lvl} C={C} {H}x{W}", timeit(lambda: correlation.split_f16(f2, fl)), 8 * b * H * W * C)
         add(f"corr9 +warp+relu+l2n {lvl} C={C} {H}x{W}", timeit(lambda: correlation.local_correlation_layer(f2, f1, flow=fl)), nb + 8 * b * H * W, fp)
         add(f"warp features        {lvl} C={C} {H}x{W}", timeit(lambda: matching.warp_nocheck(f2, fl)), 4 * b * H * W * (2 * C + 2))
         add(f"l2norm channels      {lvl} C={C} {H}x{W}", timeit(lambda: matching.l2_normalize_channels(f2)), 4 * b * H * W * 2 * C)
