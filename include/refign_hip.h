@@ -469,6 +469,21 @@ int rfn_dacs_blur(const float* x, float* tmp, float* y, int B, int C, int H, int
                   const double* sigma_y, const double* sigma_x, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * N4, second part -- source / target SAMPLING on the device (csrc/datastep.hip): the crop re-draws of rare-class sampling
+ * (data_modules/datasets/cityscapes.py:139-158) and of RandomCrop's category ratio (data_modules/transforms.py:282-361),
+ * RandomHorizontalFlip (:363-390), ConvertImageDtype (:438-464), Normalize (:467-495).  uint8 images (C, H, W) and label maps
+ * (H, W) as the reference's ToTensor leaves them (:250-279).
+ *   rfn_crop_label_hist_u8  hist[k][v] = number of pixels with label v in crop box k = (top, left, h, w) = boxes[4k..] (HOST
+ *                           array, read at call time), K <= 16 candidate boxes in one launch; hist: K x 256 DEVICE ints (zeroed
+ *                           by the call).
+ *   rfn_crop_flip_norm_u8   out_image (C, h, w) fp32 = (u8 / 255 - mean[c]) / std[c] of the crop, mirrored along x when flip;
+ *                           out_label (h, w) int64.  Either half may be NULL.  mean3 / std3: HOST arrays.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_crop_label_hist_u8(const void* label, int H, int W, const int* boxes, int K, int* hist, rfn_stream_t stream);
+int rfn_crop_flip_norm_u8(const void* image, const void* label, int C, int H, int W, int top, int left, int h, int w, int flip,
+                          const float* mean3, const float* std3, float* out_image, long* out_label, rfn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * K5 (BASELINE.json config 5, "bf16 HRDA + fp8 MFMA attention"): fp8 (OCP e4m3, fp32 accumulate) matrix-core path of
  * the gradient-free EMA teacher (segmentation_model.py:204-209 runs MiT-B5, mix_transformer.py:96-103,137-164, on 40
  * HRDA views per GPU).  No reference analogue (the reference's recipe is 16-bit AMP, README.md:262); csrc/f8.hip.

@@ -94,6 +94,8 @@ SIGNATURES = {
     "rfn_bn_train_fwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_float, c_int, c_int, c_void_p]),
     "rfn_bn_train_bwd": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_float, c_int, c_int, c_void_p]),
     "rfn_dacs_mix_jitter": (c_int, [c_void_p] * 9 + [c_int] * 3 + [c_void_p] * 7 + [c_void_p]),
+    "rfn_crop_label_hist_u8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "rfn_crop_flip_norm_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] * 4 + [c_void_p]),
     "rfn_dacs_blur": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p] * 3 + [c_void_p]),
     "rfn_gemm_nt_f8": (c_int, [c_void_p] * 3 + [c_float] + [c_void_p] * 3 + [c_int, c_int, c_void_p, c_int, c_float]
                        + [ctypes.c_long] * 6 + [c_void_p]),

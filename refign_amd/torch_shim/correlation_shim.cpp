@@ -7,8 +7,8 @@
 // on purpose: the kernels run on the CURRENT stream (the CUDA reference launches on the legacy default stream,
 // correlation_cuda_kernel.cu:271) -- which is what torch code around it expects.
 // Host-only C++: no HIP source here; built by refign_amd/torch_shim/build.py (torch.utils.cpp_extension, in-tree).
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
 #include <vector>
@@ -32,11 +32,11 @@ torch::Tensor correlation_sample_forward(torch::Tensor input1, torch::Tensor inp
                                          int padH, int padW, int dilationH, int dilationW, int dilation_patchH,
                                          int dilation_patchW, int dH, int dW) {
   check_inputs(input1, input2, "correlation.forward");
-  const c10::hip::HIPGuard guard(input1.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(input1.device());   // (ROCm torch presents its devices as "cuda")
   const int B = input1.size(0), C = input1.size(1), iH = input1.size(2), iW = input1.size(3);
   const int oH = (iH + 2 * padH - ((kH - 1) * dilationH + 1)) / dH + 1, oW = (iW + 2 * padW - ((kW - 1) * dilationW + 1)) / dW + 1;
   auto out = torch::empty({B, patchH, patchW, oH, oW}, input1.options());
-  void* st = (void*)c10::hip::getCurrentHIPStream(input1.device().index()).stream();
+  void* st = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(input1.device().index()).stream();
   if (input1.scalar_type() == torch::kFloat32)
     check_rc(rfn_corr_fwd_f32(input1.data_ptr<float>(), input2.data_ptr<float>(), out.data_ptr<float>(), B, C, iH, iW, kH, kW,
                               patchH, patchW, padH, padW, dilationH, dilationW, dilation_patchH, dilation_patchW, dH, dW, st),
@@ -54,11 +54,11 @@ std::vector<torch::Tensor> correlation_sample_backward(torch::Tensor input1, tor
   check_inputs(input1, input2, "correlation.backward");
   TORCH_CHECK(grad_output.device() == input1.device() && grad_output.scalar_type() == input1.scalar_type(),
               "correlation.backward: grad_output device / dtype");
-  const c10::hip::HIPGuard guard(input1.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(input1.device());   // (ROCm torch presents its devices as "cuda")
   auto go = grad_output.contiguous();
   const int B = input1.size(0), C = input1.size(1), iH = input1.size(2), iW = input1.size(3);
   auto g1 = torch::zeros_like(input1), g2 = torch::zeros_like(input2);
-  void* st = (void*)c10::hip::getCurrentHIPStream(input1.device().index()).stream();
+  void* st = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(input1.device().index()).stream();
   if (input1.scalar_type() == torch::kFloat32)
     check_rc(rfn_corr_bwd_f32(input1.data_ptr<float>(), input2.data_ptr<float>(), go.data_ptr<float>(), g1.data_ptr<float>(),
                               g2.data_ptr<float>(), B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilationH, dilationW,
