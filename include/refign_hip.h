@@ -180,6 +180,26 @@ int rfn_dwconv3x3_nhwc_stats(const void* x, const float* weight, const float* bi
 int rfn_dwconv3x3_bn_act_nhwc_fwd(const void* x, const float* weight, const float* bias, const float* gamma, const float* beta,
                                   const double* sums, float* running_mean, float* running_var, void* y, int B, int H, int W,
                                   int C, int dilation, float eps, float momentum, int relu, int dtype, rfn_stream_t stream);
+
+/* Three dilated depthwise 3x3 branches (dilations g, 2 g, 3 g; padding = dilation) of ONE bf16 NHWC input, one pass each
+ * (round 4; the EMA teacher's ASPP, daformer.py:46-62,65-126: dilations 6 / 12 / 18 of the concatenated 1024-channel map).  A
+ * workgroup holds one g x g phase sub-image of one image for 64 channels in LDS and computes the three branches from it: every
+ * input byte is read once per pass instead of 4.5 times per branch.
+ *   rfn_dwconv3x3_tri_usable      1 if (B, H, W, C, g) is inside the kernel's domain: C % 64 == 0, g <= min(H, W),
+ *                                 ceil(H / g) ceil(W / g) <= 944 pixels per phase
+ *   rfn_dwconv3x3_tri_stats       sums3 [3][2 C + 1] doubles <- (sum, sum of squares, rows) of the three ROUNDED results (the
+ *                                 buffers of rfn_bn_stats_fwd, zeroed here); nothing stored
+ *   rfn_dwconv3x3_tri_bn_act_fwd  y3[k] = act(bn_k(conv_k(x))) with batch statistics sums3; running buffers updated as
+ *                                 rfn_bn_apply_fwd does.  weight3 [3][9][C] tap-major fp32, bias3 [3][C] or NULL; gamma3 / beta3 /
+ *                                 running_mean3 / running_var3 / y3 / eps3 / momentum3: HOST arrays of 3 (entries of the first four
+ *                                 may be NULL), read at call time. */
+int rfn_dwconv3x3_tri_usable(int B, int H, int W, int C, int g);
+int rfn_dwconv3x3_tri_stats(const void* x, const float* weight3, const float* bias3, double* sums3, int B, int H, int W, int C, int g,
+                            rfn_stream_t stream);
+int rfn_dwconv3x3_tri_bn_act_fwd(const void* x, const float* weight3, const float* bias3, const float* const* gamma3,
+                                 const float* const* beta3, const double* sums3, float* const* running_mean3,
+                                 float* const* running_var3, void* const* y3, int B, int H, int W, int C, int g, const float* eps3,
+                                 const float* momentum3, int relu, rfn_stream_t stream);
 /* The same convolution (dilation 1) followed by GELU (exact erf) -- the DWConv + act of the Mix-FFN
  * (mix_transformer.py:99-101) in one pass: y_act = gelu(conv(x) + bias); y_pre (may be NULL) = the pre-activation,
  * which the backward of GELU needs and a gradient-free pass does not. */

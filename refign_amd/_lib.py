@@ -40,6 +40,9 @@ SIGNATURES = {
     "rfn_refine_f32": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_int, c_void_p]),
     "rfn_align_tail_f32": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "rfn_dwconv3x3_nhwc_stats": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "rfn_dwconv3x3_tri_usable": (c_int, [c_int] * 5),
+    "rfn_dwconv3x3_tri_stats": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "rfn_dwconv3x3_tri_bn_act_fwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rfn_dwconv3x3_bn_act_nhwc_fwd": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float, c_int, c_int, c_void_p]),
     "rfn_dwconv3x3_nhwc_fwd_stats": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "rfn_dwconv3x3_nhwc_fwd": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),

@@ -578,11 +578,250 @@ static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db
   return check_launch("dwconv3x3_bwd_weight_reduce_kernel");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Three dilated depthwise branches of ONE input in one pass -- the EMA teacher's ASPP (daformer.py:46-62,65-126: dilations
+// 6 / 12 / 18 on the 40 x 135 x 240 x 1024 concatenated feature map; round 3 read that 2.65 GB map six times: three statistics
+// passes and three convolution + BatchNorm + ReLU passes, each bound by L2 -> CU traffic: 4.5 loads per output, nothing of a
+// dilated window is shared through L1).  Dilations g, 2g, 3g are plain / 2- / 3-dilated 3x3 convolutions of the g x g PHASE
+// sub-images (pixels (py + g i, px + g j)): a workgroup takes one phase of one image for 32 channels -- at most 23 x 40 pixels
+// x 64 bytes -- into LDS ONCE (every input byte is read from L2 / HBM exactly once) and computes all three branches from there:
+// statistics pass (sum, sum of squares of the rounded results of the three branches, nothing stored) and apply pass (convolution
+// + BatchNorm(batch statistics) + ReLU, three outputs).  76 KB of LDS: TWO workgroups per CU, one loading while the other
+// computes (the first version -- 64 channels, 151 KB, one workgroup of 4 waves per CU -- was latency-bound end to end: 47 us per
+// workgroup, slower than six single-branch passes).  The two 32-channel halves of a 64-channel group are taken by workgroups
+// that the dispatcher places on the SAME XCD 8 blocks apart, so that the 128-byte lines they share cross the fabric once.
+// LDS pixel pitch 80 bytes: the 16 lanes of a ds_read_b128 group (4 channel vectors x 4 quads, 4 pixels apart) cover all banks.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTriPitch = 80, kTriMaxPix = 944, kTriScratch = 4 * 4 * 16 * 4;
+
+struct TriArgs {
+  const float* w;            // [3][9][C] tap-major fp32
+  const float* bias;         // [3][C] or null
+  double* sums;              // [3][2 C + 1]
+  const float* gamma[3];     // apply pass (may be null)
+  const float* beta[3];
+  float* running_mean[3];    // may be null
+  float* running_var[3];
+  float eps[3], momentum[3];
+  __hip_bfloat16* y[3];
+  int relu, ablate;
+};
+
+template <int M, int MODE>
+__device__ __forceinline__ void tri_branch(const unsigned char* __restrict__ img, float* __restrict__ scratch, const TriArgs& a,
+                                           int b, int B, int H, int W, int C, int g, int py, int px, int Hs, int Ws, int c0, int cv,
+                                           int pl, bool first_block, bool stat_block) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int k = M - 1;
+  const int c = c0 + cv * 8;
+  f2 wr[9][4], bs[4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* wp = a.w + ((size_t)k * 9 + t) * C + c;
+    const float4 lo = *reinterpret_cast<const float4*>(wp), hi = *reinterpret_cast<const float4*>(wp + 4);
+    wr[t][0] = f2{lo.x, lo.y}; wr[t][1] = f2{lo.z, lo.w}; wr[t][2] = f2{hi.x, hi.y}; wr[t][3] = f2{hi.z, hi.w};
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    bs[i] = a.bias != nullptr ? f2{a.bias[(size_t)k * C + c + 2 * i], a.bias[(size_t)k * C + c + 2 * i + 1]} : f2{0.f, 0.f};
+  float bsc[8], bsh[8], st0[8], st1[8];
+  if constexpr (MODE == 1) {
+    const double* sm = a.sums + (size_t)k * (2 * C + 1);
+    const double cnt = sm[2 * C], inv = 1.0 / cnt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double m = sm[c + i] * inv;
+      const float var = (float)fmax(sm[C + c + i] * inv - m * m, 0.0), mean = (float)m;
+      const float ga = a.gamma[k] != nullptr ? a.gamma[k][c + i] : 1.f, be = a.beta[k] != nullptr ? a.beta[k][c + i] : 0.f;
+      bsc[i] = rsqrtf(var + a.eps[k]) * ga;
+      bsh[i] = be - mean * bsc[i];
+      if (stat_block && pl == 0 && a.running_mean[k] != nullptr) {
+        const float n = (float)cnt;
+        a.running_mean[k][c + i] = (1.f - a.momentum[k]) * a.running_mean[k][c + i] + a.momentum[k] * mean;
+        a.running_var[k][c + i] = (1.f - a.momentum[k]) * a.running_var[k][c + i] + a.momentum[k] * var * (n / fmaxf(n - 1.f, 1.f));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st0[i] = st1[i] = 0.f;
+  }
+  const int QW = (Ws + 3) >> 2, nq = Hs * QW;
+  for (int q = pl; q < nq; q += 64) {
+    const int ys = q / QW, x0 = 4 * (q - ys * QW);
+    f2 acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[p][i] = bs[i];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = ys + (ky - 1) * M;
+      const bool rowok = yy >= 0 && yy < Hs;
+      const unsigned char* rowp = img + (size_t)min(max(yy, 0), Hs - 1) * Ws * kTriPitch + cv * 16;
+#pragma unroll
+      for (int o = 0; o < 4 + 2 * M; ++o) {
+        const int xx = x0 - M + o;
+        uint4 raw = *reinterpret_cast<const uint4*>(rowp + min(max(xx, 0), Ws - 1) * kTriPitch);
+        if (!(rowok && xx >= 0 && xx < Ws)) raw = make_uint4(0u, 0u, 0u, 0u);
+        f2 v[4];
+        VecIO<__hip_bfloat16>::unpack2(raw, v);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int d = o - p;                           // column offset of this load relative to output p, + M
+          if (d != 0 && d != M && d != 2 * M) continue;
+          const int kx = d / M;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[p][i] = __builtin_elementwise_fma(wr[ky * 3 + kx][i], v[i], acc[p][i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (x0 + p >= Ws) continue;
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // the unfused path stores the convolution result in bf16 before the statistics / BatchNorm read it back
+        o[2 * i] = __uint_as_float(bf16_bits(acc[p][i].x) << 16);
+        o[2 * i + 1] = __uint_as_float(bf16_bits(acc[p][i].y) << 16);
+      }
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          st0[i] += o[i];
+          st1[i] = fmaf(o[i], o[i], st1[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float z = fmaf(o[i], bsc[i], bsh[i]);
+          o[i] = (a.relu && z <= 0.f) ? 0.f : z;
+        }
+        VecIO<__hip_bfloat16>::store(a.y[k] + (((size_t)b * H + py + g * ys) * W + px + g * (x0 + p)) * C + c, o);
+      }
+    }
+  }
+  if constexpr (MODE == 0) {
+    // lanes cv + 4 j of a wave hold partial sums of the same 8 channels: fold j, then the four waves through LDS
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int sft = 4; sft < 64; sft <<= 1) {
+        st0[i] += __shfl_xor(st0[i], sft, 64);
+        st1[i] += __shfl_xor(st1[i], sft, 64);
+      }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        scratch[(wave * 4 + lane) * 16 + i] = st0[i];
+        scratch[(wave * 4 + lane) * 16 + 8 + i] = st1[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int v = threadIdx.x >> 4, e = threadIdx.x & 15;
+      const float sum = scratch[(0 * 4 + v) * 16 + e] + scratch[(1 * 4 + v) * 16 + e] + scratch[(2 * 4 + v) * 16 + e] +
+                        scratch[(3 * 4 + v) * 16 + e];
+      atomicAdd(a.sums + (size_t)k * (2 * C + 1) + (e >> 3) * C + c0 + v * 8 + (e & 7), (double)sum);
+    }
+    if (first_block && threadIdx.x == 0) atomicAdd(a.sums + (size_t)k * (2 * C + 1) + 2 * C, (double)B * H * W);
+    __syncthreads();
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_tri_kernel(const __hip_bfloat16* __restrict__ x, TriArgs a, int B, int H, int W,
+                                                               int C, int g, int nitems) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kTriMaxPix * kTriPitch + kTriScratch];
+  // block L runs on XCD L % 8 (the dispatcher's round-robin; speed only): the two halves of item i are blocks 8 apart on one XCD
+  const int L = blockIdx.x, local = L >> 3, half = local & 1, item = (local >> 1) * 8 + (L & 7);
+  if (item >= nitems) return;
+  const int gg = g * g, phase = item % gg, rest = item / gg, n64 = C / 64, b = rest / n64, c0 = (rest % n64) * 64 + half * 32;
+  const int py = phase / g, px = phase % g;
+  const int Hs = (H - py + g - 1) / g, Ws = (W - px + g - 1) / g;
+  const int cv = threadIdx.x & 3, pl = threadIdx.x >> 2;
+  const __hip_bfloat16* xb = x + (size_t)b * H * W * C + c0 + cv * 8;
+  const int npix = Hs * Ws;
+  // all of the thread's loads first (up to 15 in flight), then the LDS writes
+  constexpr int NL = (kTriMaxPix + 63) / 64;
+  uint4 v[NL];
+#pragma unroll
+  for (int it = 0; it < NL; ++it) {
+    const int p = min(pl + 64 * it, npix - 1), ys = p / Ws, xs = p - ys * Ws;
+    v[it] = (a.ablate & 1) ? uint4{0, 0, 0, 0} : *reinterpret_cast<const uint4*>(xb + ((size_t)(py + g * ys) * W + (px + g * xs)) * C);
+  }
+#pragma unroll
+  for (int it = 0; it < NL; ++it) {
+    const int p = pl + 64 * it;
+    if (p < npix) *reinterpret_cast<uint4*>(lds + (size_t)p * kTriPitch + cv * 16) = v[it];
+  }
+  __syncthreads();
+  float* scratch = reinterpret_cast<float*>(lds + kTriMaxPix * kTriPitch);
+  const bool first_block = item == 0 && half == 0, stat_block = phase == 0 && b == 0;
+  if (a.ablate & 2) return;
+  tri_branch<1, MODE>(lds, scratch, a, b, B, H, W, C, g, py, px, Hs, Ws, c0, cv, pl, first_block, stat_block);
+  if (a.ablate & 4) return;
+  tri_branch<2, MODE>(lds, scratch, a, b, B, H, W, C, g, py, px, Hs, Ws, c0, cv, pl, first_block, stat_block);
+  tri_branch<3, MODE>(lds, scratch, a, b, B, H, W, C, g, py, px, Hs, Ws, c0, cv, pl, first_block, stat_block);
+}
+
+static int tri_domain(int B, int H, int W, int C, int g) {
+  return B > 0 && g >= 1 && g <= H && g <= W && C % 64 == 0 && cdiv(H, g) * cdiv(W, g) <= kTriMaxPix &&
+         (long)g * g * (C / 64) * B < (1L << 26);
+}
+
 }  // namespace rfn
 
 using namespace rfn;
 
 extern "C" {
+// Three dilated depthwise 3x3 branches (dilations g, 2 g, 3 g; padding = dilation) of one bf16 NHWC input in ONE pass each:
+//   rfn_dwconv3x3_tri_stats        sums3 [3][2 C + 1] doubles <- (sum, sum of squares, rows) of the three rounded results;
+//   rfn_dwconv3x3_tri_bn_act_fwd   y[k] = act(bn_k(conv_k(x))) with the statistics in sums3 (a SyncBatchNorm all-reduces them in
+//                                  between).  weight3: [3][9][C] tap-major fp32, bias3: [3][C] or NULL; gamma / beta / running_mean /
+//                                  running_var / y / eps / momentum: HOST arrays of 3.  C % 64 == 0, ceil(H / g) ceil(W / g) <= 944.
+// rfn_dwconv3x3_tri_usable: 1 when a shape is inside that domain.
+int rfn_dwconv3x3_tri_usable(int B, int H, int W, int C, int g) { return tri_domain(B, H, W, C, g); }
+
+int rfn_dwconv3x3_tri_stats(const void* x, const float* weight3, const float* bias3, double* sums3, int B, int H, int W, int C, int g,
+                            rfn_stream_t stream) {
+  RFN_REQUIRE(x && weight3 && sums3, "rfn_dwconv3x3_tri_stats: null pointer");
+  RFN_REQUIRE(tri_domain(B, H, W, C, g), "rfn_dwconv3x3_tri_stats: B=%d H=%d W=%d C=%d g=%d outside the kernel's domain", B, H, W, C, g);
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = zero_async(sums3, 3 * (2 * (size_t)C + 1) * sizeof(double), st)) return rc;
+  TriArgs a{};
+  a.w = weight3, a.bias = bias3, a.sums = sums3;
+  a.ablate = getenv("RFN_TRI_ABLATE") ? atoi(getenv("RFN_TRI_ABLATE")) : 0;
+  const long nitems = (long)g * g * (C / 64) * B;
+  hipLaunchKernelGGL((dwconv3x3_tri_kernel<0>), dim3((unsigned)(16 * cdiv(nitems, 8))), dim3(256), 0, st, (const __hip_bfloat16*)x, a,
+                     B, H, W, C, g, (int)nitems);
+  return check_launch("dwconv3x3_tri_kernel<stats>");
+}
+
+int rfn_dwconv3x3_tri_bn_act_fwd(const void* x, const float* weight3, const float* bias3, const float* const* gamma3,
+                                 const float* const* beta3, const double* sums3, float* const* running_mean3,
+                                 float* const* running_var3, void* const* y3, int B, int H, int W, int C, int g, const float* eps3,
+                                 const float* momentum3, int relu, rfn_stream_t stream) {
+  RFN_REQUIRE(x && weight3 && sums3 && y3 && gamma3 && beta3 && running_mean3 && running_var3 && eps3 && momentum3,
+              "rfn_dwconv3x3_tri_bn_act_fwd: null pointer");
+  RFN_REQUIRE(tri_domain(B, H, W, C, g), "rfn_dwconv3x3_tri_bn_act_fwd: B=%d H=%d W=%d C=%d g=%d outside the kernel's domain", B, H, W, C, g);
+  TriArgs a{};
+  a.w = weight3, a.bias = bias3, a.sums = const_cast<double*>(sums3), a.relu = relu;
+  a.ablate = getenv("RFN_TRI_ABLATE") ? atoi(getenv("RFN_TRI_ABLATE")) : 0;
+  for (int k = 0; k < 3; ++k) {
+    RFN_REQUIRE(y3[k], "rfn_dwconv3x3_tri_bn_act_fwd: null output %d", k);
+    a.gamma[k] = gamma3[k], a.beta[k] = beta3[k], a.running_mean[k] = running_mean3[k], a.running_var[k] = running_var3[k];
+    a.eps[k] = eps3[k], a.momentum[k] = momentum3[k], a.y[k] = (__hip_bfloat16*)y3[k];
+  }
+  const long nitems = (long)g * g * (C / 64) * B;
+  hipLaunchKernelGGL((dwconv3x3_tri_kernel<1>), dim3((unsigned)(16 * cdiv(nitems, 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const __hip_bfloat16*)x, a, B, H, W, C, g, (int)nitems);
+  return check_launch("dwconv3x3_tri_kernel<apply>");
+}
+
 
 int rfn_dwconv3x3_nhwc_fwd(const void* x, const float* weight, const float* bias, void* y, int B, int H, int W, int C,
                            int dilation, int dtype, int flip, rfn_stream_t stream) {

@@ -188,6 +188,65 @@ def dwconv3x3_bn_act_nhwc(x, weight, bias, dilation, bn, relu):
     return y
 
 
+def tri_usable(x, convs, bns):
+    """the three (conv, bn) pairs are depthwise 3x3 with dilations g, 2 g, 3 g and padding = dilation on a shape the one-pass
+    kernel takes (csrc/dwconv.hip dwconv3x3_tri_kernel)"""
+    if len(convs) != 3 or not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    B, H, W, C = x.shape
+    d = [c.dilation[0] for c in convs]
+    ok = all(c.groups == c.in_channels == c.out_channels == C and c.kernel_size == (3, 3) and c.stride == (1, 1)
+             and c.padding == c.dilation and c.dilation[0] == c.dilation[1] for c in convs)
+    ok = ok and d[1] == 2 * d[0] and d[2] == 3 * d[0] and all(b.momentum is not None for b in bns)
+    same_bias = all((c.bias is None) == (convs[0].bias is None) for c in convs)
+    return bool(ok and same_bias and _lib.load_library().rfn_dwconv3x3_tri_usable(B, H, W, C, d[0]))
+
+
+@torch.no_grad()
+def dwconv3x3_bn_act_nhwc_tri(x, convs, bns, relu):
+    """[act(bn_k(dwconv3x3_k(x))) for k in 0..2] with BATCH statistics, gradient-free, for three depthwise branches of dilations
+    g, 2 g, 3 g of one input (the EMA teacher's ASPP): TWO passes over x in all -- statistics of the three results, then the
+    three convolutions + normalisation + ReLU -- where dwconv3x3_bn_act_nhwc makes six."""
+    import ctypes
+    from . import bn as bnk
+    B, H, W, C = x.shape
+    g = convs[0].dilation[0]
+    w3 = torch.stack([derived(c.weight, "tap_major_f32", lambda t: t.float().reshape(C, 9).t().contiguous(),
+                              lambda t: t.reshape(C, 9).t()) for c in convs]).contiguous()
+    b3 = None if convs[0].bias is None else torch.stack([as_dtype(c.bias, torch.float32).detach() for c in convs]).contiguous()
+    sums = torch.empty((3, 2 * C + 1), dtype=torch.float64, device=x.device)
+    lib = _lib.load_library()
+    with on_device(x.device):
+        rc = lib.rfn_dwconv3x3_tri_stats(ptr(x), ptr(w3), ptr(b3), ptr(sums), B, H, W, C, int(g), current_stream(x.device))
+    _lib.check(rc, "dwconv3x3_tri_stats")
+    for k, bn in enumerate(bns):
+        group = bnk.sync_group(bn)
+        if group is not None:
+            bnk._all_reduce(sums[k], group, bnk._exchange_comm(bn))
+    ys = [torch.empty_like(x) for _ in range(3)]
+    keep = []                                              # fp32 views of the affine parameters stay alive until the launch
+
+    def f32(t):
+        if t is None:
+            return None
+        keep.append(as_dtype(t, torch.float32).detach().contiguous())
+        return keep[-1]
+
+    arr = lambda ts: (ctypes.c_void_p * 3)(*[ptr(t) for t in ts])  # noqa: E731
+    ga, be = arr([f32(b.weight) for b in bns]), arr([f32(b.bias) for b in bns])
+    rm, rv = arr([b.running_mean for b in bns]), arr([b.running_var for b in bns])
+    yp = arr(ys)
+    eps = (ctypes.c_float * 3)(*[float(b.eps) for b in bns])
+    mom = (ctypes.c_float * 3)(*[float(b.momentum) for b in bns])
+    with on_device(x.device):
+        rc = lib.rfn_dwconv3x3_tri_bn_act_fwd(ptr(x), ptr(w3), ptr(b3), ga, be, ptr(sums), rm, rv, yp, B, H, W, C, int(g), eps, mom,
+                                              1 if relu else 0, current_stream(x.device))
+    _lib.check(rc, "dwconv3x3_tri_bn_act_fwd")
+    for b in bns:
+        b.num_batches_tracked.add_(1)
+    return ys
+
+
 def dwconv3x3_tokens(x, weight, bias, H, W):
     """x: (B, N=H*W, C) tokens -> (B, N, C)."""
     B, N, C = x.shape

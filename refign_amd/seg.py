@@ -461,6 +461,11 @@ class DepthwiseSeparableASPPModule(nn.ModuleList):
 
 
 _ASPP_NOCAT = os.environ.get("RFN_ASPP_NOCAT", "1") != "0"
+# the three dilated branches from ONE LDS-resident copy of the input (csrc/dwconv.hip: dwconv3x3_tri_kernel): correct, every
+# input byte fetched once at HBM speed (0.53 ms for the teacher's 2.65 GB), but the passes are VALU-bound (bf16 -> fp32
+# conversions + packed FMAs + zero-padding selects: 2.9 ms of 3.3), so it measures 8.6 ms against 8.1 ms for six single-branch
+# passes (profiles/r04_aspp_try.txt): kept, tested, OFF by default
+_ASPP_TRI = os.environ.get("RFN_ASPP_TRI", "0") != "0"
 
 
 class ASPPWrapper(nn.Module):
@@ -490,9 +495,27 @@ class ASPPWrapper(nn.Module):
             ch = [(m.pointwise_conv if m.depthwise_separable else m).conv.out_channels for m in mods]
             if all(c % 8 == 0 for c in ch):
                 cat = torch.empty((B, H, W, sum(ch)), dtype=compute_dtype(x), device=x.device)
+                # round 4: the three dilated depthwise branches (6 / 12 / 18 = g, 2 g, 3 g) of the same input from ONE statistics
+                # pass and ONE convolution + BatchNorm + ReLU pass over it (csrc/dwconv.hip dwconv3x3_tri_kernel) instead of
+                # three of each; RFN_ASPP_TRI=0: branch by branch
+                dw_out = {}
+                sep = [m for m in mods if m.depthwise_separable]
+                if _ASPP_TRI and len(sep) == 3 and compute_dtype(x) == torch.bfloat16:
+                    from .dwconv import dwconv3x3_bn_act_nhwc_tri, tri_usable
+                    dws = [m.depthwise_conv for m in sep]
+                    xh = x.permute(0, 2, 3, 1)
+                    if xh.dtype == torch.bfloat16 and xh.is_contiguous() and all(d.use_norm and d.training and d.act in (None, 'relu')
+                                                                                 and d.act == dws[0].act for d in dws) \
+                            and tri_usable(xh, [d.conv for d in dws], [d.bn for d in dws]):
+                        ys = dwconv3x3_bn_act_nhwc_tri(xh, [d.conv for d in dws], [d.bn for d in dws], dws[0].act == 'relu')
+                        dw_out = {id(m): y.permute(0, 3, 1, 2) for m, y in zip(sep, ys)}
                 o = 0
                 for m, c in zip(mods, ch):
-                    m(x, out=cat[..., o:o + c].permute(0, 3, 1, 2))
+                    out = cat[..., o:o + c].permute(0, 3, 1, 2)
+                    if id(m) in dw_out:
+                        m.pointwise_conv(dw_out[id(m)], out=out)
+                    else:
+                        m(x, out=out)
                     o += c
                 return self.bottleneck(cat.permute(0, 3, 1, 2))
         return self.bottleneck(torch.cat(self.aspp_modules(x), dim=1))

@@ -122,3 +122,45 @@ def test_gradient_free_dwconv_batchnorm_relu_in_two_input_passes(dev, B, H, W, C
     assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-6, atol=1e-7)
     assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-6, atol=1e-7)
     assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("B,H,W,C,g,relu,bias", [(2, 135, 240, 128, 6, True, True), (3, 37, 53, 64, 2, True, False),
+                                                   (2, 20, 28, 1024, 6, False, True), (1, 7, 9, 64, 1, True, True)])
+def test_three_dilations_of_one_input_in_two_passes(dev, B, H, W, C, g, relu, bias):
+    """dwconv3x3_bn_act_nhwc_tri (dilations g, 2 g, 3 g of one input: ONE statistics pass + ONE convolution + BatchNorm + ReLU
+    pass, each workgroup computing the three branches from a phase sub-image held in LDS) == three calls of the two-pass
+    single-branch path (dwconv3x3_bn_act_nhwc, itself pinned to depthwise kernel -> bn.hip above): results, running buffers,
+    batch counters.  Ragged phase sub-images (135 = 22 x 6 + 3, 37 x 53 with g = 2), images smaller than the largest dilation
+    (7 x 9 with dilation 3: every off-centre tap of that branch is padding), the teacher's map size."""
+    import copy
+    import types
+    from refign_amd.dwconv import dwconv3x3_bn_act_nhwc, dwconv3x3_bn_act_nhwc_tri, tri_usable
+    gen = torch.Generator().manual_seed(C + H + g)
+    x = (torch.randn(B, H, W, C, generator=gen) + 0.2).to(dev).to(torch.bfloat16)
+    convs, bns_a = [], []
+    for k in range(3):
+        d = g * (k + 1)
+        conv = torch.nn.Conv2d(C, C, 3, padding=d, dilation=d, groups=C, bias=bias).to(dev)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(C, 1, 3, 3, generator=gen).to(dev))
+            if bias:
+                conv.bias.copy_(torch.randn(C, generator=gen).to(dev))
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=gen).to(dev) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=gen).to(dev))
+        convs.append(conv)
+        bns_a.append(bn)
+    bns_b = copy.deepcopy(bns_a)
+    assert tri_usable(x, convs, bns_a)
+    assert not tri_usable(x, [convs[0], convs[0], convs[2]], bns_a)                  # dilations must be g, 2 g, 3 g
+    with torch.no_grad():
+        got = dwconv3x3_bn_act_nhwc_tri(x, convs, bns_a, relu)
+        want = [dwconv3x3_bn_act_nhwc(x, c.weight, c.bias, c.dilation[0], b, relu) for c, b in zip(convs, bns_b)]
+    for k in range(3):
+        err = (got[k].float() - want[k].float()).abs()
+        assert float(err.max()) <= 2.0 ** -7 * float(want[k].float().abs().max()), k   # at most a rounding step apart ...
+        assert float((err > 0).float().mean()) < 1e-3, k                               # ... and almost everywhere equal
+        assert torch.allclose(bns_a[k].running_mean, bns_b[k].running_mean, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(bns_a[k].running_var, bns_b[k].running_var, rtol=1e-6, atol=1e-7)
+        assert int(bns_a[k].num_batches_tracked) == 1

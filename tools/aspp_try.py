@@ -66,7 +66,27 @@ def per_image(n):
     return f
 
 
+def tri():
+    import ctypes
+    w3 = torch.stack(w).contiguous(); b3 = torch.stack(b).contiguous()
+    s3 = torch.zeros(3, 2 * C + 1, dtype=torch.float64, device=dev)
+    rc = lib.rfn_dwconv3x3_tri_stats(ptr(x), ptr(w3), ptr(b3), ptr(s3), B, H, W, C, 6, current_stream(dev)); assert rc == 0
+    arr = lambda ts: (ctypes.c_void_p * 3)(*[ptr(t) for t in ts])
+    rc = lib.rfn_dwconv3x3_tri_bn_act_fwd(ptr(x), ptr(w3), ptr(b3), arr([gam] * 3), arr([bet] * 3), ptr(s3), arr([None] * 3), arr([None] * 3),
+                                          arr(ys), B, H, W, C, 6, (ctypes.c_float * 3)(1e-5, 1e-5, 1e-5), (ctypes.c_float * 3)(0.1, 0.1, 0.1), 1,
+                                          current_stream(dev)); assert rc == 0
+
+
+def tri_stats():
+    w3 = torch.stack(w).contiguous(); b3 = torch.stack(b).contiguous()
+    s3 = torch.zeros(3, 2 * C + 1, dtype=torch.float64, device=dev)
+    rc = lib.rfn_dwconv3x3_tri_stats(ptr(x), ptr(w3), ptr(b3), ptr(s3), B, H, W, C, 6, current_stream(dev)); assert rc == 0
+
+
 with on_device(dev):
+    print(f"three dilations in one pass each (tri kernel): {timeit(tri):.3f} ms  (stats only: {timeit(tri_stats):.3f} ms)")
+    if os.environ.get("RFN_TRI_ONLY"):
+        sys.exit(0)
     print(f"whole batch, dilation after dilation: {timeit(whole):.3f} ms  (stats only: {timeit(lambda: [stats(x, k) for k in range(3)]):.3f} ms)")
     for n in (1, 2, 4, 8):
         print(f"{n} image(s) at a time, three dilations each: {timeit(per_image(n)):.3f} ms")
