@@ -422,7 +422,16 @@ def _ddp_guard(rank, world, progress):
         if rank == 0:
             print(f"bench.py: {DDP_STALL_MARKER} exists (an earlier multi-rank run stalled on this box): exchanges through "
                   f"torch.distributed, eager student passes", file=sys.stderr, flush=True)
-    limit = float(os.environ.get("RFN_BENCH_STALL_S", "900"))
+    # Second chance (under torchrun, whose agent keeps the rendezvous store alive): the FIRST stall of a configuration that is
+    # not already the conservative one re-executes this rank -- every rank is stuck in the same collective, so every rank's
+    # guard fires -- with every exchange through torch.distributed and eager student passes (the configuration closest to
+    # what torch's own DDP + SyncBatchNorm do), rendezvousing under a fresh store prefix.  The process id stays the same, so
+    # torchrun sees one worker that took longer.  RFN_BENCH_RETRY=0: give up at once (exit 17) as before.
+    attempt = int(os.environ.get("RFN_BENCH_ATTEMPT", "1"))
+    conservative = os.environ.get("RFN_RCCL_DIRECT", "1") == "0" and os.environ.get("RFN_GRAPH_DDP", "1") == "0"
+    can_retry = attempt == 1 and not conservative and os.environ.get("RFN_BENCH_RETRY", "1") != "0" and \
+        os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    limit = float(os.environ.get("RFN_BENCH_STALL_S", "300" if can_retry else "900"))
 
     def watch():
         while True:
@@ -438,6 +447,13 @@ def _ddp_guard(rank, world, progress):
                             f.write(f"rank {rank}/{world} stalled after {progress[1]} ({conf})\n")
                     except OSError:
                         pass
+                if can_retry:
+                    print(f"bench.py rank {rank}/{world}: second attempt, conservative configuration (RFN_RCCL_DIRECT=0 "
+                          f"RFN_GRAPH_DDP=0 RFN_DDP_DIRECT_REDUCE=0)", file=sys.stderr, flush=True)
+                    os.environ.update(RFN_RCCL_DIRECT="0", RFN_GRAPH_DDP="0", RFN_DDP_DIRECT_REDUCE="0", RFN_BENCH_ATTEMPT="2")
+                    os.environ.pop("RFN_BENCH_FAKE_STALL", None)
+                    sys.stdout.flush()
+                    os.execv(sys.executable, [sys.executable] + sys.argv)
                 os._exit(17)
 
     threading.Thread(target=watch, daemon=True, name="bench-stall-guard").start()
@@ -464,9 +480,14 @@ def main():
     if world > 1 or "RANK" in os.environ:     # under torchrun always go through RCCL, also for a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world > 1:
+        if world > 1 or os.environ.get("RFN_BENCH_FAKE_STALL"):
             _ddp_guard(rank, world, progress)
-        if os.environ.get("RFN_BENCH_LAZY_PG", "0") == "1":       # experiment: communicator created at the first collective
+        attempt = int(os.environ.get("RFN_BENCH_ATTEMPT", "1"))
+        if attempt > 1:                        # re-executed by the guard: the agent's store still holds the first attempt's keys
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=False)
+            dist.init_process_group("nccl", store=dist.PrefixStore(f"attempt{attempt}", store), rank=rank, world_size=world,
+                                    device_id=dev)
+        elif os.environ.get("RFN_BENCH_LAZY_PG", "0") == "1":     # experiment: communicator created at the first collective
             dist.init_process_group("nccl")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -493,6 +514,8 @@ def main():
         if world > 1:                                  # (N > 1 only: keeps the guard's clock honest, off the N=1 path)
             torch.cuda.synchronize()
         tick(f"prime step {i}")
+        while os.environ.get("RFN_BENCH_FAKE_STALL"):  # (test of the guard: pretend the next collective never returns)
+            time.sleep(1.0)
     for i in range(args.warmup):
         wl.step()
         if world > 1:
@@ -589,6 +612,17 @@ def main():
                                       f"gradient all-reduce per step over RCCL"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if world > 1 or "RANK" in os.environ:
+            tr = getattr(wl, "trainer", None)
+            gb = getattr(tr, "grads", None)
+            line["config"]["data_parallel"] = {
+                "attempt": int(os.environ.get("RFN_BENCH_ATTEMPT", "1")),
+                "statistics_exchanges": "RCCL calls of our own on the pass's stream" if os.environ.get("RFN_RCCL_DIRECT", "1") != "0"
+                                        else "torch.distributed",
+                "gradient_reduce": ("own communicator + stream, released ranges inside the last backward pass"
+                                    if gb is not None and gb._comm is not None else "torch.distributed buckets"),
+                "reduced_inside_last_backward": (round(getattr(gb, "overlapped_elements", 0) / gb.flat.numel(), 3)
+                                                 if gb is not None else None)}
         from refign_amd import mfma as _mfma
         # dense ops that ended up in a ROCm library (hipBLASLt / MIOpen / fused SDPA) instead of a hand-written kernel,
         # by call site and dtype, over the whole run (refign_amd/mfma.py: note_library)

@@ -140,14 +140,17 @@ class GraphedStep:
     The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
     throws leaves the pass eager for good, like GraphedNoGrad."""
 
-    def __init__(self, fn, name, warmup=2, shared=None, capture_context=None):
+    def __init__(self, fn, name, warmup=2, shared=None, capture_context=None, after_capture=None, on_replay=None):
         """`shared`: a dict the passes of ONE model share -- they are never live at the same time, so their graphs
         capture into one memory pool (held there; it dies with the model's graphs, never outlives them).  A pass that
         may run NEXT TO another one gets a pool of its own (shared=None).
         `capture_context`: callable returning a context manager the capture runs inside (e.g. the gradient buffer the
-        captured backward kernels are to accumulate into)."""
+        captured backward kernels are to accumulate into).
+        `after_capture()` -> anything, kept with the graph; `on_replay(that)` is called after every replay of it (the ranges of
+        the gradient buffer whose all-reduce is part of the graph: trainer.FlatGradBuffer.end_capture / replayed)."""
         self.fn, self.name, self.warmup = fn, name, warmup
         self.capture_context = capture_context
+        self.after_capture, self.on_replay = after_capture, on_replay
         self._last = None
         self.shared = {} if shared is None else shared
         self.generation = 0
@@ -205,6 +208,8 @@ class GraphedStep:
             if s.data_ptr() != t.data_ptr():
                 s.copy_(t)
         st["graph"].replay()
+        if self.on_replay is not None:
+            self.on_replay(st.get("extra"))
         # copies, not the pool tensors themselves: the passes of a model share one pool and are not always replayed in the
         # order they were captured in (a second input signature of the source pass is captured AFTER the mixed pass and
         # replayed before it) -- a later replay of the other pass may then reuse the blocks these few scalars live in
@@ -226,3 +231,4 @@ class GraphedStep:
             raise
         self.shared.setdefault("pool", g.pool())
         st["graph"], st["inputs"], st["outputs"] = g, inputs, outputs
+        st["extra"] = self.after_capture() if self.after_capture is not None else None

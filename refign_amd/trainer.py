@@ -92,11 +92,31 @@ class FlatGradBuffer:
         self.bucket_mb = bucket_mb
         self._works, self._released = [], []
         self._order, self.flat2 = order, None
+        self._comm = self._comm2 = self._stream = None
+        self._active = 0                                # which buffer the parameters' .grad views point into right now
+        self._in_capture, self.captured_ranges, self._direct_pending = [], (), False
+        self.overlapped_elements = 0
+
+    def use_direct(self, comm, stream=None, comm2=None):
+        """Reduce over `comm` (refign_amd/rccl.py DirectComm: ncclAllReduce on the stream WE choose) on `stream`, a stream of
+        the reduce's own that waits for the producing stream at every release -- instead of torch's process group (whose
+        collectives hop to the group's stream and back: 15 ms per step for the six 64 MB buckets of a 1-rank group, measured,
+        profiles/r04_ddp_rehearsal.txt).  Event record / wait / ncclAllReduce are all capturable, so the SAME release works
+        inside the hipGraph capture of the last backward pass: the all-reduce of the decode head / stage 4 / stage 3 ranges
+        becomes a branch of the graph next to the backward of the earlier stages (`end_capture`, `replayed`).
+        `comm2`: a second communicator for the SECOND buffer (the mixed pass running next to the source pass accumulates
+        there): the sum over ranks is linear, so the two buffers are reduced separately -- the first one whole, as soon as the
+        source pass is over and next to the mixed pass (`reduce_first_now`), the second one range by range from inside the
+        mixed pass's backward -- and added afterwards.  Twice the bytes on the links, almost all of them hidden; two
+        communicators because the two reduces run on unordered streams and one communicator's collectives must be issued in
+        the same order on every rank."""
+        self._comm, self._stream, self._comm2 = comm, stream, comm2
 
     def zero(self):
         self.flat.zero_()
         if self.flat2 is not None:
             self.flat2.zero_()
+        self._in_capture = []
 
     def into_second(self):
         """Context manager: inside it every parameter's `.grad` is its view of a SECOND flat buffer.  Used around the
@@ -115,9 +135,11 @@ class FlatGradBuffer:
                 saved.append(p.grad)
                 p.grad = self.flat2[off:off + p.numel()].view_as(p)
                 off += pad(p.numel())
+            self._active = 1
             try:
                 yield
             finally:
+                self._active = 0
                 for p, g_ in zip(self._order, saved):
                     p.grad = g_
         return ctx()
@@ -126,38 +148,104 @@ class FlatGradBuffer:
         if self.flat2 is not None:
             self.flat.add_(self.flat2)
 
-    def _reduce_range(self, a, b):
-        step = max(1, int(self.bucket_mb * 1024 * 1024 // 4))
-        for i in range(a, b, step):
-            self._works.append(dist.all_reduce(self.flat[i:min(i + step, b)], op=dist.ReduceOp.SUM, async_op=True))
+    def _buffer(self, k):
+        return self.flat if k == 0 else self.flat2
 
-    def on_ready(self, tag):
-        """A group's gradients are final (called from inside the last backward pass of the step)."""
+    def _reduce_range(self, a, b, k=0):
+        step = max(1, int(self.bucket_mb * 1024 * 1024 // 4))
+        buf = self._buffer(k)
+        comm = self._comm if k == 0 else self._comm2
+        if comm is not None:
+            import contextlib
+            on = contextlib.nullcontext()
+            if self._stream is not None:
+                self._stream.wait_stream(torch.cuda.current_stream(buf.device))           # the gradients queued so far
+                on = torch.cuda.stream(self._stream)
+            with on:
+                for i in range(a, b, step):
+                    comm.all_reduce_(buf[i:min(i + step, b)])
+            self._direct_pending = True
+            return
+        for i in range(a, b, step):
+            self._works.append(dist.all_reduce(buf[i:min(i + step, b)], op=dist.ReduceOp.SUM, async_op=True))
+
+    def on_ready(self, tag, capturing=None):
+        """A group's gradients are final (called from inside the last backward pass into the buffer the views point to)."""
         r = self.ranges.get(tag)
-        if r is None or r in self._released or not (dist.is_available() and dist.is_initialized()):
+        if r is None or not (dist.is_available() and dist.is_initialized()):
+            return
+        r = (self._active, *r)
+        if r in self._released or r in self._in_capture:
+            return
+        if capturing is None:
+            capturing = self.flat.is_cuda and torch.cuda.is_current_stream_capturing()
+        if (self._comm if self._active == 0 else self._comm2) is None and (capturing or self._active == 1):
+            # (a collective of torch's process group is not put into a capture here, and the second buffer is only reduced
+            # on its own when it has a communicator of its own: the tail takes care of both)
             return
         # (torch's NCCL process group orders an async collective after the work queued so far on the CURRENT stream --
         # inside the autograd engine that is the stream of the backward kernels that produced these gradients)
-        self._released.append(r)
-        self._reduce_range(*r)
+        (self._in_capture if capturing else self._released).append(r)
+        self._reduce_range(r[1], r[2], r[0])
+
+    def reduce_first_now(self):
+        """The FIRST buffer is final (the source pass is over; the rest of the step accumulates into the second one): put it on
+        the wire whole, behind what is queued on the current stream.  Needs both communicators (see use_direct)."""
+        if self._comm is None or self._comm2 is None or not (dist.is_available() and dist.is_initialized()):
+            return False
+        r = (0, 0, self.flat.numel())
+        if r not in self._released:
+            self._released.append(r)
+            self._reduce_range(0, self.flat.numel(), 0)
+        return True
+
+    def end_capture(self):
+        """INSIDE the capture, after the backward pass: join the reduce stream; `captured_ranges` <- the ranges the graph
+        reduces on every replay (graphs.GraphedStep hands them back to `replayed` after each replay)."""
+        if self._in_capture and self._stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._stream)
+        self.captured_ranges, self._in_capture = tuple(self._in_capture), []
+        return self.captured_ranges
+
+    def replayed(self, ranges):
+        """A graph that contains the all-reduce of `ranges` has just been replayed in this step."""
+        for r in ranges or ():
+            if r not in self._released:
+                self._released.append(r)
+
+    def _reduce_gaps(self, k):
+        pos, n = 0, self.flat.numel()
+        for _, a, b in sorted(r for r in self._released if r[0] == k):
+            if a > pos:
+                self._reduce_range(pos, a, k)
+            pos = max(pos, b)
+        if pos < n:
+            self._reduce_range(pos, n, k)
 
     def all_reduce_mean(self, bucket_mb=None):
-        if not (dist.is_available() and dist.is_initialized()):
+        """Everything the passes have not released, then: wait, add the second buffer, divide by the world size."""
+        if not (dist.is_available() and dist.is_initialized()) or os.environ.get("RFN_DDP_SKIP_REDUCE") == "1":   # (diagnostics)
+            self.merge_second()
+            self._released = []
             return
         if bucket_mb is not None:
             self.bucket_mb = bucket_mb
         world = dist.get_world_size()
-        # what the backward pass has not released: the gaps between the released ranges
-        pos = 0
-        for a, b in sorted(self._released):
-            if a > pos:
-                self._reduce_range(pos, a)
-            pos = max(pos, b)
-        if pos < self.flat.numel():
-            self._reduce_range(pos, self.flat.numel())
+        separate = self.flat2 is not None and any(r[0] == 1 or r == (0, 0, self.flat.numel()) for r in self._released)
+        if not separate:
+            self.merge_second()                       # one sum on the wire: what the second buffer holds goes with the first
+        self._reduce_gaps(0)
+        if separate:
+            self._reduce_gaps(1)
         for w in self._works:
             w.wait()
-        self.overlapped_elements = sum(b - a for a, b in self._released)     # diagnostics / tests
+        if self._direct_pending and self._stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._stream)
+        self._direct_pending = False
+        if separate:
+            self.merge_second()
+        self.overlapped_elements = sum(b - a for _, a, b in self._released)     # diagnostics / tests
+        self.overlapped_fraction = self.overlapped_elements / (self.flat.numel() * (2 if separate else 1))
         self._works, self._released = [], []
         self.flat.div_(world)
 
@@ -203,14 +291,29 @@ class Trainer:
                         teacher_comm = rccl.DirectComm(dev)
                         for m in teacher:
                             m._rfn_direct = teacher_comm
-                    # A THIRD communicator (mixed pass on its own stream next to the source pass, as on one GPU) only on
-                    # request: three communicators spinning on three streams of one device have never met a peer (one-GPU
-                    # development boxes), and concurrent collectives of different communicators can deadlock when ranks
-                    # launch them in different orders.  Default under data parallelism: two (student passes in stream
-                    # order on the main stream, teacher on the side stream) -- the pattern of torch DDP + a second process
-                    # group.  RFN_DDP_MIXED_COMM=1 restores the three-communicator mode once a 2-GPU run has proved it.
-                    if os.environ.get("RFN_GRAPH_DDP", "1") != "0" and os.environ.get("RFN_DDP_MIXED_COMM", "0") == "1":
+                    # A THIRD communicator: the mixed pass on its own stream next to the source pass, as on one GPU (12.5 ms of a 171 ms
+                    # step in the 1-rank rehearsal, profiles/r04_ddp_rehearsal.txt).  Round 3 kept this off until a 2-GPU run
+                    # had shown three concurrent communicators to be safe; no such box has been available, so round 4 turns
+                    # it ON and makes the first stall of a multi-rank bench run fall back instead (bench.py: the guard
+                    # re-executes every rank in the conservative configuration).  Every communicator's collectives are
+                    # issued from one host thread in program order on a stream of its own, the same on every rank.
+                    # RFN_DDP_MIXED_COMM=0: two communicators, student passes in stream order on the main stream.
+                    if os.environ.get("RFN_GRAPH_DDP", "1") != "0" and os.environ.get("RFN_DDP_MIXED_COMM", "1") == "1":
                         model._mixed_comm = rccl.DirectComm(dev)
+                    # The gradient reduce.  Default: torch's process group, bucketed, after the passes (with the mixed pass
+                    # next to the source pass there is no cheap way to start earlier: releases from inside a captured pass are
+                    # cross-stream branches of its graph, and two graphs replaying side by side pay ~25 ms for those --
+                    # profiles/r04_ddp_rehearsal.txt; the reduce itself is 343 MB: ~1-5 ms of link time on 8..2 GPUs).
+                    # RFN_DDP_DIRECT_REDUCE=1: a communicator and a stream of its own (FlatGradBuffer.use_direct) -- the
+                    # finished ranges then travel from inside the last backward pass, eagerly and inside the captured mixed
+                    # pass alike (meant for RFN_DDP_MIXED_COMM=0, passes in stream order).
+                    if os.environ.get("RFN_DDP_DIRECT_REDUCE", "0") == "1":
+                        self._grad_comm = rccl.DirectComm(dev)
+                        # (second buffer reduced on its own -- FlatGradBuffer.use_direct -- only on request: its in-graph
+                        # releases are cross-stream branches of the mixed pass's graph, and two graphs replaying next to each
+                        # other pay ~25 ms for those in the rehearsal: 172.7 against 147-159 ms with one reduce at the tail)
+                        self._grad_comm2 = rccl.DirectComm(dev) if getattr(model, "_mixed_comm", None) is not None and \
+                            os.environ.get("RFN_DDP_TWO_BUFFER", "0") == "1" else None
                 except (OSError, RuntimeError, AttributeError) as e:   # no librccl / init failed: torch's process group
                     import warnings
                     warnings.warn(f"refign_amd.trainer: direct RCCL communicators unavailable ({type(e).__name__}: {e}); "
@@ -219,6 +322,7 @@ class Trainer:
                     for m in teacher:
                         m.__dict__.pop("_rfn_direct", None)
                     model.__dict__.pop("_mixed_comm", None)
+                    self._grad_comm = self._grad_comm2 = None
         if fused_optimizer and model.optimizer_init["class_path"].endswith("AdamW") and \
                 next(model.parameters()).is_cuda:
             model.optimizer_init = {**model.optimizer_init,
@@ -232,6 +336,9 @@ class Trainer:
             self.fast_step = MultiTensorAdamW(opt)            # one launch per step; torch's step() where it declines
         groups = model.grad_ready_groups() if hasattr(model, "grad_ready_groups") else None
         self.grads = FlatGradBuffer([p for g in opt.param_groups for p in g["params"]], groups, bucket_mb)
+        if getattr(self, "_grad_comm", None) is not None:
+            self.grads.use_direct(self._grad_comm, torch.cuda.Stream(device=self._grad_comm.device),
+                                  getattr(self, "_grad_comm2", None))
         self.bucket_mb = bucket_mb
         model._optimizer = _OptimizerProxy(self)
         model._grad_buffer = self.grads                      # uda: second buffer for the concurrently running mixed pass
@@ -244,12 +351,15 @@ class Trainer:
         """What Lightning's manual_backward does, plus: during the LAST backward pass of a step under data parallelism
         the readiness marks of the MiT stages release finished ranges of the flat gradient buffer to the all-reduce."""
         from . import seg
-        # (not inside a hipGraph capture of the pass: the replayed pass is followed by one reduce of the whole buffer)
-        overlap = last and self.data_parallel and os.environ.get("RFN_DDP_OVERLAP", "1") != "0" and \
-            not (loss.is_cuda and torch.cuda.is_current_stream_capturing())
+        # (inside a hipGraph capture of the pass too when the buffer has a communicator of its own -- FlatGradBuffer.use_direct;
+        # on_ready declines otherwise and the replayed pass is followed by one reduce of the whole buffer)
+        capturing = loss.is_cuda and torch.cuda.is_current_stream_capturing()
+        overlap = last and self.data_parallel and os.environ.get("RFN_DDP_OVERLAP", "1") != "0"
         seg._GRAD_READY_CB = self.grads.on_ready if overlap else None
         try:
             loss.backward(retain_graph=retain_graph)
+            if capturing and overlap:
+                self.grads.end_capture()
         finally:
             seg._GRAD_READY_CB = None
 
@@ -311,8 +421,7 @@ class _OptimizerProxy:
         self.t.grads.zero()
 
     def step(self):
-        self.t.grads.merge_second()                           # what a concurrently run pass accumulated on the side
-        self.t.grads.all_reduce_mean(self.t.bucket_mb)
+        self.t.grads.all_reduce_mean(self.t.bucket_mb)        # (and what a concurrently run pass accumulated on the side)
         if self.t.fast_step is not None:
             self.t.fast_step.step()
         else:

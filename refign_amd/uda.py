@@ -280,7 +280,9 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # the mixed pass may run NEXT TO the tail of the source pass (see _training_step_graphed): a memory pool of its own,
         # and its captured backward kernels accumulate into the second flat gradient buffer
         self._graphs["mixed_pass"] = GraphedStep(self._mixed_pass_device_crop, "student mixed pass", shared=None,
-                                                 capture_context=self._mixed_capture_context)
+                                                 capture_context=self._mixed_capture_context,
+                                                 after_capture=self._mixed_captured_reduce,
+                                                 on_replay=self._mixed_replayed_reduce)
         self.teacher_f8 = _f8.ENV_DEFAULT                # K5: EMA-teacher backbone in fp8 (no reference analogue)
         self.load_weights(pretrained)
 
@@ -501,8 +503,25 @@ class DomainAdaptationSegmentationModel(nn.Module):
         mixed_pred = _logits_for_loss(self, mixed_pred, mixed_img.shape[-2:])
         mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
             self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
-        self.manual_backward(mixed_loss)
+        # the step's LAST backward pass (data parallelism: the finished ranges of the gradient buffer are all-reduced from inside
+        # it, trainer._backward / FlatGradBuffer.on_ready) -- when it accumulates into the first buffer in stream order, or into
+        # the second buffer next to the source pass AND that buffer is reduced on its own (FlatGradBuffer.use_direct: comm2)
+        buf = getattr(self, "_grad_buffer", None)
+        self.manual_backward(mixed_loss, last=not getattr(self, "_mixed_on_second", False) or
+                             (buf is not None and buf._comm2 is not None))
         return (mixed_loss.detach(),)
+
+    def _mixed_captured_reduce(self):
+        buf = getattr(self, "_grad_buffer", None)
+        if buf is None:
+            return ()
+        r, buf.captured_ranges = buf.captured_ranges, ()
+        return r
+
+    def _mixed_replayed_reduce(self, ranges):
+        buf = getattr(self, "_grad_buffer", None)
+        if buf is not None and ranges:
+            buf.replayed(ranges)
 
     def _mixed_capture_context(self):
         """What the capture of the mixed pass runs inside when the pass is to run NEXT TO the source pass: parameter
@@ -576,6 +595,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
             self.log("train_loss_featdist_src", losses[1])
         mix = self._mixed_stream(images_src) if early is not None else None
         run_on = cur if mix is None else mix
+        if mix is not None and getattr(self, "_grad_buffer", None) is not None:
+            # data parallelism: the first gradient buffer is final (the mixed pass accumulates into the second one): its
+            # all-reduce runs next to the mixed pass (no-op without the two gradient communicators)
+            self._grad_buffer.reduce_first_now()
         if mix is not None:
             self.__dict__["_mixed_concurrent_steps"] = self.__dict__.get("_mixed_concurrent_steps", 0) + 1   # diagnostics
             mix.wait_event(ready)                        # gradient buffers zeroed, EMA done, batch resident

@@ -319,3 +319,108 @@ def test_statistics_exchange_routing_over_direct_communicators(tmp_path):
         assert r["after"][1:] == (3, 2)                      # no-grad forward: one exchange, default communicator again
         assert r["teacher_torch"][1:] == (3, 2, 0)
         assert r["teacher_direct"][1:] == (3, 2, 1)
+
+
+def _graph_reduce_worker(rank, world, port, out):
+    """The bookkeeping of a gradient reduce that lives INSIDE the captured last backward pass (FlatGradBuffer.use_direct /
+    on_ready(capturing) / end_capture / replayed), with a stand-in communicator over gloo: a range reduced "by the graph" must
+    not be reduced again by the tail, a range the graph does not hold must be, step after step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from refign_amd.trainer import FlatGradBuffer
+    ps = [nn.Parameter(torch.zeros(n)) for n in (1000, 70001, 333, 4099)]
+    buf = FlatGradBuffer(ps, [("head", ps[:1]), ("stage3", ps[1:2]), ("stage1", ps[2:])], bucket_mb=0.01)
+    comm = _StandInComm(None)
+    buf.use_direct(comm, None)
+    res = []
+
+    def fill(step):
+        buf.zero()
+        for i, p in enumerate(ps):
+            p.grad.fill_(float((rank + 1) * (i + 1) + step))
+
+    # "capture": the callback fires for two of the three groups while the pass is being recorded
+    fill(0)
+    buf.on_ready("head", capturing=True)
+    buf.on_ready("stage3", capturing=True)
+    ranges = buf.end_capture()
+    assert len(ranges) == 2 and buf._released == [] and buf.captured_ranges == ranges
+    n_capture = comm.calls
+    buf.replayed(ranges)
+    buf.all_reduce_mean()
+    res.append([float(p.grad.mean()) for p in ps])
+    n_tail = comm.calls - n_capture
+    # "replays": the graph's reduces are simulated by calling them again; the tail must only add the third group
+    for step in (1, 2):
+        fill(step)
+        for _, a, b in ranges:
+            comm.all_reduce_(buf.flat[a:b])
+        buf.replayed(ranges)
+        before = comm.calls
+        buf.all_reduce_mean()
+        assert comm.calls - before == n_tail
+        res.append([float(p.grad.mean()) for p in ps])
+        assert buf.overlapped_elements == sum(b - a for _, a, b in ranges)
+    # a step whose graph did NOT replay (eager fallback): everything through the tail
+    fill(3)
+    buf.all_reduce_mean()
+    res.append([float(p.grad.mean()) for p in ps])
+    if rank == 0:
+        torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_gradient_reduce_inside_a_captured_pass_is_not_repeated_by_the_tail(tmp_path):
+    port, out = _free_port(), str(tmp_path / "r.pt")
+    mp.spawn(_graph_reduce_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    for step, row in enumerate(res):
+        for i, v in enumerate(row):
+            want = (1.5 * (i + 1)) + step                  # mean over ranks of (rank + 1)(i + 1) + step
+            assert abs(v - want) < 1e-5, (step, i, v, want)
+
+
+def _two_buffer_worker(rank, world, port, out):
+    """Two buffers reduced separately (the mixed pass next to the source pass under data parallelism): the first whole and
+    early, the second range by range from "inside its graph", the rest at the tail, then added -- equals the mean of the sum."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from refign_amd.trainer import FlatGradBuffer
+    ps = [nn.Parameter(torch.zeros(n)) for n in (1000, 70001, 333)]
+    buf = FlatGradBuffer(ps, [("head", ps[:1]), ("stage3", ps[1:2]), ("stage1", ps[2:])], bucket_mb=0.01)
+    c1, c2 = _StandInComm(None), _StandInComm(None)
+    buf.use_direct(c1, None, c2)
+    rows = []
+    for step in range(3):
+        buf.zero()
+        for i, p in enumerate(ps):
+            p.grad.fill_(float((rank + 1) * (i + 1)))                  # "source pass"
+        assert buf.reduce_first_now()
+        with buf.into_second():
+            for i, p in enumerate(ps):
+                p.grad.fill_(float(10 * (rank + 1) + step))            # "mixed pass"
+            if step == 0:                                              # the capture step: recorded, handed back at replay
+                buf.on_ready("head", capturing=True)
+                buf.on_ready("stage3", capturing=True)
+                ranges = buf.end_capture()
+                assert all(r[0] == 1 for r in ranges) and len(ranges) == 2
+            else:
+                for _, a, b in ranges:
+                    c2.all_reduce_(buf.flat2[a:b])
+        buf.replayed(ranges)
+        n1, n2 = c1.calls, c2.calls
+        buf.all_reduce_mean()
+        assert c1.calls == n1 and c2.calls > n2                        # first buffer done; only the second one's remainder
+        rows.append([float(p.grad.mean()) for p in ps])
+    if rank == 0:
+        torch.save(rows, out)
+    dist.destroy_process_group()
+
+
+def test_two_gradient_buffers_reduced_separately_and_added(tmp_path):
+    port, out = _free_port(), str(tmp_path / "r.pt")
+    mp.spawn(_two_buffer_worker, args=(2, port, out), nprocs=2, join=True)
+    for step, row in enumerate(torch.load(out)):
+        for i, v in enumerate(row):
+            want = 1.5 * (i + 1) + 15 + step
+            assert abs(v - want) < 1e-4, (step, i, v, want)

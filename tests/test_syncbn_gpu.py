@@ -180,10 +180,15 @@ def _rccl_step_worker(rank, world, port, out):
     traj = {}
     # student passes graphed (opt-in under data parallelism) / eager (the default) / graphed with the exchanges as
     # RCCL calls of our own on the capture stream and a communicator per pass (refign_amd/rccl.py)
-    for mode in ("1", "0", "direct"):
+    # "default" (the round-3 default, now RFN_DDP_MIXED_COMM=0 RFN_DDP_DIRECT_REDUCE=1): direct exchanges in the graphs, passes in
+    # stream order, and the gradient all-reduce of the finished ranges INSIDE the captured mixed pass on a communicator / stream
+    # of its own; "direct" adds the mixed pass next to the source pass with the two gradient buffers reduced separately
+    for mode in ("1", "0", "direct", "default"):
         os.environ["RFN_GRAPH_DDP"] = "0" if mode == "0" else "1"
-        os.environ["RFN_RCCL_DIRECT"] = "1" if mode == "direct" else "0"
-        os.environ["RFN_DDP_MIXED_COMM"] = "1" if mode == "direct" else "0"     # third communicator: opt-in (trainer.py)
+        os.environ["RFN_RCCL_DIRECT"] = "1" if mode in ("direct", "default") else "0"
+        os.environ["RFN_DDP_MIXED_COMM"] = "1" if mode == "direct" else "0"     # third communicator (trainer.py)
+        os.environ["RFN_DDP_DIRECT_REDUCE"] = "1" if mode in ("direct", "default") else "0"   # gradient reduce on our own comm
+        os.environ["RFN_DDP_TWO_BUFFER"] = "1" if mode == "direct" else "0"
         model = T.build(True, dev)
         trainer = Trainer(model, sync_batchnorm=True, fused_optimizer=False)
         n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
@@ -206,13 +211,15 @@ def _rccl_step_worker(rank, world, port, out):
             if mode != "0" else None
         bn = torch.cat([b.flatten().double() for n, b in model.head.named_buffers() if "running" in n]).cpu()
         traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), captured, n_sync,
-                      calls["n"], len(calls["groups"]), model.__dict__.get("_mixed_concurrent_steps", 0), bn)
+                      calls["n"], len(calls["groups"]), model.__dict__.get("_mixed_concurrent_steps", 0), bn,
+                      getattr(trainer.grads, "overlapped_fraction", 0.0),
+                      trainer.grads._comm is not None)
     torch.save(traj, f"{out}/traj.pt")
     torch.cuda.synchronize()
     from refign_amd import rccl
     n_live = len(rccl._LIVE)
     rccl.destroy_all()
-    assert n_live >= 3 and not rccl._LIVE
+    assert n_live >= 5 and not rccl._LIVE
     dist.destroy_process_group()
 
 
@@ -242,6 +249,14 @@ def test_student_graphs_with_rccl_statistics_exchange_inside(dev, tmp_path):
     assert d[2], "student passes were not captured with direct RCCL exchanges"
     assert d[5] == 0 and d[4] == 0, d[4:6]
     assert d[6] >= 2, "the mixed pass did not run next to the source pass"
+    assert d[9] and d[8] > 0.85, f"only {d[8]:.2f} of the two gradient buffers was reduced before the tail"
     np.testing.assert_allclose(d[0], e[0], rtol=3e-2)
     assert abs(d[1] - e[1]) < 1e-4 * e[1]
     assert float((d[7] - e[7]).abs().max()) < 5e-2 * float(e[7].abs().max())
+    # the N > 1 default: captured, stream order, and most of the gradient buffer reduced from inside the replayed mixed pass
+    f = traj["default"]
+    assert f[2] and f[6] == 0 and f[9], (f[2], f[6], f[9])
+    assert f[8] > 0.8, f"only {f[8]:.2f} of the gradient buffer was reduced inside the captured backward pass"
+    np.testing.assert_allclose(f[0], e[0], rtol=3e-2)
+    assert abs(f[1] - e[1]) < 1e-4 * e[1]
+    assert float((f[7] - e[7]).abs().max()) < 5e-2 * float(e[7].abs().max())
