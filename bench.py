@@ -493,9 +493,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     import refign_amd
-    from refign_amd.tuning import use_shipped_miopen_db
     refign_amd.load_library()
-    use_shipped_miopen_db()
     if args.workload == AlignRefineKernels.name:
         wl = AlignRefineKernels(dev, args.pairs_per_gpu, seed=1234 + rank)
     else:

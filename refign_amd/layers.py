@@ -100,6 +100,19 @@ class ConvBNReLU(nn.Module):
                 y = split32.conv2d(x, w, b, c.stride, c.padding, c.dilation)     # fp32 parity mode (split-bf16 products)
                 if y is not None:
                     return y
+            from .params import compute_dtype
+            cd = compute_dtype(x)
+            if c.groups == 1 and cd in (torch.float16, torch.bfloat16):
+                # blocks without a norm layer / with a BatchNorm the fused kernel does not take (the matcher's decoders,
+                # refinement and uncertainty networks under fp16 autocast -- alignment_model.py:81-146):
+                # forward, data and weight gradient on the implicit-GEMM kernels, as the student's 3x3 bottleneck
+                from .conv import conv2d_mfma, conv2d_mfma_grad
+                if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+                    y = conv2d_mfma_grad(x, w, b, c.stride, c.padding, c.dilation, cd)
+                else:
+                    y = conv2d_mfma(x, w, b, c.stride, c.padding, c.dilation, dtype=cd)
+                if y is not None:
+                    return y
             mfma.note_library("conv2d.autograd" if torch.is_grad_enabled() else "conv2d", x, w)
         return F.conv2d(x, w, b, c.stride, c.padding, c.dilation, c.groups)
 
@@ -109,8 +122,10 @@ class ConvBNReLU(nn.Module):
         3x3: the HIP stencil; dense k x k without autograd (EMA teacher): the implicit-GEMM kernel; dense k x k under
         autograd (the student's 3x3 bottleneck): the library convolution."""
         c = self.conv
+        # (under autograd the Linear's gradient GEMMs want N % 64 == 0; other widths take the implicit-GEMM path below, which
+        # pads its output channels itself)
         if c.groups == 1 and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0) and \
-                c.in_channels % 64 == 0 and c.out_channels % 8 == 0:
+                c.in_channels % 64 == 0 and c.out_channels % (64 if torch.is_grad_enabled() else 8) == 0:
             from .linear import linear_tokens
             xh = x.permute(0, 2, 3, 1)
             if xh.dtype != cd:

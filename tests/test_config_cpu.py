@@ -135,42 +135,3 @@ def test_correlation_channel_split_heuristic(monkeypatch):
     monkeypatch.setenv("RFN_CORR_SPLIT", "1")
     monkeypatch.setenv("RFN_CORR_SPLITS", "4")
     assert f(2, 256, 135, 240) == 4 and f(2, 24, 32, 32) == 1     # forced, unless the chunks would not be multiples of 8
-
-
-def test_merge_miopen_db_adds_only_what_is_missing(tmp_path):
-    """tools/merge_miopen_db.py: text databases gain the lines whose keys are new (existing keys keep THEIR entry), the
-    sqlite kernel cache gains the kernels it does not have."""
-    import os
-    import shutil
-    import sqlite3
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    work = tmp_path / "repo"
-    (work / "tools").mkdir(parents=True)
-    (work / "refign_amd" / "miopen_db").mkdir(parents=True)
-    shutil.copy(os.path.join(root, "tools", "merge_miopen_db.py"), work / "tools" / "merge_miopen_db.py")
-    dst, src = work / "refign_amd" / "miopen_db", tmp_path / "tuned"
-    src.mkdir()
-    (dst / "gfx.ufdb.txt").write_text("a=1\nb=2\n")
-    (src / "gfx.ufdb.txt").write_text("b=999\nc=3\n")
-    (src / "gfx.udb.txt").write_text("p=7\n")
-
-    def make(path, rows):
-        con = sqlite3.connect(path)
-        con.execute("CREATE TABLE `kern_db` (`id` INTEGER PRIMARY KEY ASC,`kernel_name` TEXT NOT NULL,`kernel_args` TEXT NOT "
-                    "NULL,`kernel_blob` BLOB NOT NULL,`kernel_hash` TEXT NOT NULL,`uncompressed_size` INT NOT NULL)")
-        con.execute("CREATE UNIQUE INDEX `idx_kern_db` ON kern_db(kernel_name, kernel_args)")
-        con.executemany("insert into kern_db (kernel_name, kernel_args, kernel_blob, kernel_hash, uncompressed_size) "
-                        "values (?, ?, ?, ?, ?)", rows)
-        con.commit()
-        con.close()
-    make(dst / "gfx.ukdb", [("k1", "a", b"old", "h", 3), ("k2", "a", b"x", "h", 1)])
-    make(src / "gfx.ukdb", [("k1", "a", b"new", "h", 3), ("k3", "b", b"y", "h", 1)])
-    r = subprocess.run([sys.executable, str(work / "tools" / "merge_miopen_db.py"), str(src)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    assert (dst / "gfx.ufdb.txt").read_text() == "a=1\nb=2\nc=3\n"
-    assert (dst / "gfx.udb.txt").read_text() == "p=7\n"
-    con = sqlite3.connect(dst / "gfx.ukdb")
-    rows = dict((n, bytes(b)) for n, b in con.execute("select kernel_name, kernel_blob from kern_db"))
-    assert rows == {"k1": b"old", "k2": b"x", "k3": b"y"}

@@ -23,9 +23,7 @@ import torch  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from refign_amd import _lib  # noqa: E402
-from refign_amd.tuning import use_shipped_miopen_db  # noqa: E402
 
-use_shipped_miopen_db()
 
 
 def _short(a):

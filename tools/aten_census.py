@@ -13,9 +13,7 @@ from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from refign_amd.tuning import use_shipped_miopen_db  # noqa: E402
 
-use_shipped_miopen_db()
 dev = torch.device("cuda:0")
 wl = bench.WORKLOADS["refign_hrda_step_1080x1920"](dev, 2, 1234, 1080, 1920, "bf16")
 for _ in range(3):

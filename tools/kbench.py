@@ -31,8 +31,6 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    from refign_amd import tuning
-    tuning.use_shipped_miopen_db()
     b = args.b
     g = torch.Generator().manual_seed(0)
     rows = []

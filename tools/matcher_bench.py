@@ -12,7 +12,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from refign_amd import config, tuning  # noqa: E402
+from refign_amd import config  # noqa: E402
 
 MODEL = {"class_path": "models.AlignmentModel", "init_args": {
     "pretrained": None,
@@ -40,15 +40,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp16 = the reference's recipe for matcher training (README.md:289-294: --trainer.precision 16): "
                          "fp16 autocast + loss scaling, correlation / warp / losses in fp32")
-    ap.add_argument("--tune", default="", help="directory: run MIOpen's find for every convolution problem of the step "
-                                              "(minutes) and leave the user find-db there")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    if args.tune:
-        os.makedirs(args.tune, exist_ok=True)
-        os.environ["MIOPEN_USER_DB_PATH"] = os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.abspath(args.tune)
-        torch.backends.cudnn.benchmark = True
-    tuning.use_shipped_miopen_db()
     torch.manual_seed(0)
     model = config.build_model({"model": MODEL, "optimizer": OPTIM, "lr_scheduler": SCHED}).to(dev).train()
     (opt,), (sch,) = model.configure_optimizers()
@@ -89,6 +82,8 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     print(f"matcher training step b={b} {S}x{S} {args.precision}: {dt * 1e3:.1f} ms/step, {b / dt:.2f} image-triplets/s, "
           f"loss {float(loss):.3f}, max mem {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+    from refign_amd import mfma as _mfma
+    print("library_fallbacks:", _mfma.library_summary())
 
 
 if __name__ == "__main__":

@@ -13,9 +13,7 @@ os.environ.setdefault("RFN_HIP_GRAPH", "0")      # per-phase host timing needs t
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from refign_amd.tuning import use_shipped_miopen_db  # noqa: E402
 
-use_shipped_miopen_db()
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--height", type=int, default=1080)

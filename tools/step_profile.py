@@ -9,9 +9,7 @@ from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from refign_amd.tuning import use_shipped_miopen_db  # noqa: E402
 
-use_shipped_miopen_db()
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", default="bf16")
