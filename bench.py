@@ -401,6 +401,24 @@ def cpu_baseline(wl, args):
                       f"pixels^{expo:.2f}; value = 1 pair / ({times[1]:.2f} s x ({full_px / px[1]:.2f})^{expo:.2f})"}
 
 
+def launch_series_us(launch, spaced, reps=20):
+    """Average duration of `launch()` from HIP events around EACH launch on the current stream; `spaced`: every launch behind
+    ~1 ms of an idle device (one spinning wave) -- see the roofline block of main().  Shared with tools/kbench.py so that the
+    level-1 correlation rows there and the bench line are ONE measurement (same operands, same timing)."""
+    pairs = []
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        if spaced:
+            torch.cuda._sleep(2_000_000)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a_.elapsed_time(b_) for a_, b_ in pairs) * 1e3 / reps
+
+
 DDP_STALL_MARKER = os.path.join(os.environ.get("TMPDIR", "/tmp"), "refign_amd_multi_rank_stalled")
 
 
@@ -544,19 +562,7 @@ def main():
         for _ in range(3):
             wl.roofline_launch()
 
-        def series(spaced):
-            pairs = []
-            torch.cuda.synchronize()
-            for _ in range(reps):
-                if spaced:
-                    torch.cuda._sleep(2_000_000)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                wl.roofline_launch()
-                e1.record()
-                pairs.append((e0, e1))
-            torch.cuda.synchronize()
-            return sum(a_.elapsed_time(b_) for a_, b_ in pairs) * 1e3 / reps
+        series = lambda spaced: launch_series_us(wl.roofline_launch, spaced, reps)  # noqa: E731
 
         us_b2b = series(False)
         us = series(True)

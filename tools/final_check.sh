@@ -34,3 +34,15 @@ SWEEP_CFGS=";128,128,2;128,64,2;64,64,2;256,256,2" SWEEP_PERSIST=0 timeout 600 p
 timeout 120 python tools/micro/graph_chain.py 2>&1 | grep -v "amdgpu.ids" > $O/graph_chain.txt
 if [ ! -x refign_amd/lib/ab/cu_fetch_rate ]; then mkdir -p refign_amd/lib/ab && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/cu_fetch_rate.hip -o refign_amd/lib/ab/cu_fetch_rate 2>/dev/null; fi
 timeout 120 refign_amd/lib/ab/cu_fetch_rate > $O/cu_fetch_rate.txt 2>&1
+# round 4: the other BASELINE configurations as bench lines (K3: DAFormer MiT-B5 step at 512x1024, b = 2 -- configs/cityscapes_acdc/
+# refign_daformer.yaml:11-41; K5 is written above), the N1 matcher training step, the second-generation GEMM probe, the ASPP and
+# correlation experiments, and what one rank of N does (rehearsal + the first-contact script with the one rank there is)
+timeout 600 python bench.py --workload refign_daformer_step_1080x1920 --height 512 --width 1024 --no-cpu --no-roofline 2>/dev/null | tail -1 > $O/bench_k3_daformer_512x1024.json
+timeout 600 python bench.py --workload refign_daformer_step_1080x1920 --no-cpu --no-roofline 2>/dev/null | tail -1 > $O/bench_daformer_1080x1920.json
+{ timeout 300 python tools/matcher_bench.py --precision fp16 2>&1 | tail -2; timeout 300 python tools/matcher_bench.py --precision fp32 2>&1 | tail -2; } > $O/matcher_bench.txt
+timeout 600 bash tools/gemm2_probe.sh > $O/gemm2_probe.txt 2>&1
+timeout 300 python tools/aspp_try.py 2>&1 | grep -v "amdgpu.ids" > $O/aspp_try_now.txt
+timeout 900 bash tools/ddp_rehearsal.sh $(basename $O) > /dev/null 2>&1
+timeout 900 bash tools/ddp_matrix.sh $(basename $O) > /dev/null 2>&1
+GUARD=240 timeout 1500 bash tools/ddp_first_contact.sh 1 $O/first_contact_1rank > /dev/null 2>&1
+bash tools/pmc_corr.sh corr_l1_fused > $O/pmc_corr9.txt 2>&1

@@ -37,7 +37,7 @@ def main():
 
     def add(name, us, nbytes, flops=0.0):
         rows.append((name, us, nbytes, flops))
-        print(f"{name:58s} {us:10.1f} us  {nbytes / 1e6:9.1f} MB  {nbytes / us / 1e3:8.1f} GB/s  "
+        print(f"{name:78s} {us:10.1f} us  {nbytes / 1e6:9.1f} MB  {nbytes / us / 1e3:8.1f} GB/s  "
               f"{nbytes / us / 1e3 / 8000:6.3f} of 8TB/s  {flops / us / 1e6:7.2f} TFLOP/s", flush=True)
 
     for (lvl, C, H, W) in [("L1", 128, 270, 480), ("L2", 256, 135, 240), ("L3", 256, 32, 32), ("K2-L1", 128, 128, 128)]:
@@ -45,12 +45,28 @@ def main():
             continue
         f1 = torch.nn.functional.normalize(torch.randn(b, C, H, W, generator=g), dim=1).to(dev)
         f2 = torch.nn.functional.normalize(torch.randn(b, C, H, W, generator=g), dim=1).to(dev)
+        note = ""
+        if lvl == "L1":
+            # the bench line's own measurement first: the operands the step feeds the kernel (VGG-16 pool-2 features of the bench
+            # workload's image pair, L2-normalised) and bench.py's timing (HIP events per launch, spaced / back to back).  The
+            # white-noise rows below are a different operand distribution (denser products, lower clock): labelled as such.
+            import bench
+            wl = bench.WORKLOADS["refign_hrda_step_1080x1920"](dev, b, 1234, 1080, 1920, "bf16")
+            s1, t1 = wl._level1_features()
+            nb1 = wl.roofline_bytes()
+            for _ in range(3):
+                wl.roofline_launch()
+            add(f"corr9 +relu+l2norm   L1 step operands, spaced (= bench.py roofline)", bench.launch_series_us(wl.roofline_launch, True), nb1)
+            add(f"corr9 +relu+l2norm   L1 step operands, back to back", bench.launch_series_us(wl.roofline_launch, False), nb1)
+            add(f"corr9 +relu+l2norm   L1 white noise, spaced", bench.launch_series_us(lambda: correlation.local_correlation_layer(f2, f1), True), nb1)
+            del wl, s1, t1
+            note = " [white noise, back to back]"
         fl = (5 * torch.randn(b, 2, H, W, generator=g)).to(dev)
         nb = 4 * b * H * W * (2 * C + 81)
         fp = 2.0 * 81 * C * b * H * W
-        add(f"corr9 raw            {lvl} C={C} {H}x{W}", timeit(lambda: correlation.forward(f1, f2, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)), nb, fp)
-        add(f"corr9 +relu+l2norm   {lvl} C={C} {H}x{W}", timeit(lambda: correlation.local_correlation_layer(f2, f1)), nb, fp)
-        add(f"corr9 +warp+relu+l2n {lvl} C={C} {H}x{W}", timeit(lambda: correlation.local_correlation_layer(f2, f1, flow=fl)), nb + 8 * b * H * W, fp)
+        add(f"corr9 raw            {lvl} C={C} {H}x{W}{note}", timeit(lambda: correlation.forward(f1, f2, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)), nb, fp)
+        add(f"corr9 +relu+l2norm   {lvl} C={C} {H}x{W}{note}", timeit(lambda: correlation.local_correlation_layer(f2, f1)), nb, fp)
+        add(f"corr9 +warp+relu+l2n {lvl} C={C} {H}x{W}{note}", timeit(lambda: correlation.local_correlation_layer(f2, f1, flow=fl)), nb + 8 * b * H * W, fp)
         add(f"warp features        {lvl} C={C} {H}x{W}", timeit(lambda: matching.warp_nocheck(f2, fl)), 4 * b * H * W * (2 * C + 2))
         add(f"l2norm channels      {lvl} C={C} {H}x{W}", timeit(lambda: matching.l2_normalize_channels(f2)), 4 * b * H * W * 2 * C)
         f16 = f2.half().contiguous(memory_format=torch.channels_last)
