@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
                                         (1, 40, 64, 1024, 12),
                                         # the XCD-sliced geometry (csrc/dwconv.hip sliced_geom): slices of 20 / 40 vectors
                                         # (idle threads in the block), rows in residue-class order with H % dilation != 0
-                                        (2, 9, 13, 1280, 1), (1, 23, 31, 1024, 6), (3, 5, 4, 2048, 18)])
+                                        (2, 9, 13, 1280, 1), (1, 23, 31, 1024, 6), (3, 5, 4, 2048, 18),
+                                        # the LDS-tiled kernel (bf16, C % 64 == 0): ragged tile edges, several tiles per phase,
+                                        # phases of unequal size, one-pixel-wide phase images
+                                        (1, 37, 70, 128, 1), (2, 135, 61, 64, 2), (1, 40, 67, 192, 3), (2, 19, 7, 64, 6)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_dwconv_matches_conv2d(dev, B, H, W, C, dil, dtype):
     from refign_amd.dwconv import dwconv3x3_nhwc
@@ -47,7 +50,7 @@ def test_mix_ffn_dwconv_tokens_equals_reference_formulation(dev):
     assert torch.allclose(m(x, 12, 20), want, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 9, 13, 64), (2, 9, 13, 1280), (1, 34, 60, 512)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 13, 64), (2, 9, 13, 1280), (1, 34, 60, 512), (2, 68, 120, 128), (1, 135, 240, 64)])
 def test_fused_dwconv_gelu_matches_conv_then_exact_gelu(dev, B, H, W, C):
     """gelu(DWConv(x)) in one pass (mix_transformer.py:99-101) on bf16 tokens: the activation of the 16-bit path is the
     branch-free erf of csrc/mfma.h (A&S 7.1.26, |error| < 1.5e-7) -- compared with the exact-erf GELU of an fp32
