@@ -1101,28 +1101,38 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   }
   // second-generation kernel (gemm2.h: software-pipelined K loop, stores dripped under the next tile's MFMAs) for the big
   // Linear layers whose column count is a multiple of 320 -- every GEMM of MiT-B5's stage 3 on the teacher's 40 views:
-  // 1.2-1.5x on those shapes (profiles/r04_gemm2_v3_probe.txt); bit-identical results.  RFN_GEMM2=0: the first generation.
+  // 1.2-1.5x on those shapes (profiles/r04_gemm2_v3_probe.txt); bit-identical results -- and, as 192 x 256 tiles, for the
+  // other big problems with N % 256 == 0 (stages 2 / 4, the decode heads' 1 x 1 convolutions), which the 8-wave 256 x 256
+  // tile of the first generation served.  RFN_GEMM2=0: the first generation everywhere, 1: the 320-column tiles only.
   if constexpr (!GATHER && DT == 1) {
-    static const int g2 = getenv("RFN_GEMM2") ? atoi(getenv("RFN_GEMM2")) : 1;
+    static const int g2 = getenv("RFN_GEMM2") ? atoi(getenv("RFN_GEMM2")) : 2;
     static const long g2_min = getenv("RFN_GEMM2_MIN_TILES") ? atol(getenv("RFN_GEMM2_MIN_TILES")) : 200;
-    const long t2 = (long)cdiv(M, 192) * (N / 320);
+    const int bn2 = N % 320 == 0 ? 320 : (g2 >= 2 && N % 256 == 0 ? 256 : 0);
+    const long t2 = bn2 ? (long)cdiv(M, 192) * (N / bn2) : 0;
     const bool res2 = epi.res != nullptr || epi.rowscale != nullptr;
-    if (g2 && !out32 && N % 320 == 0 && K >= 192 && (epi.act & 255) == 0 && t2 >= g2_min &&
+    if (g2 && bn2 && !out32 && K >= (bn2 == 320 ? 192 : 128) && K % 64 == 0 && (epi.act & 255) == 0 && t2 >= g2_min &&
         (M + 192) * ldy * 2 < (1L << 32) && ldx < (1L << 22) && ldw < (1L << 22) && (((size_t)X | (size_t)W | (size_t)Y) & 15) == 0 &&
         (epi.res == nullptr || ((size_t)epi.res & 15) == 0)) {
       Gemm2Epi e2{epi.bias, epi.res, epi.rowscale, epi.rows_per_sample, nullptr};
-      const int tn = (int)(N / 320);
+      const int tn = (int)(N / bn2);
       dim3 grid((unsigned)std::min<long>(t2, 256)), block(256);
-#define RFN_G2(BIAS_, RES_)                                                                                              \
-  hipLaunchKernelGGL((gemm_nt2_kernel<1, 192, 320, 2, 2, BIAS_, RES_, 0, 3, 4, 4, 8>), grid, block, 0, s, (const uint16_t*)X, \
-                     (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tn, (int)t2, e2)
-      if (epi.bias != nullptr) {
-        if (res2) RFN_G2(true, true);
-        else RFN_G2(true, false);
-      } else {
-        if (res2) RFN_G2(false, true);
-        else RFN_G2(false, false);
-      }
+#define RFN_G2(BN_, NSK_, D3_, BIAS_, RES_)                                                                              \
+  hipLaunchKernelGGL((gemm_nt2_kernel<1, 192, BN_, 2, 2, BIAS_, RES_, 0, NSK_, 4, 4, D3_>), grid, block, 0, s,           \
+                     (const uint16_t*)X, (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tn,    \
+                     (int)t2, e2)
+#define RFN_G2E(BN_, NSK_, D3_)                                                                                          \
+  do {                                                                                                                   \
+    if (epi.bias != nullptr) {                                                                                           \
+      if (res2) RFN_G2(BN_, NSK_, D3_, true, true);                                                                      \
+      else RFN_G2(BN_, NSK_, D3_, true, false);                                                                          \
+    } else {                                                                                                             \
+      if (res2) RFN_G2(BN_, NSK_, D3_, false, true);                                                                     \
+      else RFN_G2(BN_, NSK_, D3_, false, false);                                                                         \
+    }                                                                                                                    \
+  } while (0)
+      if (bn2 == 320) RFN_G2E(320, 3, 8);
+      else RFN_G2E(256, 2, 6);
+#undef RFN_G2E
 #undef RFN_G2
       return check_launch("gemm_nt2");
     }

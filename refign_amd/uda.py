@@ -938,7 +938,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if self.psweight_ignore_bottom > 0:
             pseudo_weight[:, -self.psweight_ignore_bottom:, :] = 0
         if os.environ.get("RFN_DACS_KERNEL", "1") != "0" and _dacs.usable(images_src, images_trg, gt_src,
-                                                                              getattr(self.head, "num_classes", 19)):
+                                                                              getattr(getattr(self, "head", None), "num_classes", 19)):
             # N4: the pixel work of the mix / jitter / blur as HIP kernels (refign_amd/dacs.py); the draws below are made in
             # the order the per-sample loop further down makes them
             classes = torch.unique(gt_src) if src_classes is None else src_classes

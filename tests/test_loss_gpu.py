@@ -61,13 +61,21 @@ def test_all_pixels_ignored_gives_zero_loss_and_gradient(dev):
     assert float(loss) == 0.0 and float(lg.grad.abs().max()) == 0.0
 
 
-def test_defer_logits_only_when_the_consumer_understands_it(dev, monkeypatch):
+def test_defer_logits_only_when_the_consumer_understands_it(dev):
+    """The deferred (fused up-sampling + cross-entropy) form is per model / head: a module marked by a model whose
+    loss is exactly PixelWeightedCrossEntropyLoss hands out DeferredUpsample, anything else gets a tensor."""
     from refign_amd import seg
     lg = torch.randn(1, 19, 8, 8, device=dev, requires_grad=True)
-    monkeypatch.setattr(seg, "FUSED_CE_CONSUMER", False)
-    assert torch.is_tensor(seg.defer_logits(lg, (32, 32)))
-    monkeypatch.setattr(seg, "FUSED_CE_CONSUMER", True)
-    assert isinstance(seg.defer_logits(lg, (32, 32)), seg.DeferredUpsample)
-    assert torch.is_tensor(seg.defer_logits(lg, (12, 12)))                 # scale < 2: ATen
+    assert torch.is_tensor(seg.defer_logits(lg, (32, 32)))                 # default: no fused consumer
+    head, other = torch.nn.Identity(), torch.nn.Identity()
+
+    class _Sub(seg.PixelWeightedCrossEntropyLoss):
+        def forward(self, *a, **k):
+            return super().forward(*a, **k)
+    assert seg.mark_fused_ce_consumer(head, seg.PixelWeightedCrossEntropyLoss()) is True
+    assert seg.mark_fused_ce_consumer(other, _Sub()) is False              # a subclass may override forward: tensor
+    assert torch.is_tensor(seg.defer_logits(lg, (32, 32), seg.fused_ce_consumer(other)))
+    assert isinstance(seg.defer_logits(lg, (32, 32), seg.fused_ce_consumer(head)), seg.DeferredUpsample)
+    assert torch.is_tensor(seg.defer_logits(lg, (12, 12), True))           # scale < 2: ATen
     with torch.no_grad():
-        assert torch.is_tensor(seg.defer_logits(lg, (32, 32)))             # nothing to differentiate: ATen
+        assert torch.is_tensor(seg.defer_logits(lg, (32, 32), True))       # nothing to differentiate: ATen
