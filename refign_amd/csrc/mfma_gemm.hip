@@ -1107,10 +1107,12 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   if constexpr (!GATHER && DT == 1) {
     static const int g2 = getenv("RFN_GEMM2") ? atoi(getenv("RFN_GEMM2")) : 2;
     static const long g2_min = getenv("RFN_GEMM2_MIN_TILES") ? atol(getenv("RFN_GEMM2_MIN_TILES")) : 200;
-    const int bn2 = N % 320 == 0 ? 320 : (g2 >= 2 && N % 256 == 0 ? 256 : 0);
+    // (192 x 256 from K = 256 on: at K = 128 the 8-wave tile is 3-7 % faster, at K >= 512 the new one 1.1-1.45 x --
+    // profiles/r04_gemm2_256_ab.txt)
+    const int bn2 = N % 320 == 0 ? 320 : (g2 >= 2 && N % 256 == 0 && K >= 256 ? 256 : 0);
     const long t2 = bn2 ? (long)cdiv(M, 192) * (N / bn2) : 0;
     const bool res2 = epi.res != nullptr || epi.rowscale != nullptr;
-    if (g2 && bn2 && !out32 && K >= (bn2 == 320 ? 192 : 128) && K % 64 == 0 && (epi.act & 255) == 0 && t2 >= g2_min &&
+    if (g2 && bn2 && !out32 && K >= 192 && K % 64 == 0 && (epi.act & 255) == 0 && t2 >= g2_min &&
         (M + 192) * ldy * 2 < (1L << 32) && ldx < (1L << 22) && ldw < (1L << 22) && (((size_t)X | (size_t)W | (size_t)Y) & 15) == 0 &&
         (epi.res == nullptr || ((size_t)epi.res & 15) == 0)) {
       Gemm2Epi e2{epi.bias, epi.res, epi.rowscale, epi.rows_per_sample, nullptr};

@@ -72,10 +72,10 @@ def test_gemm_nt_epilogues(dev, act):
     (38500, 320, 128 + 64, True, False, True), # per-sample scale without residual
     # N % 256 == 0 (not a multiple of 320): 192 x 256 tiles, two store-carrying K-steps
     (40001, 256, 1024, False, False, False),   # decode-head 1 x 1 convolution (ASPP branch), ragged bottom edge
-    (39000, 512, 128, True, False, False),     # stage-2 fc1: minimum K (two K-steps)
+    (39000, 512, 256, True, False, False),     # minimum K of the 256-column tiles
     (20400, 2048, 512, True, False, False),    # stage-4 fc1
     (20400, 512, 2048, True, True, True),      # stage-4 fc2 with the stochastic-depth residual
-    (38500, 256, 128, False, True, False),     # residual, minimum K of the residual kernels
+    (38500, 256, 256, False, True, False),     # residual, minimum K
 ])
 def test_gemm_nt_second_generation_kernel(dev, M, N, K, bias, res, scale):
     """Big-M, N % 320 == 0 problems run the software-pipelined kernel of csrc/gemm2.h (192 x 320 tiles, stores issued under

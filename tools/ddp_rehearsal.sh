@@ -12,6 +12,7 @@ echo -n "one GPU, no process group                                        : "; r
 echo -n "one GPU, 1-rank RCCL group                                       : "; env $D MASTER_PORT=29561 bash -c "$(declare -f run); run"
 echo -n "one rank of N, defaults (direct RCCL exchanges, graphed student) : "; env $D MASTER_PORT=29562 RFN_DDP_REHEARSAL=1 bash -c "$(declare -f run); run"
 echo -n "  the guard's second attempt (fake stall after the first step, RFN_BENCH_STALL_S=25)  : "; RFN_DDP_REHEARSAL=1 RFN_BENCH_FAKE_STALL=1 RFN_BENCH_STALL_S=25 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29569 bench.py --gpus 1 --steps 12 --warmup 3 --no-cpu --no-roofline 2>$O/second_attempt.err | grep '"metric"' | sed 's/.*"ms_per_step": \([0-9.]*\).*"attempt": \([0-9]\).*/\1 ms (attempt \2)/'
+echo -n "  the guard's second attempt (an exception in the first set-up step)               : "; RFN_DDP_REHEARSAL=1 RFN_BENCH_FAKE_RAISE=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29570 bench.py --gpus 1 --steps 12 --warmup 3 --no-cpu --no-roofline 2>$O/second_attempt_raise.err | grep '"metric"' | sed 's/.*"ms_per_step": \([0-9.]*\).*"attempt": \([0-9]\).*/\1 ms (attempt \2)/'
 echo -n "  gradient reduce over a communicator of our own at the tail (RFN_DDP_DIRECT_REDUCE=1) : "; env $D MASTER_PORT=29567 RFN_DDP_REHEARSAL=1 RFN_DDP_DIRECT_REDUCE=1 bash -c "$(declare -f run); run"
 echo -n "  stream order + in-graph gradient releases (RFN_DDP_MIXED_COMM=0 RFN_DDP_DIRECT_REDUCE=1) : "; env $D MASTER_PORT=29568 RFN_DDP_REHEARSAL=1 RFN_DDP_MIXED_COMM=0 RFN_DDP_DIRECT_REDUCE=1 bash -c "$(declare -f run); run"
 echo -n "  direct RCCL exchanges, eager student (RFN_GRAPH_DDP=0)         : "; env $D MASTER_PORT=29563 RFN_DDP_REHEARSAL=1 RFN_GRAPH_DDP=0 bash -c "$(declare -f run); run"
