@@ -50,9 +50,11 @@ const char* rfn_last_error(void);
  * (correlation_cuda_kernel.cu:50-56), which differs from its own CPU path for EVEN patch sizes with dilation_patch > 1
  * (patch 2, dilation 2: {-1, 1} vs {0, 2}); the hot path (patch 9, dilation_patch 1) is not affected, and the oracle
  * (oracle/corr_oracle.c) restates the CPU path.
- * f32 and f64 are provided (the CPU reference dispatches float/double: correlation.cpp:107).  The CUDA
- * reference additionally dispatches half (correlation_cuda_kernel.cu:267); the Python wrapper always casts to
- * float32 (correlation_function.py:51), so half is RFN_ENOTSUP here.
+ * f32 and f64 are provided (the CPU reference dispatches float/double: correlation.cpp:107), and f16 because the CUDA
+ * reference additionally dispatches half (correlation_cuda_kernel.cu:267, AT_DISPATCH_FLOATING_TYPES_AND_HALF) -- although
+ * the Python wrapper always casts to float32 (correlation_function.py:51) and never reaches it.  f16: IEEE half elements,
+ * every product formed and summed in fp32, ONE rounding per result element (forward: generic kernel; backward: a
+ * deterministic gather kernel, no 16-bit atomics); any parameterisation.
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_corr_fwd_f32(const float* in1, const float* in2, float* out, int B, int C, int iH, int iW,
                      int kH, int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
@@ -66,6 +68,14 @@ int rfn_corr_bwd_f32(const float* in1, const float* in2, const float* grad_out, 
                      rfn_stream_t stream);
 int rfn_corr_bwd_f64(const double* in1, const double* in2, const double* grad_out, double* grad_in1,
                      double* grad_in2, int B, int C, int iH, int iW, int kH, int kW, int patchH, int patchW,
+                     int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW,
+                     rfn_stream_t stream);
+
+int rfn_corr_fwd_f16(const void* in1, const void* in2, void* out, int B, int C, int iH, int iW,
+                     int kH, int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW,
+                     int dpH, int dpW, int dH, int dW, rfn_stream_t stream);
+int rfn_corr_bwd_f16(const void* in1, const void* in2, const void* grad_out, void* grad_in1,
+                     void* grad_in2, int B, int C, int iH, int iW, int kH, int kW, int patchH, int patchW,
                      int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW,
                      rfn_stream_t stream);
 

@@ -26,6 +26,8 @@ SIGNATURES = {
     "rfn_corr_fwd_f64": (c_int, [c_void_p] * 3 + [c_int] * 4 + _CORR12 + [c_void_p]),
     "rfn_corr_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
     "rfn_corr_bwd_f64": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
+    "rfn_corr_fwd_f16": (c_int, [c_void_p] * 3 + [c_int] * 4 + _CORR12 + [c_void_p]),
+    "rfn_corr_bwd_f16": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
     "rfn_local_corr_layer_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "rfn_local_corr_layer_split_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "rfn_global_corr_layer_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),

@@ -19,15 +19,16 @@ from torch.nn.modules.utils import _pair
 from . import _lib
 from ._tensor import current_stream, ptr, require_device_tensor, same_device, on_device
 
-_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+# (half: the pybind module of the reference dispatches it on the device, correlation_cuda_kernel.cu:267; `forward` / `backward`
+# below take it, `spatial_correlation_sample` casts to float32 like the reference's wrapper and never passes it)
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.float16: "f16"}
 
 
 def _suffix(t):
     try:
         return _SUFFIX[t.dtype]
     except KeyError:
-        raise RuntimeError(f"correlation: unsupported dtype {t.dtype} (float32/float64; the Python wrapper of the "
-                           f"reference always casts to float32, correlation_function.py:51)") from None
+        raise RuntimeError(f"correlation: unsupported dtype {t.dtype} (float32 / float64 / float16)") from None
 
 
 def output_size(iH, iW, kH, kW, padH, padW, dilationH, dilationW, dH, dW):

@@ -33,6 +33,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace rfn {
@@ -933,10 +935,17 @@ struct CorrParams {
   int B, C, iH, iW, oH, oW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW;
 };
 
+// accumulation type: the element type itself for float / double (the CPU reference's `scalar_t` sums, bit for bit), fp32
+// for half (the CUDA reference dispatches half too, correlation_cuda_kernel.cu:267; its sums are warp-shuffled partials in
+// half -- here every product is formed and summed in fp32 and the result is rounded once)
+template <typename T> struct CorrAcc { using type = T; };
+template <> struct CorrAcc<__half> { using type = float; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void corr_generic_fwd_kernel(const T* __restrict__ in1,
                                                                const T* __restrict__ in2, T* __restrict__ out,
                                                                CorrParams p, long total) {
+  using A = typename CorrAcc<T>::type;
   const int radH = (p.patchH - 1) / 2, radW = (p.patchW - 1) / 2;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     long t = idx;
@@ -950,7 +959,7 @@ __global__ __launch_bounds__(256) void corr_generic_fwd_kernel(const T* __restri
     const size_t plane = (size_t)p.iH * p.iW;
     const T* a = in1 + (size_t)n * p.C * plane;
     const T* b = in2 + (size_t)n * p.C * plane;
-    T acc = 0;
+    A acc = 0;
     for (int c = 0; c < p.C; ++c) {
       for (int i = 0; i < p.kH; ++i) {
         const int i1 = u + i * p.dilH, i2 = i1 + sU;
@@ -958,11 +967,11 @@ __global__ __launch_bounds__(256) void corr_generic_fwd_kernel(const T* __restri
         for (int jj = 0; jj < p.kW; ++jj) {
           const int j1 = v + jj * p.dilW, j2 = j1 + sV;
           if (j1 < 0 || j1 >= p.iW || j2 < 0 || j2 >= p.iW) continue;
-          acc += a[c * plane + (size_t)i1 * p.iW + j1] * b[c * plane + (size_t)i2 * p.iW + j2];
+          acc += (A)a[c * plane + (size_t)i1 * p.iW + j1] * (A)b[c * plane + (size_t)i2 * p.iW + j2];
         }
       }
     }
-    out[idx] = acc;
+    out[idx] = (T)acc;
   }
 }
 
@@ -1112,6 +1121,61 @@ __global__ __launch_bounds__(256) void corr_generic_bwd_kernel(const T* __restri
   }
 }
 
+// Generic backward, GATHER form (deterministic, any parameterisation): one thread per (n, c, y, x) collects, for every
+// patch offset and kernel tap, the output position that touched this pixel -- h = (y + pad - i dil) / stride when that
+// division is exact and in range (correlation.cpp:131-183 read from the gradient's side).  Sums in CorrAcc<T>, one rounding.
+// Used for half, where the scatter kernel above would need 16-bit atomics and round after every add.
+template <typename T>
+__global__ __launch_bounds__(256) void corr_generic_bwd_gather_kernel(const T* __restrict__ in1, const T* __restrict__ in2,
+                                                                      const T* __restrict__ gout, T* __restrict__ g1,
+                                                                      T* __restrict__ g2, CorrParams p, long total) {
+  using A = typename CorrAcc<T>::type;
+  const int radH = (p.patchH - 1) / 2, radW = (p.patchW - 1) / 2;
+  const size_t plane = (size_t)p.iH * p.iW, oplane = (size_t)p.oH * p.oW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int x = t % p.iW; t /= p.iW;
+    const int y = t % p.iH; t /= p.iH;
+    const int c = t % p.C;
+    const int n = t / p.C;
+    const T* a = in1 + ((size_t)n * p.C + c) * plane;
+    const T* b = in2 + ((size_t)n * p.C + c) * plane;
+    const T* go = gout + (size_t)n * p.patchH * p.patchW * oplane;
+    A s1 = 0, s2 = 0;
+    for (int ph = 0; ph < p.patchH; ++ph) {
+      const int sU = (ph - radH) * p.dpH;
+      for (int pw = 0; pw < p.patchW; ++pw) {
+        const int sV = (pw - radW) * p.dpW;
+        const T* gp = go + (size_t)(ph * p.patchW + pw) * oplane;
+        for (int i = 0; i < p.kH; ++i) {
+          // g1: this pixel is input1's tap (i1 = y); its partner in input2 is (y + sU)
+          const int hn = y + p.padH - i * p.dilH;
+          const bool hok = hn >= 0 && hn % p.dH == 0 && hn / p.dH < p.oH;
+          // g2: this pixel is input2's tap (i2 = y), so i1 = y - sU
+          const int y1 = y - sU, hn2 = y1 + p.padH - i * p.dilH;
+          const bool hok2 = y1 >= 0 && y1 < p.iH && hn2 >= 0 && hn2 % p.dH == 0 && hn2 / p.dH < p.oH;
+          if (!hok && !hok2) continue;
+          for (int jj = 0; jj < p.kW; ++jj) {
+            if (hok) {
+              const int wn = x + p.padW - jj * p.dilW;
+              const int y2 = y + sU, x2 = x + sV;
+              if (wn >= 0 && wn % p.dW == 0 && wn / p.dW < p.oW && y2 >= 0 && y2 < p.iH && x2 >= 0 && x2 < p.iW)
+                s1 += (A)gp[(size_t)(hn / p.dH) * p.oW + wn / p.dW] * (A)b[(size_t)y2 * p.iW + x2];
+            }
+            if (hok2) {
+              const int x1 = x - sV, wn2 = x1 + p.padW - jj * p.dilW;
+              if (x1 >= 0 && x1 < p.iW && wn2 >= 0 && wn2 % p.dW == 0 && wn2 / p.dW < p.oW)
+                s2 += (A)gp[(size_t)(hn2 / p.dH) * p.oW + wn2 / p.dW] * (A)a[(size_t)y1 * p.iW + x1];
+            }
+          }
+        }
+      }
+    }
+    g1[idx] = (T)s1;
+    g2[idx] = (T)s2;
+  }
+}
+
 static int fill_params(CorrParams& p, int B, int C, int iH, int iW, int kH, int kW, int patchH, int patchW,
                        int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW) {
   if (B <= 0 || C <= 0 || iH <= 0 || iW <= 0) return fail(RFN_EINVAL, "corr: non-positive tensor size");
@@ -1157,6 +1221,12 @@ static int corr_bwd_any(const T* in1, const T* in2, const T* gout, T* g1, T* g2,
       return check_launch("corr9_bwd_tile_kernel<2>");
     }
   }
+  if constexpr (std::is_same<T, __half>::value) {
+    const long total = (long)p.B * p.C * p.iH * p.iW;
+    const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 32);
+    hipLaunchKernelGGL((corr_generic_bwd_gather_kernel<T>), dim3(grid), dim3(256), 0, st, in1, in2, gout, g1, g2, p, total);
+    return check_launch("corr_generic_bwd_gather_kernel");
+  } else {
   if (is_k1(p)) {
     const long total = (long)p.B * p.C * p.iH * p.iW;
     const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 32);
@@ -1171,6 +1241,7 @@ static int corr_bwd_any(const T* in1, const T* in2, const T* gout, T* g1, T* g2,
   hipLaunchKernelGGL((corr_generic_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, in1, in2, gout, g1, g2, p,
                      total);
   return check_launch("corr_generic_bwd_kernel");
+  }
 }
 
 }  // namespace rfn
@@ -1221,6 +1292,27 @@ int rfn_corr_bwd_f64(const double* in1, const double* in2, const double* grad_ou
   if (int rc = fill_params(p, B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW))
     return rc;
   return corr_bwd_any<double>(in1, in2, grad_out, grad_in1, grad_in2, p, (hipStream_t)stream);
+}
+
+int rfn_corr_fwd_f16(const void* in1, const void* in2, void* out, int B, int C, int iH, int iW, int kH, int kW, int patchH,
+                     int patchW, int padH, int padW, int dilH, int dilW, int dpH, int dpW, int dH, int dW,
+                     rfn_stream_t stream) {
+  RFN_REQUIRE(in1 && in2 && out, "rfn_corr_fwd_f16: null pointer");
+  CorrParams p;
+  if (int rc = fill_params(p, B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW))
+    return rc;
+  return corr_fwd_any<__half>((const __half*)in1, (const __half*)in2, (__half*)out, p, (hipStream_t)stream);
+}
+
+int rfn_corr_bwd_f16(const void* in1, const void* in2, const void* grad_out, void* grad_in1, void* grad_in2, int B, int C,
+                     int iH, int iW, int kH, int kW, int patchH, int patchW, int padH, int padW, int dilH, int dilW, int dpH,
+                     int dpW, int dH, int dW, rfn_stream_t stream) {
+  RFN_REQUIRE(in1 && in2 && grad_out && grad_in1 && grad_in2, "rfn_corr_bwd_f16: null pointer");
+  CorrParams p;
+  if (int rc = fill_params(p, B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilH, dilW, dpH, dpW, dH, dW))
+    return rc;
+  return corr_bwd_any<__half>((const __half*)in1, (const __half*)in2, (const __half*)grad_out, (__half*)grad_in1,
+                              (__half*)grad_in2, p, (hipStream_t)stream);
 }
 
 int rfn_local_corr_layer_f32(const float* feature_target, const float* feature_source, const float* flow,

@@ -3,7 +3,7 @@
 // binds (:62-70 forward, :92-101 backward, :129-132 PYBIND11_MODULE), on top of the C ABI of librefign_hip.so
 // (include/refign_hip.h: rfn_corr_fwd_* / rfn_corr_bwd_*).  Contract kept: contiguous NCHW inputs on one device
 // (CHECK_CONTIGUOUS / CHECK_SAME_DEVICE, correlation_sampler.cpp:13-16 -> RuntimeError), freshly allocated results returned by
-// value, float / double (half: the reference's Python wrapper never passes it, correlation_function.py:51).  One difference,
+// value, float / double / half (AT_DISPATCH_FLOATING_TYPES_AND_HALF, correlation_cuda_kernel.cu:267).  One difference,
 // on purpose: the kernels run on the CURRENT stream (the CUDA reference launches on the legacy default stream,
 // correlation_cuda_kernel.cu:271) -- which is what torch code around it expects.
 // Host-only C++: no HIP source here; built by refign_amd/torch_shim/build.py (torch.utils.cpp_extension, in-tree).
@@ -22,8 +22,9 @@ void check_inputs(const torch::Tensor& a, const torch::Tensor& b, const char* wh
   TORCH_CHECK(a.device() == b.device(), what, ": inputs must be on the same device");
   TORCH_CHECK(a.is_cuda(), what, ": this build serves HIP tensors (the CPU path is the reference's own correlation.cpp)");
   TORCH_CHECK(a.dim() == 4 && b.sizes() == a.sizes(), what, ": inputs must be (B, C, H, W) of equal shape");
-  TORCH_CHECK(a.scalar_type() == b.scalar_type() && (a.scalar_type() == torch::kFloat32 || a.scalar_type() == torch::kFloat64),
-              what, ": float32 / float64");
+  TORCH_CHECK(a.scalar_type() == b.scalar_type() && (a.scalar_type() == torch::kFloat32 || a.scalar_type() == torch::kFloat64 ||
+                                                     a.scalar_type() == torch::kFloat16),
+              what, ": float32 / float64 / float16");
 }
 
 void check_rc(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": ", rfn_last_error()); }
@@ -40,6 +41,10 @@ torch::Tensor correlation_sample_forward(torch::Tensor input1, torch::Tensor inp
   if (input1.scalar_type() == torch::kFloat32)
     check_rc(rfn_corr_fwd_f32(input1.data_ptr<float>(), input2.data_ptr<float>(), out.data_ptr<float>(), B, C, iH, iW, kH, kW,
                               patchH, patchW, padH, padW, dilationH, dilationW, dilation_patchH, dilation_patchW, dH, dW, st),
+             "correlation.forward");
+  else if (input1.scalar_type() == torch::kFloat16)
+    check_rc(rfn_corr_fwd_f16(input1.data_ptr(), input2.data_ptr(), out.data_ptr(), B, C, iH, iW, kH, kW, patchH, patchW, padH,
+                              padW, dilationH, dilationW, dilation_patchH, dilation_patchW, dH, dW, st),
              "correlation.forward");
   else
     check_rc(rfn_corr_fwd_f64(input1.data_ptr<double>(), input2.data_ptr<double>(), out.data_ptr<double>(), B, C, iH, iW, kH, kW,
@@ -63,6 +68,11 @@ std::vector<torch::Tensor> correlation_sample_backward(torch::Tensor input1, tor
     check_rc(rfn_corr_bwd_f32(input1.data_ptr<float>(), input2.data_ptr<float>(), go.data_ptr<float>(), g1.data_ptr<float>(),
                               g2.data_ptr<float>(), B, C, iH, iW, kH, kW, patchH, patchW, padH, padW, dilationH, dilationW,
                               dilation_patchH, dilation_patchW, dH, dW, st),
+             "correlation.backward");
+  else if (input1.scalar_type() == torch::kFloat16)
+    check_rc(rfn_corr_bwd_f16(input1.data_ptr(), input2.data_ptr(), go.data_ptr(), g1.data_ptr(), g2.data_ptr(), B, C, iH, iW,
+                              kH, kW, patchH, patchW, padH, padW, dilationH, dilationW, dilation_patchH, dilation_patchW, dH,
+                              dW, st),
              "correlation.backward");
   else
     check_rc(rfn_corr_bwd_f64(input1.data_ptr<double>(), input2.data_ptr<double>(), go.data_ptr<double>(), g1.data_ptr<double>(),

@@ -47,6 +47,30 @@ def test_corr_hot_vs_oracle_ragged(dev, oracle, shape):
     np.testing.assert_allclose(tb.grad.cpu().numpy(), w2, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", golden_names("corr_"))
+def test_corr_half_dispatch(dev, oracle, name):
+    """The CUDA reference dispatches half as well (correlation_cuda_kernel.cu:267); `correlation.forward / backward` take
+    float16 tensors of EVERY golden parameterisation: products and sums in fp32, one rounding per element -- so the result is
+    the fp64 oracle's on the half-rounded operands to within one half rounding of the result's scale."""
+    from refign_amd import correlation
+    g = golden(name)
+    a = [int(v) for v in g["args"]]
+    kw = dict(kernel_size=(a[0], a[1]), patch_size=(a[2], a[3]), padding=(a[4], a[5]), dilation=(a[6], a[7]),
+              dilation_patch=(a[8], a[9]), stride=(a[10], a[11]))
+    h1, h2, hg = (T(g[k].astype(np.float16), dev) for k in ("in1", "in2", "grad_out"))
+    d1, d2, dg = (t.cpu().numpy().astype(np.float64) for t in (h1, h2, hg))
+    out = correlation.forward(h1, h2, *a)
+    assert out.dtype == torch.float16
+    want = oracle.corr_forward(d1, d2, **kw)
+    eps = 2.0 ** -10
+    assert np.abs(out.cpu().numpy().astype(np.float64) - want).max() <= eps * max(np.abs(want).max(), 1e-3)
+    g1, g2 = correlation.backward(h1, h2, hg, *a)
+    w1, w2 = oracle.corr_backward(d1, d2, dg, **kw)
+    for got, ref in ((g1, w1), (g2, w2)):
+        assert got.dtype == torch.float16
+        assert np.abs(got.cpu().numpy().astype(np.float64) - ref).max() <= eps * max(np.abs(ref).max(), 1e-3)
+
+
 def test_corr_errors(dev):
     from refign_amd import correlation
     a = torch.zeros(1, 2, 4, 4, device=dev)
@@ -55,7 +79,7 @@ def test_corr_errors(dev):
     with pytest.raises(RuntimeError):
         correlation.forward(a, a, 9, 9, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1)      # kernel larger than the image
     with pytest.raises(RuntimeError):
-        correlation.forward(a.half(), a.half(), 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)
+        correlation.forward(a.bfloat16(), a.bfloat16(), 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)   # float32 / float64 / float16 only
     with pytest.raises(RuntimeError):
         correlation.forward(a.transpose(2, 3), a, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)   # non-contiguous
 

@@ -38,3 +38,13 @@ def test_shim_matches_reference_goldens(dev, name):
     np.testing.assert_allclose(g2.cpu().numpy(), g["grad_in2"], rtol=1e-4, atol=1e-5)
     with pytest.raises(RuntimeError):
         m.forward(in1.transpose(2, 3), in2.transpose(2, 3), *a)   # CHECK_CONTIGUOUS
+    # half, as the reference's device dispatch takes it (correlation_cuda_kernel.cu:267): fp32 sums, one rounding
+    oh = m.forward(in1.half(), in2.half(), *a)
+    assert oh.dtype == torch.float16
+    want = m.forward(in1.half().float(), in2.half().float(), *a)
+    assert float((oh.float() - want).abs().max()) <= 2.0 ** -10 * max(float(want.abs().max()), 1e-3)
+    h1, h2 = m.backward(in1.half(), in2.half(), torch.from_numpy(g["grad_out"]).to(dev).half(), *a)
+    w1, w2 = m.backward(in1.half().float(), in2.half().float(), torch.from_numpy(g["grad_out"]).to(dev).half().float(), *a)
+    for got, ref in ((h1, w1), (h2, w2)):
+        assert got.dtype == torch.float16
+        assert float((got.float() - ref).abs().max()) <= 2.0 ** -10 * max(float(ref.abs().max()), 1e-3)
