@@ -24,7 +24,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (without it RCCL / tensor sharing across processes fails with
+# hipIpcGetMemHandle: invalid argument); the image exports it already -- kept here for a launcher that scrubs the environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
