@@ -67,7 +67,11 @@ def main():
         add(f"corr9 raw            {lvl} C={C} {H}x{W}{note}", timeit(lambda: correlation.forward(f1, f2, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)), nb, fp)
         add(f"corr9 +relu+l2norm   {lvl} C={C} {H}x{W}{note}", timeit(lambda: correlation.local_correlation_layer(f2, f1)), nb, fp)
         add(f"corr9 +warp+relu+l2n {lvl} C={C} {H}x{W}{note}", timeit(lambda: correlation.local_correlation_layer(f2, f1, flow=fl)), nb + 8 * b * H * W, fp)
-        add(f"warp features        {lvl} C={C} {H}x{W}", timeit(lambda: matching.warp_nocheck(f2, fl)), 4 * b * H * W * (2 * C + 2))
+        add(f"warp features        {lvl} C={C} {H}x{W} [white-noise flow, sigma 5 px]", timeit(lambda: matching.warp_nocheck(f2, fl)), 4 * b * H * W * (2 * C + 2))
+        # a SMOOTH flow (what a matcher emits: a 1/16-resolution field up-sampled): neighbouring lanes gather neighbouring taps
+        fs = torch.nn.functional.interpolate(5 * torch.randn(b, 2, max(H // 16, 2), max(W // 16, 2), generator=g), size=(H, W),
+                                             mode="bilinear", align_corners=False).contiguous().to(dev)
+        add(f"warp features        {lvl} C={C} {H}x{W} [smooth flow]", timeit(lambda: matching.warp_nocheck(f2, fs)), 4 * b * H * W * (2 * C + 2))
         add(f"l2norm channels      {lvl} C={C} {H}x{W}", timeit(lambda: matching.l2_normalize_channels(f2)), 4 * b * H * W * 2 * C)
         f16 = f2.half().contiguous(memory_format=torch.channels_last)
         add(f"l2norm nhwc16->nchw  {lvl} C={C} {H}x{W}", timeit(lambda: matching.l2_normalize_channels(f16)), 6 * b * H * W * C)
