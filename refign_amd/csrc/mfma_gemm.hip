@@ -1117,7 +1117,13 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
         (epi.res == nullptr || ((size_t)epi.res & 15) == 0)) {
       Gemm2Epi e2{epi.bias, epi.res, epi.rowscale, epi.rows_per_sample, nullptr};
       const int tn = (int)(N / bn2);
-      dim3 grid((unsigned)std::min<long>(t2, 256)), block(256);
+      // persistent grid: the tiles are dealt round-robin, so the launch takes ceil(t2 / G) rounds whatever G <= 256 is -- the
+      // smallest G with the same round count leaves the other CUs to the streams that run next to the teacher (425 tiles: 213
+      // workgroups of 2 tiles instead of 256 of which 87 run one; RFN_GEMM2_BALANCE=0: always 256)
+      static const int g2_bal = getenv("RFN_GEMM2_BALANCE") ? atoi(getenv("RFN_GEMM2_BALANCE")) : 1;
+      static const long g2_cap = getenv("RFN_GEMM2_GRID_CAP") ? atol(getenv("RFN_GEMM2_GRID_CAP")) : 256;   // (experiment knob)
+      const long rounds = cdiv(t2, g2_cap);
+      dim3 grid((unsigned)(g2_bal ? cdiv(t2, rounds) : std::min<long>(t2, g2_cap))), block(256);
 #define RFN_G2(BN_, NSK_, D3_, BIAS_, RES_)                                                                              \
   hipLaunchKernelGGL((gemm_nt2_kernel<1, 192, BN_, 2, 2, BIAS_, RES_, 0, NSK_, 4, 4, D3_>), grid, block, 0, s,           \
                      (const uint16_t*)X, (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tn,    \
