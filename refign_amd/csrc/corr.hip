@@ -292,6 +292,21 @@ __device__ __forceinline__ void lds_dma16_nt(const float* gsrc, float* lds_wave_
 #pragma clang diagnostic pop
 }
 
+// The same under a lane mask, WITHOUT control flow the compiler can see: exec is narrowed and restored inside the asm
+// statement.  (An `if (ok) lds_dma16(...)` is a branch around the instruction; between the unrolled product steps of
+// corr9_pipe2_kernel such branches split the chunk into basic blocks, and the products -- pure arithmetic -- then sink
+// out of their steps: spills, and no pipeline left.)
+// (scalar 64-bit base + 32-bit byte offset per lane: one address VGPR instead of two)
+__device__ __forceinline__ void lds_dma16_masked(const void* sbase, unsigned voff, unsigned lds_wave_base,
+                                                 unsigned long long mask) {
+  unsigned long long saved;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %3\n\ts_and_saveexec_b64 %0, %4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved) : "v"(voff), "s"(sbase), "s"(lds_wave_base), "s"(mask) : "memory", "m0", "scc");
+#pragma clang diagnostic pop
+}
+
 // NTILE = 2: the workgroup is two independent halves, each owning its own tile (ids 2b, 2b+1 of the launch's tile
 // order), its own LDS region and its own DMA stream; only the per-chunk barrier is shared.  This doubles the waves per
 // CU (6-wave workgroups do not co-reside: their 2,2,1,1 wave placement over the SIMDs leaves no room for a second one
@@ -705,20 +720,30 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe_ke
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
+  // The counted wait assumes TWO newer chunks in flight behind the one about to be read.  That is not true for a tile's last
+  // two chunks (nothing is issued any more): `vmcnt(NWAIT)` then lets a wave through with its own slots of the chunk still
+  // in flight -- found in round 4 with tools/micro/corr_race.py (11 of 300 launches differed, by the products of the last
+  // 2-4 channels, whenever another stream kept the memory system busy).  The last two hand-offs of a tile wait for everything.
+  auto handoff_all = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   issue(ring0);
   issue(ring1);
   issue(ring2);
   for (int ck = 0; ck < nchunks; ck += 4) {
+    const bool last = ck + 4 >= nchunks;               // (scalar)
     handoff();                                         // chunk ck in ring0; ring3 (chunk ck-1) free
     if (ck + 3 < nchunks) issue(ring3);
     compute(ring0);
     handoff();
     if (ck + 4 < nchunks) issue(ring0);
     compute(ring1);
-    handoff();
+    if (last) handoff_all(); else handoff();
     if (ck + 5 < nchunks) issue(ring1);
     compute(ring2);
-    handoff();
+    if (last) handoff_all(); else handoff();
     if (ck + 6 < nchunks) issue(ring2);
     compute(ring3);
   }
@@ -769,6 +794,312 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe_ke
   }
 }
 
+// ---- 4-stage variant, second take (round 4, second half) ---------------------------------------------------------
+// What the counters said about corr9_pipe_kernel (profiles/r04_pmc_corr9.txt): it is VALU-bound, not LDS-bound
+// (`ds_read_b128` moves 256 B / clock / CU on gfx950: 10 reads x 12 waves x 4 clocks = 480 clocks per channel against
+// 3 waves x 66 VALU x 4 = 792 per SIMD), with 66 VALU instructions per channel where 54 are products (5 address
+// computations + 7 moves), every `ds_read` waited for right behind its issue (the other two waves of the SIMD are the
+// only latency cover) and 24 VGPRs holding wave-uniform LDS-DMA destinations as generic pointers.  Same decomposition,
+// same products in the same order (identical results), but
+//   * the wave index is a scalar (`readfirstlane`): DMA destinations live in SGPRs;
+//   * a chunk's six (channel, vertical shift) row steps are unrolled with immediate offsets from two per-lane bases,
+//     and software-pipelined: the three `ds_read_b128` of step s + 1 are issued into a second register set before the
+//     18 packed products of step s (`sched_barrier` pins the order; hipcc's waitcnt pass then emits lgkmcnt(3));
+//   * the DMA of the chunk three ahead is issued behind the first reads of a chunk, inside their latency.
+template <int TH, int TW, bool FUSE, int MINW, int NTILE>
+__global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_kernel(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
+    int tilesX, int tilesY, int ntiles, int ablate, int xcd_remap) {
+  static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
+  constexpr int CC = 2;
+  constexpr int STRIPS = TW / 4;
+  constexpr int RPW = 64 / STRIPS;
+  constexpr int NT = TH * STRIPS * 3;
+  constexpr int NW = NT / 64;
+  constexpr int R2 = TH + 2 * kHalo;
+  constexpr int ROWS = R2 + TH;
+  constexpr int PITCH = (TW == 64) ? 72 : 48;        // (bank geometry: see corr9_pipe_kernel)
+  constexpr int V = PITCH / 4;
+  constexpr int VU2 = (TW + 2 * kHalo) / 4;
+  constexpr int SLOTS = CC * ROWS * V;
+  constexpr int NINSTR = (SLOTS + 63) / 64;
+  constexpr int K = (NINSTR + NW - 1) / NW;
+  constexpr int BUF = NINSTR * 64 * 4;
+  __shared__ __attribute__((aligned(16))) float ring0_all[NTILE * BUF];
+  __shared__ __attribute__((aligned(16))) float ring1_all[NTILE * BUF];
+  __shared__ __attribute__((aligned(16))) float ring2_all[NTILE * BUF];
+  __shared__ __attribute__((aligned(16))) float ring3_all[NTILE * BUF];
+
+  const int gw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: wave of the workgroup
+  const int half = gw / NW, wave = gw % NW;
+  const int lane = threadIdx.x & 63;
+  const int tid = wave * 64 + lane;
+  float* const ring0 = ring0_all + half * BUF;
+  float* const ring1 = ring1_all + half * BUF;
+  float* const ring2 = ring2_all + half * BUF;
+  float* const ring3 = ring3_all + half * BUF;
+  // xcd_remap: workgroup b runs on XCD b % 8 (round-robin dispatch); give every XCD a contiguous band of tiles, so that the
+  // halo rows two neighbouring tiles both fetch meet in ONE L2 (the launch is a single round: neighbours run side by side)
+  int wg = blockIdx.x;
+  if (xcd_remap) {
+    const int nwg = gridDim.x, qq = nwg / 8, rr = nwg % 8, xcd = wg % 8, loc = wg / 8;
+    wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+  }
+  const int tile = wg * NTILE + half;
+  const bool live = tile < ntiles;
+  int bid = live ? tile : 0;
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY;
+  const int n = bid / tilesY;
+  const int h0 = ty * TH, w0 = tx * TW;
+  constexpr int WPG = TH / RPW;
+  const int dyg = wave / WPG;
+  const int q = lane / STRIPS, j = lane % STRIPS;
+  const int row = (wave % WPG) * RPW + q;
+  const int strip = (TW == 64) ? ((q & 1) ? ((j + 14) & 15) : j) : (j ^ ((((q & 3) == 1) || ((q & 3) == 2)) ? 4 : 0));
+
+  const size_t plane = (size_t)H * W;
+  const float* p1 = in1 + (size_t)n * C * plane;
+  const float* p2 = in2 + (size_t)n * C * plane;
+
+  for (int i = tid; i < BUF / 4; i += NT) {
+    reinterpret_cast<float4*>(ring0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(ring1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(ring2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(ring3)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // DMA sources as 32-bit byte offsets from the lower of the two tensors (the launcher checks that both fit in 4 GB from
+  // there): half the address registers, and the loop has none to spare (a spilled pointer is reloaded through `s_waitcnt
+  // vmcnt(0)`, which also waits for every DMA in flight)
+  const char* const gbase = reinterpret_cast<const char*>(in1 < in2 ? in1 : in2);
+  unsigned goff[K];
+  unsigned long long gmask[K];                         // lanes of my k-th DMA instruction that have a source (scalar)
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int wi = wave + k * NW;
+    const int slot = wi * 64 + lane;
+    const int v = slot % V, rr = (slot / V) % ROWS, c = slot / (V * ROWS);
+    bool ok = live && (wi < NINSTR) && (slot < SLOTS) && !(ablate & 1);   // (ablate: profiling -- bit 0 no DMA, bit 2 no stores)
+    const float* src;
+    if (rr < R2) {
+      const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
+      ok = ok && v < VU2 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+      src = p2 + (size_t)c * plane + (long)gy * W + gx;
+    } else {
+      const int gy = h0 + rr - R2, gx = w0 + 4 * v;
+      ok = ok && v < STRIPS && gy < H && gx + 3 < W;
+      src = p1 + (size_t)c * plane + (long)gy * W + gx;
+    }
+    goff[k] = ok ? (unsigned)(reinterpret_cast<const char*>(src) - gbase) : 0u;
+    gmask[k] = __builtin_amdgcn_ballot_w64(ok);
+  }
+  __syncthreads();
+
+  // one DMA instruction of mine (k-th of the chunk; `on` = all ones, or zero for the chunks past the tile's last) -- issued
+  // ONE AT A TIME between the row steps of a chunk: right behind the barrier every wave of the SIMD is in the same phase,
+  // and three vector-memory issues in a row there idle the VALU
+  const unsigned chunk_bytes = (unsigned)(CC * plane * sizeof(float));
+  auto lds_addr = [](float* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) float*)p; };
+  auto issue1 = [&](unsigned ring, int k, unsigned long long on) {
+    const int wi = wave + k * NW;                      // scalar
+    lds_dma16_masked(gbase, goff[k], ring + (unsigned)wi * 1024u, gmask[k] & on);
+    goff[k] += chunk_bytes;
+  };
+  auto issue = [&](float* ring) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) issue1(lds_addr(ring), k, ~0ull);
+  };
+
+  f32x2 accp[3][4][4];
+  float accs[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      accs[a][i] = 0.0f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) accp[a][i][p] = f32x2{0.0f, 0.0f};
+    }
+
+  const int a_off = (R2 + row) * PITCH + 4 * strip;          // my 4 target pixels
+  const int b_off = (row + dyg * 3) * PITCH + 4 * strip;     // my first source row (vertical shift dyg * 3)
+
+  // one (channel, vertical shift) step: 36 products of 4 target pixels with 12 source pixels = 16 packed + 4 single FMAs,
+  // written as volatile asm: (a) products are pure arithmetic, and nothing else keeps instruction selection from emitting them
+  // after the block's last side effect (= behind the next chunks' barriers, every loaded row spilled: seen); volatile asm
+  // statements keep their order among themselves and with the DMA statements and barriers; (b) the broadcast of a target
+  // pixel is an op_sel of the pair it was loaded in (hipcc moved pixel 3 into a fresh pair: one move per channel).
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  auto step = [&](const f32x4& a, const f32x4* b, int dyi) {
+    const f32x2 ap[2] = {a.xy, a.zw};
+    const f32x2 bp[6] = {b[0].xy, b[0].zw, b[1].xy, b[1].zw, b[2].xy, b[2].zw};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const f32x2 bb = bp[(i + 2 * p + (i & 1)) / 2];
+        if (i & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(accp[dyi][i][p]) : "v"(ap[i >> 1]), "v"(bb));
+        else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(accp[dyi][i][p]) : "v"(ap[i >> 1]), "v"(bb));
+      }
+      const int kb = (i & 1) ? i : i + 8;
+      asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(accs[dyi][i]) : "v"(a[i]), "v"(b[kb >> 2][kb & 3]));
+    }
+  };
+  // LDS reads by byte address: per-lane base (of the ring in use) + immediate offset
+  typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
+  auto lds_ld = [](unsigned addr) { return *(lds_f32x4_ptr)(size_t)addr; };
+  auto ldrow = [&](f32x4* b, unsigned pb, int st) {          // st = c * 3 + dyi, compile-time after unrolling
+    const unsigned rp = pb + (unsigned)(((st / 3) * ROWS + (st % 3)) * PITCH * 4);
+    b[0] = lds_ld(rp);
+    b[1] = lds_ld(rp + 16);
+    b[2] = lds_ld(rp + 32);
+  };
+  // A chunk in two parts of three row steps.  `nxt`: the ring that takes the chunk three ahead (`on` = 0 for the tile's last
+  // three chunks: nothing to fetch); its K DMA instructions go between the row steps of the part that has ISSUE set.  Each part
+  // is ONE basic block: no run-time test in here.  The row registers live across the parts (the first row of part two is
+  // requested under the last step of part one).
+  static_assert(K <= 3 && CC == 2, "one DMA instruction per row step of a part");
+  f32x4 ra[CC], rb[2][3];
+  unsigned pa = 0, pb = 0;                             // my target-row / first-source-row byte addresses in the ring in use
+  auto part = [&](float* cur, float* nxt, unsigned long long on, auto second, auto with_issue) {
+    constexpr int S0 = decltype(second)::value ? 3 : 0;
+    constexpr bool ISSUE = decltype(with_issue)::value;
+    const unsigned nx = lds_addr(nxt);
+    if constexpr (S0 == 0) {
+      // (the ring's address passes through a volatile asm: otherwise the compiler keeps eight per-lane addresses, two per
+      // ring, alive across the loop, and at 168 registers that is eight spills reloaded through `s_waitcnt vmcnt(0)`)
+      unsigned sb = lds_addr(cur);
+      asm volatile("" : "+s"(sb));
+      pa = sb + (unsigned)a_off * 4u;
+      pb = sb + (unsigned)b_off * 4u;
+      ra[0] = lds_ld(pa);
+      ldrow(rb[0], pb, 0);
+      ra[1] = lds_ld(pa + (unsigned)(ROWS * PITCH * 4));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int st = S0; st < S0 + 3; ++st) {
+      if (st + 1 < CC * 3) ldrow(rb[(st + 1) & 1], pb, st + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      step(ra[st / 3], rb[st & 1], st % 3);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ISSUE) {
+        if (st - S0 < K) {
+          issue1(nx, st - S0, on);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+
+  const int nchunks = C / CC;                          // multiple of 4 (checked by the launcher)
+  // chunk hand-off: my own DMA of the chunk has landed once at most NW_ newer instructions of mine are in flight (in-order
+  // completion), the barrier extends that to every wave's and says that everybody is done with the ring about to be refilled
+  auto handoff = [&](auto nwait) {
+    constexpr int NW_ = decltype(nwait)::value;
+    if constexpr (NW_ <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (NW_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (NW_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (NW_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  static_assert(K - 1 == 0 || K - 1 == 1 || K - 1 == 2, "wait counts below");
+  const std::integral_constant<int, 2 * (K - 1)> two_ahead{};     // chunks c+1, c+2 issued behind c (K or K-1 instructions each)
+  const std::integral_constant<int, K - 1> one_ahead{};
+  const std::integral_constant<int, 0> none_ahead{};
+  const std::false_type first{}, no_issue{};
+  const std::true_type second{}, do_issue{};
+  issue(ring0);
+  issue(ring1);
+  issue(ring2);
+  float* const rings[4] = {ring0, ring1, ring2, ring3};
+  // barrier in FRONT of chunk c (chunk c landed; chunks c+1, c+2 in flight), DMA of chunk c+3 under its first part.
+  // (Tried and dropped, profiles/r04_corr_pipe2.txt: the workgroup's second tile half a chunk out of phase -- the same barriers
+  // in the MIDDLE of its chunks, so that one tile's waves multiply while the other's wait for the first rows of a new chunk:
+  // 100 instead of 88 us; two instruction streams per CU cost more than the bubbles.)
+  for (int ck = 0; ck < nchunks - 4; ck += 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      handoff(two_ahead);
+      part(rings[r], rings[(r + 3) & 3], ~0ull, first, do_issue);
+      part(rings[r], rings[(r + 3) & 3], ~0ull, second, no_issue);
+    }
+  }
+  // The tile's last four chunks, with the waits THEIR queue needs: behind chunk n-2 only chunk n-1 is in flight, behind chunk
+  // n-1 nothing -- a constant `vmcnt(2 (K - 1))` would let a wave read them before they have landed (the first 4-stage kernel
+  // did: tools/micro/corr_race.py, 11 of 300 launches off by the last channels' products under memory load).
+  handoff(two_ahead);
+  part(ring0, ring3, ~0ull, first, do_issue);          // chunk n-1 goes out under chunk n-4
+  part(ring0, ring3, ~0ull, second, no_issue);
+  handoff(two_ahead);
+  part(ring1, ring0, 0ull, first, no_issue);
+  part(ring1, ring0, 0ull, second, no_issue);
+  handoff(one_ahead);
+  part(ring2, ring1, 0ull, first, no_issue);
+  part(ring2, ring1, 0ull, second, no_issue);
+  handoff(none_ahead);
+  part(ring3, ring2, 0ull, first, no_issue);
+  part(ring3, ring2, 0ull, second, no_issue);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: ReLU + L2 norm over the 81 shifts on the register PAIRS (packed squares, the ReLU kept in the accumulators; the sum of squares is taken pair-wise, then across the three vertical-shift groups) ----
+  auto get = [&](int dyi, int dx, int i) -> float {
+    if (i & 1) return dx == 0 ? accs[dyi][i] : accp[dyi][i][(dx - 1) >> 1][(dx - 1) & 1];
+    return dx == 8 ? accs[dyi][i] : accp[dyi][i][dx >> 1][dx & 1];
+  };
+  const int h = h0 + row, wx = w0 + 4 * strip;
+  float scale[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (FUSE) {
+    f32x2 ssp[4];
+    float ss[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ssp[i] = f32x2{0.f, 0.f};
+      ss[i] = 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const f32x2 v = __builtin_elementwise_max(accp[a][i][p], f32x2{0.f, 0.f});
+          accp[a][i][p] = v;
+          ssp[i] = __builtin_elementwise_fma(v, v, ssp[i]);
+        }
+        const float v = fmaxf(accs[a][i], 0.0f);
+        accs[a][i] = v;
+        ss[i] = fmaf(v, v, ss[i]);
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ss[i] += ssp[i][0] + ssp[i][1];
+    __syncthreads();
+    float* red = ring0;  // [3][TH][TW]
+    *reinterpret_cast<float4*>(&red[(dyg * TH + row) * TW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float tot = red[(0 * TH + row) * TW + 4 * strip + i] + red[(1 * TH + row) * TW + 4 * strip + i] +
+                        red[(2 * TH + row) * TW + 4 * strip + i];
+      scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+    }
+  }
+  if (live && h < H && wx + 3 < W && !(ablate & 4)) {
+    float* o = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi)
+#pragma unroll
+      for (int dx = 0; dx < 9; ++dx) {
+        *reinterpret_cast<float4*>(o) = make_float4(get(dyi, dx, 0) * scale[0], get(dyi, dx, 1) * scale[1],
+                                                    get(dyi, dx, 2) * scale[2], get(dyi, dx, 3) * scale[3]);
+        o += plane;                                    // (a running pointer: one 64-bit add per store instead of a 64-bit multiply-add)
+      }
+  }
+}
+
 // (The fp32-matrix-pipe formulation of this forward -- exact, measured slower: 166-171 vs 139 us, profiles/r02_corr_mfma_*.txt,
 // r03_corr_f16_ablation.txt -- lives in tools/experiments/matrix_pipe_corr/, outside the product library.)
 
@@ -779,6 +1110,8 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
     if ((W & 3) == 0 && (C % 8) == 0) {
       static const int variant = getenv("RFN_CORR_VARIANT") ? atoi(getenv("RFN_CORR_VARIANT")) : 0;  // tuning knob
       static const int xcd_remap = getenv("RFN_CORR_XCD") ? atoi(getenv("RFN_CORR_XCD")) : 0;
+      // (the second take is fetch-sensitive enough for the XCD-local tile order to pay: DMA alone 65 -> 46 us, kernel -1..-4 us)
+      static const int xcd_remap2 = getenv("RFN_CORR_XCD") ? atoi(getenv("RFN_CORR_XCD")) : 1;
       // profiling only: bit0 no DMA, bit1 no FMAs, bit2 no stores (results are then meaningless)
       static const int ablate = getenv("RFN_CORR_ABLATE") ? atoi(getenv("RFN_CORR_ABLATE")) : 0;
 #define RFN_LAUNCH_DMA(TH_, TW_, CC_, MINW_, UNR_, NTILE_, ILV_)                                                      \
@@ -803,10 +1136,29 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
                        (int)ntiles, xcd_remap);                                                                   \
     return check_launch("corr9_pipe_kernel");                                                                     \
   }
+#define RFN_LAUNCH_PIPE2(TH_, TW_, MINW_, NTILE_)                                                                 \
+  {                                                                                                               \
+    const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
+    const long ntiles = (long)B * tilesX * tilesY;                                                                \
+    const long blocks = (ntiles + NTILE_ - 1) / NTILE_;                                                           \
+    if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
+    hipLaunchKernelGGL((corr9_pipe2_kernel<TH_, TW_, FUSE, MINW_, NTILE_>), dim3((unsigned)blocks),               \
+                       dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
+                       (int)ntiles, ablate, xcd_remap2);                                                          \
+    return check_launch("corr9_pipe2_kernel");                                                                    \
+  }
       // Round 4: at K4 level 1 the 4-stage ring with counted waits (two-channel chunks, three chunks in flight) is the
-      // default -- 102 us against 111 us for the 2-stage kernel on the step's kind of operands (profiles/r04_corr_try.txt);
-      // identical results (same products, same order).
-      if (variant == 0 && ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2 >= 192) RFN_LAUNCH_PIPE(16, 32, 3, 2)
+      // default: 102 us against 111 us for the 2-stage kernel on the step's kind of operands (profiles/r04_corr_try.txt), and
+      // its software-pipelined second take 90 us (profiles/r04_corr_pipe2.txt; needs both tensors within 4 GB of each other
+      // for its 32-bit DMA offsets, otherwise the first take runs).  Same products in the same order.
+      const bool level1 = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2 >= 192;
+      {
+        const size_t lo = std::min((size_t)in1, (size_t)in2), hi = std::max((size_t)in1, (size_t)in2);
+        const bool near4g = hi - lo + (size_t)B * C * H * W * sizeof(float) < (1ull << 32);   // 32-bit DMA offsets
+        if (((variant == 0 && level1) || variant == 40) && near4g) RFN_LAUNCH_PIPE2(16, 32, 3, 2)
+      }
+#undef RFN_LAUNCH_PIPE2
+      if (variant == 0 && level1) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 20) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 21) RFN_LAUNCH_PIPE(16, 64, 3, 1)
       if (variant == 22) RFN_LAUNCH_PIPE(8, 64, 3, 1)
