@@ -317,8 +317,10 @@ def rocprof_in_step_us():
         try:
             with open(path) as f:
                 for r in csv.DictReader(f):
-                    # round 4: the 4-stage-ring kernel is the level-1 default; older summaries hold its predecessor
-                    if "corr9_pipe_kernel<16, 32" in r["Name"] or "corr9_dma_kernel<16, 32" in r["Name"]:
+                    # round 4: the software-pipelined 4-stage-ring kernel is the level-1 default; older summaries hold its
+                    # predecessors
+                    if any(k in r["Name"] for k in ("corr9_pipe2_kernel<16, 32", "corr9_pipe_kernel<16, 32",
+                                                    "corr9_dma_kernel<16, 32")):
                         return {"avg_launch_us": round(float(r["AverageNs"]) / 1e3, 2), "launches": int(r["Calls"]),
                                 "source": os.path.relpath(path, ROOT)}
         except Exception:
@@ -589,7 +591,7 @@ def main():
         us_b2b = series(False)
         us = series(True)
         ach = wl.roofline_bytes() / (us * 1e-6) / 1e9
-        roof = {"kernel": "corr9_pipe_kernel<16x32 tiles, 4-stage LDS-DMA ring, fused ReLU+L2norm> level 1 (C=128, 270x480, "
+        roof = {"kernel": "corr9_pipe2_kernel<16x32 tiles, 4-stage LDS-DMA ring, software-pipelined rows, fused ReLU+L2norm> level 1 (C=128, 270x480, "
                           "b=%d)" % wl.b,
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(), "avg_launch_us": round(us, 2),

@@ -869,29 +869,38 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
     reinterpret_cast<float4*>(ring3)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  // DMA sources as 32-bit byte offsets from the lower of the two tensors (the launcher checks that both fit in 4 GB from
-  // there): half the address registers, and the loop has none to spare (a spilled pointer is reloaded through `s_waitcnt
-  // vmcnt(0)`, which also waits for every DMA in flight)
-  const char* const gbase = reinterpret_cast<const char*>(in1 < in2 ? in1 : in2);
+  // LDS image of a chunk (differs from corr9_pipe_kernel's): the TARGET rows of both channels first, then the source rows --
+  // [f1 c0 | f1 c1 | f2 c0 | f2 c1] -- so that the f1 / f2 border falls on a DMA instruction border (CC * TH * V slots = a
+  // multiple of 64): every instruction then has ONE tensor as its source, i.e. a scalar 64-bit base (the sample's plane 0) +
+  // a 32-bit byte offset per lane: half the address registers, and the loop has none to spare (a spilled pointer is reloaded
+  // through `s_waitcnt vmcnt(0)`, which also waits for every DMA in flight).
+  constexpr int F1SLOTS = CC * TH * V;
+  static_assert(F1SLOTS % 64 == 0, "the target rows of a chunk must fill whole DMA instructions");
+  constexpr int F2BASE = CC * TH * PITCH;              // float offset of the source rows in a ring buffer
   unsigned goff[K];
   unsigned long long gmask[K];                         // lanes of my k-th DMA instruction that have a source (scalar)
+  const float* gbase[K];                               // scalar: p1 or p2
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int wi = wave + k * NW;
     const int slot = wi * 64 + lane;
-    const int v = slot % V, rr = (slot / V) % ROWS, c = slot / (V * ROWS);
     bool ok = live && (wi < NINSTR) && (slot < SLOTS) && !(ablate & 1);   // (ablate: profiling -- bit 0 no DMA, bit 2 no stores)
-    const float* src;
-    if (rr < R2) {
+    long off;
+    if (wi * 64 < F1SLOTS) {                           // scalar
+      const int v = slot % V, rr = (slot / V) % TH, c = slot / (V * TH);
+      const int gy = h0 + rr, gx = w0 + 4 * v;
+      ok = ok && v < STRIPS && gy < H && gx + 3 < W;
+      off = (long)c * (long)plane + (long)gy * W + gx;
+      gbase[k] = p1;
+    } else {
+      const int s2 = slot - F1SLOTS;
+      const int v = s2 % V, rr = (s2 / V) % R2, c = s2 / (V * R2);
       const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
       ok = ok && v < VU2 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
-      src = p2 + (size_t)c * plane + (long)gy * W + gx;
-    } else {
-      const int gy = h0 + rr - R2, gx = w0 + 4 * v;
-      ok = ok && v < STRIPS && gy < H && gx + 3 < W;
-      src = p1 + (size_t)c * plane + (long)gy * W + gx;
+      off = (long)c * (long)plane + (long)gy * W + gx;
+      gbase[k] = p2;
     }
-    goff[k] = ok ? (unsigned)(reinterpret_cast<const char*>(src) - gbase) : 0u;
+    goff[k] = ok ? (unsigned)(off * (long)sizeof(float)) : 0u;
     gmask[k] = __builtin_amdgcn_ballot_w64(ok);
   }
   __syncthreads();
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   auto lds_addr = [](float* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) float*)p; };
   auto issue1 = [&](unsigned ring, int k, unsigned long long on) {
     const int wi = wave + k * NW;                      // scalar
-    lds_dma16_masked(gbase, goff[k], ring + (unsigned)wi * 1024u, gmask[k] & on);
+    lds_dma16_masked(gbase[k], goff[k], ring + (unsigned)wi * 1024u, gmask[k] & on);
     goff[k] += chunk_bytes;
   };
   auto issue = [&](float* ring) {
@@ -922,8 +931,8 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
       for (int p = 0; p < 4; ++p) accp[a][i][p] = f32x2{0.0f, 0.0f};
     }
 
-  const int a_off = (R2 + row) * PITCH + 4 * strip;          // my 4 target pixels
-  const int b_off = (row + dyg * 3) * PITCH + 4 * strip;     // my first source row (vertical shift dyg * 3)
+  const int a_off = row * PITCH + 4 * strip;                           // my 4 target pixels (channel 0 of the chunk)
+  const int b_off = F2BASE + (row + dyg * 3) * PITCH + 4 * strip;      // my first source row (vertical shift dyg * 3)
 
   // one (channel, vertical shift) step: 36 products of 4 target pixels with 12 source pixels = 16 packed + 4 single FMAs,
   // written as volatile asm: (a) products are pure arithmetic, and nothing else keeps instruction selection from emitting them
@@ -950,7 +959,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
   auto lds_ld = [](unsigned addr) { return *(lds_f32x4_ptr)(size_t)addr; };
   auto ldrow = [&](f32x4* b, unsigned pb, int st) {          // st = c * 3 + dyi, compile-time after unrolling
-    const unsigned rp = pb + (unsigned)(((st / 3) * ROWS + (st % 3)) * PITCH * 4);
+    const unsigned rp = pb + (unsigned)(((st / 3) * R2 + (st % 3)) * PITCH * 4);
     b[0] = lds_ld(rp);
     b[1] = lds_ld(rp + 16);
     b[2] = lds_ld(rp + 32);
@@ -975,7 +984,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
       pb = sb + (unsigned)b_off * 4u;
       ra[0] = lds_ld(pa);
       ldrow(rb[0], pb, 0);
-      ra[1] = lds_ld(pa + (unsigned)(ROWS * PITCH * 4));
+      ra[1] = lds_ld(pa + (unsigned)(TH * PITCH * 4));
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -1149,14 +1158,11 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
   }
       // Round 4: at K4 level 1 the 4-stage ring with counted waits (two-channel chunks, three chunks in flight) is the
       // default: 102 us against 111 us for the 2-stage kernel on the step's kind of operands (profiles/r04_corr_try.txt), and
-      // its software-pipelined second take 90 us (profiles/r04_corr_pipe2.txt; needs both tensors within 4 GB of each other
-      // for its 32-bit DMA offsets, otherwise the first take runs).  Same products in the same order.
+      // its software-pipelined second take 89 us (profiles/r04_corr_pipe2.txt; a sample must be < 4 GB for its 32-bit DMA
+      // offsets, otherwise the first take runs).  Same products in the same order.
       const bool level1 = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2 >= 192;
-      {
-        const size_t lo = std::min((size_t)in1, (size_t)in2), hi = std::max((size_t)in1, (size_t)in2);
-        const bool near4g = hi - lo + (size_t)B * C * H * W * sizeof(float) < (1ull << 32);   // 32-bit DMA offsets
-        if (((variant == 0 && level1) || variant == 40) && near4g) RFN_LAUNCH_PIPE2(16, 32, 3, 2)
-      }
+      if (((variant == 0 && level1) || variant == 40) && (size_t)C * H * W * sizeof(float) < (1ull << 32))   // 32-bit offsets within a sample
+        RFN_LAUNCH_PIPE2(16, 32, 3, 2)
 #undef RFN_LAUNCH_PIPE2
       if (variant == 0 && level1) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 20) RFN_LAUNCH_PIPE(16, 32, 3, 2)

@@ -1,0 +1,65 @@
+"""Repeat-and-compare checks of the kernels whose chunk / stage hand-offs are COUNTED waits (`s_waitcnt vmcnt(n)` + barrier over
+LDS-DMA instructions the compiler does not track): the same launch, many times, with another stream keeping the memory system
+busy -- every result must equal the first bit for bit.  A hand-off that lets a wave read a ring slot before its DMA has landed
+passes every golden on a quiet device and shows up here as a few launches that differ by the products of a chunk or two
+(round 4: the first 4-stage correlation kernel did, at the tail of every tile; tools/micro/corr_race.py is the long form)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _repeat(fn, reps, noise_src):
+    ref = fn().clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    bad = 0
+    for i in range(reps):
+        if i % 2 == 0:
+            with torch.cuda.stream(side):
+                _ = noise_src.clone()            # ~130-260 MB copy in flight next to the kernel under test
+        out = fn()
+        if not torch.equal(out, ref):
+            bad += 1
+    torch.cuda.synchronize()
+    return bad
+
+
+def test_local_correlation_level1_is_repeatable_under_memory_load():
+    """corr9_pipe2_kernel / corr9_pipe_kernel at the K4 level-1 size (2 x 128 x 270 x 480): 150 launches, identical results."""
+    from refign_amd import correlation
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    f1 = torch.nn.functional.normalize(torch.relu(torch.randn(2, 128, 270, 480, generator=g)), dim=1).to(dev)
+    f2 = torch.nn.functional.normalize(torch.relu(torch.randn(2, 128, 270, 480, generator=g)), dim=1).to(dev)
+    assert _repeat(lambda: correlation.local_correlation_layer(f2, f1), 150, f1) == 0
+
+
+@pytest.mark.parametrize("M,N,K,res", [(81600, 320, 320, True), (81600, 320, 1280, True), (20400, 512, 2048, False),
+                                       (8160, 1280, 320, False)])
+def test_gemm_nt_is_repeatable_under_memory_load(M, N, K, res):
+    """gemm_nt2_kernel (counted hand-off behind dripped stores) and gemm_nt_kernel (ring with counted waits): 60 launches."""
+    from refign_amd import mfma
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
+    b = torch.randn(N, generator=g).to(dev).bfloat16()
+    r = torch.randn(M, N, generator=g).to(dev).bfloat16() if res else None
+    noise = torch.empty(64 << 20, device=dev, dtype=torch.float32).normal_()
+    assert _repeat(lambda: mfma.gemm_nt(x, w, b, res=r), 60, noise) == 0
+
+
+def test_attention_forward_is_repeatable_under_memory_load():
+    """attn_fwd_kernel on the teacher's stage-3 shape (40 views x 5 heads, 2040 queries, 510 keys): 40 launches."""
+    from refign_amd import mfma
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(8, 2040, 320, generator=g).to(dev).bfloat16()
+    kv = torch.randn(8, 510, 640, generator=g).to(dev).bfloat16()
+    noise = torch.empty(64 << 20, device=dev, dtype=torch.float32).normal_()
+
+    def fn():
+        with torch.no_grad():
+            return mfma.attention(q, kv, 5, 0.125)
+    assert _repeat(fn, 40, noise) == 0
