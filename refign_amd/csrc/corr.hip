@@ -833,7 +833,6 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   const int gw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: wave of the workgroup
   const int half = gw / NW, wave = gw % NW;
   const int lane = threadIdx.x & 63;
-  const int tid = wave * 64 + lane;
   float* const ring0 = ring0_all + half * BUF;
   float* const ring1 = ring1_all + half * BUF;
   float* const ring2 = ring2_all + half * BUF;
@@ -861,13 +860,6 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   const size_t plane = (size_t)H * W;
   const float* p1 = in1 + (size_t)n * C * plane;
   const float* p2 = in2 + (size_t)n * C * plane;
-
-  for (int i = tid; i < BUF / 4; i += NT) {
-    reinterpret_cast<float4*>(ring0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(ring1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(ring2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(ring3)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
 
   // LDS image of a chunk (differs from corr9_pipe_kernel's): the TARGET rows of both channels first, then the source rows --
   // [f1 c0 | f1 c1 | f2 c0 | f2 c1] -- so that the f1 / f2 border falls on a DMA instruction border (CC * TH * V slots = a
@@ -903,7 +895,6 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
     goff[k] = ok ? (unsigned)(off * (long)sizeof(float)) : 0u;
     gmask[k] = __builtin_amdgcn_ballot_w64(ok);
   }
-  __syncthreads();
 
   // one DMA instruction of mine (k-th of the chunk; `on` = all ones, or zero for the chunks past the tile's last) -- issued
   // ONE AT A TIME between the row steps of a chunk: right behind the barrier every wave of the SIMD is in the same phase,
@@ -1024,6 +1015,21 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   issue(ring0);
   issue(ring1);
   issue(ring2);
+  // Zero padding: a slot without a source (outside the image, or the unused tail of a row) is never written by the DMA -- and
+  // is the same slot in every chunk.  Each lane zeroes ITS slots of the four rings once, AFTER the first three chunks are on
+  // their way (disjoint addresses): the first kernel zeroed all 120 KB and synchronised before its first DMA (~1 us).
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int wi = wave + k * NW;
+    if (wi < NINSTR && !((gmask[k] >> lane) & 1)) {
+      const int o = wi * 256 + lane * 4;
+      *reinterpret_cast<float4*>(ring0 + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(ring1 + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(ring2 + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(ring3 + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible to the others behind the first hand-off's barrier
   float* const rings[4] = {ring0, ring1, ring2, ring3};
   // barrier in FRONT of chunk c (chunk c landed; chunks c+1, c+2 in flight), DMA of chunk c+3 under its first part.
   // (Tried and dropped, profiles/r04_corr_pipe2.txt: the workgroup's second tile half a chunk out of phase -- the same barriers
