@@ -1169,6 +1169,11 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
       const bool level1 = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2 >= 192;
       if (((variant == 0 && level1) || variant == 40) && (size_t)C * H * W * sizeof(float) < (1ull << 32))   // 32-bit offsets within a sample
         RFN_LAUNCH_PIPE2(16, 32, 3, 2)
+      // Smaller maps (K4 level 2: 2 x 256 x 135 x 240; K2 level 1: 128 x 128): single 8 x 32 tiles, 3-wave workgroups -- 272
+      // workgroups instead of 136 on the 256 CUs, and the pipelined chunk: 115 -> 88 us and 59 -> 34 us against the 2-stage
+      // 8 x 64 kernel (profiles/r04_corr_pipe2.txt; 16 x 32 tiles 91 us, two / four tiles per workgroup 88 / 120 us).
+      if (((variant == 0 && !level1) || variant == 41) && C >= 16 && (size_t)C * H * W * sizeof(float) < (1ull << 32))
+        RFN_LAUNCH_PIPE2(8, 32, 3, 1)
 #undef RFN_LAUNCH_PIPE2
       if (variant == 0 && level1) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 20) RFN_LAUNCH_PIPE(16, 32, 3, 2)

@@ -25,14 +25,17 @@ def _repeat(fn, reps, noise_src):
     return bad
 
 
-def test_local_correlation_level1_is_repeatable_under_memory_load():
-    """corr9_pipe2_kernel / corr9_pipe_kernel at the K4 level-1 size (2 x 128 x 270 x 480): 150 launches, identical results."""
+@pytest.mark.parametrize("B,C,H,W,reps", [(2, 128, 270, 480, 150), (2, 256, 135, 240, 150), (2, 128, 128, 128, 150), (1, 64, 71, 52, 60)])
+def test_local_correlation_is_repeatable_under_memory_load(B, C, H, W, reps):
+    """corr9_pipe2_kernel at the K4 level-1 / level-2 and K2 level-1 sizes (16 x 32 paired and 8 x 32 single tiles) and on a
+    ragged map: identical results, launch after launch."""
     from refign_amd import correlation
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    f1 = torch.nn.functional.normalize(torch.relu(torch.randn(2, 128, 270, 480, generator=g)), dim=1).to(dev)
-    f2 = torch.nn.functional.normalize(torch.relu(torch.randn(2, 128, 270, 480, generator=g)), dim=1).to(dev)
-    assert _repeat(lambda: correlation.local_correlation_layer(f2, f1), 150, f1) == 0
+    f1 = torch.nn.functional.normalize(torch.relu(torch.randn(B, C, H, W, generator=g)), dim=1).to(dev)
+    f2 = torch.nn.functional.normalize(torch.relu(torch.randn(B, C, H, W, generator=g)), dim=1).to(dev)
+    noise = torch.empty(48 << 20, device=dev, dtype=torch.float32).normal_()
+    assert _repeat(lambda: correlation.local_correlation_layer(f2, f1), reps, noise) == 0
 
 
 @pytest.mark.parametrize("M,N,K,res", [(81600, 320, 320, True), (81600, 320, 1280, True), (20400, 512, 2048, False),
