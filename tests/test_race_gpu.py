@@ -66,3 +66,56 @@ def test_attention_forward_is_repeatable_under_memory_load():
         with torch.no_grad():
             return mfma.attention(q, kv, 5, 0.125)
     assert _repeat(fn, 40, noise) == 0
+
+
+def test_implicit_gemm_convolution_is_repeatable_under_memory_load():
+    """gemm_nt_kernel<GATHER> (3 x 3 convolution of the teacher's fusion layer, 4 views here): DMA gather + zero page, ring."""
+    from refign_amd import mfma
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 135, 240, 1024, generator=g).to(dev).bfloat16()
+    w = (torch.randn(256, 1024, 3, 3, generator=g) / 96).to(dev)
+    wp = mfma.pack_conv_weight(w, torch.bfloat16)
+    noise = torch.empty(64 << 20, device=dev, dtype=torch.float32).normal_()
+    assert _repeat(lambda: mfma.conv2d_nhwc(x, wp, None, 3, 3, pad=1), 30, noise) == 0
+
+
+@pytest.mark.parametrize("T,N,K", [(8160, 1280, 320), (8160, 320, 320), (129600, 256, 1024)])
+def test_weight_gradient_partials_are_repeatable_under_memory_load(T, N, K):
+    """gemm_tn3_kernel, deterministic form (fp32 partials per slab): 40 launches."""
+    from refign_amd import mfma
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    gy = torch.randn(T, N, generator=g).to(dev).bfloat16()
+    x = torch.randn(T, K, generator=g).to(dev).bfloat16()
+    noise = torch.empty(64 << 20, device=dev, dtype=torch.float32).normal_()
+    assert _repeat(lambda: mfma.gemm_tn(gy, x), 40, noise) == 0
+
+
+def test_attention_input_gradients_are_repeatable_under_memory_load():
+    """attn_bwd_dq_kernel (deterministic); dK / dV are accumulated with fp32 atomics over query blocks, so THEIR bits depend
+    on the order of arrival: compared with a tolerance, the query gradient bit for bit."""
+    from refign_amd import mfma
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    q0 = torch.randn(4, 2040, 320, generator=g).to(dev).bfloat16()
+    kv0 = torch.randn(4, 510, 640, generator=g).to(dev).bfloat16()
+    go = torch.randn(4, 2040, 320, generator=g).to(dev).bfloat16()
+    noise = torch.empty(64 << 20, device=dev, dtype=torch.float32).normal_()
+    side = torch.cuda.Stream()
+
+    def grads():
+        q, kv = q0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
+        out = mfma.attention(q, kv, 5, 0.125)
+        out.backward(go)
+        return q.grad, kv.grad
+    rq, rkv = grads()
+    torch.cuda.synchronize()
+    for i in range(30):
+        if i % 2 == 0:
+            with torch.cuda.stream(side):
+                _ = noise.clone()
+        gq, gkv = grads()
+        assert torch.equal(gq, rq), f"query gradient differs in launch {i}"
+        torch.testing.assert_close(gkv.float(), rkv.float(), rtol=2e-2, atol=2e-2)
+    torch.cuda.synchronize()
