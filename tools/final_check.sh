@@ -46,3 +46,5 @@ timeout 900 bash tools/ddp_rehearsal.sh $(basename $O) > /dev/null 2>&1
 timeout 900 bash tools/ddp_matrix.sh $(basename $O) > /dev/null 2>&1
 GUARD=240 timeout 1500 bash tools/ddp_first_contact.sh 1 $O/first_contact_1rank > /dev/null 2>&1
 bash tools/pmc_corr.sh corr_l1_fused > $O/pmc_corr9.txt 2>&1
+python tools/pmc_corr_json.py $O/pmc_corr9.txt $O/pmc_traffic_corr9.json > /dev/null 2>&1
+bash tools/micro/corr_p2.sh 2>&1 | grep -v amdgpu.ids > $O/corr_pipe2_now.txt
