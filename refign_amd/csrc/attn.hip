@@ -172,15 +172,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
     const int key0 = st * 64;
     f32x16 sacc[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+    {
+      // K fragments four MFMAs ahead, in a rolling window of four register sets (round 4, second half): hipcc kept TWO in
+      // flight and waited for each pair right behind its reads -- four LDS latencies per stage in front of the matrix pipe
+      vec8 kfr[4];
+      auto kfrag = [&](int idx) {
+        return *(const vec8*)(ks + (idx >> 2) * kPackBlock + ((2 * (idx & 3) + g) * 32 + col) * 16);
+      };
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const vec8 kf = *(const vec8*)(ks + kb * kPackBlock + ((2 * kk + g) * 32 + col) * 16);
-        sacc[kb] = E::mma(kf, qf[kk], sacc[kb]);
+      for (int idx = 0; idx < 4; ++idx) kfr[idx] = kfrag(idx);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) {
+        sacc[idx >> 2] = E::mma(kfr[idx & 3], qf[idx & 3], sacc[idx >> 2]);
+        if (idx + 4 < 8) kfr[idx & 3] = kfrag(idx + 4);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    vec8 vfr[4];
+    auto vfrag = [&](int idx) {                          // idx = (key block, m, head-dimension block)
+      const unsigned char* vq = vs + (idx >> 2) * kPackBlock + ((idx & 1) * 32 + col) * 8;
+      const int m = (idx >> 1) & 1;
+      return join8<DT>(*(const u32x2*)(vq + (4 * m + g) * 512), *(const u32x2*)(vq + (4 * m + 2 + g) * 512));
+    };
+#pragma unroll
+    for (int idx = 0; idx < 4; ++idx) vfr[idx] = vfrag(idx);
+    __builtin_amdgcn_sched_barrier(0);
     float p[2][16];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -221,18 +241,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
         ps += p[kb][r];
       }
     lrun += ps;
+    {
+      // PV: the V fragments of the first key block were requested in front of the softmax arithmetic (below), the second
+      // block's go out one MFMA group behind -- a rolling window of four, like the K fragments
+      vec8 pb[2][2];
+      to_operands<DT>(p[0], pb[0]);
+      to_operands<DT>(p[1], pb[1]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      vec8 pb[2];
-      to_operands<DT>(p[kb], pb);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const unsigned char* vq = vs + kb * kPackBlock + (db * 32 + col) * 8;
-          const vec8 vf = join8<DT>(*(const u32x2*)(vq + (4 * m + g) * 512), *(const u32x2*)(vq + (4 * m + 2 + g) * 512));
-          oacc[db] = E::mma(vf, pb[m], oacc[db]);
-        }
+      for (int idx = 0; idx < 8; ++idx) {
+        const int kb = idx >> 2, m = (idx >> 1) & 1, db = idx & 1;
+        oacc[db] = E::mma(vfr[idx & 3], pb[kb][m], oacc[db]);
+        if (idx + 4 < 8) vfr[idx & 3] = vfrag(idx + 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     wait_dma_all();
     wg_barrier();
@@ -318,18 +339,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     const int key0 = st * 64;
     f32x16 sacc[2], dpacc[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const unsigned char* krs = base + kb * kPackBlock;
-      const unsigned char* vrs = base + (2 + kb) * kPackBlock;
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = dpacc[kb][r] = 0.f;
+    {
+      // K / V fragments four MFMAs ahead (rolling window of four register sets; see attn_fwd_kernel): idx = (kb, kk, K | V)
+      vec8 fr[4];
+      auto frag = [&](int idx) {
+        const int kb = idx >> 3, kk = (idx >> 1) & 3;
+        return *(const vec8*)(base + ((idx & 1) * 2 + kb) * kPackBlock + ((2 * kk + g) * 32 + col) * 16);
+      };
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int off = ((2 * kk + g) * 32 + col) * 16;
-        sacc[kb] = E::mma(*(const vec8*)(krs + off), qf[kk], sacc[kb]);
-        dpacc[kb] = E::mma(*(const vec8*)(vrs + off), gf[kk], dpacc[kb]);
+      for (int idx = 0; idx < 4; ++idx) fr[idx] = frag(idx);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int idx = 0; idx < 16; ++idx) {
+        const int kb = idx >> 3, kk = (idx >> 1) & 3;
+        if (idx & 1) dpacc[kb] = E::mma(fr[idx & 3], gf[kk], dpacc[kb]);
+        else sacc[kb] = E::mma(fr[idx & 3], qf[kk], sacc[kb]);
+        if (idx + 4 < 16) fr[idx & 3] = frag(idx + 4);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // the K^T fragments of the first key block: requested in front of the element-wise part
+    vec8 ktf[4];
+    auto ktfrag = [&](int idx) {                          // idx = (key block, m, head-dimension block)
+      const unsigned char* kq = base + (4 + (idx >> 2)) * kPackBlock + ((idx & 1) * 32 + col) * 8;
+      const int m = (idx >> 1) & 1;
+      return join8<DT>(*(const u32x2*)(kq + (4 * m + g) * 512), *(const u32x2*)(kq + (4 * m + 2 + g) * 512));
+    };
+#pragma unroll
+    for (int idx = 0; idx < 4; ++idx) ktf[idx] = ktfrag(idx);
+    __builtin_amdgcn_sched_barrier(0);
     float ds[2][16];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -343,19 +384,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
         for (int r = 0; r < 16; ++r)
           if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g >= Nkv) ds[kb][r] = 0.f;
     }
+    {
+      vec8 sb[2][2];
+      to_operands<DT>(ds[0], sb[0]);
+      to_operands<DT>(ds[1], sb[1]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const unsigned char* kts = base + (4 + kb) * kPackBlock;
-      vec8 sb[2];
-      to_operands<DT>(ds[kb], sb);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const unsigned char* kq = kts + (db * 32 + col) * 8;
-          const vec8 kf = join8<DT>(*(const u32x2*)(kq + (4 * m + g) * 512), *(const u32x2*)(kq + (4 * m + 2 + g) * 512));
-          dq[db] = E::mma(kf, sb[m], dq[db]);
-        }
+      for (int idx = 0; idx < 8; ++idx) {
+        dq[idx & 1] = E::mma(ktf[idx & 3], sb[idx >> 2][(idx >> 1) & 1], dq[idx & 1]);
+        if (idx + 4 < 8) ktf[idx & 3] = ktfrag(idx + 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     wait_dma_all();
     wg_barrier();
@@ -453,12 +491,33 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __res
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+      {
+        // Q / dO fragments four MFMAs ahead (rolling window of four register sets; see attn_fwd_kernel): idx = (kk, Q | dO)
+        vec8 fr[4];
+        auto frag = [&](int idx) {
+          return *(const vec8*)(base + (idx & 1) * kPackBlock + ((2 * (idx >> 1) + g) * 32 + col) * 16);
+        };
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int off = ((2 * kk + g) * 32 + col) * 16;
-        s = E::mma(*(const vec8*)(base + off), kf[kk], s);                      // S[q][key]
-        dp = E::mma(*(const vec8*)(base + kPackBlock + off), vf[kk], dp);       // dP[q][key]
+        for (int idx = 0; idx < 4; ++idx) fr[idx] = frag(idx);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+          if (idx & 1) dp = E::mma(fr[idx & 3], vf[idx >> 1], dp);             // dP[q][key]
+          else s = E::mma(fr[idx & 3], kf[idx >> 1], s);                       // S[q][key]
+          if (idx + 4 < 8) fr[idx & 3] = frag(idx + 4);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      // the transposed Q / dO fragments of the products below: the first four requested in front of the element-wise part
+      vec8 tf[4];
+      auto tfrag = [&](int idx) {                          // idx = (m, head-dimension block, dO | Q)
+        const int m = idx >> 2, db = (idx >> 1) & 1;
+        const unsigned char* pq = base + (2 + ((idx & 1) ^ 1)) * kPackBlock + (db * 32 + col) * 8;   // even idx: dO (pack 3), odd: Q (pack 2)
+        return join8<DT>(*(const u32x2*)(pq + (4 * m + g) * 512), *(const u32x2*)(pq + (4 * m + 2 + g) * 512));
+      };
+#pragma unroll
+      for (int idx = 0; idx < 4; ++idx) tf[idx] = tfrag(idx);
+      __builtin_amdgcn_sched_barrier(0);
       float p[16], ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -471,16 +530,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const uint16_t* __res
       to_operands<DT>(p, pb);
       to_operands<DT>(ds, sb);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const unsigned char* qq = base + 2 * kPackBlock + (db * 32 + col) * 8;
-          const unsigned char* gq = base + 3 * kPackBlock + (db * 32 + col) * 8;
-          const vec8 qa = join8<DT>(*(const u32x2*)(qq + (4 * m + g) * 512), *(const u32x2*)(qq + (4 * m + 2 + g) * 512));
-          const vec8 ga = join8<DT>(*(const u32x2*)(gq + (4 * m + g) * 512), *(const u32x2*)(gq + (4 * m + 2 + g) * 512));
-          dv[db] = E::mma(ga, pb[m], dv[db]);
-          dk[db] = E::mma(qa, sb[m], dk[db]);
-        }
+      for (int idx = 0; idx < 8; ++idx) {
+        const int m = idx >> 2, db = (idx >> 1) & 1;
+        if (idx & 1) dk[db] = E::mma(tf[idx & 3], sb[m], dk[db]);
+        else dv[db] = E::mma(tf[idx & 3], pb[m], dv[db]);
+        if (idx + 4 < 8) tf[idx & 3] = tfrag(idx + 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   if (kok) {

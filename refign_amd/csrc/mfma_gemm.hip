@@ -230,20 +230,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
     produce();                                // step s + 3 into the buffer step s - 1 occupied
     drained = false;
     const unsigned char* st = smem + (int)(s % NS) * STAGE;
+    // fragment reads ONE k-sub-step ahead of the MFMAs (round 4, second half): left to itself hipcc re-uses one register set
+    // and emits read, `s_waitcnt lgkmcnt(0)`, MFMA, read, wait, MFMA ... -- four LDS latencies in a row per K-step and wave,
+    // which on the student's 64 x 64 tiles (one MFMA per sub-step) IS the K-step.  `sched_barrier` pins the order.
+    // (one MFMA per sub-step -- the 64 x 64 tile: all four sub-steps' fragments up front, 32 registers it has to spare)
+    constexpr int FD = (IB * JB == 1) ? BK / 16 : 2;     // fragment register sets
+    vec8 wf[FD][IB], xf[FD][JB];
+    auto read_frags = [&](int ks, int b) {
+      const int coff = ((2 * ks + g) ^ swz) * 16;
+#pragma unroll
+      for (int i = 0; i < IB; ++i) wf[b][i] = *(const vec8*)(st + woff + i * 32 * ROWB + coff);
+#pragma unroll
+      for (int j = 0; j < JB; ++j) xf[b][j] = *(const vec8*)(st + xoff + j * 32 * ROWB + coff);
+    };
+#pragma unroll
+    for (int ks = 0; ks < FD - 1; ++ks) read_frags(ks, ks);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      const int coff = ((2 * ks + g) ^ swz) * 16;
-      vec8 wf[IB], xf[JB];
-#pragma unroll
-      for (int i = 0; i < IB; ++i) wf[i] = *(const vec8*)(st + woff + i * 32 * ROWB + coff);
-#pragma unroll
-      for (int j = 0; j < JB; ++j) xf[j] = *(const vec8*)(st + xoff + j * 32 * ROWB + coff);
+      if (ks + FD - 1 < BK / 16) read_frags(ks + FD - 1, (ks + FD - 1) % FD);
+      __builtin_amdgcn_sched_barrier(0);
       if (!(ablate & 2)) {
 #pragma unroll
         for (int i = 0; i < IB; ++i)
 #pragma unroll
-          for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(wf[i], xf[j], acc[i][j]);
+          for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(wf[ks % FD][i], xf[ks % FD][j], acc[i][j]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (++c_kt == nk) {
       // ---- epilogue.  Registers -> (bias, activation, 16-bit rounding) -> a per-wave LDS staging block -> row-contiguous
@@ -994,48 +1006,59 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
     wait_dma_all();
     wg_barrier();                                  // stage `it` has landed everywhere; everybody is done reading stage it - 1
     if (it + 1 < nit) issue(it + 1, buf ^ 1);
-#pragma unroll
-    for (int ks = 0; ks < BT / 16; ++ks) {
+    // Transpose reads run AHEAD of the MFMAs (round 4, second half): the fragments of sub-step ks + 1 (64 x 64 tiles, one MFMA
+    // per sub-step: of all the stage's sub-steps) are requested before the products of ks, and the wait counts what is allowed
+    // to be in flight -- it used to be read, `lgkmcnt(0)`, MFMA, read ... : one LDS latency per sub-step and wave in a row.
+    // The reads are inline asm: the compiler does not know that their results arrive asynchronously, and nothing ties the MFMAs
+    // to the wait -- volatile asms keep their order, and the empty ones give the users of a register set a dependency on it.
+    constexpr int NSUB = BT / 16;
+    constexpr int FD = (IB * JB == 1) ? NSUB : 2;      // fragment register sets
+    constexpr int NRD = 2 * (IB + JB);                 // reads per sub-step
+    static_assert(NRD * (FD - 1) <= 15, "lgkmcnt is a 4-bit count");
+    u32x2 a0[FD][IB], a1[FD][IB], b0[FD][JB], b1[FD][JB];
+    auto read_frags = [&](int ks, int set) {
       const int row = 16 * ks + frow;
-      typename E::vec8 af[IB], bf[JB];
-      u32x2 a0[IB], a1[IB], b0[JB], b1[JB];
 #pragma unroll
       for (int i = 0; i < IB; ++i) {
         const int c = wn * (BN / 2) + i * 32 + fcol;
-        a0[i] = lds_read_tr16(gaddr(buf, row, c));
-        a1[i] = lds_read_tr16(gaddr(buf, row + 4, c));
+        a0[set][i] = lds_read_tr16(gaddr(buf, row, c));
+        a1[set][i] = lds_read_tr16(gaddr(buf, row + 4, c));
       }
 #pragma unroll
       for (int j = 0; j < JB; ++j) {
         const int c = wk * (BK / 2) + j * 32 + fcol;
-        b0[j] = lds_read_tr16(xaddr(buf, row, c));
-        b1[j] = lds_read_tr16(xaddr(buf, row + 4, c));
+        b0[set][j] = lds_read_tr16(xaddr(buf, row, c));
+        b1[set][j] = lds_read_tr16(xaddr(buf, row + 4, c));
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // the transpose reads are inline asm: the compiler does not know that their results arrive asynchronously, and nothing
-      // ties the MFMAs below to the wait above -- it scheduled the first of them in front of it (found when the run-time
-      // rowscale branch that used to sit here went away).  Volatile asms keep their order; these give the users a dependency.
+    };
+    static_for<0, FD - 1>([&](auto kc) { read_frags(decltype(kc)::value, decltype(kc)::value); });
+    static_for<0, NSUB>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value, set = ks % FD;
+      if constexpr (ks + FD - 1 < NSUB) read_frags(ks + FD - 1, (ks + FD - 1) % FD);
+      constexpr int ahead = (NSUB - 1 - ks < FD - 1 ? NSUB - 1 - ks : FD - 1) * NRD;   // reads of younger sub-steps in flight
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(ahead) : "memory");
+      typename E::vec8 af[IB], bf[JB];
 #pragma unroll
-      for (int i = 0; i < IB; ++i) asm volatile("" : "+v"(a0[i]), "+v"(a1[i]));
+      for (int i = 0; i < IB; ++i) asm volatile("" : "+v"(a0[set][i]), "+v"(a1[set][i]));
 #pragma unroll
-      for (int j = 0; j < JB; ++j) asm volatile("" : "+v"(b0[j]), "+v"(b1[j]));
+      for (int j = 0; j < JB; ++j) asm volatile("" : "+v"(b0[set][j]), "+v"(b1[set][j]));
 #pragma unroll
       for (int i = 0; i < IB; ++i) {
         if (do_bias) {
           float f[8];
-          unpack4<DT>(a0[i], *(float(*)[4])&f[0]);
-          unpack4<DT>(a1[i], *(float(*)[4])&f[4]);
+          unpack4<DT>(a0[set][i], *(float(*)[4])&f[0]);
+          unpack4<DT>(a1[set][i], *(float(*)[4])&f[4]);
           bsum[i] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         }
-        af[i] = join8<DT>(a0[i], a1[i]);
+        af[i] = join8<DT>(a0[set][i], a1[set][i]);
       }
 #pragma unroll
-      for (int j = 0; j < JB; ++j) bf[j] = join8<DT>(b0[j], b1[j]);
+      for (int j = 0; j < JB; ++j) bf[j] = join8<DT>(b0[set][j], b1[set][j]);
 #pragma unroll
       for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < JB; ++j) acc[i][j] = E::mma(af[i], bf[j], acc[i][j]);
-    }
+    });
     if constexpr (SEG) {
       ctb += BT;
       if (ctb >= cend) {                               // the sample is complete: fold it in with its scale
