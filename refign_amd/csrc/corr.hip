@@ -268,6 +268,14 @@ __global__ __launch_bounds__(TH * kStrips * 3) void corr9_tile_kernel(
 // --------------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. N - 1
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // One LDS-DMA instruction (global -> LDS, 16 bytes per lane, lane i lands at lds_wave_base + 16 i), issued through
 // inline asm ON PURPOSE.  With the `__builtin_amdgcn_global_load_lds` builtin hipcc tracks the pending LDS write and,
 // whenever it cannot prove that a later `ds_read` touches a different object, inserts `s_waitcnt vmcnt(0)` in front of
@@ -806,7 +814,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe_ke
 //     and software-pipelined: the three `ds_read_b128` of step s + 1 are issued into a second register set before the
 //     18 packed products of step s (`sched_barrier` pins the order; hipcc's waitcnt pass then emits lgkmcnt(3));
 //   * the DMA of the chunk three ahead is issued behind the first reads of a chunk, inside their latency.
-template <int TH, int TW, bool FUSE, int MINW, int NTILE>
+template <int TH, int TW, bool FUSE, int MINW, int NTILE, int DEPTH = 1, int NS = 4>
 __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_kernel(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
     int tilesX, int tilesY, int ntiles, int ablate, int xcd_remap) {
@@ -825,18 +833,16 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   constexpr int NINSTR = (SLOTS + 63) / 64;
   constexpr int K = (NINSTR + NW - 1) / NW;
   constexpr int BUF = NINSTR * 64 * 4;
-  __shared__ __attribute__((aligned(16))) float ring0_all[NTILE * BUF];
-  __shared__ __attribute__((aligned(16))) float ring1_all[NTILE * BUF];
-  __shared__ __attribute__((aligned(16))) float ring2_all[NTILE * BUF];
-  __shared__ __attribute__((aligned(16))) float ring3_all[NTILE * BUF];
+  // NS ring stages of [tile of the workgroup][BUF]: NS - 1 chunks are in flight while one is consumed.  Level 1 (12 waves per
+  // CU, a chunk's arithmetic ~1 us): 4 stages.  The small-map instance (one 3-wave workgroup per CU, a chunk's arithmetic ~0.3 us)
+  // is bound by chunks-in-flight / DMA latency with 4 (3 chunks per ~2 us = what it measured: 0.67 us per chunk): 8 stages.
+  static_assert(NS >= 3 && NS * NTILE * BUF * 4 <= 160 * 1024, "ring fits the LDS");
+  __shared__ __attribute__((aligned(16))) float rings_all[NS * NTILE * BUF];
+  constexpr unsigned RB = NTILE * BUF * 4;             // bytes from one stage to the next
 
   const int gw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: wave of the workgroup
   const int half = gw / NW, wave = gw % NW;
   const int lane = threadIdx.x & 63;
-  float* const ring0 = ring0_all + half * BUF;
-  float* const ring1 = ring1_all + half * BUF;
-  float* const ring2 = ring2_all + half * BUF;
-  float* const ring3 = ring3_all + half * BUF;
   // xcd_remap: workgroup b runs on XCD b % 8 (round-robin dispatch); give every XCD a contiguous band of tiles, so that the
   // halo rows two neighbouring tiles both fetch meet in ONE L2 (the launch is a single round: neighbours run side by side)
   int wg = blockIdx.x;
@@ -906,9 +912,10 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
     lds_dma16_masked(gbase[k], goff[k], ring + (unsigned)wi * 1024u, gmask[k] & on);
     goff[k] += chunk_bytes;
   };
-  auto issue = [&](float* ring) {
+  const unsigned lds0 = lds_addr(rings_all + half * BUF);              // my tile's stage 0 (scalar); stage r at lds0 + r * RB
+  auto issue = [&](unsigned ring) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) issue1(lds_addr(ring), k, ~0ull);
+    for (int k = 0; k < K; ++k) issue1(ring, k, ~0ull);
   };
 
   f32x2 accp[3][4][4];
@@ -960,29 +967,34 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   // is ONE basic block: no run-time test in here.  The row registers live across the parts (the first row of part two is
   // requested under the last step of part one).
   static_assert(K <= 3 && CC == 2, "one DMA instruction per row step of a part");
-  f32x4 ra[CC], rb[2][3];
+  // DEPTH: how many row steps the source-row reads run ahead of the products (DEPTH + 1 register sets of three `ds_read_b128`).
+  // One step covers the LDS latency when three waves share a SIMD (level 1); a 3-wave workgroup of the small-map instance has
+  // a SIMD to itself per wave and registers to spare: two steps.
+  static_assert(DEPTH == 1 || DEPTH == 2, "read-ahead of one or two row steps");
+  f32x4 ra[CC], rb[DEPTH + 1][3];
   unsigned pa = 0, pb = 0;                             // my target-row / first-source-row byte addresses in the ring in use
-  auto part = [&](float* cur, float* nxt, unsigned long long on, auto second, auto with_issue) {
+  auto part = [&](int cur, int nxt, unsigned long long on, auto second, auto with_issue) {     // stage indices
     constexpr int S0 = decltype(second)::value ? 3 : 0;
     constexpr bool ISSUE = decltype(with_issue)::value;
-    const unsigned nx = lds_addr(nxt);
+    const unsigned nx = lds0 + (unsigned)nxt * RB;
     if constexpr (S0 == 0) {
       // (the ring's address passes through a volatile asm: otherwise the compiler keeps eight per-lane addresses, two per
       // ring, alive across the loop, and at 168 registers that is eight spills reloaded through `s_waitcnt vmcnt(0)`)
-      unsigned sb = lds_addr(cur);
+      unsigned sb = lds0 + (unsigned)cur * RB;
       asm volatile("" : "+s"(sb));
       pa = sb + (unsigned)a_off * 4u;
       pb = sb + (unsigned)b_off * 4u;
       ra[0] = lds_ld(pa);
-      ldrow(rb[0], pb, 0);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) ldrow(rb[d], pb, d);
       ra[1] = lds_ld(pa + (unsigned)(TH * PITCH * 4));
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int st = S0; st < S0 + 3; ++st) {
-      if (st + 1 < CC * 3) ldrow(rb[(st + 1) & 1], pb, st + 1);
+      if (st + DEPTH < CC * 3) ldrow(rb[(st + DEPTH) % (DEPTH + 1)], pb, st + DEPTH);
       __builtin_amdgcn_sched_barrier(0);
-      step(ra[st / 3], rb[st & 1], st % 3);
+      step(ra[st / 3], rb[st % (DEPTH + 1)], st % 3);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (ISSUE) {
         if (st - S0 < K) {
@@ -997,67 +1009,52 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   // chunk hand-off: my own DMA of the chunk has landed once at most NW_ newer instructions of mine are in flight (in-order
   // completion), the barrier extends that to every wave's and says that everybody is done with the ring about to be refilled
   auto handoff = [&](auto nwait) {
-    constexpr int NW_ = decltype(nwait)::value;
-    if constexpr (NW_ <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (NW_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (NW_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (NW_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(nwait)::value) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
-  static_assert(K - 1 == 0 || K - 1 == 1 || K - 1 == 2, "wait counts below");
-  const std::integral_constant<int, 2 * (K - 1)> two_ahead{};     // chunks c+1, c+2 issued behind c (K or K-1 instructions each)
-  const std::integral_constant<int, K - 1> one_ahead{};
-  const std::integral_constant<int, 0> none_ahead{};
+  static_assert((NS - 2) * (K - 1) <= 63, "vmcnt is a 6-bit count");
   const std::false_type first{}, no_issue{};
   const std::true_type second{}, do_issue{};
-  issue(ring0);
-  issue(ring1);
-  issue(ring2);
+#pragma unroll
+  for (int r = 0; r < NS - 1; ++r) issue(lds0 + r * RB);               // chunks 0 .. NS - 2
   // Zero padding: a slot without a source (outside the image, or the unused tail of a row) is never written by the DMA -- and
-  // is the same slot in every chunk.  Each lane zeroes ITS slots of the four rings once, AFTER the first three chunks are on
-  // their way (disjoint addresses): the first kernel zeroed all 120 KB and synchronised before its first DMA (~1 us).
+  // is the same slot in every chunk.  Each lane zeroes ITS slots of the stages once, AFTER the first chunks are on their way
+  // (disjoint addresses): the first kernel zeroed all 120 KB and synchronised before its first DMA (~1 us).
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int wi = wave + k * NW;
     if (wi < NINSTR && !((gmask[k] >> lane) & 1)) {
-      const int o = wi * 256 + lane * 4;
-      *reinterpret_cast<float4*>(ring0 + o) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(ring1 + o) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(ring2 + o) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(ring3 + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < NS; ++r)
+        *reinterpret_cast<float4*>(rings_all + (r * NTILE + half) * BUF + wi * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible to the others behind the first hand-off's barrier
-  float* const rings[4] = {ring0, ring1, ring2, ring3};
-  // barrier in FRONT of chunk c (chunk c landed; chunks c+1, c+2 in flight), DMA of chunk c+3 under its first part.
+  // barrier in FRONT of chunk c (chunk c landed; chunks c+1 .. c+NS-2 in flight), DMA of chunk c+NS-1 under its first part.
   // (Tried and dropped, profiles/r04_corr_pipe2.txt: the workgroup's second tile half a chunk out of phase -- the same barriers
   // in the MIDDLE of its chunks, so that one tile's waves multiply while the other's wait for the first rows of a new chunk:
   // 100 instead of 88 us; two instruction streams per CU cost more than the bubbles.)
-  for (int ck = 0; ck < nchunks - 4; ck += 4) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      handoff(two_ahead);
-      part(rings[r], rings[(r + 3) & 3], ~0ull, first, do_issue);
-      part(rings[r], rings[(r + 3) & 3], ~0ull, second, no_issue);
-    }
+  const std::integral_constant<int, (NS - 2) * (K - 1)> full_behind{};  // NS - 2 newer chunks, K or K - 1 instructions each
+  for (int ck = 0; ck < nchunks - NS; ck += NS) {        // nchunks is a multiple of NS (checked by the launcher)
+    static_for<0, NS>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      handoff(full_behind);
+      part(r, (r + NS - 1) % NS, ~0ull, first, do_issue);
+      part(r, (r + NS - 1) % NS, ~0ull, second, no_issue);
+    });
   }
-  // The tile's last four chunks, with the waits THEIR queue needs: behind chunk n-2 only chunk n-1 is in flight, behind chunk
-  // n-1 nothing -- a constant `vmcnt(2 (K - 1))` would let a wave read them before they have landed (the first 4-stage kernel
-  // did: tools/micro/corr_race.py, 11 of 300 launches off by the last channels' products under memory load).
-  handoff(two_ahead);
-  part(ring0, ring3, ~0ull, first, do_issue);          // chunk n-1 goes out under chunk n-4
-  part(ring0, ring3, ~0ull, second, no_issue);
-  handoff(two_ahead);
-  part(ring1, ring0, 0ull, first, no_issue);
-  part(ring1, ring0, 0ull, second, no_issue);
-  handoff(one_ahead);
-  part(ring2, ring1, 0ull, first, no_issue);
-  part(ring2, ring1, 0ull, second, no_issue);
-  handoff(none_ahead);
-  part(ring3, ring2, 0ull, first, no_issue);
-  part(ring3, ring2, 0ull, second, no_issue);
+  // The tile's last NS chunks, with the waits THEIR queue needs: behind chunk n - NS + r only NS - 1 - r chunks are in flight -- a
+  // constant count would let a wave read the last chunks before they have landed (the first 4-stage kernel did:
+  // tools/micro/corr_race.py, 11 of 300 launches off by the last channels' products under memory load).
+  static_for<0, NS>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    constexpr int behind = (r == 0 ? NS - 2 : NS - 1 - r) * (K - 1);
+    handoff(std::integral_constant<int, behind>{});
+    if constexpr (r == 0) part(0, NS - 1, ~0ull, first, do_issue);      // chunk n - 1 goes out under chunk n - NS
+    else part(r, 0, 0ull, first, no_issue);
+    part(r, 0, 0ull, second, no_issue);
+  });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: ReLU + L2 norm over the 81 shifts on the register PAIRS (packed squares, the ReLU kept in the accumulators; the sum of squares is taken pair-wise, then across the three vertical-shift groups) ----
@@ -1092,7 +1089,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
 #pragma unroll
     for (int i = 0; i < 4; ++i) ss[i] += ssp[i][0] + ssp[i][1];
     __syncthreads();
-    float* red = ring0;  // [3][TH][TW]
+    float* red = rings_all + half * BUF;  // [3][TH][TW]: stage 0 of my tile
     *reinterpret_cast<float4*>(&red[(dyg * TH + row) * TW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
     __syncthreads();
 #pragma unroll
@@ -1151,13 +1148,13 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
                        (int)ntiles, xcd_remap);                                                                   \
     return check_launch("corr9_pipe_kernel");                                                                     \
   }
-#define RFN_LAUNCH_PIPE2(TH_, TW_, MINW_, NTILE_)                                                                 \
+#define RFN_LAUNCH_PIPE2(TH_, TW_, MINW_, NTILE_, NS_)                                                                    \
   {                                                                                                               \
     const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
     const long ntiles = (long)B * tilesX * tilesY;                                                                \
     const long blocks = (ntiles + NTILE_ - 1) / NTILE_;                                                           \
     if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
-    hipLaunchKernelGGL((corr9_pipe2_kernel<TH_, TW_, FUSE, MINW_, NTILE_>), dim3((unsigned)blocks),               \
+    hipLaunchKernelGGL((corr9_pipe2_kernel<TH_, TW_, FUSE, MINW_, NTILE_, 1, NS_>), dim3((unsigned)blocks),       \
                        dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
                        (int)ntiles, ablate, xcd_remap2);                                                          \
     return check_launch("corr9_pipe2_kernel");                                                                    \
@@ -1168,12 +1165,15 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
       // offsets, otherwise the first take runs).  Same products in the same order.
       const bool level1 = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2 >= 192;
       if (((variant == 0 && level1) || variant == 40) && (size_t)C * H * W * sizeof(float) < (1ull << 32))   // 32-bit offsets within a sample
-        RFN_LAUNCH_PIPE2(16, 32, 3, 2)
+        RFN_LAUNCH_PIPE2(16, 32, 3, 2, 4)
       // Smaller maps (K4 level 2: 2 x 256 x 135 x 240; K2 level 1: 128 x 128): single 8 x 32 tiles, 3-wave workgroups -- 272
       // workgroups instead of 136 on the 256 CUs, and the pipelined chunk: 115 -> 88 us and 59 -> 34 us against the 2-stage
       // 8 x 64 kernel (profiles/r04_corr_pipe2.txt; 16 x 32 tiles 91 us, two / four tiles per workgroup 88 / 120 us).
+      // (8 ring stages instead of 4, and source rows read two steps ahead instead of one, change nothing there -- 89-91 / 88-89
+      // against 87-88 us: a lone wave per SIMD is bound neither by chunks in flight nor by LDS latency; RFN_CORR_VARIANT=46: 8 stages)
       if (((variant == 0 && !level1) || variant == 41) && C >= 16 && (size_t)C * H * W * sizeof(float) < (1ull << 32))
-        RFN_LAUNCH_PIPE2(8, 32, 3, 1)
+        RFN_LAUNCH_PIPE2(8, 32, 3, 1, 4)
+      if (variant == 46 && C % 16 == 0) RFN_LAUNCH_PIPE2(8, 32, 3, 1, 8)
 #undef RFN_LAUNCH_PIPE2
       if (variant == 0 && level1) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 20) RFN_LAUNCH_PIPE(16, 32, 3, 2)
