@@ -814,7 +814,12 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe_ke
 //     and software-pipelined: the three `ds_read_b128` of step s + 1 are issued into a second register set before the
 //     18 packed products of step s (`sched_barrier` pins the order; hipcc's waitcnt pass then emits lgkmcnt(3));
 //   * the DMA of the chunk three ahead is issued behind the first reads of a chunk, inside their latency.
-template <int TH, int TW, bool FUSE, int MINW, int NTILE, int DEPTH = 1, int NS = 4>
+//   * KSPLIT (NTILE == 2): the two wave groups of the workgroup walk the two HALVES of the channels of ONE tile, each through
+//     its own ring, and the second group's 108 sums per lane are added to the first's through the LDS in front of the epilogue
+//     (three rounds of 36 floats per lane in the ring's own memory).  For maps of at most one tile per CU: a chunk takes a CU
+//     0.5 us with three waves and 0.85 us with six, so half the chunks per wave is ~15-20 % off the launch (not half: the
+//     CU, not the wave, is what a chunk waits for).
+template <int TH, int TW, bool FUSE, int MINW, int NTILE, int DEPTH = 1, int NS = 4, bool KSPLIT = false>
 __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_kernel(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
     int tilesX, int tilesY, int ntiles, int ablate, int xcd_remap) {
@@ -837,6 +842,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   // CU, a chunk's arithmetic ~1 us): 4 stages.  The small-map instance (one 3-wave workgroup per CU, a chunk's arithmetic ~0.3 us)
   // is bound by chunks-in-flight / DMA latency with 4 (3 chunks per ~2 us = what it measured: 0.67 us per chunk): 8 stages.
   static_assert(NS >= 3 && NS * NTILE * BUF * 4 <= 160 * 1024, "ring fits the LDS");
+  static_assert(!KSPLIT || (NTILE == 2 && NS * NTILE * BUF >= 36 * NT), "channel split: two wave groups, sums exchanged in the rings");
   __shared__ __attribute__((aligned(16))) float rings_all[NS * NTILE * BUF];
   constexpr unsigned RB = NTILE * BUF * 4;             // bytes from one stage to the next
 
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
     const int nwg = gridDim.x, qq = nwg / 8, rr = nwg % 8, xcd = wg % 8, loc = wg / 8;
     wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
   }
-  const int tile = wg * NTILE + half;
+  const int tile = KSPLIT ? wg : wg * NTILE + half;
   const bool live = tile < ntiles;
   int bid = live ? tile : 0;
   const int tx = bid % tilesX; bid /= tilesX;
@@ -864,8 +870,9 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   const int strip = (TW == 64) ? ((q & 1) ? ((j + 14) & 15) : j) : (j ^ ((((q & 3) == 1) || ((q & 3) == 2)) ? 4 : 0));
 
   const size_t plane = (size_t)H * W;
-  const float* p1 = in1 + (size_t)n * C * plane;
-  const float* p2 = in2 + (size_t)n * C * plane;
+  const int Cw = KSPLIT ? C / 2 : C;                  // the channels this wave group walks (KSPLIT: group g takes [g C/2, (g+1) C/2))
+  const float* p1 = in1 + ((size_t)n * C + (KSPLIT ? (size_t)half * Cw : 0)) * plane;
+  const float* p2 = in2 + ((size_t)n * C + (KSPLIT ? (size_t)half * Cw : 0)) * plane;
 
   // LDS image of a chunk (differs from corr9_pipe_kernel's): the TARGET rows of both channels first, then the source rows --
   // [f1 c0 | f1 c1 | f2 c0 | f2 c1] -- so that the f1 / f2 border falls on a DMA instruction border (CC * TH * V slots = a
@@ -1005,7 +1012,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
     }
   };
 
-  const int nchunks = C / CC;                          // multiple of 4 (checked by the launcher)
+  const int nchunks = Cw / CC;                         // multiple of NS (checked by the launcher)
   // chunk hand-off: my own DMA of the chunk has landed once at most NW_ newer instructions of mine are in flight (in-order
   // completion), the barrier extends that to every wave's and says that everybody is done with the ring about to be refilled
   auto handoff = [&](auto nwait) {
@@ -1057,6 +1064,36 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  if constexpr (KSPLIT) {
+    // the second wave group's sums join the first's: [36][NT] floats per round (16 pairs + 4 singles of one vertical shift), lane-
+    // contiguous (no bank conflict), in the rings' memory -- behind a barrier, because a slower wave may still be reading its last chunk
+    const int t = (int)threadIdx.x - half * NT;
+    f32x2* red2 = reinterpret_cast<f32x2*>(rings_all);
+    float* red1 = rings_all + 32 * NT;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (half == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) red2[(i * 4 + p) * NT + t] = accp[a][i][p];
+          red1[i * NT + t] = accs[a][i];
+        }
+      }
+      __syncthreads();
+      if (half == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) accp[a][i][p] += red2[(i * 4 + p) * NT + t];
+          accs[a][i] += red1[i * NT + t];
+        }
+      }
+      __syncthreads();
+    }
+  }
+
   // ---- epilogue: ReLU + L2 norm over the 81 shifts on the register PAIRS (packed squares, the ReLU kept in the accumulators; the sum of squares is taken pair-wise, then across the three vertical-shift groups) ----
   auto get = [&](int dyi, int dx, int i) -> float {
     if (i & 1) return dx == 0 ? accs[dyi][i] : accp[dyi][i][(dx - 1) >> 1][(dx - 1) & 1];
@@ -1099,7 +1136,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
       scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
     }
   }
-  if (live && h < H && wx + 3 < W && !(ablate & 4)) {
+  if (live && (!KSPLIT || half == 0) && h < H && wx + 3 < W && !(ablate & 4)) {
     float* o = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
 #pragma unroll
     for (int dyi = 0; dyi < 3; ++dyi)
@@ -1159,6 +1196,16 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
                        (int)ntiles, ablate, xcd_remap2);                                                          \
     return check_launch("corr9_pipe2_kernel");                                                                    \
   }
+#define RFN_LAUNCH_PIPE2K(TH_, TW_, MINW_, NS_)                                                                   \
+  {                                                                                                               \
+    const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
+    const long ntiles = (long)B * tilesX * tilesY;                                                                \
+    if (ntiles <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                   \
+    hipLaunchKernelGGL((corr9_pipe2_kernel<TH_, TW_, FUSE, MINW_, 2, 1, NS_, true>), dim3((unsigned)ntiles),      \
+                       dim3(TH_ * (TW_ / 4) * 3 * 2), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,              \
+                       (int)ntiles, ablate, xcd_remap2);                                                          \
+    return check_launch("corr9_pipe2_kernel");                                                                    \
+  }
       // Round 4: at K4 level 1 the 4-stage ring with counted waits (two-channel chunks, three chunks in flight) is the
       // default: 102 us against 111 us for the 2-stage kernel on the step's kind of operands (profiles/r04_corr_try.txt), and
       // its software-pipelined second take 89 us (profiles/r04_corr_pipe2.txt; a sample must be < 4 GB for its 32-bit DMA
@@ -1171,10 +1218,22 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
       // 8 x 64 kernel (profiles/r04_corr_pipe2.txt; 16 x 32 tiles 91 us, two / four tiles per workgroup 88 / 120 us).
       // (8 ring stages instead of 4, and source rows read two steps ahead instead of one, change nothing there -- 89-91 / 88-89
       // against 87-88 us: a lone wave per SIMD is bound neither by chunks in flight nor by LDS latency; RFN_CORR_VARIANT=46: 8 stages)
+      // Up to 256 of those tiles (one workgroup per CU): the workgroup's second wave group takes the second half of the tile's
+      // channels (KSPLIT; C / 2 a multiple of the ring's 8 channels) -- 136 tiles 59 -> 47 us, 256 tiles 64.5 -> 54.7 us, K2
+      // level 1 (128 tiles, C = 128) 33.8 -> 28.6 us.  NOT at K4 level 2: its 272 tiles put a second workgroup on 16 CUs
+      // (tools/micro/wg_placement.hip: 240 CUs x 1 + 16 x 2), and those pace the launch -- 83 us against 64.5 us for 256 tiles
+      // as it is, 89 us with twelve waves on them (profiles/r04_corr_ksplit.txt).  RFN_CORR_VARIANT=41: never, 47: always.
+      {
+        const long nt8 = (long)B * cdiv(W, 32) * cdiv(H, 8);
+        if (((variant == 0 && !level1 && nt8 <= 256) || variant == 47) && C >= 32 && C % 16 == 0 &&
+            (size_t)C * H * W * sizeof(float) < (1ull << 32))
+          RFN_LAUNCH_PIPE2K(8, 32, 3, 4)
+      }
       if (((variant == 0 && !level1) || variant == 41) && C >= 16 && (size_t)C * H * W * sizeof(float) < (1ull << 32))
         RFN_LAUNCH_PIPE2(8, 32, 3, 1, 4)
       if (variant == 46 && C % 16 == 0) RFN_LAUNCH_PIPE2(8, 32, 3, 1, 8)
 #undef RFN_LAUNCH_PIPE2
+#undef RFN_LAUNCH_PIPE2K
       if (variant == 0 && level1) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 20) RFN_LAUNCH_PIPE(16, 32, 3, 2)
       if (variant == 21) RFN_LAUNCH_PIPE(16, 64, 3, 1)

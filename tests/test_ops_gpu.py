@@ -47,6 +47,22 @@ def test_corr_hot_vs_oracle_ragged(dev, oracle, shape):
     np.testing.assert_allclose(tb.grad.cpu().numpy(), w2, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(2, 48, 23, 72), (1, 256, 19, 36), (1, 32, 40, 32), (2, 64, 8, 64), (1, 80, 9, 132), (2, 32, 72, 160)])
+def test_corr_channel_split_tiles_vs_oracle(dev, oracle, shape):
+    """Maps of up to 256 8 x 32 tiles (at most one workgroup per CU) with C % 16 == 0 run the pipelined kernel with the workgroup's
+    two wave groups on the two halves of the channels (KSPLIT: sums joined through the LDS in front of the epilogue): raw volume
+    and fused layer against the oracle, ragged rows / columns, 16 ... 128 channels per group (the last shape is large enough for
+    the fused layer to stay off the cross-workgroup split of tiny maps)."""
+    from refign_amd.correlation import local_correlation_layer, spatial_correlation_sample
+    rng = np.random.default_rng(sum(shape) + 1)
+    a = oracle.l2_normalize(np.maximum(rng.standard_normal(shape), 0).astype(np.float32) + 1e-3)
+    b = oracle.l2_normalize(np.maximum(rng.standard_normal(shape), 0).astype(np.float32) + 1e-3)
+    out = spatial_correlation_sample(T(a, dev), T(b, dev), patch_size=9)
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.corr_forward(a, b, patch_size=9), rtol=1e-4, atol=1e-5)
+    fused = local_correlation_layer(T(b, dev), T(a, dev))
+    np.testing.assert_allclose(fused.cpu().numpy(), oracle.local_correlation_layer(b, a), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", golden_names("corr_"))
 def test_corr_half_dispatch(dev, oracle, name):
     """The CUDA reference dispatches half as well (correlation_cuda_kernel.cu:267); `correlation.forward / backward` take
