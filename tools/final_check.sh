@@ -22,8 +22,11 @@ python tools/trace_queues.py $(find /tmp/prof_bench -name "*kernel_trace.csv") $
 timeout 600 python bench.py --precision k5 --no-cpu 2>/dev/null | tail -1 > $O/bench_k5_n1.json
 timeout 300 python tools/f8_bench.py 2>&1 | grep -v "amdgpu.ids" > $O/f8_bench.txt
 timeout 300 python tools/kbench.py --only L1,L2 2>&1 | grep -v "amdgpu.ids\|MIOpen" > $O/kbench_corr.txt
-for t in f8gemm_fc1_s3:gemm_nt_f8 f8gemm_fc2_s3:gemm_nt_f8 f8attn_s3:attn_fwd_f8 gemm_fc1_s3:gemm_nt_kernel; do
+for t in f8gemm_fc1_s3:gemm_nt_f8 f8gemm_fc2_s3:gemm_nt_f8 f8attn_s3:attn_fwd_f8; do
   echo "== ${t%%:*}"; bash tools/pmc_mfma.sh ${t%%:*} ${t##*:}; done > $O/pmc_f8_kernels.txt 2>&1
+# (kernel-name substrings: "gemm_nt" matches both generations of the NT GEMM -- the teacher's big Linear layers run gemm_nt2_kernel)
+for t in gemm_fc1_s3:gemm_nt gemm_fc2_s3:gemm_nt conv_bottleneck:gemm_nt attn_fwd_s3:attn_fwd wgrad_s3:gemm_tn; do
+  echo "== ${t%%:*}"; bash tools/pmc_mfma.sh ${t%%:*} ${t##*:}; done > $O/pmc_mfma_kernels.txt 2>&1
 # round 3, second half: per-entry-point census of the step, what is left in ATen, attention / depthwise / GEMM sweeps on replayed
 # graphs, per-CU fetch rates (L2 / MALL / HBM), cost of a node in a linear graph
 timeout 300 python tools/abi_census.py --top 60 2>&1 | grep -v "amdgpu.ids" > $O/abi_census.txt
