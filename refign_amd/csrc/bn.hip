@@ -213,8 +213,9 @@ static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const d
   const int CV = C / 8, cvb = bn_cvb(CV), gx = cdiv(CV, cvb), pl = 256 / cvb;
   // workgroups per launch.  A statistics workgroup ends with 2 x (its channels) atomics on the SAME 2C sums: 512 of them
   // instead of 2048 (129 600 x 256 backward statistics 68 -> 37 us, 1 296 000 x 256 forward 142 -> 116 us); the apply passes
-  // keep 2048 (191 vs 166 us at 512).  RFN_BN_STATS_WGS / RFN_BN_WGS.
-  static const long wgs_apply = getenv("RFN_BN_WGS") ? atol(getenv("RFN_BN_WGS")) : 2048;
+  // 2048 in isolation (191 vs 166 us at 512) -- and 1024 in the step, where three streams share the CUs (end of round 4, together
+  // with the GEMM tile threshold and the fused GELU backward: -1.5 ms, profiles/r04_knob_ab.txt).  RFN_BN_STATS_WGS / RFN_BN_WGS.
+  static const long wgs_apply = getenv("RFN_BN_WGS") ? atol(getenv("RFN_BN_WGS")) : 1024;
   static const long wgs_stats = getenv("RFN_BN_STATS_WGS") ? atol(getenv("RFN_BN_STATS_WGS")) : 512;
   const long wgs = apply ? wgs_apply : wgs_stats;
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(T, (long)pl * 4), std::max<long>(1, wgs / gx)));

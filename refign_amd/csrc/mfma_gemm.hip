@@ -1171,8 +1171,9 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   // tile: the largest of 128 x 128 (N % 128 == 0), 128 x 64, 64 x 64 that still gives ~1000 tiles (2-4 workgroups per CU
   // are resident; a launch of 300-600 big tiles is one and a bit rounds of a latency chain -- swept on replayed graphs in
   // round 3, profiles/r03_gemm_sweep.txt: 8160 x 320 -> 1280: 21.6 -> 18.1 us, 8160 x 1280 -> 320: 19.5 -> 17.5,
-  // 2040 x 512 -> 2048: 13.7 -> 11.1)
-  static const long min_tiles = getenv("RFN_GEMM_NT_MIN_TILES") ? atol(getenv("RFN_GEMM_NT_MIN_TILES")) : 1000;
+  // 2040 x 512 -> 2048: 13.7 -> 11.1).  ~2000 since the end of round 4: in the step, next to two other streams, the smaller
+  // tiles of the 1000-2000 band win (profiles/r04_knob_sweep.txt, r04_knob_ab.txt).
+  static const long min_tiles = getenv("RFN_GEMM_NT_MIN_TILES") ? atol(getenv("RFN_GEMM_NT_MIN_TILES")) : 2000;
   int bn = (N % 128 == 0) ? 128 : 64, bm = 128;
   if ((long)cdiv(M, 128) * cdiv(N, bn) < min_tiles) {
     bn = 64;

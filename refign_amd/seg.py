@@ -118,11 +118,12 @@ class Mlp(nn.Module):
             from .dwconv import dwconv3x3_gelu_tokens           # depthwise conv + GELU in one pass (csrc/dwconv.hip)
             dw = self.dwconv.dwconv
             if torch.is_grad_enabled() and x.requires_grad and self.drop.p == 0. and x.dtype in (torch.bfloat16, torch.float16) \
-                    and os.environ.get("RFN_FUSED_GELU_BWD", "0") == "1":
-                # opt-in (RFN_FUSED_GELU_BWD=1): the activation + its pre-activation; fc2's input-gradient GEMM applies gelu' in
-                # its epilogue instead of a gelu_backward pass over the 4C-wide hidden tensor.  Built, parity-tested
-                # (test_mix_ffn_gelu_backward_in_the_fc2_dgrad_epilogue), measured NEUTRAL on the step (182.4 / 183.0 vs 182.4 /
-                # 182.5 ms: what the 156 launches cost is what the erf in 156 GEMM epilogues costs)
+                    and os.environ.get("RFN_FUSED_GELU_BWD", "1") == "1":
+                # the activation + its pre-activation; fc2's input-gradient GEMM applies gelu' in its epilogue instead of a
+                # gelu_backward pass over the 4C-wide hidden tensor (test_mix_ffn_gelu_backward_in_the_fc2_dgrad_epilogue).
+                # Neutral on the step in rounds 2-3 (182.4 / 183.0 vs 182.4 / 182.5 ms); on the round-4 kernels -0.5 ms alone and
+                # -1.5 ms together with RFN_BN_WGS=1024 and RFN_GEMM_NT_MIN_TILES=2000 (three alternating runs each,
+                # profiles/r04_knob_ab.txt): on since the end of round 4.  RFN_FUSED_GELU_BWD=0: the separate pass.
                 a, z = dwconv3x3_gelu_tokens(x, dw.weight, dw.bias, H, W, with_z=True)
                 if res is not None:
                     return self.fc2(a, res=res, rowscale=rowscale, z=z)
