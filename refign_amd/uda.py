@@ -397,13 +397,21 @@ class DomainAdaptationSegmentationModel(nn.Module):
 
     # -- the student passes as replayable units (refign_amd/graphs.py: GraphedStep) ----------------------------------
     def _student_graphs(self, x):
-        """Graph replay of the student passes: HRDA training on a GPU, one process (see GraphedStep.usable)."""
-        return self.use_hrda and self.training and GraphedStep.usable(x) and torch.is_grad_enabled()
+        """Graph replay of the student passes: training on a GPU (see GraphedStep.usable).  HRDA and, since the end of round 4,
+        the single-scale DAFormer / SegFormer configurations too (K3: the eager passes kept the host busy for most of a 115 ms
+        step, and the line moved with the box's other tenants: profiles/r04_k3_host_sensitivity.txt)."""
+        return self.training and GraphedStep.usable(x) and torch.is_grad_enabled()
 
     def _crop_offsets(self, images, slot):
         """Draw the HRDA crop offsets of the next student forward on the host (python `random`, the reference's stream
         and order: hrda.py:22-27), or take the pre-drawn ones, and put them into the device tensor the pass reads."""
         from . import seg
+        if not self.use_hrda:                              # no crop, no draw: a constant input of the replayed pass
+            bufs = self.__dict__.setdefault("_crop_off", {})
+            dev = bufs.get(slot)
+            if dev is None or dev.device != images.device:
+                dev = bufs[slot] = torch.zeros(2, dtype=torch.long, device=images.device)
+            return dev
         H, W = images.shape[-2:]
         size, div = (int(H * 0.5), int(W * 0.5)), self.hrda_output_stride * 2.0
         if seg._PREDRAWN_CROPS:
@@ -422,13 +430,18 @@ class DomainAdaptationSegmentationModel(nn.Module):
         """SOURCE (:156-179) + ImageNet feature distance (:181-189), forward and both backward passes.
         `feat_imnet_last`: the frozen ImageNet encoder's last-stage feature of `images_src` when it was computed ahead
         of the step (prefetch_imnet_features); else it is computed here."""
-        push_device_crop(off, self.hrda_output_stride * 2.0)
-        feats_src = self.backbone(images_src)
-        logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
-        feats_src = feats_src[0]
-        logits_src = _logits_for_loss(self, logits_src, images_src.shape[-2:])
-        loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
-            self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
+        if self.use_hrda:
+            push_device_crop(off, self.hrda_output_stride * 2.0)
+            feats_src = self.backbone(images_src)
+            logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
+            feats_src = feats_src[0]
+            logits_src = _logits_for_loss(self, logits_src, images_src.shape[-2:])
+            loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
+                self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
+        else:                                              # single scale (:171-173): `off` is unused
+            feats_src = self.backbone(images_src)
+            logits_src = _logits_for_loss(self, self.head(feats_src), images_src.shape[-2:])
+            loss_src = self.loss(logits_src, gt_src)
         self.manual_backward(loss_src, retain_graph=self.enable_fdist)
         out = [loss_src.detach()]
         if self.enable_fdist:
@@ -498,11 +511,15 @@ class DomainAdaptationSegmentationModel(nn.Module):
 
     def _mixed_pass_device_crop(self, mixed_img, mixed_lbl, mixed_weight, off):
         """MIXED (:226-250), forward and backward."""
-        push_device_crop(off, self.hrda_output_stride * 2.0)
-        mixed_pred, hr_mixed_pred, box = self.head(self.backbone(mixed_img))
-        mixed_pred = _logits_for_loss(self, mixed_pred, mixed_img.shape[-2:])
-        mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
-            self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
+        if self.use_hrda:
+            push_device_crop(off, self.hrda_output_stride * 2.0)
+            mixed_pred, hr_mixed_pred, box = self.head(self.backbone(mixed_img))
+            mixed_pred = _logits_for_loss(self, mixed_pred, mixed_img.shape[-2:])
+            mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
+                self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
+        else:
+            mixed_pred = _logits_for_loss(self, self.head(self.backbone(mixed_img)), mixed_img.shape[-2:])
+            mixed_loss = self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight)
         # the step's LAST backward pass (data parallelism: the finished ranges of the gradient buffer are all-reduced from inside
         # it, trainer._backward / FlatGradBuffer.on_ready) -- when it accumulates into the first buffer in stream order, or into
         # the second buffer next to the source pass AND that buffer is reduced on its own (FlatGradBuffer.use_direct: comm2)

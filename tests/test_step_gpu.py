@@ -347,6 +347,35 @@ def test_student_passes_graph_replay_equals_eager(dev, monkeypatch):
     assert abs(traj["1"][1] - traj["0"][1]) < 1e-5 * traj["0"][1]
 
 
+def test_student_passes_graph_replay_equals_eager_single_scale(dev, monkeypatch):
+    """The same for the single-scale configuration (DAFormer head, no HRDA crop: K3's step -- its student passes replay from
+    graphs since the end of round 4): 5 steps graphed == 5 steps eager, both passes captured, and no crop offset is drawn (the
+    host's `random` stream must stay the reference's, which draws none here: segmentation_model.py:171-173)."""
+    from refign_amd.trainer import Trainer
+    H = W = 128
+    traj = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RFN_GRAPH_STUDENT", mode)
+        model = build(False, dev)
+        Trainer(model, fused_optimizer=False)
+        random.seed(6); np.random.seed(6); torch.manual_seed(6)
+        rows = []
+        for it in range(5):
+            batch = make_batch(2, H, W, 64, dev)
+            batch["image_src"] = batch["image_src"] + 0.1 * it
+            model.training_step(batch, it)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src",
+                                                          "train_loss_uda_trg")])
+        traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), random.random())
+        if mode == "1":
+            for name in ("source_pass", "mixed_pass"):
+                st = list(model._graphs[name].states.values())
+                assert len(st) == 1 and st[0]["graph"] is not None and not st[0]["failed"], f"{name}: not captured"
+    np.testing.assert_allclose(traj["1"][0], traj["0"][0], rtol=2e-3)
+    assert abs(traj["1"][1] - traj["0"][1]) < 1e-5 * traj["0"][1]
+    assert traj["1"][2] == traj["0"][2], "the graphed step consumed a different number of host random draws"
+
+
 def test_graph_replays_see_live_weights_under_autocast(dev, monkeypatch):
     """Every cached derived copy of a parameter (16-bit, transposed, tap-major, implicit-GEMM packed ...) that a captured
     graph may point at must be re-filled IN PLACE after the optimiser / EMA update -- a copy that is dropped and re-made
