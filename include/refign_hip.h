@@ -135,6 +135,14 @@ int rfn_l2norm_channels_nhwc16_f32(const void* x, float* out, int B, int C, int 
 /* 2 x 2 / stride 2 max-pool (floor mode) of a channels-last 16-bit map: the pools of the VGG-16 pyramid
  * (models/backbones/vgg.py:33-60: nn.MaxPool2d(2, 2)).  x (B, H, W, C) -> y (B, H / 2, W / 2, C); C % 8 == 0; dtype 1 bf16, 2 f16 */
 int rfn_maxpool2x2_nhwc16(const void* x, void* y, int B, int H, int W, int C, int dtype, rfn_stream_t stream);
+/* Re-tiling between the layers of the uncertainty head's micro-image chain (models/modules.py:528-545: valid 3x3 convolutions of
+ * one s x s correlation patch per pixel) when the patches of an h x w map are held as the (k + 2) x (k + 2) tiles of ONE channels-last
+ * image: forward (backward = 0) src (B, (k+2) h - 2, (k+2) w - 2, .) -> dst (B, k h, k w, .), the k x k result of every tile;
+ * backward = 1: src = the gradient of that dst, dst = the gradient of that src (zero at the dropped positions).  A pixel is `units16`
+ * 16-byte units of any element type (C * element size / 16); consecutive pixels of src are `src_stride16` >= units16 such units apart
+ * (a channel-padded convolution result), dst is dense. */
+int rfn_retile_copy(const void* src, void* dst, int B, int h, int w, int k, int units16, int src_stride16, int backward,
+                    rfn_stream_t stream);
 
 /* refine() + eta() (segmentation_model.py:438-491), gamma = trust-score exponent.
  * logits_trg, logits_ref: (B,19,H,W); warp_mask (nullable): (B,H,W) uint8; certs (nullable): (B,1,H,W);

@@ -36,6 +36,7 @@ SIGNATURES = {
     "rfn_l2norm_channels_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "rfn_l2norm_channels_nhwc16_f32": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "rfn_maxpool2x2_nhwc16": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
+    "rfn_retile_copy": (c_int, [c_void_p] * 2 + [c_int] * 7 + [c_void_p]),
     "rfn_area_resize_f32": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "rfn_refine_workspace_bytes": (ctypes.c_ulong, [c_int]),
     "rfn_label_majority": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_float, c_void_p]),

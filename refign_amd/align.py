@@ -173,6 +173,9 @@ class UncertaintyModule(nn.Module):
         b, _, h, w = corr.shape
 
         def retile(y, k):                                # (b, C, k h + 2 - 2.., ..): valid part of every (k+2)-tile
+            r = matching.retile_valid(y, h, w, k)        # one gather kernel on channels-last memory (csrc/warp.hip)
+            if r is not None:
+                return r
             y = F.pad(y, (0, 2, 0, 2))
             c = y.shape[1]
             return y.view(b, c, h, k + 2, w, k + 2)[:, :, :, :k, :, :k].reshape(b, c, k * h, k * w)

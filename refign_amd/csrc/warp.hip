@@ -313,6 +313,38 @@ __global__ __launch_bounds__(256) void area_resize_kernel(const float* __restric
 // 2 x 2 / stride 2 max-pool of a channels-last 16-bit map (the pools of the VGG-16 pyramid, models/backbones/vgg.py:33-60:
 // nn.MaxPool2d(2, 2), floor mode): a thread owns 8 channels of 2 adjacent output pixels -- 8 independent 16-byte loads in
 // flight (ATen's channels-last pool: 0.54 ms for 4 x 1080 x 1920 x 64 = 2.4 TB/s).  Max of representable values: exact.
+// Re-tiling of the uncertainty head's micro-image chain under autograd (align.py UncertaintyModule._patch_statistics_tiled;
+// models/modules.py:528-545 runs one 3x3 valid convolution per s x s micro-image): the micro-images are the (k + 2) x (k + 2) tiles of
+// one channels-last image, a valid 3x3 convolution of it holds every tile's k x k result at rows / columns t (k + 2) + i, i < k, and the
+// next layer wants those as the k x k tiles of a (k h, k w) image.  Forward: dst (B, k h, k w, .) gathers from src (B, (k + 2) h - 2,
+// (k + 2) w - 2, .); backward: the gradient of src gathers from the gradient of dst, zero at the dropped positions (windows that
+// straddle two tiles) -- no atomics either way.  A pixel is U 16-byte units of any element type (ATen's strided copy of the 6-d view
+// ran at 0.4 TB/s and came with two layout conversions per layer: 26 ms of a 125 ms matcher step, profiles/r04_matcher_census.txt).
+// `Us`: 16-byte units from one source pixel to the next (>= U: the implicit-GEMM convolution pads its output channels to 64).
+__global__ __launch_bounds__(256) void retile_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int h, int w, int k,
+                                                          int U, int Us, int backward, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int k2 = k + 2, Hs = k2 * h - 2, Ws = k2 * w - 2, Hd = k * h, Wd = k * w;
+  const int u = (int)(idx % U);
+  long t = idx / U;
+  if (!backward) {                                         // idx over dst (B, Hd, Wd, U)
+    const int x = (int)(t % Wd);
+    t /= Wd;
+    const int y = (int)(t % Hd), b = (int)(t / Hd);
+    const int sy = (y / k) * k2 + y % k, sx = (x / k) * k2 + x % k;
+    dst[idx] = src[(((long)b * Hs + sy) * Ws + sx) * Us + u];
+  } else {                                                 // idx over the gradient of src (B, Hs, Ws, U)
+    const int x = (int)(t % Ws);
+    t /= Ws;
+    const int y = (int)(t % Hs), b = (int)(t / Hs);
+    const int i = y % k2, j = x % k2;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (i < k && j < k) v = src[(((long)b * Hd + (y / k2) * k + i) * Wd + (x / k2) * k + j) * Us + u];
+    dst[idx] = v;
+  }
+}
+
 template <typename S>
 __global__ __launch_bounds__(256) void maxpool2x2_nhwc16_kernel(const S* __restrict__ x, S* __restrict__ y, int H, int W,
                                                                 int OH, int OW, int CV, long total) {
@@ -462,6 +494,19 @@ int rfn_maxpool2x2_nhwc16(const void* x, void* y, int B, int H, int W, int C, in
     hipLaunchKernelGGL(maxpool2x2_nhwc16_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,
                        (_Float16*)y, H, W, OH, OW, CV, total);
   return check_launch("maxpool2x2_nhwc16");
+}
+
+int rfn_retile_copy(const void* src, void* dst, int B, int h, int w, int k, int units16, int src_stride16, int backward,
+                    rfn_stream_t stream) {
+  RFN_REQUIRE(src && dst, "rfn_retile_copy: null pointer");
+  RFN_REQUIRE(B > 0 && h > 0 && w > 0 && k > 0 && units16 > 0 && src_stride16 >= units16, "rfn_retile_copy: bad size");
+  RFN_REQUIRE((((size_t)src | (size_t)dst) & 15) == 0, "rfn_retile_copy: pointers must be 16-byte aligned");
+  const long Hs = (long)(k + 2) * h - 2, Ws = (long)(k + 2) * w - 2;
+  const long total = backward ? (long)B * Hs * Ws * units16 : (long)B * k * h * k * w * units16;
+  RFN_REQUIRE(total / 256 < 0x7fffffffL && Hs < 0x7fffffffL && Ws < 0x7fffffffL, "rfn_retile_copy: too large");
+  hipLaunchKernelGGL(retile_copy_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+                     (uint4*)dst, h, w, k, units16, src_stride16, backward, total);
+  return check_launch("retile_copy");
 }
 
 }  // extern "C"

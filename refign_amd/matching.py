@@ -116,6 +116,48 @@ def uncertainty9_frontend(corr, packed_weights):
     return out
 
 
+class _RetileFn(torch.autograd.Function):
+    """csrc/warp.hip rfn_retile_copy under autograd: y (B, C, (k+2) h - 2, (k+2) w - 2) with channels-last memory (pixels `S` elements
+    apart, S >= C: the convolution kernels pad their output channels) -> (B, C, k h, k w), channels-last."""
+
+    @staticmethod
+    def forward(ctx, y, h, w, k):
+        B, C, Hs, Ws = y.shape
+        ctx.geom = (B, h, w, k, C)
+        es = y.element_size()
+        out = torch.empty((B, k * h, k * w, C), dtype=y.dtype, device=y.device)
+        rc = _lib.load_library().rfn_retile_copy(ptr(y), ptr(out), B, h, w, k, C * es // 16, y.stride(3) * es // 16, 0,
+                                                 current_stream(y.device))
+        _lib.check(rc, "retile_copy")
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        B, h, w, k, C = ctx.geom
+        gh = go.permute(0, 2, 3, 1).contiguous()
+        u = C * gh.element_size() // 16
+        gy = torch.empty((B, (k + 2) * h - 2, (k + 2) * w - 2, C), dtype=gh.dtype, device=gh.device)
+        rc = _lib.load_library().rfn_retile_copy(ptr(gh), ptr(gy), B, h, w, k, u, u, 1, current_stream(gh.device))
+        _lib.check(rc, "retile_copy (backward)")
+        return gy.permute(0, 3, 1, 2), None, None, None
+
+
+def retile_valid(y, h, w, k):
+    """The k x k valid part of every (k + 2) x (k + 2) tile of an NCHW-shaped map y (B, C, (k+2) h - 2, (k+2) w - 2), re-tiled into
+    (B, C, k h, k w) -- one gather kernel on channels-last memory, differentiable (align.py UncertaintyModule._patch_statistics_tiled).
+    None outside the kernel's domain (not on a GPU, not channels-last rows of whole 16-byte units): the caller pads, views and slices
+    instead."""
+    if not y.is_cuda or y.dim() != 4 or y.shape[2] != (k + 2) * h - 2 or y.shape[3] != (k + 2) * w - 2:
+        return None
+    B, C, Hs, Ws = y.shape
+    es, S = y.element_size(), y.stride(3)
+    if y.stride(1) != 1 or S < C or y.stride(2) != Ws * S or y.stride(0) != Hs * Ws * S or (C * es) % 16 or (S * es) % 16 \
+            or y.data_ptr() % 16:
+        return None
+    return _RetileFn.apply(y, h, w, k)
+
+
 def area_resize(x, size):
     """F.interpolate(x, size=size, mode='area') (segmentation_model.py:498-501) on the HIP kernel."""
     x = require_device_tensor(x.float().contiguous(), "x", torch.float32)

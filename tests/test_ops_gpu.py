@@ -435,3 +435,30 @@ def test_maxpool2x2_kernel_equals_max_pool2d(B, C, H, W, dtype):
         got = _maxpool2x2(x, m)
     assert got is not None and torch.equal(got, torch.nn.functional.max_pool2d(x, 2, 2))
     assert _maxpool2x2(x.float(), m) is None and _maxpool2x2(x, torch.nn.MaxPool2d(3, 2)) is None
+
+
+@pytest.mark.parametrize("B,C,h,w,k,dt", [(2, 32, 5, 7, 7, torch.float16), (1, 16, 9, 4, 3, torch.float32), (3, 32, 4, 6, 5, torch.bfloat16),
+                                          (1, 8, 3, 3, 1, torch.float16)])
+def test_retile_valid_equals_pad_view_slice(dev, B, C, h, w, k, dt):
+    """csrc/warp.hip rfn_retile_copy (the uncertainty head's micro-image chain under autograd, models/modules.py:528-545 as tiles of
+    one image): the k x k valid part of every (k + 2)-tile == F.pad + 6-d view + slice + reshape, forward and gradient, bit for bit
+    (a gather each way)."""
+    import torch.nn.functional as F
+    from refign_amd.matching import retile_valid
+    g = torch.Generator().manual_seed(B * 100 + C + k)
+    y = torch.randn(B, C, (k + 2) * h - 2, (k + 2) * w - 2, generator=g).to(dev).to(dt).contiguous(memory_format=torch.channels_last)
+    ya, yb = y.clone().requires_grad_(), y.clone().requires_grad_()
+    got = retile_valid(ya, h, w, k)
+    assert got is not None and tuple(got.shape) == (B, C, k * h, k * w)
+    want = F.pad(yb, (0, 2, 0, 2)).view(B, C, h, k + 2, w, k + 2)[:, :, :, :k, :, :k].reshape(B, C, k * h, k * w)
+    assert torch.equal(got, want)
+    go = torch.randn(B, C, k * h, k * w, generator=g).to(dev).to(dt)
+    got.backward(go)
+    want.backward(go)
+    assert torch.equal(ya.grad, yb.grad)
+    assert retile_valid(y.contiguous(), h, w, k) is None               # NCHW memory: the caller's formulation
+    # a channel-padded convolution result: the first C of 64 channels per pixel
+    wide = torch.zeros(B, (k + 2) * h - 2, (k + 2) * w - 2, 64, device=dev, dtype=dt)
+    wide[..., :C] = y.permute(0, 2, 3, 1)
+    got2 = retile_valid(wide[..., :C].permute(0, 3, 1, 2), h, w, k)
+    assert got2 is not None and torch.equal(got2, want.detach())

@@ -36,9 +36,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host = (time.perf_counter() - t0) / args.steps        # what the host needs to enqueue a batch (== dt: host-bound)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f"evaluation forward b={args.b} 1080x1920 ({args.precision}): {dt * 1e3:.1f} ms/batch, {args.b / dt:.2f} images/s, "
+    print(f"evaluation forward b={args.b} 1080x1920 ({args.precision}): {dt * 1e3:.1f} ms/batch (host enqueue {host * 1e3:.1f} ms), {args.b / dt:.2f} images/s, "
           f"max mem {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
 
 

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp16 = the reference's recipe for matcher training (README.md:289-294: --trainer.precision 16): "
                          "fp16 autocast + loss scaling, correlation / warp / losses in fp32")
+    ap.add_argument("--census", action="store_true", help="torch.profiler on one step: ATen operators with device time, by input shape")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -75,12 +76,30 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.census:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        rows = []
+        for e in prof.key_averages(group_by_input_shape=True):
+            dt = getattr(e, "self_device_time_total", None)
+            if dt is None:
+                dt = e.self_cuda_time_total
+            if dt > 0 and e.key.startswith("aten::"):
+                rows.append((dt / 1e3, e.count, e.key, str(e.input_shapes)[:110]))
+        rows.sort(reverse=True)
+        print(f"# ATen operators with device time in one matcher training step: {sum(r[0] for r in rows):.1f} ms in {sum(r[1] for r in rows)} calls")
+        for r in rows[:40]:
+            print(f"{r[0]:8.2f} {r[1]:6d}  {r[2]:34s} {r[3]}")
+        return
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host = (time.perf_counter() - t0) / args.steps        # what the host needs to enqueue a step (== dt: host-bound)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(f"matcher training step b={b} {S}x{S} {args.precision}: {dt * 1e3:.1f} ms/step, {b / dt:.2f} image-triplets/s, "
+    print(f"matcher training step b={b} {S}x{S} {args.precision}: {dt * 1e3:.1f} ms/step (host enqueue {host * 1e3:.1f} ms), {b / dt:.2f} image-triplets/s, "
           f"loss {float(loss):.3f}, max mem {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
     from refign_amd import mfma as _mfma
     print("library_fallbacks:", _mfma.library_summary())
