@@ -15,7 +15,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
-wl = bench.WORKLOADS["refign_hrda_step_1080x1920"](dev, 2, 1234, 1080, 1920, "bf16")
+# aten_census.py [workload [height width]] -- default: the bench line's HRDA step; K3: refign_daformer_step_1080x1920 512 1024
+name = sys.argv[1] if len(sys.argv) > 1 else "refign_hrda_step_1080x1920"
+hh, ww = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1080, 1920)
+os.environ.setdefault("RFN_GRAPH_STUDENT", "0")
+wl = bench.WORKLOADS[name](dev, 2, 1234, hh, ww, "bf16")
 for _ in range(3):
     wl.step()
 torch.cuda.synchronize()
