@@ -493,7 +493,11 @@ int rfn_conv2d_nhwc_wgrad(const void* GY, const void* X, float* P, float* grad_b
  *                        colour-jitter chain on the de-normalised image: order[4n + k] = operator applied k-th (0 brightness
  *                        additive, 1 contrast about the image mean, 2 saturation about the luma, 3 hue = 3x3 matrix hue[9n..]),
  *                        factor[4n + op], clamp to [0, 1] after every operator.  mean_ws: 8 doubles of device scratch.  Host
- *                        arrays are read at call time (they travel as kernel arguments).
+ *                        arrays are read at call time (they travel as kernel arguments).  Either half may be left out (round 5:
+ *                        only the mixed LABEL depends on the teacher's pseudo-labels, segmentation_model.py:558-574, so the
+ *                        student's forward on the mixed image starts before they exist): mixed_img == NULL -> labels and weights
+ *                        only (src / trg unused), mixed_lbl == NULL -> image only (pseudo_label / pseudo_weight / mixed_weight
+ *                        unused); both halves cut with the same mask when gt_src / class_bits are the same.
  *   rfn_dacs_blur        separable Gaussian of ksize_y x ksize_x taps (odd; kornia: ~0.1 x the image extent) normalised over the
  *                        window, reflect border, where blur_on[n]; tmp = scratch like x.  sigma <= 1.25: taps beyond +-16
  *                        vanish in fp32 for kornia's sigma range 0.15 ... 1.15, so at most 33 taps are evaluated.

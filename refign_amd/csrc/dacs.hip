@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void dacs_mix_jitter_kernel(const float* __res
       const long l = g4[i];
       m[i] = ((l >= 0 && l < 31) ? (bits >> l) & 1u : (l == 255 ? bits >> 31 : 0u)) != 0u;
     }
+    // img == nullptr: labels / weights only (the image half was mixed earlier in the step, with the same class set);
+    // lbl == nullptr: image only (the pseudo-labels do not exist yet)
+    if (img != nullptr) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float4 s4 = *reinterpret_cast<const float4*>(src + (n * 3 + ch) * plane + p0);
@@ -112,6 +115,9 @@ __global__ __launch_bounds__(256) void dacs_mix_jitter_kernel(const float* __res
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch)
         *reinterpret_cast<float4*>(img + (n * 3 + ch) * plane + p0) = make_float4(c[ch][0], c[ch][1], c[ch][2], c[ch][3]);
+    }
+    }
+    if (PASS == 1 && lbl != nullptr) {
       const long* ps = pseudo + n * plane + p0;
       const float4 w4 = *reinterpret_cast<const float4*>(pweight + n * plane + p0);
       const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
@@ -181,8 +187,11 @@ int rfn_dacs_mix_jitter(const float* src, const float* trg, const long* gt_src, 
                         const float* factor, const float* hue, const float* mean3, const float* std3,
                         rfn_stream_t stream) {
   using namespace rfn;
-  RFN_REQUIRE(src && trg && gt_src && pseudo_label && pseudo_weight && mixed_img && mixed_lbl && mixed_weight && mean_ws,
-              "dacs_mix_jitter: null pointer");
+  // either half may be left out: mixed_img == NULL -> labels / weights only (src / trg unused), mixed_lbl == NULL -> image only
+  // (pseudo_label / pseudo_weight / mixed_weight unused); the masks of the two halves agree when gt_src / class_bits do
+  RFN_REQUIRE(gt_src && mean_ws && (mixed_img || mixed_lbl), "dacs_mix_jitter: null pointer");
+  RFN_REQUIRE(!mixed_img || (src && trg), "dacs_mix_jitter: image half without src / trg");
+  RFN_REQUIRE(!mixed_lbl || (pseudo_label && pseudo_weight && mixed_weight), "dacs_mix_jitter: label half without pseudo-labels");
   RFN_REQUIRE(B > 0 && B <= kDacsMaxBatch && H > 0 && W > 0 && ((long)H * W) % 4 == 0, "dacs_mix_jitter: B=%d (<= %d) H=%d W=%d "
               "(H*W %% 4)", B, kDacsMaxBatch, H, W);
   RFN_REQUIRE(class_bits && jitter_on && order && factor && hue && mean3 && std3, "dacs_mix_jitter: null parameter array");
@@ -196,7 +205,7 @@ int rfn_dacs_mix_jitter(const float* src, const float* trg, const long* gt_src, 
       a.s[n].factor[k] = factor[4 * n + k];
     }
     for (int k = 0; k < 9; ++k) a.s[n].hue[k] = hue[9 * n + k];
-    need_mean = need_mean || jitter_on[n];
+    need_mean = need_mean || (jitter_on[n] && mixed_img != nullptr);
   }
   for (int k = 0; k < 3; ++k) {
     a.mean[k] = mean3[k];

@@ -65,17 +65,25 @@ def draw_jitter(s):
     return order, factor, hue
 
 
-def mix(images_src, images_trg, gt_src, pseudo_label, pseudo_weight, class_bits, jitter, blur_sigma):
+def mix(images_src, images_trg, gt_src, pseudo_label, pseudo_weight, class_bits, jitter, blur_sigma, part="all"):
     """jitter: per sample None or (order, factor, hue); blur_sigma: per sample None or sigma.  Returns
-    (mixed_img (B,3,H,W) fp32, mixed_lbl (B,H,W) int64, mixed_weight (B,H,W) fp32)."""
-    B, _, H, W = images_src.shape
-    dev = images_src.device
-    src, trg = images_src.contiguous(), images_trg.contiguous()
-    gt, ps = gt_src.contiguous(), pseudo_label.contiguous()
-    pw = pseudo_weight.to(torch.float32).contiguous()
-    img = torch.empty_like(src)
-    lbl = torch.empty_like(gt)
-    wgt = torch.empty_like(pw)
+    (mixed_img (B,3,H,W) fp32, mixed_lbl (B,H,W) int64, mixed_weight (B,H,W) fp32).
+    `part`: "all", or one half of the mix -- "image" (mixed_img only; pseudo_label / pseudo_weight may be None: the mixed
+    image is a function of the two images and the source labels alone, so the student's forward on it need not wait for the
+    teacher) / "labels" (mixed_lbl, mixed_weight only).  Both halves take the class set from `class_bits`."""
+    assert part in ("all", "image", "labels")
+    B, H, W = gt_src.shape
+    dev = gt_src.device
+    gt = gt_src.contiguous()
+    img = lbl = wgt = src = trg = ps = pw = None
+    if part != "labels":
+        src, trg = images_src.contiguous(), images_trg.contiguous()
+        img = torch.empty_like(src)
+    if part != "image":
+        ps = pseudo_label.contiguous()
+        pw = pseudo_weight.to(torch.float32).contiguous()
+        lbl = torch.empty_like(gt)
+        wgt = torch.empty_like(pw)
     ws = torch.empty(MAX_BATCH, dtype=torch.float64, device=dev)
     on = (ctypes.c_int * B)(*[0 if j is None else 1 for j in jitter])
     order = (ctypes.c_int * (4 * B))(*[v for j in jitter for v in ([0, 1, 2, 3] if j is None else j[0])])
@@ -85,12 +93,13 @@ def mix(images_src, images_trg, gt_src, pseudo_label, pseudo_weight, class_bits,
     mean3, std3 = (ctypes.c_float * 3)(*IMNET_MEAN), (ctypes.c_float * 3)(*IMNET_STD)
     lib = _lib.load_library()
     cast = lambda a: ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
+    optr = lambda t: None if t is None else ptr(t)  # noqa: E731
     with on_device(dev):
-        rc = lib.rfn_dacs_mix_jitter(ptr(src), ptr(trg), ptr(gt), ptr(ps), ptr(pw), ptr(img), ptr(lbl), ptr(wgt), ptr(ws),
+        rc = lib.rfn_dacs_mix_jitter(optr(src), optr(trg), ptr(gt), optr(ps), optr(pw), optr(img), optr(lbl), optr(wgt), ptr(ws),
                                      B, H, W, ptr(class_bits.contiguous()), cast(on), cast(order), cast(factor), cast(hue),
                                      cast(mean3), cast(std3), current_stream(dev))
         _lib.check(rc, "dacs_mix_jitter")
-        if any(s is not None for s in blur_sigma):
+        if img is not None and any(s is not None for s in blur_sigma):
             bon = (ctypes.c_int * B)(*[0 if s is None else 1 for s in blur_sigma])
             sig = (ctypes.c_double * B)(*[1.0 if s is None else float(s) for s in blur_sigma])
             tmp, out = torch.empty_like(img), torch.empty_like(img)

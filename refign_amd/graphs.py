@@ -232,3 +232,126 @@ class GraphedStep:
         self.shared.setdefault("pool", g.pool())
         st["graph"], st["inputs"], st["outputs"] = g, inputs, outputs
         st["extra"] = self.after_capture() if self.after_capture is not None else None
+
+
+class GraphedSplitStep(GraphedStep):
+    """A student pass as TWO replayable units sharing one memory pool: `forward(*tensors)` (network forward up to the
+    low-resolution class logits; the autograd graph of the captured call is kept) and `backward(*tensors)` (losses +
+    `backward()` through that graph) -- the layout of torch's make_graphed_callables, driven by hand.
+
+    Why two units: only the LOSS of the mixed pass depends on the teacher's pseudo-labels (segmentation_model.py:214-250: the
+    mixed image is a function of the source / target images and the source labels alone), so its forward can be queued at the
+    start of the step and run next to the teacher branch; and an event between the source pass's two units orders the decode
+    head's BatchNorm running-statistics updates of the two forwards (source first, as in the reference) without waiting for
+    the source backward.
+
+    `fwd_fn(*tensors) -> held` (anything; tensors inside keep their grad_fn), `bwd_fn(held, *tensors) -> tuple of losses`.
+    Every call of forward() must be followed by exactly one backward() before the next forward().  Warm-up calls and a
+    failed capture run both functions eagerly, like GraphedStep."""
+
+    def __init__(self, fwd_fn, bwd_fn, name, **kw):
+        super().__init__(None, name, **kw)
+        self.fwd_fn, self.bwd_fn = fwd_fn, bwd_fn
+        self._held = None            # (state, held, fwd inputs) of the forward that awaits its backward
+
+    def reset(self):
+        super().reset()
+        self._held = None
+
+    def _ctx(self):
+        import contextlib
+        return self.capture_context() if self.capture_context is not None else contextlib.nullcontext()
+
+    def forward(self, *tensors, variant=None):
+        if not self.usable(tensors[0]):
+            self._held = (None, self.fwd_fn(*tensors), tensors)
+            return
+        key = (tuple((tuple(t.shape), t.dtype, t.device) for t in tensors), torch.is_autocast_enabled("cuda"),
+               torch.get_autocast_dtype("cuda"), self.generation, variant)
+        st = self.states.get(key)
+        if st is None:
+            st = self.states[key] = {"calls": 0, "graph": None, "graph_bwd": None, "failed": False}
+        self._last = st
+        if st["failed"]:
+            self._held = (None, self.fwd_fn(*tensors), tensors)
+            return
+        if st["graph"] is None:
+            st["calls"] += 1
+            if st["calls"] <= self.warmup:
+                self._held = (None, self.fwd_fn(*tensors), tensors)
+                return
+            try:
+                inputs = [t.clone() for t in tensors]
+                cur = torch.cuda.current_stream()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with self._ctx(), _no_cyclic_gc():
+                        with torch.cuda.graph(g, pool=self.shared.get("pool"), capture_error_mode="thread_local"):
+                            held = self.fwd_fn(*inputs)
+                except BaseException:
+                    torch.cuda.set_stream(cur)
+                    raise
+                self.shared.setdefault("pool", g.pool())
+                st["graph"], st["inputs"], st["held"] = g, inputs, held
+                # the static inputs already hold this call's values (they were cloned from them), and the captured autograd graph
+                # may have saved them (a single-scale backbone's first convolution saves the image for its weight gradient): an
+                # in-place copy before the backward capture would bump their version under it
+                st["graph"].replay()
+                self._held = (st, None, tensors)
+                return
+            except Exception as e:
+                st["failed"] = True
+                warnings.warn(f"refign_amd.graphs: capture of '{self.name}' (forward) failed ({type(e).__name__}: {e}); "
+                              f"running it eagerly")
+                torch.cuda.synchronize()
+                self._held = (None, self.fwd_fn(*tensors), tensors)
+                return
+        for s, t in zip(st["inputs"], tensors):
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t)
+        st["graph"].replay()
+        self._held = (st, None, tensors)
+
+    def backward(self, *tensors):
+        st, held, fwd_tensors = self._held
+        self._held = None
+        if st is None:
+            return self.bwd_fn(held, *tensors)
+        if st["graph_bwd"] is None:
+            try:
+                inputs = [t.clone() for t in tensors]
+                cur = torch.cuda.current_stream()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with self._ctx(), _no_cyclic_gc():
+                        with torch.cuda.graph(g, pool=self.shared.get("pool"), capture_error_mode="thread_local"):
+                            outputs = self.bwd_fn(st["held"], *inputs)
+                except BaseException:
+                    torch.cuda.set_stream(cur)
+                    raise
+                st["graph_bwd"], st["inputs_bwd"], st["outputs"] = g, inputs, outputs
+                st["held"] = None                 # the autograd graph has been consumed; its buffers live in the pool
+                st["extra"] = self.after_capture() if self.after_capture is not None else None
+            except Exception as e:
+                # the forward of this step has only run as a replay whose autograd graph the failed capture may have consumed:
+                # run the whole pass again eagerly (its forward kernels twice in this one step), eager for good afterwards
+                st["failed"], st["graph"], st["held"] = True, None, None
+                warnings.warn(f"refign_amd.graphs: capture of '{self.name}' (backward) failed ({type(e).__name__}: {e}); "
+                              f"running it eagerly")
+                torch.cuda.synchronize()
+                return self.bwd_fn(self.fwd_fn(*fwd_tensors), *tensors)
+        for s, t in zip(st["inputs_bwd"], tensors):
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t)
+        st["graph_bwd"].replay()
+        if self.on_replay is not None:
+            self.on_replay(st.get("extra"))
+        return tuple(o.clone() for o in st["outputs"])
+
+    def captured(self):
+        return self._last is not None and self._last["graph"] is not None and self._last.get("graph_bwd") is not None
+
+    def __call__(self, *a, **k):
+        raise TypeError("GraphedSplitStep: call forward() and backward()")

@@ -34,7 +34,7 @@ from . import refine as refine_mod
 from ._tensor import const_tensor, upload_async
 from . import dacs as _dacs
 from . import f8 as _f8
-from .graphs import GraphedNoGrad, GraphedStep
+from .graphs import GraphedNoGrad, GraphedSplitStep, GraphedStep
 from .params import ema_update
 from .config import instantiate_class
 from . import seg as _seg
@@ -172,6 +172,8 @@ def _logits_for_loss(model, logits, size):
 
 
 _ALIGN_PREFETCH = os.environ.get("RFN_ALIGN_PREFETCH", "1") != "0"
+_MERGE_FD_BACKWARD = os.environ.get("RFN_MERGE_FD_BACKWARD", "1") != "0"
+_EARLY_MIXED_FWD = os.environ.get("RFN_EARLY_MIXED_FWD", "1") != "0"
 
 
 class DomainAdaptationSegmentationModel(nn.Module):
@@ -276,13 +278,13 @@ class DomainAdaptationSegmentationModel(nn.Module):
             self._graphs["imnet_features"] = GraphedNoGrad(self._imnet_features, "ImageNet features")
         # forward + backward of the student passes (single process; eager under DDP: SyncBatchNorm collectives)
         shared = {}
-        self._graphs["source_pass"] = GraphedStep(self._source_pass_device_crop, "student source pass", shared=shared)
+        self._graphs["source_pass"] = GraphedSplitStep(self._source_fwd, self._source_bwd, "student source pass", shared=shared)
         # the mixed pass may run NEXT TO the tail of the source pass (see _training_step_graphed): a memory pool of its own,
         # and its captured backward kernels accumulate into the second flat gradient buffer
-        self._graphs["mixed_pass"] = GraphedStep(self._mixed_pass_device_crop, "student mixed pass", shared=None,
-                                                 capture_context=self._mixed_capture_context,
-                                                 after_capture=self._mixed_captured_reduce,
-                                                 on_replay=self._mixed_replayed_reduce)
+        self._graphs["mixed_pass"] = GraphedSplitStep(self._mixed_fwd, self._mixed_bwd, "student mixed pass", shared=None,
+                                                      capture_context=self._mixed_capture_context,
+                                                      after_capture=self._mixed_captured_reduce,
+                                                      on_replay=self._mixed_replayed_reduce)
         self.teacher_f8 = _f8.ENV_DEFAULT                # K5: EMA-teacher backbone in fp8 (no reference analogue)
         self.load_weights(pretrained)
 
@@ -348,8 +350,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
             logits_src = _logits_for_loss(self, logits_src, images_src.shape[-2:])
             loss_src = self.loss(logits_src, gt_src)
         self.log("train_loss_src", loss_src)
-        self.manual_backward(loss_src, retain_graph=self.enable_fdist)
-        del loss_src, logits_src
+        merged = self.enable_fdist and _MERGE_FD_BACKWARD    # one backward pass of loss_src + loss_fd (see _source_bwd)
+        if not merged:
+            self.manual_backward(loss_src, retain_graph=self.enable_fdist)
+            del loss_src
+        del logits_src
 
         # ImageNet feature distance (:181-189)
         if self.enable_fdist:
@@ -360,7 +365,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
             loss_fd = self.calc_feat_dist(images_src, gt_src, feats_src,
                                           feat_imnet=None if early_imnet is None else early_imnet[0])
             self.log("train_loss_featdist_src", loss_fd)
-            self.manual_backward(loss_fd)
+            if merged:
+                self.manual_backward(loss_src + loss_fd)
+                del loss_src
+            else:
+                self.manual_backward(loss_fd)
             del loss_fd
         del feats_src
 
@@ -426,30 +435,45 @@ class DomainAdaptationSegmentationModel(nn.Module):
         dev.copy_(upload_async(list(off), torch.long, images.device), non_blocking=True)
         return dev
 
-    def _source_pass_device_crop(self, images_src, gt_src, off, feat_imnet_last=None):
-        """SOURCE (:156-179) + ImageNet feature distance (:181-189), forward and both backward passes.
-        `feat_imnet_last`: the frozen ImageNet encoder's last-stage feature of `images_src` when it was computed ahead
-        of the step (prefetch_imnet_features); else it is computed here."""
+    def _source_fwd(self, images_src, off):
+        """SOURCE (:156-163), forward half: backbone + decode head up to the low-resolution class logits."""
         if self.use_hrda:
             push_device_crop(off, self.hrda_output_stride * 2.0)
             feats_src = self.backbone(images_src)
             logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
-            feats_src = feats_src[0]
-            logits_src = _logits_for_loss(self, logits_src, images_src.shape[-2:])
+            return {"feat": feats_src[0], "logits": logits_src, "hr": hr_logits_src, "box": crop_box_src,
+                    "size": tuple(images_src.shape[-2:])}
+        feats_src = self.backbone(images_src)              # single scale (:171-173): `off` is unused
+        return {"feat": feats_src, "logits": self.head(feats_src), "size": tuple(images_src.shape[-2:])}
+
+    def _source_bwd(self, held, images_src, gt_src, feat_imnet_last=None):
+        """SOURCE (:164-189), loss half: cross-entropy + ImageNet feature distance and their backward.
+        `feat_imnet_last`: the frozen ImageNet encoder's last-stage feature of `images_src` when it was computed ahead
+        of the step (prefetch_imnet_features); else it is computed here.
+        The reference runs two backward passes over the one forward graph (manual_backward(loss_src, retain_graph=True), then
+        manual_backward(loss_featdist_src), :179-186), both accumulating into `.grad`: that sum of two gradients is the
+        gradient of the sum of the two losses, so ONE backward pass of `loss_src + loss_fd` gives every parameter the same
+        gradient (up to the rounding order of the additions) and walks the low-resolution MiT-B5 backbone once instead of
+        twice.  RFN_MERGE_FD_BACKWARD=0: the two passes."""
+        logits_src = _logits_for_loss(self, held["logits"], held["size"])
+        if self.use_hrda:
             loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
-                self.hr_loss_weight * self.loss(hr_logits_src, crop(gt_src, crop_box_src))
-        else:                                              # single scale (:171-173): `off` is unused
-            feats_src = self.backbone(images_src)
-            logits_src = _logits_for_loss(self, self.head(feats_src), images_src.shape[-2:])
+                self.hr_loss_weight * self.loss(held["hr"], crop(gt_src, held["box"]))
+        else:
             loss_src = self.loss(logits_src, gt_src)
-        self.manual_backward(loss_src, retain_graph=self.enable_fdist)
-        out = [loss_src.detach()]
-        if self.enable_fdist:
-            loss_fd = self.calc_feat_dist(images_src, gt_src, feats_src,
-                                          feat_imnet=None if feat_imnet_last is None else [feat_imnet_last])
-            self.manual_backward(loss_fd)
-            out.append(loss_fd.detach())
-        return tuple(out)
+        if not self.enable_fdist:
+            self.manual_backward(loss_src)
+            return (loss_src.detach(),)
+        if not _MERGE_FD_BACKWARD:
+            self.manual_backward(loss_src, retain_graph=True)
+        loss_fd = self.calc_feat_dist(images_src, gt_src, held["feat"],
+                                      feat_imnet=None if feat_imnet_last is None else [feat_imnet_last])
+        self.manual_backward(loss_src + loss_fd if _MERGE_FD_BACKWARD else loss_fd)
+        return loss_src.detach(), loss_fd.detach()
+
+    def _source_pass_device_crop(self, images_src, gt_src, off, feat_imnet_last=None):
+        """SOURCE (:156-179) + ImageNet feature distance (:181-189): forward and backward in one call."""
+        return self._source_bwd(self._source_fwd(images_src, off), images_src, gt_src, feat_imnet_last)
 
     @torch.no_grad()
     def prefetch_imnet_features(self, images_src_next, after=None):
@@ -509,16 +533,22 @@ class DomainAdaptationSegmentationModel(nn.Module):
         pf[3].record_stream(torch.cuda.current_stream())
         return pf[3]
 
-    def _mixed_pass_device_crop(self, mixed_img, mixed_lbl, mixed_weight, off):
-        """MIXED (:226-250), forward and backward."""
+    def _mixed_fwd(self, mixed_img, off):
+        """MIXED (:226-231), forward half."""
         if self.use_hrda:
             push_device_crop(off, self.hrda_output_stride * 2.0)
             mixed_pred, hr_mixed_pred, box = self.head(self.backbone(mixed_img))
-            mixed_pred = _logits_for_loss(self, mixed_pred, mixed_img.shape[-2:])
+            return {"logits": mixed_pred, "hr": hr_mixed_pred, "box": box, "size": tuple(mixed_img.shape[-2:])}
+        return {"logits": self.head(self.backbone(mixed_img)), "size": tuple(mixed_img.shape[-2:])}
+
+    def _mixed_bwd(self, held, mixed_lbl, mixed_weight):
+        """MIXED (:232-250), loss half: pixel-weighted cross-entropy against the (refined) pseudo-labels + backward."""
+        mixed_pred = _logits_for_loss(self, held["logits"], held["size"])
+        if self.use_hrda:
+            box = held["box"]
             mixed_loss = (1 - self.hr_loss_weight) * self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight) + \
-                self.hr_loss_weight * self.loss(hr_mixed_pred, crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
+                self.hr_loss_weight * self.loss(held["hr"], crop(mixed_lbl, box), pixel_weight=crop(mixed_weight, box))
         else:
-            mixed_pred = _logits_for_loss(self, self.head(self.backbone(mixed_img)), mixed_img.shape[-2:])
             mixed_loss = self.loss(mixed_pred, mixed_lbl, pixel_weight=mixed_weight)
         # the step's LAST backward pass (data parallelism: the finished ranges of the gradient buffer are all-reduced from inside
         # it, trainer._backward / FlatGradBuffer.on_ready) -- when it accumulates into the first buffer in stream order, or into
@@ -527,6 +557,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
         self.manual_backward(mixed_loss, last=not getattr(self, "_mixed_on_second", False) or
                              (buf is not None and buf._comm2 is not None))
         return (mixed_loss.detach(),)
+
+    def _mixed_pass_device_crop(self, mixed_img, mixed_lbl, mixed_weight, off):
+        """MIXED (:226-250), forward and backward in one call."""
+        return self._mixed_bwd(self._mixed_fwd(mixed_img, off), mixed_lbl, mixed_weight)
 
     def _mixed_captured_reduce(self):
         buf = getattr(self, "_grad_buffer", None)
@@ -599,12 +633,17 @@ class DomainAdaptationSegmentationModel(nn.Module):
         off = self._crop_offsets(images_src, "src")
         cur = torch.cuda.current_stream()
         feat_next = self._take_imnet_prefetch(images_src) if self.enable_fdist else None
+        src_graph, mix_graph = self._graphs["source_pass"], self._graphs["mixed_pass"]
+        # the source pass as two units (graphs.GraphedSplitStep): the event between them is what the mixed pass's forward waits
+        # for -- the decode head's BatchNorm running statistics are updated by both forwards, source first (as in the reference)
+        src_graph.forward(images_src, off, variant=feat_next is not None)
+        src_fwd_done = cur.record_event()
         if feat_next is not None:
             feat_next = feat_next.clone()
             prefetch_free = cur.record_event()           # the prefetch buffer is free again from here on
-            losses = self._graphs["source_pass"](images_src, gt_src, off, feat_next)
+            losses = src_graph.backward(images_src, gt_src, feat_next)
         else:
-            losses = self._graphs["source_pass"](images_src, gt_src, off)
+            losses = src_graph.backward(images_src, gt_src)
             prefetch_free = cur.record_event()           # (the encoder ran inside the pass: its buffers are busy until then)
         early = None if ready is None else self._start_target_branch(batch, images_src, after=ready)
         self.log("train_loss_src", losses[0])
@@ -616,33 +655,61 @@ class DomainAdaptationSegmentationModel(nn.Module):
             # data parallelism: the first gradient buffer is final (the mixed pass accumulates into the second one): its
             # all-reduce runs next to the mixed pass (no-op without the two gradient communicators)
             self._grad_buffer.reduce_first_now()
+        nb = batch['image_trg'].shape[0]
+        src_nb, gt_nb = (images_src[:nb], gt_src[:nb]) if images_src.shape[0] > nb else (images_src, gt_src)
+        # The mixed pass's FORWARD does not need the teacher: the mixed image is cut from the source and target images with a
+        # mask of the SOURCE labels (dacs_transforms.py:81-112); only the mixed label / weight, i.e. the loss, need the refined
+        # pseudo-labels (:541-574).  On its own stream the forward therefore starts as soon as the source forward has updated the
+        # BatchNorm statistics and runs next to the teacher branch; loss + backward follow when the pseudo-labels are there.
+        # Same host draws in the same order (source crop, coin, DACS parameters, mixed crop), same numbers.
+        early_fwd = (_EARLY_MIXED_FWD and mix is not None and self._dacs_kernels_usable(src_nb, early[0], gt_nb))
         if mix is not None:
             self.__dict__["_mixed_concurrent_steps"] = self.__dict__.get("_mixed_concurrent_steps", 0) + 1   # diagnostics
             mix.wait_event(ready)                        # gradient buffers zeroed, EMA done, batch resident
-            mix.wait_stream(self._side_stream)           # pseudo-labels
+            if early_fwd:
+                mix.wait_event(src_fwd_done)
+                self.__dict__["_mixed_early_forwards"] = self.__dict__.get("_mixed_early_forwards", 0) + 1   # diagnostics
+            else:
+                mix.wait_stream(self._side_stream)       # pseudo-labels
+        from .bn import direct_comm
+        comm = getattr(self, "_mixed_comm", None)
         with torch.cuda.stream(run_on):
-            with torch.no_grad():
-                if early is None:
-                    images_trg, m_probs_trg = self._target_branch(batch)
-                else:
-                    images_trg, m_probs_trg = early
-                    if mix is None:
-                        cur.wait_stream(self._side_stream)
+            if early_fwd:
+                images_trg, m_probs_trg = early
+                with torch.no_grad():
+                    d = self._dacs_draw(nb, gt_nb, src_classes)
+                    mixed_img, _, _ = _dacs.mix(src_nb, images_trg, gt_nb, None, None, d["bits"], d["jitter"], d["sigma"],
+                                                part="image")
+                off = self._crop_offsets(mixed_img, "mix")
+                with (direct_comm(comm) if comm is not None else contextlib.nullcontext()):
+                    mix_graph.forward(mixed_img.to(images_src.dtype).contiguous(), off)
+                    mix.wait_stream(self._side_stream)   # pseudo-labels
                     m_probs_trg.record_stream(run_on)
-                mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src,
-                                                                       src_classes)
-            off = self._crop_offsets(mixed_img, "mix")
-            # one input signature for the replay: the blur of the DACS augmentation runs under autocast and hands back a
-            # 16-bit image on the steps where it fires (a second signature = a second capture with its own eager warm-up)
-            # (data parallelism with direct RCCL exchanges: the mixed pass ALWAYS exchanges over its own communicator --
-            # eager warm-up, capture, replay and the eager fallback of a failed capture alike -- so that a rank whose
-            # capture fails still meets its peers on the communicator their graphs were captured with)
-            from .bn import direct_comm
-            comm = getattr(self, "_mixed_comm", None)
-            with (direct_comm(comm) if comm is not None else contextlib.nullcontext()):
-                (mixed_loss,) = self._graphs["mixed_pass"](mixed_img.to(images_src.dtype).contiguous(),
-                                                           mixed_lbl.contiguous(),
-                                                           mixed_weight.to(torch.float32).contiguous(), off)
+                    with torch.no_grad():
+                        pseudo_label, pseudo_weight = self._pseudo_labels(m_probs_trg)
+                        _, mixed_lbl, mixed_weight = _dacs.mix(None, None, gt_nb, pseudo_label, pseudo_weight, d["bits"],
+                                                               d["jitter"], d["sigma"], part="labels")
+                    (mixed_loss,) = mix_graph.backward(mixed_lbl.contiguous(), mixed_weight.to(torch.float32).contiguous())
+            else:
+                with torch.no_grad():
+                    if early is None:
+                        images_trg, m_probs_trg = self._target_branch(batch)
+                    else:
+                        images_trg, m_probs_trg = early
+                        if mix is None:
+                            cur.wait_stream(self._side_stream)
+                        m_probs_trg.record_stream(run_on)
+                    mixed_img, mixed_lbl, mixed_weight = self.get_dacs_mix(images_trg, m_probs_trg, images_src, gt_src,
+                                                                           src_classes)
+                off = self._crop_offsets(mixed_img, "mix")
+                # one input signature for the replay: the blur of the DACS augmentation runs under autocast and hands back a
+                # 16-bit image on the steps where it fires (a second signature = a second capture with its own eager warm-up)
+                # (data parallelism with direct RCCL exchanges: the mixed pass ALWAYS exchanges over its own communicator --
+                # eager warm-up, capture, replay and the eager fallback of a failed capture alike -- so that a rank whose
+                # capture fails still meets its peers on the communicator their graphs were captured with)
+                with (direct_comm(comm) if comm is not None else contextlib.nullcontext()):
+                    mix_graph.forward(mixed_img.to(images_src.dtype).contiguous(), off)
+                    (mixed_loss,) = mix_graph.backward(mixed_lbl.contiguous(), mixed_weight.to(torch.float32).contiguous())
         if mix is not None:
             cur.wait_stream(mix)                         # both passes done before the optimiser merges their gradients
             mixed_loss.record_stream(cur)
@@ -939,13 +1006,27 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return align_mod.align(self.alignment_backbone, self.alignment_head, logits_ref, images_ref, images_trg)
 
     # -- DACS (:525-582) -----------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def get_dacs_mix(self, images_trg, probs_trg, images_src, gt_src, src_classes=None):
-        nb = images_trg.shape[0]
-        if images_src.shape[0] > nb:
-            images_src, gt_src = images_src[:nb], gt_src[:nb]
+    def _dacs_draw(self, nb, gt_src, src_classes):
+        """The host draws of one get_dacs_mix call in the reference's order (:533-540 python `random` coins; then per sample
+        dacs_transforms.py: class choice (numpy), jitter (torch CPU generator), blur sigma (numpy)) for the HIP-kernel form of
+        the mix.  Nothing here looks at the teacher's output."""
         params = {'mix': None, 'color_jitter': random.uniform(0, 1), 'color_jitter_s': self.color_jitter_s,
                   'color_jitter_p': self.color_jitter_p, 'blur': random.uniform(0, 1) if self.blur else 0}
+        classes = torch.unique(gt_src) if src_classes is None else src_classes
+        bits = _dacs.draw_class_bits(classes, nb)
+        jit, sig = [], []
+        for i in range(nb):
+            jit.append(_dacs.draw_jitter(self.color_jitter_s) if params['color_jitter'] > params['color_jitter_p']
+                       else None)
+            sig.append(np.random.uniform(0.15, 1.15) if params['blur'] > 0.5 else None)
+        return {"bits": bits, "jitter": jit, "sigma": sig}
+
+    def _dacs_kernels_usable(self, images_src, images_trg, gt_src):
+        return os.environ.get("RFN_DACS_KERNEL", "1") != "0" and _dacs.usable(
+            images_src, images_trg, gt_src, getattr(getattr(self, "head", None), "num_classes", 19))
+
+    def _pseudo_labels(self, probs_trg):
+        """(:541-556) arg-max pseudo-label and ONE confidence weight for the whole batch."""
         pseudo_prob, pseudo_label = torch.max(probs_trg, dim=1)
         # ONE scalar for the whole batch: fraction of confident pixels (:552-556)
         weight = (pseudo_prob >= self.pseudo_label_threshold).sum() / pseudo_label.numel()
@@ -954,18 +1035,23 @@ class DomainAdaptationSegmentationModel(nn.Module):
             pseudo_weight[:, :self.psweight_ignore_top, :] = 0
         if self.psweight_ignore_bottom > 0:
             pseudo_weight[:, -self.psweight_ignore_bottom:, :] = 0
-        if os.environ.get("RFN_DACS_KERNEL", "1") != "0" and _dacs.usable(images_src, images_trg, gt_src,
-                                                                              getattr(getattr(self, "head", None), "num_classes", 19)):
-            # N4: the pixel work of the mix / jitter / blur as HIP kernels (refign_amd/dacs.py); the draws below are made in
+        return pseudo_label, pseudo_weight
+
+    @torch.no_grad()
+    def get_dacs_mix(self, images_trg, probs_trg, images_src, gt_src, src_classes=None):
+        nb = images_trg.shape[0]
+        if images_src.shape[0] > nb:
+            images_src, gt_src = images_src[:nb], gt_src[:nb]
+        cls = DomainAdaptationSegmentationModel          # (tests call this with a bare namespace for `self`)
+        if cls._dacs_kernels_usable(self, images_src, images_trg, gt_src):
+            # N4: the pixel work of the mix / jitter / blur as HIP kernels (refign_amd/dacs.py); the draws are made in
             # the order the per-sample loop further down makes them
-            classes = torch.unique(gt_src) if src_classes is None else src_classes
-            bits = _dacs.draw_class_bits(classes, nb)
-            jit, sig = [], []
-            for i in range(nb):
-                jit.append(_dacs.draw_jitter(self.color_jitter_s) if params['color_jitter'] > params['color_jitter_p']
-                           else None)
-                sig.append(np.random.uniform(0.15, 1.15) if params['blur'] > 0.5 else None)
-            return _dacs.mix(images_src, images_trg, gt_src, pseudo_label, pseudo_weight, bits, jit, sig)
+            d = cls._dacs_draw(self, nb, gt_src, src_classes)
+            pseudo_label, pseudo_weight = cls._pseudo_labels(self, probs_trg)
+            return _dacs.mix(images_src, images_trg, gt_src, pseudo_label, pseudo_weight, d["bits"], d["jitter"], d["sigma"])
+        params = {'mix': None, 'color_jitter': random.uniform(0, 1), 'color_jitter_s': self.color_jitter_s,
+                  'color_jitter_p': self.color_jitter_p, 'blur': random.uniform(0, 1) if self.blur else 0}
+        pseudo_label, pseudo_weight = cls._pseudo_labels(self, probs_trg)
         gt_weight = torch.ones_like(pseudo_weight)
         masks = get_class_masks(gt_src.unsqueeze(1), src_classes)
         mixed_img, mixed_lbl = [None] * nb, [None] * nb

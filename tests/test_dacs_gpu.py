@@ -82,3 +82,25 @@ def test_class_set_prefetch_equals_torch_unique():
     assert M._take_class_prefetch(ns, gt, 2) is None                      # consumed
     M._prefetch_classes(ns, gt, 2)
     assert M._take_class_prefetch(ns, gt.clone(), 2) is None              # a different tensor: not this prefetch
+
+
+@pytest.mark.parametrize("jitter", [False, True])
+@pytest.mark.parametrize("blur", [False, True])
+def test_dacs_mix_halves_equal_the_whole(jitter, blur):
+    """Round 5: the mix in two launches -- the image half before the teacher's pseudo-labels exist (the student's forward on the
+    mixed image starts next to the teacher branch), labels + weights afterwards -- is bit for bit the one-launch mix."""
+    from refign_amd import dacs
+    dev = torch.device("cuda:0")
+    B, H, W = 2, 64, 96
+    src, trg, gt, probs = _inputs(dev, B, H, W, 11)
+    pp, pl = torch.max(probs, 1)
+    pw = torch.full_like(pp, 0.37)
+    np.random.seed(5); torch.manual_seed(7)
+    bits = dacs.draw_class_bits(torch.unique(gt), B)
+    jit = [dacs.draw_jitter(0.2) if jitter else None for _ in range(B)]
+    sig = [0.8 if blur else None for _ in range(B)]
+    img, lbl, wgt = dacs.mix(src, trg, gt, pl, pw, bits, jit, sig)
+    img_a, none_l, none_w = dacs.mix(src, trg, gt, None, None, bits, jit, sig, part="image")
+    none_i, lbl_b, wgt_b = dacs.mix(None, None, gt, pl, pw, bits, jit, sig, part="labels")
+    assert none_l is None and none_w is None and none_i is None
+    assert torch.equal(img, img_a) and torch.equal(lbl, lbl_b) and torch.equal(wgt, wgt_b)

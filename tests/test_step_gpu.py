@@ -509,8 +509,37 @@ def test_concurrent_mixed_pass_equals_serial(dev, monkeypatch):
             rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
         bn = torch.cat([b.flatten().double() for n, b in model.head.named_buffers() if "running" in n])
         out[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), bn.cpu(),
-                     model.__dict__.get("_mixed_concurrent_steps", 0))
+                     model.__dict__.get("_mixed_concurrent_steps", 0), model.__dict__.get("_mixed_early_forwards", 0))
     assert out["1"][3] >= 4 and out["0"][3] == 0
+    # round 5: on its own stream the mixed pass's forward starts before the pseudo-labels exist (image half of the DACS mix first)
+    assert out["1"][4] >= 4 and out["0"][4] == 0
     np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=2e-3)
     assert abs(out["1"][1] - out["0"][1]) < 1e-5 * out["0"][1]
     assert float((out["1"][2] - out["0"][2]).abs().max()) < 1e-4 * float(out["0"][2].abs().max())
+
+
+def test_merged_source_backward_equals_the_two_passes(dev, monkeypatch):
+    """Round 5: ONE backward pass of loss_src + loss_featdist instead of the reference's two passes over the same forward graph
+    (segmentation_model.py:179 retain_graph=True, :186): the accumulated gradients are the gradient of the sum, so 5 steps
+    either way give the same three losses per step and the same parameters (fp32: summation order only)."""
+    from refign_amd import uda
+    from refign_amd.trainer import Trainer
+    out = {}
+    for merged in (True, False):
+        monkeypatch.setattr(uda, "_MERGE_FD_BACKWARD", merged)
+        for graphs in ("1", "0"):
+            monkeypatch.setenv("RFN_GRAPH_STUDENT", graphs)
+            model = build(True, dev)
+            trainer = Trainer(model, fused_optimizer=False)
+            random.seed(21); np.random.seed(21); torch.manual_seed(21)
+            rows = []
+            for it in range(5):
+                batch = make_batch(2, 128, 128, 64, dev)
+                batch["image_src"] = batch["image_src"] + 0.1 * it
+                trainer.step(batch, it)
+                rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+            out[(merged, graphs)] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())))
+    ref = out[(False, "0")]
+    for key, (rows, chk) in out.items():
+        np.testing.assert_allclose(rows, ref[0], rtol=2e-3, err_msg=str(key))
+        assert abs(chk - ref[1]) < 1e-5 * ref[1], key
