@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (it re-executes itself under
+torch.distributed.run on 127.0.0.1, one rank per GPU; it refuses when the node has fewer than N GPUs) -- the form the
+reference takes its ranks in (`--trainer.gpus N`, README.md:262).  Under an external torchrun it is one of the ranks.
+
 One "step" = one pass of the hot path over one batch of b=2 synthetic (target, reference) image pairs per GPU at
 1080x1920 (BASELINE.json's metric configuration).  Image pairs are independent, so ranks shard pairs with no data-path
 collective ("scaling": "weak").  The timed region is bracketed by a barrier + torch.cuda.synchronize() on both sides, the
@@ -56,7 +60,12 @@ def parse():
                     help="cpu_baseline leg: one step at the full image size (default, ~1 min) or two reduced sizes + extrapolation")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="ONLY time the CPU baseline at the full image size (minutes) and print it as one JSON line")
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo only with --workload launcher_selftest (tests/test_bench_cpu.py)")
+    args = ap.parse_args()
+    if args.workload == "uawarpc_align_512x512" and (args.height, args.width) == (1080, 1920):
+        args.height = args.width = 512                    # K2's own size unless another one is asked for
+    return args
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -223,6 +232,7 @@ class RefignStep:
         self.model.teacher_f8 = precision == "k5"                   # K5: EMA-teacher backbone on the fp8 kernels
         self.precision = precision = "bf16" if precision == "k5" else precision
         self.b, self.H, self.W = b, H, W
+        self.name = type(self).name.replace("1080x1920", f"{H}x{W}")     # the label says the size that ran
         g = torch.Generator(device="cpu").manual_seed(seed)
         lbl = torch.randint(0, 19, (b, (H + 31) // 32, (W + 31) // 32), generator=g)
         lbl = lbl.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :H, :W].contiguous()
@@ -292,6 +302,89 @@ class RefignAlignRefine(RefignStep):
             return torch.max(m._teacher_align_refine(trg, ref), dim=1)
 
 
+class UAWarpCAlign:
+    """K2 (BASELINE.json config 2: "UAWarpC align-only, MegaDepth config, 512x512 pairs"): AlignmentModel.forward
+    (models/alignment_model.py:55-79) -- VGG-16 pyramids of both images at the input size and at 256 x 256, the UAWarpC head
+    (global + three local correlation levels, flow decoders, uncertainty), flow and 1 - P_R up-sampled to the input size -- on
+    b pairs per GPU, random-init networks (no checkpoints offline), the reference's AMP recipe (convolutions fp16, correlation /
+    warp / uncertainty fp32).  `--workload uawarpc_align_512x512`."""
+    name = "uawarpc_align_512x512"
+    use_hrda = False
+
+    def __init__(self, dev, b, seed, H=512, W=512, precision="bf16"):
+        from refign_amd.align import VGG, UAWarpCHead
+        from refign_amd.alignment_model import AlignmentModel
+        torch.manual_seed(seed)
+        self.model = AlignmentModel(alignment_backbone=VGG('vgg16', out_indices=[2, 3, 4]),
+                                    alignment_head=UAWarpCHead(in_index=[0, 1], input_transform='multiple_select',
+                                                               estimate_uncertainty=True)).to(dev).eval()
+        self.precision = "bf16" if precision == "k5" else precision
+        self.b, self.H, self.W = b, H, W
+        self.name = f"uawarpc_align_{H}x{W}"
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        img_i = torch.randn(b, 3, H, W, generator=g)
+        self.img_i = img_i.to(dev)
+        self.img_j = (0.8 * torch.roll(img_i, (3, -5), (2, 3)) + 0.2 * torch.randn(b, 3, H, W, generator=g)).to(dev)
+        self._l1 = None
+
+    @torch.no_grad()
+    def step(self):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.precision == "bf16"):
+            return self.model(self.img_i, self.img_j)
+
+    def _level1_features(self):
+        if self._l1 is None:
+            from refign_amd import align as A
+            from refign_amd.matching import l2_normalize_channels
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.precision == "bf16"):
+                dt = A.align_compute_dtype()
+                with torch.autocast("cuda", enabled=dt != torch.float32, dtype=dt if dt != torch.float32 else None):
+                    pt, pr, _, _ = A.extract_pyramids(self.model.alignment_backbone, self.img_j.float(), self.img_i.float())
+                self._l1 = (l2_normalize_channels(pr[0]), l2_normalize_channels(pt[0]))
+        return self._l1
+
+    def roofline_launch(self):
+        from refign_amd.correlation import local_correlation_layer
+        return local_correlation_layer(*self._level1_features())
+
+    def roofline_bytes(self):
+        b, c, h, w = self._level1_features()[0].shape
+        return 4 * b * h * w * (2 * c + 81)
+
+    def cpu_pairs_per_s(self, cores):
+        """The same forward on the host: oracle/cpu_align.alignment_forward (pinned against the reference's output,
+        tests/test_oracle_cpu.py) on this workload's b pairs, fp32."""
+        import copy
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import cpu_align
+        kind, corr_fn = cpu_align._corr_fn_default()
+        m = copy.deepcopy(self.model).cpu().float()
+        i, j = self.img_i.cpu(), self.img_j.cpu()
+        cpu_align.alignment_forward(m.alignment_backbone, m.alignment_head, i[:1], j[:1], corr_fn)      # thread pool / allocator
+        t0 = time.perf_counter()
+        cpu_align.alignment_forward(m.alignment_backbone, m.alignment_head, i, j, corr_fn)
+        dt = time.perf_counter() - t0
+        return {"value": round(self.b / dt, 4), "unit": "image-pairs/s", "cores": cores,
+                "kind": "restatement+reference-correlation" if kind == "reference" else "port",
+                "sample": f"AlignmentModel.forward for {self.b} pairs at {self.H}x{self.W} on the host with {cores} threads, fp32: "
+                          f"{dt:.2f} s wall (oracle/cpu_align.alignment_forward; correlation = "
+                          f"{'reference correlation.cpp (oracle/_ref)' if kind == 'reference' else 'oracle/corr_oracle.c'})"}
+
+
+class LauncherSelfTest:
+    """No kernels: a CPU stand-in for a workload so that the launcher half of this file (self-launch of N ranks, rendezvous on
+    127.0.0.1, barrier + max-over-ranks timing, the one JSON line of rank 0) can be exercised without a GPU
+    (tests/test_bench_cpu.py, backend gloo).  Never a measurement."""
+    name = "launcher_selftest"
+    use_hrda = False
+
+    def __init__(self, *a, **k):
+        self.x = torch.ones(1024)
+
+    def step(self):
+        self.x = self.x * 1.0001
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md; separate passes) -- the latest profiles/rNN_pmc_traffic_corr9.json; null if absent."""
@@ -329,7 +422,8 @@ def rocprof_in_step_us():
 
 
 WORKLOADS = {AlignRefineKernels.name: AlignRefineKernels, RefignStep.name: RefignStep,
-             RefignDAFormerStep.name: RefignDAFormerStep, RefignAlignRefine.name: RefignAlignRefine}
+             RefignDAFormerStep.name: RefignDAFormerStep, RefignAlignRefine.name: RefignAlignRefine,
+             UAWarpCAlign.name: UAWarpCAlign, LauncherSelfTest.name: LauncherSelfTest}
 
 
 def cpu_baseline(wl, args):
@@ -345,6 +439,8 @@ def cpu_baseline(wl, args):
     os.environ["OMP_NUM_THREADS"] = str(cores)
     import cpu_align
     kind, corr_fn = cpu_align._corr_fn_default()
+    if isinstance(wl, UAWarpCAlign):
+        return wl.cpu_pairs_per_s(cores)
     if isinstance(wl, AlignRefineKernels):
         dt = wl.cpu_step(kind, corr_fn)
         return {"value": round(1.0 / dt, 5), "unit": "image-pairs/s", "cores": cores, "kind": kind,
@@ -426,141 +522,111 @@ def launch_series_us(launch, spaced, reps=20):
     return sum(a_.elapsed_time(b_) for a_, b_ in pairs) * 1e3 / reps
 
 
-DDP_STALL_MARKER = os.path.join(os.environ.get("TMPDIR", "/tmp"), "refign_amd_multi_rank_stalled")
-
-
-def _ddp_guard(rank, world, progress):
-    """N > 1 only.  The multi-rank step (student passes replayed from hipGraphs with the SyncBatchNorm exchanges inside
-    as RCCL calls of our own, three communicators on three streams: refign_amd/rccl.py) could only ever be rehearsed
-    with ONE rank on the one-GPU development boxes (RFN_DDP_REHEARSAL).  If a multi-rank run makes no progress for
-    RFN_BENCH_STALL_S seconds: say where it stopped, leave a marker and exit non-zero instead of hanging the node.  A
-    later run on the same box that finds the marker uses the conservative configuration -- every exchange through
-    torch.distributed, eager student passes (RFN_RCCL_DIRECT=0 RFN_GRAPH_DDP=0: 214-231 ms/step per rank in the
-    rehearsal instead of 192) -- unless those variables are set explicitly."""
+def _stall_guard(rank, world, progress):
+    """N > 1 only: if a multi-rank run makes no progress for RFN_BENCH_STALL_S seconds (default 600), say where it stopped and
+    exit non-zero instead of hanging the node.  (Round 4 re-executed every rank in another configuration here; the multi-rank
+    default is now the configuration that needs no second chance -- refign_amd/trainer.py -- and a stalled run is an error.)"""
     import threading
-    explicit = "RFN_GRAPH_DDP" in os.environ or "RFN_RCCL_DIRECT" in os.environ
-    # the marker only changes a later run's configuration when asked to (RFN_BENCH_STALL_MARKER=1): a leftover file in /tmp
-    # must not silently reconfigure a benchmark
-    use_marker = os.environ.get("RFN_BENCH_STALL_MARKER", "0") == "1"
-    if use_marker and not explicit and os.path.exists(DDP_STALL_MARKER):
-        os.environ["RFN_GRAPH_DDP"] = os.environ["RFN_RCCL_DIRECT"] = "0"
-        if rank == 0:
-            print(f"bench.py: {DDP_STALL_MARKER} exists (an earlier multi-rank run stalled on this box): exchanges through "
-                  f"torch.distributed, eager student passes", file=sys.stderr, flush=True)
-    # Second chance (under torchrun, whose agent keeps the rendezvous store alive): the FIRST stall of a configuration that is
-    # not already the conservative one re-executes this rank -- every rank is stuck in the same collective, so every rank's
-    # guard fires -- with every exchange through torch.distributed and eager student passes (the configuration closest to
-    # what torch's own DDP + SyncBatchNorm do), rendezvousing under a fresh store prefix.  The process id stays the same, so
-    # torchrun sees one worker that took longer.  RFN_BENCH_RETRY=0: give up at once (exit 17) as before.
-    attempt = int(os.environ.get("RFN_BENCH_ATTEMPT", "1"))
-    conservative = os.environ.get("RFN_RCCL_DIRECT", "1") == "0" and os.environ.get("RFN_GRAPH_DDP", "1") == "0"
-    can_retry = attempt == 1 and not conservative and os.environ.get("RFN_BENCH_RETRY", "1") != "0" and \
-        os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
-    limit = float(os.environ.get("RFN_BENCH_STALL_S", "300" if can_retry else "900"))
+    limit = float(os.environ.get("RFN_BENCH_STALL_S", "600"))
 
     def watch():
         while True:
             time.sleep(5.0)
             idle = time.monotonic() - progress[0]
             if idle > limit:
-                conf = f"RFN_RCCL_DIRECT={os.environ.get('RFN_RCCL_DIRECT', '1')} RFN_GRAPH_DDP={os.environ.get('RFN_GRAPH_DDP', 'auto')}"
-                print(f"bench.py rank {rank}/{world}: no progress for {idle:.0f} s after '{progress[1]}' ({conf}); "
-                      f"giving up", file=sys.stderr, flush=True)
-                if use_marker and os.environ.get("RFN_RCCL_DIRECT", "1") != "0":
-                    try:
-                        with open(DDP_STALL_MARKER, "w") as f:
-                            f.write(f"rank {rank}/{world} stalled after {progress[1]} ({conf})\n")
-                    except OSError:
-                        pass
-                if can_retry:
-                    second_attempt()
+                print(f"bench.py rank {rank}/{world}: no progress for {idle:.0f} s after '{progress[1]}'; giving up",
+                      file=sys.stderr, flush=True)
                 os._exit(17)
 
-    def second_attempt():
-        print(f"bench.py rank {rank}/{world}: second attempt, conservative configuration (RFN_RCCL_DIRECT=0 "
-              f"RFN_GRAPH_DDP=0 RFN_DDP_DIRECT_REDUCE=0)", file=sys.stderr, flush=True)
-        os.environ.update(RFN_RCCL_DIRECT="0", RFN_GRAPH_DDP="0", RFN_DDP_DIRECT_REDUCE="0", RFN_BENCH_ATTEMPT="2")
-        os.environ.pop("RFN_BENCH_FAKE_STALL", None)
-        os.environ.pop("RFN_BENCH_FAKE_RAISE", None)
-        sys.stdout.flush()
-        os.execv(sys.executable, [sys.executable] + sys.argv)
-
     threading.Thread(target=watch, daemon=True, name="bench-stall-guard").start()
-    # for the caller: a rank whose set-up steps RAISE (an RCCL error inside a capture, say) takes the same second chance at
-    # once; its peers, stuck in the collective it left, follow when their guards fire
-    return second_attempt if can_retry else None
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: become N ranks.  One node, one rank per GPU, rendezvous on 127.0.0.1
+    (the container's hostname may not resolve) at a free port; the children see RANK / LOCAL_RANK / WORLD_SIZE and take the
+    ordinary path through main().  Fails loudly when the node cannot give every rank its own GPU."""
+    import socket
+    import subprocess
+    if args.backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} GPU(s); one rank per GPU, no oversubscription")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.cpu_baseline_full:                  # host cores only: one full-size CPU step, one JSON line, done
         import types
         wl = types.SimpleNamespace(use_hrda=WORKLOADS[args.workload].use_hrda)
         print(json.dumps(cpu_baseline(wl, args)), flush=True)
         return
-    if not torch.cuda.is_available():
+    selftest = args.workload == LauncherSelfTest.name
+    if args.backend == "gloo" and not selftest:
+        raise SystemExit("--backend gloo is for --workload launcher_selftest only (the product path has no CPU fallback)")
+    if not selftest and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu")
+    if not selftest:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
-    second_attempt = None
     progress = [time.monotonic(), "start"]
-    if world > 1 or "RANK" in os.environ:     # under torchrun always go through RCCL, also for a single rank
+    if world > 1 or "RANK" in os.environ:     # under torchrun always a process group, also for a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world > 1 or os.environ.get("RFN_BENCH_FAKE_STALL") or os.environ.get("RFN_BENCH_FAKE_RAISE"):
-            second_attempt = _ddp_guard(rank, world, progress)
-        attempt = int(os.environ.get("RFN_BENCH_ATTEMPT", "1"))
-        if attempt > 1:                        # re-executed by the guard: the agent's store still holds the first attempt's keys
-            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=False)
-            dist.init_process_group("nccl", store=dist.PrefixStore(f"attempt{attempt}", store), rank=rank, world_size=world,
-                                    device_id=dev)
-        elif os.environ.get("RFN_BENCH_LAZY_PG", "0") == "1":     # experiment: communicator created at the first collective
-            dist.init_process_group("nccl")
+        if world > 1:
+            _stall_guard(rank, world, progress)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    import refign_amd
-    refign_amd.load_library()
-    if args.workload == AlignRefineKernels.name:
-        wl = AlignRefineKernels(dev, args.pairs_per_gpu, seed=1234 + rank)
+    if selftest:
+        wl = LauncherSelfTest()
     else:
-        wl = WORKLOADS[args.workload](dev, args.pairs_per_gpu, 1234 + rank, args.height, args.width, args.precision)
+        import refign_amd
+        refign_amd.load_library()
+        if args.workload == AlignRefineKernels.name:
+            wl = AlignRefineKernels(dev, args.pairs_per_gpu, seed=1234 + rank)
+        else:
+            wl = WORKLOADS[args.workload](dev, args.pairs_per_gpu, 1234 + rank, args.height, args.width, args.precision)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def tick(what):
         progress[0], progress[1] = time.monotonic(), what
 
-    try:
-        for i in range(getattr(wl, "prime_steps", 0)):     # set-up, not warm-up: solver selection, caches, hipGraph capture
-            wl.step()
-            if world > 1:                                  # (N > 1 only: keeps the guard's clock honest, off the N=1 path)
-                torch.cuda.synchronize()
-            tick(f"prime step {i}")
-            while os.environ.get("RFN_BENCH_FAKE_STALL"):  # (test of the guard: pretend the next collective never returns)
-                time.sleep(1.0)
-            if os.environ.get("RFN_BENCH_FAKE_RAISE"):     # (test of the guard: pretend the multi-rank set-up failed)
-                raise RuntimeError("RFN_BENCH_FAKE_RAISE")
-        for i in range(args.warmup):
-            wl.step()
-            if world > 1:
-                torch.cuda.synchronize()
-            tick(f"warm-up step {i}")
-    except Exception as exc:                               # noqa: BLE001 -- multi-rank set-up only; N = 1 re-raises
-        if second_attempt is None:
-            raise
-        print(f"bench.py rank {rank}/{world}: {type(exc).__name__} during set-up after '{progress[1]}': {exc}",
-              file=sys.stderr, flush=True)
-        second_attempt()
+    for i in range(getattr(wl, "prime_steps", 0)):     # set-up, not warm-up: solver selection, caches, hipGraph capture
+        wl.step()
+        if world > 1:                                  # (N > 1 only: keeps the guard's clock honest, off the N=1 path)
+            sync()
+        tick(f"prime step {i}")
+    for i in range(args.warmup):
+        wl.step()
+        if world > 1:
+            sync()
+        tick(f"warm-up step {i}")
     barrier()
     tick("timed region")
     t0 = time.perf_counter()
@@ -575,7 +641,7 @@ def main():
         dt = float(tt.item())
 
     roof = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline and rank == 0 and not selftest:
         # HIP events around EACH launch of the dominant kernel, on the stream it is launched on.  Two series of 20:
         # "spaced" -- every launch behind ~1 ms of an idle device (one spinning wave), which also hides the host's launch
         # latency: the kernel as it runs in the step, between other work (the rocprofv3 kernel trace of the timed steps
@@ -591,42 +657,59 @@ def main():
         us_b2b = series(False)
         us = series(True)
         ach = wl.roofline_bytes() / (us * 1e-6) / 1e9
-        roof = {"kernel": "corr9_pipe2_kernel<16x32 tiles, 4-stage LDS-DMA ring, software-pipelined rows, fused ReLU+L2norm> level 1 (C=128, 270x480, "
-                          "b=%d)" % wl.b,
+        rb, rc, rh, rw = (wl._level1_features()[0].shape if hasattr(wl, "_level1_features") else wl.c11.shape)
+        roof = {"kernel": "corr9_pipe2_kernel<16x32 tiles, 4-stage LDS-DMA ring, software-pipelined rows, fused ReLU+L2norm> level 1 "
+                          f"(C={rc}, {rh}x{rw}, b={rb})",
                 "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(), "avg_launch_us": round(us, 2),
+                "frac": round(ach / HBM_PEAK_GBS, 4),
+                # (the committed counter passes and kernel trace are of the 1080x1920 level-1 shape only)
+                "traffic": pmc_traffic() if (rh, rw, rb) == (270, 480, 2) else None, "avg_launch_us": round(us, 2),
                 "avg_launch_us_back_to_back": round(us_b2b, 2),
                 "frac_back_to_back": round(wl.roofline_bytes() / (us_b2b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_launch": wl.roofline_bytes(), "rocprofv3_in_step": rocprof_in_step_us()}
+                "algorithmic_bytes_per_launch": wl.roofline_bytes(), "rocprofv3_in_step": rocprof_in_step_us() if (rh, rw, rb) == (270, 480, 2) else None}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not selftest:
         cpu = cpu_baseline(wl, args)
 
+    ranks_in_group = world
     if dist is not None:
+        ranks_in_group = dist.get_world_size()
         dist.barrier()
-        torch.cuda.synchronize()
-        from refign_amd import rccl
-        rccl.destroy_all()                         # our own communicators (SyncBatchNorm exchanges), creation order
+        sync()
+        if not selftest:
+            from refign_amd import rccl
+            rccl.destroy_all()                     # our own communicators (SyncBatchNorm exchanges), creation order
         dist.destroy_process_group()
 
+    if rank == 0 and selftest:
+        print(json.dumps({"metric": "launcher self-test (no kernels, not a measurement)", "value": 0.0, "unit": "none",
+                          "n_gpus": world, "ranks_in_group": ranks_in_group, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "config": {"workload": wl.name}}))
+        return
     if rank == 0:
         pairs = args.pairs_per_gpu * world * args.steps
+        size = f"{getattr(wl, 'H', args.height)}x{getattr(wl, 'W', args.width)}"
+        step_kind = isinstance(wl, RefignStep) and type(wl) is not RefignAlignRefine
         line = {
-            "metric": {AlignRefineKernels.name: "image-pairs/s (align+refine HIP kernels only, 1080x1920)",
-                       RefignAlignRefine.name: "image-pairs/s (teacher fwd + align + refine, no student fwd/bwd, "
-                                               "1080x1920)"}.get(args.workload,
-                                                                  "image-pairs/s (align+seg fwd+bwd, 1080x1920)"),
-            "value": round(pairs / dt, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+            "metric": {AlignRefineKernels.name: f"image-pairs/s (align+refine HIP kernels only, {size})",
+                       RefignAlignRefine.name: f"image-pairs/s (teacher fwd + align + refine, no student fwd/bwd, {size})",
+                       UAWarpCAlign.name: f"image-pairs/s (UAWarpC align-only: AlignmentModel.forward, {size})"}.get(
+                           args.workload, f"image-pairs/s (align+seg fwd+bwd, {size})"),
+            "value": round(pairs / dt, 3), "unit": "image-pairs/s", "n_gpus": world, "ranks_in_group": ranks_in_group,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (3 x bf16 split products)" if args.precision == "fp32" and args.workload != AlignRefineKernels.name
                       and os.environ.get("RFN_FP32_SPLIT", "1") != "0" else "f32")
                      if (args.workload == AlignRefineKernels.name or args.precision == "fp32") else
-                     ("bf16+fp8(e4m3) teacher" if args.precision == "k5" else "bf16"),
+                     ("bf16+fp8(e4m3) teacher" if args.precision == "k5" else
+                      ("f16 convolutions, f32 correlation / warp / uncertainty" if args.workload == UAWarpCAlign.name else "bf16")),
             "data": "synthetic",
-            "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": f"{args.height}x{args.width}",
-                       "networks": "HRDA MiT-B5 + DAFormer head + VGG-16/UAWarpC align (random init)",
+            "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": size,
+                       "networks": ("VGG-16 + UAWarpC head (random init)" if args.workload == UAWarpCAlign.name else
+                                    ("HRDA MiT-B5" if getattr(wl, "use_hrda", True) else "MiT-B5") +
+                                    " + DAFormer head + VGG-16/UAWarpC align (random init)"),
                        "precision_map": (("fp32 storage everywhere; Linear / convolution / attention products as three bf16 "
                                           "products on the MFMA kernels (refign_amd/split32.py, ~2^-16 relative)"
                                           if os.environ.get("RFN_FP32_SPLIT", "1") != "0" else "fp32 everywhere (library GEMMs)")
@@ -637,18 +720,22 @@ def main():
                                          "reference AMP recipe: seg nets bf16 autocast (fp32 master weights, grads, "
                                          "norm statistics, losses); align convolutions fp16 autocast; correlation, "
                                          "warp, L2-norm, uncertainty and refine kernels fp32"),
-                       "parallelism": f"dp{world}: pairs sharded, align/refine/teacher replica-local, one flat "
-                                      f"gradient all-reduce per step over RCCL"},
+                       "parallelism": (f"dp{world}: pairs sharded, align/refine/teacher replica-local, one flat "
+                                       f"gradient all-reduce per step over RCCL") if step_kind else
+                                      f"dp{world}: pairs sharded, gradient-free, no collective in the timed region"},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if world > 1 or "RANK" in os.environ:
+        if step_kind and (world > 1 or "RANK" in os.environ):
+            from refign_amd import bn as _bn
             tr = getattr(wl, "trainer", None)
             gb = getattr(tr, "grads", None)
             line["config"]["data_parallel"] = {
-                "attempt": int(os.environ.get("RFN_BENCH_ATTEMPT", "1")),
-                "statistics_exchanges": "RCCL calls of our own on the pass's stream" if os.environ.get("RFN_RCCL_DIRECT", "1") != "0"
-                                        else "torch.distributed",
-                "gradient_reduce": ("own communicator + stream, released ranges inside the last backward pass"
+                "mode": getattr(tr, "ddp_mode", None),
+                "statistics_exchanges": ("none (one rank: batch statistics are local)" if world == 1 and not _bn.data_parallel() else
+                                         "RCCL calls of our own on the pass's stream" if _bn._DIRECT["default"] is not None
+                                         else "torch.distributed"),
+                "gradient_reduce": ("none (one rank: the all-reduce is the identity)" if world == 1 and not _bn.data_parallel() else
+                                    "own communicator + stream, released ranges inside the last backward pass"
                                     if gb is not None and gb._comm is not None else "torch.distributed buckets"),
                 "reduced_inside_last_backward": (round(getattr(gb, "overlapped_elements", 0) / gb.flat.numel(), 3)
                                                  if gb is not None else None)}
@@ -663,14 +750,12 @@ def main():
             st = {k: [("replay" if s_["graph"] is not None else ("eager (capture failed)" if s_["failed"] else "eager"))
                       for s_ in g.states.values()] for k, g in graphs.items()}
             line["config"]["hipgraph_regions"] = {k: (v[0] if len(v) == 1 else v) for k, v in st.items() if v}
-            if world > 1:
-                from refign_amd import bn as _bn
-                line["config"]["statistics_exchange"] = ("RCCL called directly on the pass's stream (refign_amd/rccl.py)"
-                                                         if _bn._DIRECT["default"] is not None else "torch.distributed")
             steps_m = getattr(wl.model, "_mixed_concurrent_steps", None)
             if steps_m is not None:
-                line["config"]["mixed_pass"] = ("own stream next to the tail of the source pass" if steps_m else
-                                                "in stream order after the source pass")
+                early = getattr(wl.model, "_mixed_early_forwards", 0)
+                line["config"]["mixed_pass"] = (("own stream; forward queued before the pseudo-labels exist, loss + backward behind "
+                                                 "the teacher branch" if early else "own stream next to the tail of the source pass")
+                                                if steps_m else "in stream order after the source pass")
         if isinstance(wl, RefignStep) and type(wl) is not RefignAlignRefine:
             line["config"]["next_batch_prefetch"] = (
                 "frozen ImageNet-encoder features of the next step's source images and the frozen matcher's flow of the next "

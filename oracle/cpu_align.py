@@ -128,6 +128,22 @@ def align(alignment_backbone, alignment_head, logits_ref, images_ref, images_trg
 
 
 @torch.no_grad()
+def alignment_forward(alignment_backbone, alignment_head, images_i, images_j, corr_fn=None):
+    """AlignmentModel.forward (models/alignment_model.py:55-79): flow i -> j at full resolution and 1 - P_R (K2: what
+    `bench.py --workload uawarpc_align_512x512` times on the GPU and this times on the host)."""
+    b, _, h, w = images_i.shape
+    i_256 = F.interpolate(images_i, size=(256, 256), mode='area')
+    j_256 = F.interpolate(images_j, size=(256, 256), mode='area')
+    feats = alignment_backbone(torch.cat([images_j, images_i]), extract_only_indices=[-3, -2])
+    feats_256 = alignment_backbone(torch.cat([j_256, i_256]), extract_only_indices=[-2, -1])
+    pyr_j, pyr_i = zip(*[torch.split(f, [b, b]) for f in feats])
+    pyr_j_256, pyr_i_256 = zip(*[torch.split(f, [b, b]) for f in feats_256])
+    flow, uncert = head_forward(alignment_head, pyr_i, pyr_j, pyr_i_256, pyr_j_256, (h, w), corr_fn)[-1]
+    flow, uncert = _up(flow, (h, w)), _up(uncert, (h, w))
+    return flow, 1.0 - (1.0 - torch.exp(-1.0 / (2 * torch.exp(uncert))))       # matching_utils.py:52-57, R = 1
+
+
+@torch.no_grad()
 def refine(logits_trg, logits_ref, warp_mask, certs, gamma=0.25):
     """segmentation_model.py:438-482 in torch-CPU ops."""
     pt, pr = F.softmax(logits_trg, dim=1), F.softmax(logits_ref, dim=1)

@@ -33,6 +33,29 @@ def data_parallel():
     return dist.get_world_size() > 1 or os.environ.get("RFN_DDP_REHEARSAL", "0") == "1"
 
 
+DDP_MODES = ("torch", "direct", "direct3")
+
+
+def ddp_mode():
+    """How one rank of N > 1 exchanges (RFN_DDP_MODE):
+      torch    (default) every exchange through torch.distributed's process group -- SyncBatchNorm statistics as all-reduces of
+               the default group (the teacher's on a group of its own), the flat gradient buffer in buckets after the passes --
+               and eager student passes: one communicator per stream, collectives issued from one host thread in program
+               order, the configuration torch's own DDP + SyncBatchNorm runs in.  Nothing here is left to a rehearsal.
+      direct   RCCL called directly on the pass's stream (refign_amd/rccl.py): two communicators (student passes on the main
+               stream, teacher on the side stream), student passes replayed from hipGraphs with the exchanges inside, passes
+               in stream order.
+      direct3  + a third communicator, so that the mixed pass runs next to the source pass as on one GPU.
+    `direct` / `direct3` have only ever run with ONE rank (RFN_DDP_REHEARSAL=1 on a one-GPU box): concurrent communicators on
+    one device can deadlock if two ranks' queues serialise their collectives in different orders, which no one-rank run can
+    show -- they stay opt-in until a multi-GPU run has passed tools/ddp_first_contact.sh."""
+    import os
+    m = os.environ.get("RFN_DDP_MODE", "torch")
+    if m not in DDP_MODES:
+        raise RuntimeError(f"RFN_DDP_MODE={m!r}: one of {DDP_MODES}")
+    return m
+
+
 # RCCL called directly on the calling stream for the STUDENT's exchanges (refign_amd/rccl.py; set up by the trainer): `default` is the
 # communicator of the pass on the main stream, `current` the one of the pass being captured / run inside direct_comm().
 _DIRECT = {"default": None, "current": None}

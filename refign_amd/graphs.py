@@ -173,12 +173,11 @@ class GraphedStep:
         import torch.distributed as dist
         from .bn import data_parallel
         if data_parallel():
-            # default: on when the statistics exchanges are RCCL calls of our own on the pass's stream (plain kernel
-            # nodes), off when they go through torch's process group (cross-stream branches: no gain over eager)
+            # on when the statistics exchanges are RCCL calls of our own on the pass's stream (plain kernel nodes:
+            # RFN_DDP_MODE=direct / direct3), off when they go through torch's process group (cross-stream branches of the
+            # graph: no gain over eager, measured)
             from . import bn
-            env = os.environ.get("RFN_GRAPH_DDP")
-            on = (bn._DIRECT["default"] is not None) if env is None else env == "1"
-            return on and dist.get_backend() == "nccl"
+            return bn.ddp_mode() != "torch" and bn._DIRECT["default"] is not None and dist.get_backend() == "nccl"
         return True
 
     def __call__(self, *tensors):

@@ -72,7 +72,8 @@ def _check(rc, what):
 
 
 def enabled():
-    return os.environ.get("RFN_RCCL_DIRECT", "1") != "0"
+    from .bn import ddp_mode
+    return ddp_mode() != "torch"
 
 
 class DirectComm:

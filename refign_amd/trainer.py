@@ -224,7 +224,12 @@ class FlatGradBuffer:
 
     def all_reduce_mean(self, bucket_mb=None):
         """Everything the passes have not released, then: wait, add the second buffer, divide by the world size."""
-        if not (dist.is_available() and dist.is_initialized()) or os.environ.get("RFN_DDP_SKIP_REDUCE") == "1":   # (diagnostics)
+        from .bn import data_parallel
+        if not (dist.is_available() and dist.is_initialized()) or not data_parallel():
+            # no group, or a group of ONE rank (torchrun --nproc-per-node 1): the sum over one rank is the identity and the
+            # mean divides by 1 -- no collective is issued (round 4 sent the 343 MB buffer through six bucketed all-reduces of
+            # the 1-rank group anyway: 144.9 -> 159.9 ms/step, the all-reduce kernels of torch's process group running on its
+            # own stream next to the three busy compute streams).  RFN_DDP_REHEARSAL=1 makes a 1-rank group exchange for real.
             self.merge_second()
             self._released = []
             return
@@ -262,6 +267,8 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         from .bn import data_parallel
         self.data_parallel = data_parallel()                 # world > 1, or a 1-rank rehearsal of it
+        from .bn import ddp_mode
+        self.ddp_mode = ddp_mode() if self.data_parallel else None
         if sync_batchnorm and dist.is_available() and dist.is_initialized():
             nn.SyncBatchNorm.convert_sync_batchnorm(model)   # student AND teacher BNs (reference: sync_batchnorm: True)
             # The EMA teacher runs on a side stream next to the student (and next to hipGraph replays that contain the
@@ -291,14 +298,11 @@ class Trainer:
                         teacher_comm = rccl.DirectComm(dev)
                         for m in teacher:
                             m._rfn_direct = teacher_comm
-                    # A THIRD communicator: the mixed pass on its own stream next to the source pass, as on one GPU (12.5 ms of a 171 ms
-                    # step in the 1-rank rehearsal, profiles/r04_ddp_rehearsal.txt).  Round 3 kept this off until a 2-GPU run
-                    # had shown three concurrent communicators to be safe; no such box has been available, so round 4 turns
-                    # it ON and makes the first stall of a multi-rank bench run fall back instead (bench.py: the guard
-                    # re-executes every rank in the conservative configuration).  Every communicator's collectives are
-                    # issued from one host thread in program order on a stream of its own, the same on every rank.
-                    # RFN_DDP_MIXED_COMM=0: two communicators, student passes in stream order on the main stream.
-                    if os.environ.get("RFN_GRAPH_DDP", "1") != "0" and os.environ.get("RFN_DDP_MIXED_COMM", "1") == "1":
+                    # A THIRD communicator (RFN_DDP_MODE=direct3 only): the mixed pass on its own stream next to the source pass, as
+                    # on one GPU.  Every communicator's collectives are issued from one host thread in program order on a stream
+                    # of its own, the same on every rank -- but three communicators' kernels on one device have never met a
+                    # second rank (bn.ddp_mode), so this is opt-in.
+                    if _bn.ddp_mode() == "direct3":
                         model._mixed_comm = rccl.DirectComm(dev)
                     # The gradient reduce.  Default: torch's process group, bucketed, after the passes (with the mixed pass
                     # next to the source pass there is no cheap way to start earlier: releases from inside a captured pass are

@@ -64,9 +64,35 @@ def g7_k4():
     save("align_smooth_1080x1920", **arrays)
 
 
+def g_k2():
+    """K2 (BASELINE.json config 2: "UAWarpC align-only, 512x512 pairs"): the reference's AlignmentModel.forward
+    (models/alignment_model.py:55-79) on b = 2 pairs at 512 x 512, closed-form weights: flow i -> j at full resolution and
+    1 - P_R.  -> alignment_forward_512x512.npz (strided samples + fp64 checksums)."""
+    am = R.ref_module("models.alignment_model")
+    vggm = R.ref_module("models.backbones.vgg")
+    vgg = closed_form_fill(vggm.VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone.").eval()
+    head = _head()
+    B, H, W = 2, 512, 512
+    img_i = (hashed_uniform((B, 3, H, W), "k2/i") * 4 - 2).astype(np.float32)
+    img_j = (0.8 * np.roll(img_i, (3, -2), (2, 3)) + 0.2 * (hashed_uniform((B, 3, H, W), "k2/j") * 4 - 2)).astype(np.float32)
+    ns = types.SimpleNamespace(alignment_backbone=vgg, alignment_head=head)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        flow, uncert = am.AlignmentModel.forward(ns, t(img_i), t(img_j))
+    dt = time.perf_counter() - t0
+    print(f"  reference AlignmentModel.forward at {B}x{H}x{W}: {dt:.1f} s on {torch.get_num_threads()} threads")
+    fl, un = flow.numpy(), uncert.numpy()
+    save("alignment_forward_512x512", size=np.array([B, H, W]), cpu_seconds=np.float32(dt),
+         flow_sample=fl[:, :, ::4, ::4].copy(), flow_abs_checksum=np.float64(np.abs(fl.astype(np.float64)).sum()),
+         uncert_sample=un[:, :, ::4, ::4].copy(), uncert_checksum=np.float64(un.astype(np.float64).sum()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
     torch.set_num_threads(8)
     R.setup()
-    g7_k4()
+    if len(sys.argv) > 1 and sys.argv[1] == "K2":
+        g_k2()
+    else:
+        g7_k4()

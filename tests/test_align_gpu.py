@@ -293,3 +293,29 @@ def test_align_amp_precision_map(dev, monkeypatch):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         wp, mp, cp = align(*args)
     assert torch.allclose(wp, w32, atol=5e-3) and torch.allclose(cp, c32, atol=1e-4)
+
+
+@torch.no_grad()
+def test_alignment_forward_k2_golden_512x512(dev):
+    """K2 (BASELINE.json config 2, "UAWarpC align-only, 512x512 pairs"): AlignmentModel.forward (models/alignment_model.py:55-79)
+    on b = 2 pairs at 512 x 512 against the reference CPU path's output (tests/golden/make_golden_k4.py K2): flow i -> j at full
+    resolution and 1 - P_R.  This is the computation `bench.py --workload uawarpc_align_512x512` times."""
+    from refign_amd.align import VGG, UAWarpCHead
+    from refign_amd.alignment_model import AlignmentModel
+    g = golden("alignment_forward_512x512")
+    B, H, W = [int(v) for v in g["size"]]
+    assert (B, H, W) == (2, 512, 512)
+    vgg = closed_form_fill(VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone.")
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True))
+    model = AlignmentModel(alignment_backbone=vgg, alignment_head=head).to(dev).eval()
+    img_i = (hashed_uniform((B, 3, H, W), "k2/i") * 4 - 2).astype(np.float32)
+    img_j = (0.8 * np.roll(img_i, (3, -2), (2, 3)) + 0.2 * (hashed_uniform((B, 3, H, W), "k2/j") * 4 - 2)).astype(np.float32)
+    flow, uncert = model(T(img_i, dev), T(img_j, dev))
+    assert tuple(flow.shape) == (B, 2, H, W) and tuple(uncert.shape) == (B, 1, H, W)
+    ef = float(np.abs(flow[:, :, ::4, ::4].cpu().numpy() - g["flow_sample"]).max())
+    eu = float(np.abs(uncert[:, :, ::4, ::4].cpu().numpy() - g["uncert_sample"]).max())
+    print(f"\nAlignmentModel.forward @2x512x512 vs reference CPU path: flow {ef:.2e} px, 1 - P_R {eu:.2e}")
+    assert ef < 2e-2 and eu < 1e-3, (ef, eu)
+    cs = float(flow.double().abs().sum())
+    assert abs(cs - float(g["flow_abs_checksum"])) < 1e-4 * float(g["flow_abs_checksum"])
+    assert abs(float(uncert.double().sum()) - float(g["uncert_checksum"])) < 5e-4 * abs(float(g["uncert_checksum"]))

@@ -127,3 +127,27 @@ def test_cpu_head_restatement_matches_reference_golden(oracle):
     for lvl, (fl, un) in zip((4, 3, 2, 1), outs):
         np.testing.assert_allclose(fl.numpy(), g[f"flow{lvl}"], rtol=1e-3, atol=2e-2, err_msg=f"flow{lvl}")
         np.testing.assert_allclose(un.numpy(), g[f"uncert{lvl}"], rtol=1e-3, atol=5e-3, err_msg=f"uncert{lvl}")
+
+
+def test_cpu_alignment_forward_restatement_matches_reference_k2_golden():
+    """oracle/cpu_align.alignment_forward (AlignmentModel.forward, models/alignment_model.py:55-79, restated on torch-CPU ops +
+    the correlation oracle) against the reference's own output on the K2 input (tests/golden/make_golden_k4.py K2): the CPU
+    baseline of `bench.py --workload uawarpc_align_512x512` is a pinned computation."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    from conftest import golden
+    from fill import closed_form_fill, hashed_uniform
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import cpu_align
+    from refign_amd.align import VGG, UAWarpCHead
+    g = golden("alignment_forward_512x512")
+    B, H, W = [int(v) for v in g["size"]]
+    vgg = closed_form_fill(VGG('vgg16', out_indices=[2, 3, 4]), "alignment_backbone.").eval()
+    head = closed_form_fill(UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True)).eval()
+    img_i = (hashed_uniform((B, 3, H, W), "k2/i") * 4 - 2).astype(np.float32)
+    img_j = (0.8 * np.roll(img_i, (3, -2), (2, 3)) + 0.2 * (hashed_uniform((B, 3, H, W), "k2/j") * 4 - 2)).astype(np.float32)
+    flow, uncert = cpu_align.alignment_forward(vgg, head, torch.from_numpy(img_i), torch.from_numpy(img_j))
+    np.testing.assert_allclose(flow[:, :, ::4, ::4].numpy(), g["flow_sample"], atol=2e-3)
+    np.testing.assert_allclose(uncert[:, :, ::4, ::4].numpy(), g["uncert_sample"], atol=2e-4)
