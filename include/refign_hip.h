@@ -27,7 +27,7 @@ extern "C" {
 #define RFN_ELAUNCH (-2)   /* hipLaunchKernel / runtime error, see rfn_last_error() */
 #define RFN_ENOTSUP (-3)   /* valid in the reference but not built here (documented per function) */
 
-#define RFN_ABI_VERSION 1
+#define RFN_ABI_VERSION 2
 
 typedef void* rfn_stream_t; /* hipStream_t */
 
@@ -100,10 +100,12 @@ int rfn_local_corr_layer_split_f32(const float* feature_target, const float* fea
 /* GlobalFeatureCorrelationLayer.forward (modules.py:294-308): '3D' H-first correlation (modules.py:361-375),
  * mutual matching with eps 1e-5 (modules.py:310-333), ReLU, L2-normalise over the source axis.
  * src: (B,C,Hs,Ws), trg: (B,C,Ht,Wt) -> out: (B,Hs*Ws,Ht,Wt).  Requires Hs*Ws <= 1024 and Ht*Wt <= 1024
- * (the reference asserts 16x16: uawarpc.py:114). */
-int rfn_global_corr_layer_f32(const float* feature_source, const float* feature_target, float* out, int B,
-                              int C, int Hs, int Ws, int Ht, int Wt, int cyclic_consistency,
-                              rfn_stream_t stream);
+ * (the reference asserts 16x16: uawarpc.py:114).  workspace (ABI 2): B*Hs*Ws floats of device scratch for the row maxima of
+ * the mutual matching (may be NULL when cyclic_consistency == 0): the scores are normalised in place by one workgroup per 16
+ * target positions, so the maxima every workgroup needs are taken by a launch of their own first. */
+int rfn_global_corr_layer_f32(const float* feature_source, const float* feature_target, float* out,
+                              float* workspace, int B, int C, int Hs, int Ws, int Ht, int Wt,
+                              int cyclic_consistency, rfn_stream_t stream);
 
 /* warp() (helpers/matching_utils.py:11-49): bilinear grid_sample, align_corners=True, zero padding.
  * x: (B,C,H,W); flow: (B,2,H,W) pixels; out: (B,C,H,W); mask (nullable): (B,H,W) uint8, 1 where the

@@ -30,7 +30,7 @@ SIGNATURES = {
     "rfn_corr_bwd_f16": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
     "rfn_local_corr_layer_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "rfn_local_corr_layer_split_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
-    "rfn_global_corr_layer_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
+    "rfn_global_corr_layer_f32": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "rfn_warp_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "rfn_warp_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "rfn_l2norm_channels_f32": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
@@ -117,6 +117,11 @@ SIGNATURES = {
 }
 
 
+# RFN_ABI_VERSION of include/refign_hip.h this table was written against (2: rfn_global_corr_layer_f32 takes a workspace,
+# rfn_dacs_mix_jitter accepts one half of the mix)
+ABI_VERSION = 2
+
+
 def library_path():
     return _LIB_PATH
 
@@ -145,6 +150,9 @@ def load_library():
                 raise RuntimeError(f"refign_amd: {_LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
+        if lib.rfn_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"refign_amd: {_LIB_PATH} speaks ABI {lib.rfn_abi_version()}, this package binds ABI {ABI_VERSION} "
+                               f"(include/refign_hip.h: RFN_ABI_VERSION): rebuild the library")
         _lib = lib
     return _lib
 

@@ -290,16 +290,6 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(sbase) : "memory", "m0");
 #pragma clang diagnostic pop
 }
-// the same with the non-temporal hint (experiment: RFN_CORR_ABLATE bit 3)
-__device__ __forceinline__ void lds_dma16_nt(const float* gsrc, float* lds_wave_base) {
-  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base;
-  const unsigned sbase = __builtin_amdgcn_readfirstlane(base);
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "s"(sbase) : "memory", "m0");
-#pragma clang diagnostic pop
-}
-
 // The same under a lane mask, WITHOUT control flow the compiler can see: exec is narrowed and restored inside the asm
 // statement.  (An `if (ok) lds_dma16(...)` is a branch around the instruction; between the unrolled product steps of
 // corr9_pipe2_kernel such branches split the chunk into basic blocks, and the products -- pure arithmetic -- then sink
@@ -315,493 +305,17 @@ __device__ __forceinline__ void lds_dma16_masked(const void* sbase, unsigned vof
 #pragma clang diagnostic pop
 }
 
+// (Rounds 1-4 kept three earlier generations of this kernel in the library behind RFN_CORR_VARIANT -- the 2-stage LDS-DMA
+// kernel `corr9_dma_kernel`, the first 4-stage ring `corr9_pipe_kernel` with its tile-tail race, and ~25 tile / chunk
+// variants of them.  Round 5 removed them: one pipelined kernel below serves every map the tiled path takes, the round-1
+// register-staged `corr9_tile_kernel` above everything else (odd widths, few channels, the fused-warp form, samples of 4 GB
+// and more).  Their measurements stay in profiles/r01-r04_*corr*.)
+
 // NTILE = 2: the workgroup is two independent halves, each owning its own tile (ids 2b, 2b+1 of the launch's tile
 // order), its own LDS region and its own DMA stream; only the per-chunk barrier is shared.  This doubles the waves per
 // CU (6-wave workgroups do not co-reside: their 2,2,1,1 wave placement over the SIMDs leaves no room for a second one
-// at 168 VGPRs) while keeping the fine 16x32 tile granularity that fills 256 CUs evenly.
-template <int TH, int TW, int CC, bool FUSE, int MINW, int UNR, int NTILE, bool ILV>
-__global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_dma_kernel(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
-    int tilesX, int tilesY, int ntiles, int xcd_remap, int ablate, int Ctot, long part_stride) {
-  // Channel split (small maps, launch_corr9_split below): blockIdx.y selects a chunk of C of the Ctot channels and
-  // the workgroup writes its partial sums to out + blockIdx.y * part_stride.  One chunk: Ctot == C, part_stride == 0.
-  static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
-  constexpr int STRIPS = TW / 4;                     // 4-pixel strips per tile row
-  constexpr int RPW = 64 / STRIPS;                   // tile rows covered by one wave (4 or 8)
-  constexpr int NT = TH * STRIPS * 3;                // threads per tile
-  constexpr int NW = NT / 64;                        // waves per tile
-  constexpr int R2 = TH + 2 * kHalo;
-  constexpr int ROWS = R2 + TH;
-  // LDS row pitch in dwords.  It is chosen together with the lane->strip permutation below so that every
-  // ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31} and their +32 twins) covers all 64 banks once:
-  //   TW=64: pitch 72 (18 slots of 16 B), lanes of odd wave-rows take their strips rotated by 14;
-  //   TW=32: pitch 48 (12 slots, 10 used): row offsets 0,12,8,4 (mod 16 slots), lanes of wave-rows 1,2 (mod 4)
-  //          swap their strip halves (j ^ 4).
-  constexpr int PITCH = (TW == 64) ? 72 : 48;
-  constexpr int V = PITCH / 4;                       // float4 slots per LDS row
-  constexpr int VU2 = (TW + 2 * kHalo) / 4;          // slots of a source row that carry data
-  constexpr int SLOTS = CC * ROWS * V;               // float4 slots per chunk
-  constexpr int NINSTR = (SLOTS + 63) / 64;          // wave-level DMA instructions per chunk
-  constexpr int K = (NINSTR + NW - 1) / NW;          // per wave
-  constexpr int BUF = NINSTR * 64 * 4;               // floats per ring buffer (rounded up to whole instructions)
-  // TWO separate LDS objects on purpose: hipcc's waitcnt pass only lets a ds_read run past an in-flight LDS-DMA
-  // when alias analysis proves they touch different objects; one array indexed by (chunk & 1) forces
-  // s_waitcnt vmcnt(0) before the first ds_read of every chunk, i.e. no overlap at all.
-  __shared__ __attribute__((aligned(16))) float ring0_all[NTILE * BUF];
-  __shared__ __attribute__((aligned(16))) float ring1_all[NTILE * BUF];
-
-  const int half = threadIdx.x / NT;                 // which of the workgroup's tiles (wave-uniform)
-  const int tid = threadIdx.x % NT;
-  float* const ring0 = ring0_all + half * BUF;
-  float* const ring1 = ring1_all + half * BUF;
-  // Tile order = dispatch order.  An XCD-aware remap (each XCD a contiguous band of tiles, T1) was measured and is
-  // WORSE here (16x32 single tile 145 -> 179 us at K4 level 1): the inputs are Infinity-Cache resident and spreading
-  // the eight XCDs over eight distant bands costs more in fabric/DRAM-page locality than the shared halos save.
-  int tile;
-  if (xcd_remap) {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int qq = nwg / 8, rr = nwg % 8, xcd = b % 8, loc = b / 8;
-    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
-    tile = wg * NTILE + half;
-  } else {
-    tile = blockIdx.x * NTILE + half;
-  }
-  const bool live = tile < ntiles;                   // odd tile count: the last half only keeps the barriers company
-  int bid = live ? tile : 0;
-  const int tx = bid % tilesX; bid /= tilesX;
-  const int ty = bid % tilesY;
-  const int n = bid / tilesY;
-  const int h0 = ty * TH, w0 = tx * TW;
-  const int lane = tid & 63, wave = tid >> 6;
-  constexpr int WPG = TH / RPW;                      // waves per vertical-shift group
-  const int dyg = wave / WPG;
-  const int q = lane / STRIPS, j = lane % STRIPS;
-  const int row = (wave % WPG) * RPW + q;
-  const int strip = (TW == 64) ? ((q & 1) ? ((j + 14) & 15) : j) : (j ^ ((((q & 3) == 1) || ((q & 3) == 2)) ? 4 : 0));
-
-  const size_t plane = (size_t)H * W;
-  const float* p1 = in1 + ((size_t)n * Ctot + (size_t)blockIdx.y * C) * plane;
-  const float* p2 = in2 + ((size_t)n * Ctot + (size_t)blockIdx.y * C) * plane;
-  out += (size_t)blockIdx.y * part_stride;
-
-  // zero both buffers once (out-of-image slots stay zero forever)
-  for (int i = tid; i < BUF / 4; i += NT) {
-    reinterpret_cast<float4*>(ring0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(ring1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
-  // per-thread DMA descriptors: source pointer (for chunk 0) and validity of each of my K slots
-  const float* gsrc[K];
-  bool gok[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int wi = wave + k * NW;                    // wave-level instruction index
-    const int slot = wi * 64 + lane;
-    const int v = slot % V, rr = (slot / V) % ROWS, c = slot / (V * ROWS);
-    bool ok = live && (wi < NINSTR) && (slot < SLOTS);
-    const float* src;
-    if (rr < R2) {
-      const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
-      ok = ok && v < VU2 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
-      src = p2 + (size_t)c * plane + (long)gy * W + gx;
-    } else {
-      const int gy = h0 + rr - R2, gx = w0 + 4 * v;
-      ok = ok && v < STRIPS && gy < H && gx + 3 < W;
-      src = p1 + (size_t)c * plane + (long)gy * W + gx;
-    }
-    gsrc[k] = ok ? src : p1;
-    gok[k] = ok;
-  }
-  __syncthreads();
-
-  // one DMA instruction of the next chunk (k-th of this wave); spread over the channel loop of the current chunk so
-  // that the 12 waves do not all queue on the CU's single address path right after the barrier
-  auto issue_one = [&](float* ring, int k) {
-    const int wi = wave + k * NW;
-    if (wi < NINSTR) {
-      if (gok[k]) lds_dma16(gsrc[k], ring + wi * 256);
-      gsrc[k] += (size_t)CC * plane;
-    }
-  };
-  auto issue = [&](float* ring) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int wi = wave + k * NW;
-      if (wi < NINSTR) {                               // wave-uniform
-        float* ldst = ring + wi * 256;                 // wave-uniform LDS base; lane lands at +lane*16 B
-        if (ablate & 8) {
-          if (gok[k]) lds_dma16_nt(gsrc[k], ldst);
-        } else {
-          if (gok[k]) lds_dma16(gsrc[k], ldst);
-        }
-        gsrc[k] += (size_t)CC * plane;
-      }
-    }
-  };
-
-  // accumulators as explicit register pairs so that every packed FMA operand is a naturally aligned pair:
-  //   pixel i even: pairs of horizontal shifts (0,1)(2,3)(4,5)(6,7) + single 8
-  //   pixel i odd : pairs (1,2)(3,4)(5,6)(7,8) + single 0
-  f32x2 accp[3][4][4];
-  float accs[3][4];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      accs[a][i] = 0.0f;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) accp[a][i][p] = f32x2{0.0f, 0.0f};
-    }
-
-  auto compute = [&](const float* __restrict__ s2, float* next_ring, bool prefetch) {
-#pragma unroll UNR
-    for (int c = 0; c < CC; ++c) {
-      if constexpr (ILV) {
-        // Round 3 experiment (variants 17-19 only): STAGGERED issue -- wave w issues all of its DMA instructions in front of
-        // channel (w mod CC) of the chunk instead of everybody right after the barrier, so that a quarter of the waves queue
-        // on the CU's address path while the others run their FMAs.  Hypothesis: the DMA-issue time (53 us with the FMAs
-        // ablated) and the product time (56 us) of a launch ADD because all waves stall on issue together.  Measured: 140.0
-        // vs 143.2 us (kbench, L1) -- 2 %: the phases do not add for that reason.  Not the default.
-        if (prefetch && c == ((int)(threadIdx.x >> 6) & (CC - 1))) issue(next_ring);
-      }
-      const float* cb = s2 + c * ROWS * PITCH;
-      const float4 a = *reinterpret_cast<const float4*>(&cb[(R2 + row) * PITCH + 4 * strip]);
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int dyi = 0; dyi < 3; ++dyi) {
-        const float* rp = &cb[(row + dyg * 3 + dyi) * PITCH + 4 * strip];
-        const float4 b0 = *reinterpret_cast<const float4*>(rp);
-        const float4 b1 = *reinterpret_cast<const float4*>(rp + 4);
-        const float4 b2 = *reinterpret_cast<const float4*>(rp + 8);
-        const f32x2 bp[6] = {f32x2{b0.x, b0.y}, f32x2{b0.z, b0.w}, f32x2{b1.x, b1.y},
-                             f32x2{b1.z, b1.w}, f32x2{b2.x, b2.y}, f32x2{b2.z, b2.w}};
-        const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x2 aa = f32x2{av[i], av[i]};
-#pragma unroll
-          for (int p = 0; p < 4; ++p)
-            accp[dyi][i][p] = __builtin_elementwise_fma(aa, bp[(i + 2 * p + (i & 1)) / 2], accp[dyi][i][p]);
-          accs[dyi][i] = fmaf(av[i], (i & 1) ? bv[i] : bv[i + 8], accs[dyi][i]);
-        }
-      }
-    }
-  };
-
-  const int nchunks = C / CC;                          // even (checked by the launcher)
-  issue(ring0);
-  for (int ck = 0; ck < nchunks; ck += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my slots of chunk ck have landed ...
-    __syncthreads();                                   // ... and everybody's: chunk ck in ring0; ring1 free
-    if constexpr (ILV) {
-      compute(ring0, ring1, !(ablate & 1));
-    } else {
-      if (!(ablate & 1)) issue(ring1);
-      if (!(ablate & 2)) compute(ring0, ring1, false);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // chunk ck+1 landed in ring1; ring0 free
-    if constexpr (ILV) {
-      compute(ring1, ring0, (ck + 2 < nchunks) && !(ablate & 1));
-    } else {
-      if (ck + 2 < nchunks && !(ablate & 1)) issue(ring0);
-      if (!(ablate & 2)) compute(ring1, ring0, false);
-    }
-  }
-
-  // ---- epilogue ----
-  auto get = [&](int dyi, int dx, int i) -> float {
-    if (i & 1) return dx == 0 ? accs[dyi][i] : accp[dyi][i][(dx - 1) >> 1][(dx - 1) & 1];
-    return dx == 8 ? accs[dyi][i] : accp[dyi][i][dx >> 1][dx & 1];
-  };
-  const int h = h0 + row, wx = w0 + 4 * strip;
-  float scale[4] = {1.f, 1.f, 1.f, 1.f};
-  if constexpr (FUSE) {
-    float ss[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 9; ++b)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = fmaxf(get(a, b, i), 0.0f);
-          ss[i] = fmaf(v, v, ss[i]);
-        }
-    __syncthreads();
-    float* red = ring0;  // [3][TH][64]
-    *reinterpret_cast<float4*>(&red[(dyg * TH + row) * TW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float tot = red[(0 * TH + row) * TW + 4 * strip + i] + red[(1 * TH + row) * TW + 4 * strip + i] +
-                        red[(2 * TH + row) * TW + 4 * strip + i];
-      scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
-    }
-  }
-  if (live && h < H && wx + 3 < W && !(ablate & 4)) {
-    float* obase = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
-#pragma unroll
-    for (int dyi = 0; dyi < 3; ++dyi)
-#pragma unroll
-      for (int dx = 0; dx < 9; ++dx) {
-        float r0 = get(dyi, dx, 0), r1 = get(dyi, dx, 1), r2 = get(dyi, dx, 2), r3 = get(dyi, dx, 3);
-        if constexpr (FUSE) {
-          r0 = fmaxf(r0, 0.f) * scale[0]; r1 = fmaxf(r1, 0.f) * scale[1];
-          r2 = fmaxf(r2, 0.f) * scale[2]; r3 = fmaxf(r3, 0.f) * scale[3];
-        }
-        *reinterpret_cast<float4*>(obase + (size_t)(dyi * 9 + dx) * plane) = make_float4(r0, r1, r2, r3);
-      }
-  }
-}
-
-// ---- 4-stage variant --------------------------------------------------------------------------------------------
-// Same decomposition, but the LDS ring is FOUR separate objects of 2-channel chunks and the DMA of chunk c+3 is issued
-// while chunk c is consumed.  `__syncthreads()` would drain every outstanding DMA (its fence carries vmcnt(0)), so the
-// chunk hand-off is: counted `s_waitcnt vmcnt(N)` (in-order completion: the wave's own slots of chunk c have landed
-// once at most the N instructions of chunks c+1, c+2 are still in flight) + raw `s_barrier` (every wave's slots landed,
-// and everybody finished reading chunk c-1 whose ring is about to be refilled).  Waves issue K or K-1 DMA instructions
-// per chunk; N = 2 (K-1) is the safe count for both.
-// NTILE = 2: the workgroup is two independent halves, each owning its own tile (ids 2b, 2b+1 of the launch's tile
-// order), its own LDS region and its own DMA stream; only the per-chunk barrier is shared.  This doubles the waves per
-// CU (6-wave workgroups do not co-reside: their 2,2,1,1 wave placement over the SIMDs leaves no room for a second one
-// at 168 VGPRs) while keeping the fine 16x32 tile granularity that fills 256 CUs evenly.
-template <int TH, int TW, bool FUSE, int MINW, int NTILE>
-__global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe_kernel(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
-    int tilesX, int tilesY, int ntiles, int xcd_remap) {
-  static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
-  constexpr int CC = 2;                              // channels per chunk
-  constexpr int STRIPS = TW / 4;                     // 4-pixel strips per tile row
-  constexpr int RPW = 64 / STRIPS;                   // tile rows covered by one wave (4 or 8)
-  constexpr int NT = TH * STRIPS * 3;                // threads per tile
-  constexpr int NW = NT / 64;                        // waves per tile
-  constexpr int R2 = TH + 2 * kHalo;
-  constexpr int ROWS = R2 + TH;
-  // LDS row pitch in dwords.  It is chosen together with the lane->strip permutation below so that every
-  // ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31} and their +32 twins) covers all 64 banks once:
-  //   TW=64: pitch 72 (18 slots of 16 B), lanes of odd wave-rows take their strips rotated by 14;
-  //   TW=32: pitch 48 (12 slots, 10 used): row offsets 0,12,8,4 (mod 16 slots), lanes of wave-rows 1,2 (mod 4)
-  //          swap their strip halves (j ^ 4).
-  constexpr int PITCH = (TW == 64) ? 72 : 48;
-  constexpr int V = PITCH / 4;                       // float4 slots per LDS row
-  constexpr int VU2 = (TW + 2 * kHalo) / 4;          // slots of a source row that carry data
-  constexpr int SLOTS = CC * ROWS * V;               // float4 slots per chunk
-  constexpr int NINSTR = (SLOTS + 63) / 64;          // wave-level DMA instructions per chunk
-  constexpr int K = (NINSTR + NW - 1) / NW;          // per wave
-  constexpr int BUF = NINSTR * 64 * 4;               // floats per ring buffer (rounded up to whole instructions)
-  // TWO separate LDS objects on purpose: hipcc's waitcnt pass only lets a ds_read run past an in-flight LDS-DMA
-  // when alias analysis proves they touch different objects; one array indexed by (chunk & 1) forces
-  // s_waitcnt vmcnt(0) before the first ds_read of every chunk, i.e. no overlap at all.
-  __shared__ __attribute__((aligned(16))) float ring0_all[NTILE * BUF];
-  __shared__ __attribute__((aligned(16))) float ring1_all[NTILE * BUF];
-  __shared__ __attribute__((aligned(16))) float ring2_all[NTILE * BUF];
-  __shared__ __attribute__((aligned(16))) float ring3_all[NTILE * BUF];
-
-  const int half = threadIdx.x / NT;                 // which of the workgroup's tiles (wave-uniform)
-  const int tid = threadIdx.x % NT;
-  float* const ring0 = ring0_all + half * BUF;
-  float* const ring1 = ring1_all + half * BUF;
-  float* const ring2 = ring2_all + half * BUF;
-  float* const ring3 = ring3_all + half * BUF;
-  // Tile order = dispatch order.  An XCD-aware remap (each XCD a contiguous band of tiles, T1) was measured and is
-  // WORSE here (16x32 single tile 145 -> 179 us at K4 level 1): the inputs are Infinity-Cache resident and spreading
-  // the eight XCDs over eight distant bands costs more in fabric/DRAM-page locality than the shared halos save.
-  int tile;
-  if (xcd_remap) {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int qq = nwg / 8, rr = nwg % 8, xcd = b % 8, loc = b / 8;
-    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
-    tile = wg * NTILE + half;
-  } else {
-    tile = blockIdx.x * NTILE + half;
-  }
-  const bool live = tile < ntiles;                   // odd tile count: the last half only keeps the barriers company
-  int bid = live ? tile : 0;
-  const int tx = bid % tilesX; bid /= tilesX;
-  const int ty = bid % tilesY;
-  const int n = bid / tilesY;
-  const int h0 = ty * TH, w0 = tx * TW;
-  const int lane = tid & 63, wave = tid >> 6;
-  constexpr int WPG = TH / RPW;                      // waves per vertical-shift group
-  const int dyg = wave / WPG;
-  const int q = lane / STRIPS, j = lane % STRIPS;
-  const int row = (wave % WPG) * RPW + q;
-  const int strip = (TW == 64) ? ((q & 1) ? ((j + 14) & 15) : j) : (j ^ ((((q & 3) == 1) || ((q & 3) == 2)) ? 4 : 0));
-
-  const size_t plane = (size_t)H * W;
-  const float* p1 = in1 + (size_t)n * C * plane;
-  const float* p2 = in2 + (size_t)n * C * plane;
-
-  // zero both buffers once (out-of-image slots stay zero forever)
-  for (int i = tid; i < BUF / 4; i += NT) {
-    reinterpret_cast<float4*>(ring0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(ring1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(ring2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(ring3)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
-  // per-thread DMA descriptors: source pointer (for chunk 0) and validity of each of my K slots
-  const float* gsrc[K];
-  bool gok[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int wi = wave + k * NW;                    // wave-level instruction index
-    const int slot = wi * 64 + lane;
-    const int v = slot % V, rr = (slot / V) % ROWS, c = slot / (V * ROWS);
-    bool ok = live && (wi < NINSTR) && (slot < SLOTS);
-    const float* src;
-    if (rr < R2) {
-      const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
-      ok = ok && v < VU2 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
-      src = p2 + (size_t)c * plane + (long)gy * W + gx;
-    } else {
-      const int gy = h0 + rr - R2, gx = w0 + 4 * v;
-      ok = ok && v < STRIPS && gy < H && gx + 3 < W;
-      src = p1 + (size_t)c * plane + (long)gy * W + gx;
-    }
-    gsrc[k] = ok ? src : p1;
-    gok[k] = ok;
-  }
-  __syncthreads();
-
-  auto issue = [&](float* ring) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int wi = wave + k * NW;
-      if (wi < NINSTR) {                               // wave-uniform
-        float* ldst = ring + wi * 256;                 // wave-uniform LDS base; lane lands at +lane*16 B
-        if (gok[k]) lds_dma16(gsrc[k], ldst);
-        gsrc[k] += (size_t)CC * plane;
-      }
-    }
-  };
-
-  // accumulators as explicit register pairs so that every packed FMA operand is a naturally aligned pair:
-  //   pixel i even: pairs of horizontal shifts (0,1)(2,3)(4,5)(6,7) + single 8
-  //   pixel i odd : pairs (1,2)(3,4)(5,6)(7,8) + single 0
-  f32x2 accp[3][4][4];
-  float accs[3][4];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      accs[a][i] = 0.0f;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) accp[a][i][p] = f32x2{0.0f, 0.0f};
-    }
-
-  auto compute = [&](const float* __restrict__ s2) {
-#pragma unroll 1
-    for (int c = 0; c < CC; ++c) {
-      const float* cb = s2 + c * ROWS * PITCH;
-      const float4 a = *reinterpret_cast<const float4*>(&cb[(R2 + row) * PITCH + 4 * strip]);
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int dyi = 0; dyi < 3; ++dyi) {
-        const float* rp = &cb[(row + dyg * 3 + dyi) * PITCH + 4 * strip];
-        const float4 b0 = *reinterpret_cast<const float4*>(rp);
-        const float4 b1 = *reinterpret_cast<const float4*>(rp + 4);
-        const float4 b2 = *reinterpret_cast<const float4*>(rp + 8);
-        const f32x2 bp[6] = {f32x2{b0.x, b0.y}, f32x2{b0.z, b0.w}, f32x2{b1.x, b1.y},
-                             f32x2{b1.z, b1.w}, f32x2{b2.x, b2.y}, f32x2{b2.z, b2.w}};
-        const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x2 aa = f32x2{av[i], av[i]};
-#pragma unroll
-          for (int p = 0; p < 4; ++p)
-            accp[dyi][i][p] = __builtin_elementwise_fma(aa, bp[(i + 2 * p + (i & 1)) / 2], accp[dyi][i][p]);
-          accs[dyi][i] = fmaf(av[i], (i & 1) ? bv[i] : bv[i + 8], accs[dyi][i]);
-        }
-      }
-    }
-  };
-
-  const int nchunks = C / CC;                          // multiple of 4 (checked by the launcher)
-  constexpr int NWAIT = 2 * (K - 1);                   // see header: chunk c landed once <= NWAIT newer DMAs in flight
-  auto handoff = [&]() {
-    if constexpr (NWAIT <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (NWAIT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (NWAIT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (NWAIT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  // The counted wait assumes TWO newer chunks in flight behind the one about to be read.  That is not true for a tile's last
-  // two chunks (nothing is issued any more): `vmcnt(NWAIT)` then lets a wave through with its own slots of the chunk still
-  // in flight -- found in round 4 with tools/micro/corr_race.py (11 of 300 launches differed, by the products of the last
-  // 2-4 channels, whenever another stream kept the memory system busy).  The last two hand-offs of a tile wait for everything.
-  auto handoff_all = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  issue(ring0);
-  issue(ring1);
-  issue(ring2);
-  for (int ck = 0; ck < nchunks; ck += 4) {
-    const bool last = ck + 4 >= nchunks;               // (scalar)
-    handoff();                                         // chunk ck in ring0; ring3 (chunk ck-1) free
-    if (ck + 3 < nchunks) issue(ring3);
-    compute(ring0);
-    handoff();
-    if (ck + 4 < nchunks) issue(ring0);
-    compute(ring1);
-    if (last) handoff_all(); else handoff();
-    if (ck + 5 < nchunks) issue(ring1);
-    compute(ring2);
-    if (last) handoff_all(); else handoff();
-    if (ck + 6 < nchunks) issue(ring2);
-    compute(ring3);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  // ---- epilogue ----
-  auto get = [&](int dyi, int dx, int i) -> float {
-    if (i & 1) return dx == 0 ? accs[dyi][i] : accp[dyi][i][(dx - 1) >> 1][(dx - 1) & 1];
-    return dx == 8 ? accs[dyi][i] : accp[dyi][i][dx >> 1][dx & 1];
-  };
-  const int h = h0 + row, wx = w0 + 4 * strip;
-  float scale[4] = {1.f, 1.f, 1.f, 1.f};
-  if constexpr (FUSE) {
-    float ss[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 9; ++b)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = fmaxf(get(a, b, i), 0.0f);
-          ss[i] = fmaf(v, v, ss[i]);
-        }
-    __syncthreads();
-    float* red = ring0;  // [3][TH][64]
-    *reinterpret_cast<float4*>(&red[(dyg * TH + row) * TW + 4 * strip]) = make_float4(ss[0], ss[1], ss[2], ss[3]);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float tot = red[(0 * TH + row) * TW + 4 * strip + i] + red[(1 * TH + row) * TW + 4 * strip + i] +
-                        red[(2 * TH + row) * TW + 4 * strip + i];
-      scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
-    }
-  }
-  if (live && h < H && wx + 3 < W) {
-    float* obase = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
-#pragma unroll
-    for (int dyi = 0; dyi < 3; ++dyi)
-#pragma unroll
-      for (int dx = 0; dx < 9; ++dx) {
-        float r0 = get(dyi, dx, 0), r1 = get(dyi, dx, 1), r2 = get(dyi, dx, 2), r3 = get(dyi, dx, 3);
-        if constexpr (FUSE) {
-          r0 = fmaxf(r0, 0.f) * scale[0]; r1 = fmaxf(r1, 0.f) * scale[1];
-          r2 = fmaxf(r2, 0.f) * scale[2]; r3 = fmaxf(r3, 0.f) * scale[3];
-        }
-        *reinterpret_cast<float4*>(obase + (size_t)(dyi * 9 + dx) * plane) = make_float4(r0, r1, r2, r3);
-      }
-  }
-}
-
+// at 168 VGPRs) while keeping the fine 16x32 tile granularity that fills 256 CUs evenly: K4 level 1 (2 x 270 x 480) is
+// 510 tiles = 255 workgroups = one even round over the 256 CUs.
 // ---- 4-stage variant, second take (round 4, second half) ---------------------------------------------------------
 // What the counters said about corr9_pipe_kernel (profiles/r04_pmc_corr9.txt): it is VALU-bound, not LDS-bound
 // (`ds_read_b128` moves 256 B / clock / CU on gfx950: 10 reads x 12 waves x 4 clocks = 480 clocks per channel against
@@ -819,11 +333,23 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe_ke
 //     (three rounds of 36 floats per lane in the ring's own memory).  For maps of at most one tile per CU: a chunk takes a CU
 //     0.5 us with three waves and 0.85 us with six, so half the chunks per wave is ~15-20 % off the launch (not half: the
 //     CU, not the wave, is what a chunk waits for).
-template <int TH, int TW, bool FUSE, int MINW, int NTILE, int DEPTH = 1, int NS = 4, bool KSPLIT = false>
+//   * PAIR (round 5; K4 level 2: 2 x 135 x 240): a map whose width leaves at most HALF a tile column over (240 = 7 x 32 + 16)
+//     spends a whole tile per row band on it -- 17 x 8 x 2 = 272 tiles, and the 16 CUs that get a second workgroup pace the
+//     launch (83 us against 64.5 us for 256 tiles, profiles/r04_corr_ksplit.txt).  With PAIR the left-over column band of TWO
+//     images shares one tile: strips 0..3 of the tile are image n's last columns, strips 4..7 image n + 1's (same rows), each
+//     half with its own 4-pixel halo in the 48-float LDS row (2 x 24).  Only per-lane constants change (DMA source offsets,
+//     the source-row base, the store address); the LDS image, the products and the hand-offs are the same.  `tilesX` then
+//     counts the FULL tile columns, tiles [0, nreg) are regular and tiles [nreg, ntiles) are the (image pair, row band) edge
+//     tiles: 2 x 17 x 7 + 17 = 255 workgroups -- one per CU, which also lets the channel split (KSPLIT) apply.
+template <int TH, int TW, bool FUSE, int MINW, int NTILE, int DEPTH = 1, int NS = 4, bool KSPLIT = false, bool PAIR = false>
 __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_kernel(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
-    int tilesX, int tilesY, int ntiles, int ablate, int xcd_remap) {
+    int tilesX, int tilesY, int ntiles, int xcd_remap, int nreg, int Ctot, long part_stride) {
+  // (C = the channels THIS workgroup walks, Ctot = the tensors' channel count: equal except in the cross-workgroup channel
+  // split of tiny maps, launch_corr9_split, where blockIdx.y picks the slice [blockIdx.y C, (blockIdx.y + 1) C) and the raw
+  // partial sums go to out + blockIdx.y * part_stride)
   static_assert(TW == 64 || TW == 32, "tile width 64 or 32");
+  static_assert(!PAIR || TW == 32, "paired edge tiles: two 16-column halves with their halos fill the 48-float row of TW = 32");
   constexpr int CC = 2;
   constexpr int STRIPS = TW / 4;
   constexpr int RPW = 64 / STRIPS;
@@ -859,9 +385,18 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   const int tile = KSPLIT ? wg : wg * NTILE + half;
   const bool live = tile < ntiles;
   int bid = live ? tile : 0;
-  const int tx = bid % tilesX; bid /= tilesX;
-  const int ty = bid % tilesY;
-  const int n = bid / tilesY;
+  const bool edge = PAIR && bid >= nreg;               // (scalar) a left-over column band shared by images n and n + 1
+  int tx, ty, n;
+  if (edge) {
+    bid -= nreg;
+    tx = tilesX;
+    ty = bid % tilesY;
+    n = 2 * (bid / tilesY);
+  } else {
+    tx = bid % tilesX; bid /= tilesX;
+    ty = bid % tilesY;
+    n = bid / tilesY;
+  }
   const int h0 = ty * TH, w0 = tx * TW;
   constexpr int WPG = TH / RPW;
   const int dyg = wave / WPG;
@@ -871,8 +406,10 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
 
   const size_t plane = (size_t)H * W;
   const int Cw = KSPLIT ? C / 2 : C;                  // the channels this wave group walks (KSPLIT: group g takes [g C/2, (g+1) C/2))
-  const float* p1 = in1 + ((size_t)n * C + (KSPLIT ? (size_t)half * Cw : 0)) * plane;
-  const float* p2 = in2 + ((size_t)n * C + (KSPLIT ? (size_t)half * Cw : 0)) * plane;
+  const size_t c0 = (size_t)blockIdx.y * C + (KSPLIT ? (size_t)half * Cw : 0);
+  const float* p1 = in1 + ((size_t)n * Ctot + c0) * plane;
+  const float* p2 = in2 + ((size_t)n * Ctot + c0) * plane;
+  out += (size_t)blockIdx.y * part_stride;
 
   // LDS image of a chunk (differs from corr9_pipe_kernel's): the TARGET rows of both channels first, then the source rows --
   // [f1 c0 | f1 c1 | f2 c0 | f2 c1] -- so that the f1 / f2 border falls on a DMA instruction border (CC * TH * V slots = a
@@ -889,20 +426,23 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   for (int k = 0; k < K; ++k) {
     const int wi = wave + k * NW;
     const int slot = wi * 64 + lane;
-    bool ok = live && (wi < NINSTR) && (slot < SLOTS) && !(ablate & 1);   // (ablate: profiling -- bit 0 no DMA, bit 2 no stores)
+    bool ok = live && (wi < NINSTR) && (slot < SLOTS);
     long off;
     if (wi * 64 < F1SLOTS) {                           // scalar
       const int v = slot % V, rr = (slot / V) % TH, c = slot / (V * TH);
-      const int gy = h0 + rr, gx = w0 + 4 * v;
+      const int sel = (edge && v >= STRIPS / 2) ? 1 : 0;                   // second image of an edge tile
+      const int gy = h0 + rr, gx = w0 + 4 * (v - sel * (STRIPS / 2));
       ok = ok && v < STRIPS && gy < H && gx + 3 < W;
-      off = (long)c * (long)plane + (long)gy * W + gx;
+      off = ((long)c + (long)sel * Ctot) * (long)plane + (long)gy * W + gx;
       gbase[k] = p1;
     } else {
       const int s2 = slot - F1SLOTS;
       const int v = s2 % V, rr = (s2 / V) % R2, c = s2 / (V * R2);
-      const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * v;
-      ok = ok && v < VU2 && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
-      off = (long)c * (long)plane + (long)gy * W + gx;
+      // edge tile: vectors 0 .. V/2 - 1 = image n's columns w0 - 4 .. w0 + 19, vectors V/2 .. V - 1 the same of image n + 1
+      const int sel = (edge && v >= V / 2) ? 1 : 0;
+      const int gy = h0 - kHalo + rr, gx = w0 - kHalo + 4 * (v - sel * (V / 2));
+      ok = ok && (edge || v < VU2) && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+      off = ((long)c + (long)sel * Ctot) * (long)plane + (long)gy * W + gx;
       gbase[k] = p2;
     }
     goff[k] = ok ? (unsigned)(off * (long)sizeof(float)) : 0u;
@@ -937,7 +477,9 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
     }
 
   const int a_off = row * PITCH + 4 * strip;                           // my 4 target pixels (channel 0 of the chunk)
-  const int b_off = F2BASE + (row + dyg * 3) * PITCH + 4 * strip;      // my first source row (vertical shift dyg * 3)
+  // my first source row (vertical shift dyg * 3); the second half of an edge tile reads the second image's columns, which
+  // start V / 2 vectors into the row (a uniform shift per LDS lane group: strips 0..3 and 4..7 are never in one group)
+  const int b_off = F2BASE + (row + dyg * 3) * PITCH + 4 * strip + ((edge && strip >= STRIPS / 2) ? 4 * (V / 2 - STRIPS / 2) : 0);
 
   // one (channel, vertical shift) step: 36 products of 4 target pixels with 12 source pixels = 16 packed + 4 single FMAs,
   // written as volatile asm: (a) products are pure arithmetic, and nothing else keeps instruction selection from emitting them
@@ -1099,7 +641,8 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
     if (i & 1) return dx == 0 ? accs[dyi][i] : accp[dyi][i][(dx - 1) >> 1][(dx - 1) & 1];
     return dx == 8 ? accs[dyi][i] : accp[dyi][i][dx >> 1][dx & 1];
   };
-  const int h = h0 + row, wx = w0 + 4 * strip;
+  const bool img2 = edge && strip >= STRIPS / 2;
+  const int h = h0 + row, wx = w0 + 4 * (img2 ? strip - STRIPS / 2 : strip);
   float scale[4] = {1.f, 1.f, 1.f, 1.f};
   if constexpr (FUSE) {
     f32x2 ssp[4];
@@ -1136,8 +679,8 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
       scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
     }
   }
-  if (live && (!KSPLIT || half == 0) && h < H && wx + 3 < W && !(ablate & 4)) {
-    float* o = out + ((size_t)n * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
+  if (live && (!KSPLIT || half == 0) && h < H && wx + 3 < W) {
+    float* o = out + ((size_t)(n + (img2 ? 1 : 0)) * 81 + (size_t)(dyg * 3) * 9) * plane + (size_t)h * W + wx;
 #pragma unroll
     for (int dyi = 0; dyi < 3; ++dyi)
 #pragma unroll
@@ -1156,119 +699,46 @@ template <bool FUSE, bool WARP>
 static int launch_corr9(const float* in1, const float* in2, const float* flow, float* out, int B, int C, int H,
                         int W, hipStream_t st) {
   if constexpr (!WARP) {
-    if ((W & 3) == 0 && (C % 8) == 0) {
-      static const int variant = getenv("RFN_CORR_VARIANT") ? atoi(getenv("RFN_CORR_VARIANT")) : 0;  // tuning knob
-      static const int xcd_remap = getenv("RFN_CORR_XCD") ? atoi(getenv("RFN_CORR_XCD")) : 0;
-      // (the second take is fetch-sensitive enough for the XCD-local tile order to pay: DMA alone 65 -> 46 us, kernel -1..-4 us)
-      static const int xcd_remap2 = getenv("RFN_CORR_XCD") ? atoi(getenv("RFN_CORR_XCD")) : 1;
-      // profiling only: bit0 no DMA, bit1 no FMAs, bit2 no stores (results are then meaningless)
-      static const int ablate = getenv("RFN_CORR_ABLATE") ? atoi(getenv("RFN_CORR_ABLATE")) : 0;
-#define RFN_LAUNCH_DMA(TH_, TW_, CC_, MINW_, UNR_, NTILE_, ILV_)                                                      \
-  {                                                                                                               \
-    const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
-    const long ntiles = (long)B * tilesX * tilesY;                                                                \
-    const long blocks = (ntiles + NTILE_ - 1) / NTILE_;                                                           \
-    if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
-    hipLaunchKernelGGL((corr9_dma_kernel<TH_, TW_, CC_, FUSE, MINW_, UNR_, NTILE_, ILV_>), dim3((unsigned)blocks), \
-                       dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
-                       (int)ntiles, xcd_remap, ablate, C, 0L);                                                    \
-    return check_launch("corr9_dma_kernel");                                                                      \
-  }
-#define RFN_LAUNCH_PIPE(TH_, TW_, MINW_, NTILE_)                                                                  \
-  {                                                                                                               \
-    const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
-    const long ntiles = (long)B * tilesX * tilesY;                                                                \
-    const long blocks = (ntiles + NTILE_ - 1) / NTILE_;                                                           \
-    if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
-    hipLaunchKernelGGL((corr9_pipe_kernel<TH_, TW_, FUSE, MINW_, NTILE_>), dim3((unsigned)blocks),                \
-                       dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
-                       (int)ntiles, xcd_remap);                                                                   \
-    return check_launch("corr9_pipe_kernel");                                                                     \
-  }
-#define RFN_LAUNCH_PIPE2(TH_, TW_, MINW_, NTILE_, NS_)                                                                    \
-  {                                                                                                               \
-    const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
-    const long ntiles = (long)B * tilesX * tilesY;                                                                \
-    const long blocks = (ntiles + NTILE_ - 1) / NTILE_;                                                           \
-    if (blocks <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                    \
-    hipLaunchKernelGGL((corr9_pipe2_kernel<TH_, TW_, FUSE, MINW_, NTILE_, 1, NS_>), dim3((unsigned)blocks),       \
-                       dim3(TH_ * (TW_ / 4) * 3 * NTILE_), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,         \
-                       (int)ntiles, ablate, xcd_remap2);                                                          \
-    return check_launch("corr9_pipe2_kernel");                                                                    \
-  }
-#define RFN_LAUNCH_PIPE2K(TH_, TW_, MINW_, NS_)                                                                   \
-  {                                                                                                               \
-    const int tilesX = cdiv(W, TW_), tilesY = cdiv(H, TH_);                                                       \
-    const long ntiles = (long)B * tilesX * tilesY;                                                                \
-    if (ntiles <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");                   \
-    hipLaunchKernelGGL((corr9_pipe2_kernel<TH_, TW_, FUSE, MINW_, 2, 1, NS_, true>), dim3((unsigned)ntiles),      \
-                       dim3(TH_ * (TW_ / 4) * 3 * 2), 0, st, in1, in2, out, C, H, W, tilesX, tilesY,              \
-                       (int)ntiles, ablate, xcd_remap2);                                                          \
-    return check_launch("corr9_pipe2_kernel");                                                                    \
-  }
-      // Round 4: at K4 level 1 the 4-stage ring with counted waits (two-channel chunks, three chunks in flight) is the
-      // default: 102 us against 111 us for the 2-stage kernel on the step's kind of operands (profiles/r04_corr_try.txt), and
-      // its software-pipelined second take 89 us (profiles/r04_corr_pipe2.txt; a sample must be < 4 GB for its 32-bit DMA
-      // offsets, otherwise the first take runs).  Same products in the same order.
-      const bool level1 = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2 >= 192;
-      if (((variant == 0 && level1) || variant == 40) && (size_t)C * H * W * sizeof(float) < (1ull << 32))   // 32-bit offsets within a sample
-        RFN_LAUNCH_PIPE2(16, 32, 3, 2, 4)
-      // Smaller maps (K4 level 2: 2 x 256 x 135 x 240; K2 level 1: 128 x 128): single 8 x 32 tiles, 3-wave workgroups -- 272
-      // workgroups instead of 136 on the 256 CUs, and the pipelined chunk: 115 -> 88 us and 59 -> 34 us against the 2-stage
-      // 8 x 64 kernel (profiles/r04_corr_pipe2.txt; 16 x 32 tiles 91 us, two / four tiles per workgroup 88 / 120 us).
-      // (8 ring stages instead of 4, and source rows read two steps ahead instead of one, change nothing there -- 89-91 / 88-89
-      // against 87-88 us: a lone wave per SIMD is bound neither by chunks in flight nor by LDS latency; RFN_CORR_VARIANT=46: 8 stages)
-      // Up to 256 of those tiles (one workgroup per CU): the workgroup's second wave group takes the second half of the tile's
-      // channels (KSPLIT; C / 2 a multiple of the ring's 8 channels) -- 136 tiles 59 -> 47 us, 256 tiles 64.5 -> 54.7 us, K2
-      // level 1 (128 tiles, C = 128) 33.8 -> 28.6 us.  NOT at K4 level 2: its 272 tiles put a second workgroup on 16 CUs
-      // (tools/micro/wg_placement.hip: 240 CUs x 1 + 16 x 2), and those pace the launch -- 83 us against 64.5 us for 256 tiles
-      // as it is, 89 us with twelve waves on them (profiles/r04_corr_ksplit.txt).  RFN_CORR_VARIANT=41: never, 47: always.
-      {
-        const long nt8 = (long)B * cdiv(W, 32) * cdiv(H, 8);
-        if (((variant == 0 && !level1 && nt8 <= 256) || variant == 47) && C >= 32 && C % 16 == 0 &&
-            (size_t)C * H * W * sizeof(float) < (1ull << 32))
-          RFN_LAUNCH_PIPE2K(8, 32, 3, 4)
+    // The pipelined kernel: W % 4 == 0 (16-byte DMA pieces), C a multiple of the ring's NS x 2 = 8 channels (16 with the
+    // channel split), and -- its DMA offsets are 32-bit within a sample (a sample PAIR for edge tiles) -- samples below 4 GB.
+    // Anything else takes the register-staged kernel below.
+    const size_t sample = (size_t)C * H * W * sizeof(float);
+    if ((W & 3) == 0 && (C % 8) == 0 && C >= 16 && sample < (1ull << 32)) {
+      const int xcd = 1;      // XCD-local tile order: the halo rows two neighbours fetch meet in one L2 (DMA alone 65 -> 46 us)
+      // K4 level 1 (2 x 270 x 480) and larger: two independent 16 x 32 tiles per 12-wave workgroup, 3 waves per SIMD
+      const long pairs16 = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2;
+      if (pairs16 >= 192) {
+        const int tilesX = cdiv(W, 32), tilesY = cdiv(H, 16);
+        const long ntiles = (long)B * tilesX * tilesY, blocks = (ntiles + 1) / 2;
+        if (ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");
+        hipLaunchKernelGGL((corr9_pipe2_kernel<16, 32, FUSE, 3, 2, 1, 4>), dim3((unsigned)blocks), dim3(16 * 8 * 3 * 2), 0, st,
+                           in1, in2, out, C, H, W, tilesX, tilesY, (int)ntiles, xcd, 0, C, 0L);
+        return check_launch("corr9_pipe2_kernel");
       }
-      if (((variant == 0 && !level1) || variant == 41) && C >= 16 && (size_t)C * H * W * sizeof(float) < (1ull << 32))
-        RFN_LAUNCH_PIPE2(8, 32, 3, 1, 4)
-      if (variant == 46 && C % 16 == 0) RFN_LAUNCH_PIPE2(8, 32, 3, 1, 8)
-#undef RFN_LAUNCH_PIPE2
-#undef RFN_LAUNCH_PIPE2K
-      if (variant == 0 && level1) RFN_LAUNCH_PIPE(16, 32, 3, 2)
-      if (variant == 20) RFN_LAUNCH_PIPE(16, 32, 3, 2)
-      if (variant == 21) RFN_LAUNCH_PIPE(16, 64, 3, 1)
-      if (variant == 22) RFN_LAUNCH_PIPE(8, 64, 3, 1)
-      if (variant == 23) RFN_LAUNCH_PIPE(8, 32, 3, 4)
-#undef RFN_LAUNCH_PIPE
-      // Default: two independent 16x32 tiles per 12-wave workgroup (3 waves/SIMD) when that yields enough workgroups
-      // to occupy the chip -- K4 level 1 (2 x 270x480): 510 tiles = 255 workgroups = one even round over 256 CUs,
-      // 141 us vs 166-200 us for 16x64 tiles (272 workgroups = two rounds, the second nearly empty).  Smaller maps
-      // (K4 level 2: 2 x 135x240) are wave-starved either way; 8x64 single tiles give the most workgroups per byte of
-      // halo (101 us vs 153 us paired).  Measurements: profiles/r01_kbench_corr_tiles*.txt.
-      if (variant == 0) {
-        const long pairs = ((long)B * cdiv(W, 32) * cdiv(H, 16) + 1) / 2;
-        if (pairs >= 192) RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2, false)
-        RFN_LAUNCH_DMA(8, 64, 4, 3, 1, 1, false)
+      // Smaller maps: single 8 x 32 tiles, 3-wave workgroups.  Up to 256 of them (one workgroup per CU) the workgroup's second
+      // wave group takes the second half of the tile's channels (KSPLIT: 136 tiles 59 -> 47 us, 256 tiles 64.5 -> 54.7 us,
+      // K2 level 1 33.8 -> 28.6 us; profiles/r04_corr_ksplit.txt).  A map that needs MORE than 256 because its width leaves
+      // half a tile column over (K4 level 2: 2 x 135 x 240 = 272 tiles) shares that column band between image pairs (PAIR)
+      // when that brings it to <= 256: 255 tiles there.
+      const int tilesY = cdiv(H, 8);
+      const long nt8 = (long)B * cdiv(W, 32) * tilesY;
+      const bool ksplit_ok = C >= 32 && C % 16 == 0;
+      const int rem = W % 32;
+      const long nreg = (long)B * (W / 32) * tilesY, npair = nreg + (long)(B / 2) * tilesY;
+      if (ksplit_ok && nt8 > 256 && rem > 0 && rem <= 16 && B % 2 == 0 && npair <= 256 && 2 * sample < (1ull << 32)) {
+        hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 2, 1, 4, true, true>), dim3((unsigned)npair), dim3(8 * 8 * 3 * 2), 0,
+                           st, in1, in2, out, C, H, W, W / 32, tilesY, (int)npair, xcd, (int)nreg, C, 0L);
+        return check_launch("corr9_pipe2_kernel");
       }
-      switch (variant) {
-        case 3: RFN_LAUNCH_DMA(8, 64, 4, 3, 1, 1, false)
-        case 5: RFN_LAUNCH_DMA(16, 64, 4, 3, 1, 1, false)
-        case 10: RFN_LAUNCH_DMA(8, 32, 4, 3, 1, 1, false)
-        case 12: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 1, false)
-        case 14: RFN_LAUNCH_DMA(8, 32, 4, 3, 1, 4, false)
-        case 16: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2, false)
-        case 17: RFN_LAUNCH_DMA(16, 32, 4, 3, 1, 2, true)
-        case 18: RFN_LAUNCH_DMA(16, 64, 4, 3, 1, 1, true)
-        case 19: RFN_LAUNCH_DMA(8, 64, 4, 3, 1, 1, true)
-        // round 3: 8-channel chunks (half the chunk hand-offs per tile)
-        case 31: RFN_LAUNCH_DMA(8, 64, 8, 3, 1, 1, false)
-        case 32: RFN_LAUNCH_DMA(16, 32, 8, 3, 1, 1, false)
-        case 33: RFN_LAUNCH_DMA(8, 32, 8, 3, 1, 2, false)
-        case 34: RFN_LAUNCH_DMA(8, 32, 8, 3, 1, 1, false)
-        case 35: RFN_LAUNCH_DMA(8, 32, 16, 3, 1, 1, false)
-        default: break;   // 9: register-staged kernel below
+      if (nt8 > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");
+      if (ksplit_ok && nt8 <= 256) {
+        hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 2, 1, 4, true>), dim3((unsigned)nt8), dim3(8 * 8 * 3 * 2), 0, st,
+                           in1, in2, out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L);
+        return check_launch("corr9_pipe2_kernel");
       }
-#undef RFN_LAUNCH_DMA
+      hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 1, 1, 4>), dim3((unsigned)nt8), dim3(8 * 8 * 3), 0, st, in1, in2,
+                         out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L);
+      return check_launch("corr9_pipe2_kernel");
     }
   }
   constexpr int TH = 8, CC = 8;
@@ -1340,16 +810,17 @@ __global__ __launch_bounds__(256) void corr9_split_reduce_kernel(const float* __
 template <bool FUSE>
 static int launch_corr9_split(const float* in1, const float* in2, float* out, float* workspace, int B, int C, int H, int W,
                               int S, hipStream_t st) {
-  constexpr int TH = 8, TW = 64;
+  constexpr int TH = 8, TW = 32;
   const int Cc = C / S;
   const int tilesX = cdiv(W, TW), tilesY = cdiv(H, TH);
   const long ntiles = (long)B * tilesX * tilesY;
   if (ntiles <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9 split: grid too large");
+  if ((size_t)C * H * W * sizeof(float) >= (1ull << 32)) return fail(RFN_EINVAL, "corr9 split: samples of 4 GB and more are not tiny maps");
   const long plane = (long)H * W, part_stride = (long)B * 81 * plane;
-  hipLaunchKernelGGL((corr9_dma_kernel<TH, TW, 4, false, 3, 1, 1, false>), dim3((unsigned)ntiles, (unsigned)S),
-                     dim3(TH * (TW / 4) * 3), 0, st, in1, in2, workspace, Cc, H, W, tilesX, tilesY, (int)ntiles, 0, 0, C,
-                     part_stride);
-  if (int rc = check_launch("corr9_dma_kernel (channel split)")) return rc;
+  // slice blockIdx.y of the channels per workgroup (Cc % 8 == 0: whole rounds of the 4-stage ring), raw partial volumes
+  hipLaunchKernelGGL((corr9_pipe2_kernel<TH, TW, false, 3, 1, 1, 4>), dim3((unsigned)ntiles, (unsigned)S), dim3(TH * (TW / 4) * 3),
+                     0, st, in1, in2, workspace, Cc, H, W, tilesX, tilesY, (int)ntiles, 0, 0, C, part_stride);
+  if (int rc = check_launch("corr9_pipe2_kernel (channel split)")) return rc;
   const long total = (long)B * plane;
   hipLaunchKernelGGL((corr9_split_reduce_kernel<FUSE>), dim3(cdiv(total, 32)), dim3(256), 0, st, workspace, out, S,
                      part_stride, plane, total);

@@ -50,9 +50,10 @@ class GlobalFeatureCorrelationLayer(nn.Module):
         if B != B2 or C != C2:
             raise RuntimeError("GlobalFeatureCorrelationLayer: batch/channel mismatch")
         out = torch.empty((B, hs * ws, ht, wt), dtype=torch.float32, device=dev)
+        ws_ = torch.empty((B, hs * ws), dtype=torch.float32, device=dev) if self.cyclic_consistency else None
         lib = _lib.load_library()
         with on_device(dev):
-            rc = lib.rfn_global_corr_layer_f32(ptr(fs), ptr(ft), ptr(out), B, C, hs, ws, ht, wt,
+            rc = lib.rfn_global_corr_layer_f32(ptr(fs), ptr(ft), ptr(out), None if ws_ is None else ptr(ws_), B, C, hs, ws, ht, wt,
                                                1 if self.cyclic_consistency else 0, current_stream(dev))
         _lib.check(rc, "GlobalFeatureCorrelationLayer")
         return out

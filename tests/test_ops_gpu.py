@@ -63,6 +63,24 @@ def test_corr_channel_split_tiles_vs_oracle(dev, oracle, shape):
     np.testing.assert_allclose(fused.cpu().numpy(), oracle.local_correlation_layer(b, a), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 135, 240), (2, 48, 130, 236), (2, 32, 129, 228)])
+def test_corr_paired_edge_tiles_vs_oracle(dev, oracle, shape):
+    """Round 5 (K4 level 2, 2 x C x 135 x 240): a map of MORE than 256 8 x 32 tiles whose width leaves at most half a tile column
+    over shares that column band between the two images of a pair (corr9_pipe2_kernel<.., PAIR>: strips 0..3 of an edge tile are
+    image n's last columns, strips 4..7 image n + 1's) -- 255 workgroups instead of 272, one per CU, channel split on top.  Raw
+    volume and fused layer against the oracle at the production geometry and with ragged rows and a narrower left-over band."""
+    from refign_amd.correlation import local_correlation_layer, spatial_correlation_sample
+    B, C, H, W = shape
+    assert B * -(-W // 32) * -(-H // 8) > 256 and 0 < W % 32 <= 16          # the shapes this test is about
+    rng = np.random.default_rng(sum(shape) + 5)
+    a = oracle.l2_normalize(np.maximum(rng.standard_normal(shape), 0).astype(np.float32) + 1e-3)
+    b = oracle.l2_normalize(np.maximum(rng.standard_normal(shape), 0).astype(np.float32) + 1e-3)
+    out = spatial_correlation_sample(T(a, dev), T(b, dev), patch_size=9)
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.corr_forward(a, b, patch_size=9), rtol=1e-4, atol=1e-5)
+    fused = local_correlation_layer(T(b, dev), T(a, dev))
+    np.testing.assert_allclose(fused.cpu().numpy(), oracle.local_correlation_layer(b, a), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", golden_names("corr_"))
 def test_corr_half_dispatch(dev, oracle, name):
     """The CUDA reference dispatches half as well (correlation_cuda_kernel.cu:267); `correlation.forward / backward` take
