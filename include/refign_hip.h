@@ -381,6 +381,14 @@ int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* 
 int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, long ldg, long ldx, int rows_per_slab,
                 int accumulate, float* grad_bias, const float* rowscale, int rows_per_sample, int dtype,
                 rfn_stream_t stream);
+/* Up to 8 weight gradients of the accumulate form (P[i] += (diag(rowscale[i]) G[i])^T X[i], grad_bias[i] += column sums; fp32
+ * atomics into the parameters' gradient views) in ONE launch of 64 x 64 tiles (round 5): the weight gradients of a MiT block's
+ * Linear layers are off the backward pass's dependency chain, the host queues them and hands a block's worth over at once
+ * (refign_amd/linear.py).  Arrays of `count` entries; grad_bias[i] / rowscale[i] may be NULL, but a group is all-with or
+ * all-without a row scale; operands 16-byte aligned, ldg / ldx % 8 == 0, N / K % 64 == 0, rows_per_slab % 32 == 0. */
+int rfn_gemm_tn_grouped(int count, const void* const* G, const void* const* X, float* const* P, float* const* grad_bias,
+                        const float* const* rowscale, const long* T, const long* N, const long* K, const long* ldg,
+                        const long* ldx, const int* rows_per_slab, const int* rows_per_sample, int dtype, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Hand-written matrix-core attention for MiT's efficient self-attention (mix_transformer.py:137-164):

@@ -83,6 +83,7 @@ SIGNATURES = {
                                       c_void_p]),
     "rfn_gemm_tn": (c_int, [c_void_p] * 3 + [ctypes.c_long] * 5 + [c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                             c_void_p]),
+    "rfn_gemm_tn_grouped": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_void_p]),
     "rfn_attn_pack": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] + [c_int] * 4 + [c_void_p] * 6),
     "rfn_attn_fwd": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_void_p, ctypes.c_long,
                              ctypes.c_long, c_void_p] + [c_int] * 6 + [c_float, c_int, c_int, c_void_p]),

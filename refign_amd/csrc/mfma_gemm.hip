@@ -848,12 +848,14 @@ __device__ __forceinline__ u32x2 lds_read_tr16(unsigned addr) {
 // folded into the result with the sample's scale when the sample ends: sum_s scale_s (G_s^T X_s) in fp32.  (The first
 // version scaled the G FRAGMENTS -- unpack, multiply, round, repack, 40 VALU instructions per 16-row step in every one of
 // the K / 64 tiles that share a G panel: 8 160 x 320 x 1 280 took 42 us against 25 us without a scale.)
+// (the kernel's body as a device function: `bid` of `nblocks` = this workgroup's place in ITS problem's grid -- the whole
+// launch for gemm_tn3_kernel, a sub-range of it for gemm_tn3_group_kernel)
 template <int DT, int BN, int BK, int BT, bool GATHER = false, bool SEG = false>
-__global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
-                                                       float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
-                                                       int R, int tiles_k, int accumulate, float* __restrict__ gbias,
-                                                       const float* __restrict__ rowscale, int rows_per_sample,
-                                                       const void* zero, int xcd, WgradGeom wg = WgradGeom{}) {
+__device__ __forceinline__ void gemm_tn3_body(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
+                                              float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
+                                              int R, int tiles_k, int accumulate, float* __restrict__ gbias,
+                                              const float* __restrict__ rowscale, int rows_per_sample,
+                                              const void* zero, int xcd, const WgradGeom& wg, int bid, int nblocks) {
   using E = Elem<DT>;
   constexpr int IB = BN / 64, JB = BK / 64;
   constexpr int GROW = BN * 2, XROW = BK * 2;                      // bytes per LDS row
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles = (N / BN) * tiles_k;
-  const int lid = xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int lid = xcd ? xcd_remap(bid, nblocks) : bid;
   const int slab = lid / tiles, tile = lid % tiles;
   const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
   const long t0 = (long)slab * R;
@@ -1109,6 +1111,48 @@ __global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restric
       if (g == 0) atomicAdd(gbias + n0 + wn * (BN / 2) + i * 32 + col, sum);
     }
   }
+}
+
+template <int DT, int BN, int BK, int BT, bool GATHER = false, bool SEG = false>
+__global__ __launch_bounds__(256) void gemm_tn3_kernel(const uint16_t* __restrict__ G, const uint16_t* __restrict__ X,
+                                                       float* __restrict__ P, int T, int N, int K, long ldg, long ldx,
+                                                       int R, int tiles_k, int accumulate, float* __restrict__ gbias,
+                                                       const float* __restrict__ rowscale, int rows_per_sample,
+                                                       const void* zero, int xcd, WgradGeom wg = WgradGeom{}) {
+  gemm_tn3_body<DT, BN, BK, BT, GATHER, SEG>(G, X, P, T, N, K, ldg, ldx, R, tiles_k, accumulate, gbias, rowscale,
+                                             rows_per_sample, zero, xcd, wg, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several weight gradients in ONE launch (round 5): the weight gradients of a MiT block's Linear layers are off the backward
+// pass's dependency chain (only the data gradients feed the next layer), but as launches of their own they sit IN it -- six
+// latency-bound launches of 15-25 us per block between the data-gradient GEMMs.  The host queues them (refign_amd/linear.py)
+// and hands a whole block's worth over at once: workgroup b belongs to problem i with first[i] <= b < first[i + 1] and runs the
+// body above on that problem's operands, 64 x 64 tiles, fp32 atomics into the parameters' views of the flat gradient buffer
+// (+ the bias column sums).  The problems travel as kernel arguments (no host-to-device copy; a captured launch keeps them).
+constexpr int kTnGroupMax = 8;
+struct TnProblem {
+  const uint16_t* G;
+  const uint16_t* X;
+  float* P;
+  float* gbias;
+  const float* rowscale;
+  long ldg, ldx;
+  int T, N, K, R, tiles_k, rows_per_sample, first, nblk;
+};
+struct TnGroup {
+  TnProblem p[kTnGroupMax];
+  int count;
+};
+
+template <int DT, bool SEG>
+__global__ __launch_bounds__(256) void gemm_tn3_group_kernel(TnGroup grp, const void* zero, int xcd) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < kTnGroupMax; ++k)
+    if (k < grp.count && (int)blockIdx.x >= grp.p[k].first) i = k;
+  const TnProblem& q = grp.p[i];
+  gemm_tn3_body<DT, 64, 64, 64, false, SEG>(q.G, q.X, q.P, q.T, q.N, q.K, q.ldg, q.ldx, q.R, q.tiles_k, 1, q.gbias, q.rowscale,
+                                            q.rows_per_sample, zero, xcd, WgradGeom{}, (int)blockIdx.x - q.first, q.nblk);
 }
 
 __device__ uint4 g_zero_page[4];          // zero-initialised: DMA source of out-of-image / padding pieces
@@ -1461,6 +1505,66 @@ int rfn_gemm_tn(const void* G, const void* X, float* P, long T, long N, long K, 
   hipStream_t s = (hipStream_t)stream;
   return dtype == 1 ? launch_tn<1>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, accumulate, grad_bias, rowscale, rows_per_sample, s)
                     : launch_tn<2>(G, X, P, T, N, K, ldg, ldx, rows_per_slab, accumulate, grad_bias, rowscale, rows_per_sample, s);
+}
+
+int rfn_gemm_tn_grouped(int count, const void* const* G, const void* const* X, float* const* P, float* const* grad_bias,
+                        const float* const* rowscale, const long* T, const long* N, const long* K, const long* ldg,
+                        const long* ldx, const int* rows_per_slab, const int* rows_per_sample, int dtype, rfn_stream_t stream) {
+  using namespace rfn;
+  RFN_REQUIRE(count > 0 && count <= kTnGroupMax, "gemm_tn_grouped: 1 .. %d problems (got %d)", kTnGroupMax, count);
+  RFN_REQUIRE(G && X && P && grad_bias && rowscale && T && N && K && ldg && ldx && rows_per_slab && rows_per_sample,
+              "gemm_tn_grouped: null array");
+  RFN_REQUIRE(dtype == 1 || dtype == 2, "gemm_tn_grouped: dtype %d", dtype);
+  TnGroup grp{};
+  grp.count = count;
+  long blocks = 0;
+  const bool seg = rowscale[0] != nullptr;
+  for (int i = 0; i < count; ++i) {
+    RFN_REQUIRE(G[i] && X[i] && P[i], "gemm_tn_grouped: null operand in problem %d", i);
+    RFN_REQUIRE((rowscale[i] != nullptr) == seg, "gemm_tn_grouped: problems with and without a row scale in one group");
+    RFN_REQUIRE(T[i] > 0 && T[i] < (1L << 31) && rows_per_slab[i] > 0 && rows_per_slab[i] % 32 == 0,
+                "gemm_tn_grouped: T=%ld rows_per_slab=%d (%% 32)", T[i], rows_per_slab[i]);
+    RFN_REQUIRE(N[i] % 64 == 0 && K[i] % 64 == 0 && N[i] > 0 && K[i] > 0, "gemm_tn_grouped: N=%ld K=%ld (%% 64)", N[i], K[i]);
+    RFN_REQUIRE(ldx[i] % 8 == 0 && ldg[i] % 8 == 0 && ((size_t)X[i] & 15) == 0 && ((size_t)G[i] & 15) == 0,
+                "gemm_tn_grouped: operands must be 16-byte aligned with row pitches that are multiples of 8");
+    const long S = cdiv(T[i], (long)rows_per_slab[i]);
+    if (seg) {
+      RFN_REQUIRE(rows_per_sample[i] > 0, "gemm_tn_grouped: rowscale needs rows_per_sample");
+      const long span = ((long)rows_per_slab[i] + rows_per_sample[i] - 1) / rows_per_sample[i] + 1;
+      RFN_REQUIRE(span <= 64, "gemm_tn_grouped: more than 64 samples per slab");
+    }
+    TnProblem& q = grp.p[i];
+    q.G = (const uint16_t*)G[i];
+    q.X = (const uint16_t*)X[i];
+    q.P = P[i];
+    q.gbias = grad_bias[i];
+    q.rowscale = rowscale[i];
+    q.ldg = ldg[i];
+    q.ldx = ldx[i];
+    q.T = (int)T[i];
+    q.N = (int)N[i];
+    q.K = (int)K[i];
+    q.R = rows_per_slab[i];
+    q.tiles_k = (int)(K[i] / 64);
+    q.rows_per_sample = rows_per_sample[i];
+    q.first = (int)blocks;
+    q.nblk = (int)((N[i] / 64) * (K[i] / 64) * S);
+    blocks += q.nblk;
+    RFN_REQUIRE(blocks < (1L << 31), "gemm_tn_grouped: grid too large");
+  }
+  static void* zero_page = nullptr;
+  if (zero_page == nullptr && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero_page)) != hipSuccess)
+    return fail(RFN_ELAUNCH, "gemm_tn_grouped: zero page symbol");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)blocks), block(256);
+  if (dtype == 1) {
+    if (seg) hipLaunchKernelGGL((gemm_tn3_group_kernel<1, true>), grid, block, 0, s, grp, (const void*)zero_page, 1);
+    else hipLaunchKernelGGL((gemm_tn3_group_kernel<1, false>), grid, block, 0, s, grp, (const void*)zero_page, 1);
+  } else {
+    if (seg) hipLaunchKernelGGL((gemm_tn3_group_kernel<2, true>), grid, block, 0, s, grp, (const void*)zero_page, 1);
+    else hipLaunchKernelGGL((gemm_tn3_group_kernel<2, false>), grid, block, 0, s, grp, (const void*)zero_page, 1);
+  }
+  return check_launch("gemm_tn3_group_kernel");
 }
 
 }  // extern "C"

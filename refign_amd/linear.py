@@ -116,7 +116,9 @@ class _LinearFn(torch.autograd.Function):
             # (Forking it to a second stream inside the captured pass was measured and dropped in round 2: 449 vs 244 ms per
             # step -- hipGraph replays cross-stream branches with a synchronisation per edge.)
             x2 = x.reshape(-1, K)
-            if mfma.gemm_tn(g2, x2, out=sink_w, bias_out=sink_b if need_b else None) is not None:
+            # (inside the trainer's backward: queued and launched with the block's other weight gradients, mfma.deferred_wgrads)
+            if mfma.defer_gemm_tn(g2, x2, sink_w, sink_b if need_b else None) or \
+                    mfma.gemm_tn(g2, x2, out=sink_w, bias_out=sink_b if need_b else None) is not None:
                 return route((gx, None, None, None, None))
         if need_w:
             x2 = x.reshape(-1, K)
@@ -174,8 +176,9 @@ class _LinearFn(torch.autograd.Function):
                 return None
             gx = gx.view(x.shape)
         if need_w:
-            if mfma.gemm_tn(g2, x.reshape(-1, K), out=sink_w, bias_out=sink_b if need_b else None, rowscale=rowscale,
-                            rows_per_sample=ctx.rps) is None:
+            if not mfma.defer_gemm_tn(g2, x.reshape(-1, K), sink_w, sink_b if need_b else None, rowscale, ctx.rps) and \
+                    mfma.gemm_tn(g2, x.reshape(-1, K), out=sink_w, bias_out=sink_b if need_b else None, rowscale=rowscale,
+                                 rows_per_sample=ctx.rps) is None:
                 if gx is not None:
                     return None                          # (nothing accumulated yet: gemm_tn declined before launching)
                 return None

@@ -7,6 +7,7 @@
 16-bit operands only (bf16 under the step's autocast, f16 inside align()); fp32 callers stay on their own path -- these
 functions return None for anything outside the kernels' domain and raise if the HIP library is missing.
 """
+import ctypes
 import os
 
 import torch
@@ -225,6 +226,129 @@ def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None, rowscale=None, ro
                              int(rows_per_sample), _DT16[g.dtype], current_stream(g.device))
     _lib.check(rc, "gemm_tn")
     return part
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# deferred weight gradients (round 5): a backward pass's weight gradients are off its dependency chain -- only the data
+# gradients feed the next layer -- but launched where autograd reaches them they sit IN the chain: six latency-bound launches
+# of 15-25 us per MiT block between the data-gradient GEMMs.  Inside `deferred_wgrads()` (the trainer's backward) the
+# accumulate-form calls of Linear layers are queued with their operands kept alive and handed to the grouped kernel
+# (rfn_gemm_tn_grouped, up to 8 problems per launch, 64 x 64 tiles) at the marks the MiT blocks leave in the autograd graph and
+# at the end of the pass.  Same products, same fp32 atomics into the flat gradient buffer; only the launch structure changes.
+# ---------------------------------------------------------------------------------------------------------------------
+GROUP_WGRADS = os.environ.get("RFN_GROUP_WGRADS", "1") != "0"
+_TN_GROUP_MAX = 8
+_WGRAD_QUEUE = None          # None: not deferring; else a list of (g, x, out, bias_out, rowscale, rows_per_sample, rows_per_slab)
+
+
+def _tn_domain(g, x, rowscale, rows_per_sample):
+    if not (ENABLED and g.is_cuda and g.dtype in _DT16 and x.dtype == g.dtype and g.dim() == 2 and x.dim() == 2
+            and g.stride(1) == 1 and x.stride(1) == 1 and g.stride(0) % 2 == 0 and x.stride(0) % 2 == 0
+            and g.data_ptr() % 4 == 0 and x.data_ptr() % 4 == 0):
+        return False
+    T, N = g.shape
+    K = x.shape[1]
+    if x.shape[0] != T or N % 64 != 0 or K % 64 != 0 or T == 0:
+        return False
+    if rowscale is not None and not (rowscale.dtype == torch.float32 and rowscale.is_contiguous() and rows_per_sample > 0
+                                     and rowscale.numel() * rows_per_sample >= T):
+        return False
+    return True
+
+
+def defer_gemm_tn(g, x, out, bias_out=None, rowscale=None, rows_per_sample=0):
+    """Queue `out += (diag(rowscale) g)^T x` (+ `bias_out += column sums of g`) for the next flush.  False when nothing is being
+    deferred or the problem is outside the grouped kernel's domain (the caller then launches it where it stands)."""
+    q = _WGRAD_QUEUE
+    if q is None or not _tn_domain(g, x, rowscale, rows_per_sample):
+        return False
+    T, N = g.shape
+    K = x.shape[1]
+    if not (out.dtype == torch.float32 and out.is_contiguous() and out.numel() == N * K and
+            (bias_out is None or (bias_out.dtype == torch.float32 and bias_out.is_contiguous() and bias_out.numel() == N))):
+        return False
+    if g.stride(0) % 8 or x.stride(0) % 8 or g.data_ptr() % 16 or x.data_ptr() % 16:
+        return False
+    rows = slab_rows(T, (N // 64) * (K // 64), N * K)
+    if rowscale is not None and (rows + rows_per_sample - 1) // rows_per_sample + 1 > 64:
+        return False
+    q.append((g, x, out, bias_out, rowscale, int(rows_per_sample), int(rows)))
+    return True
+
+
+def flush_wgrads():
+    """Launch what has been queued: one grouped launch per (with / without row scale, dtype) class and 8 problems."""
+    q = _WGRAD_QUEUE
+    if not q:
+        return
+    items, q[:] = list(q), []
+    classes = {}
+    for it in items:
+        classes.setdefault((it[4] is not None, it[0].dtype, it[0].device), []).append(it)
+    lib = _lib.load_library()
+    vp, lg, it_ = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+    for (seg, dt, dev), lst in classes.items():
+        for a in range(0, len(lst), _TN_GROUP_MAX):
+            grp = lst[a:a + _TN_GROUP_MAX]
+            n = len(grp)
+            arr = lambda ty, vals: (ty * n)(*vals)  # noqa: E731
+            G = arr(vp, [t[0].data_ptr() for t in grp])
+            X = arr(vp, [t[1].data_ptr() for t in grp])
+            P = arr(vp, [t[2].data_ptr() for t in grp])
+            Bv = arr(vp, [None if t[3] is None else t[3].data_ptr() for t in grp])
+            R = arr(vp, [None if t[4] is None else t[4].data_ptr() for t in grp])
+            T = arr(lg, [t[0].shape[0] for t in grp])
+            N = arr(lg, [t[0].shape[1] for t in grp])
+            K = arr(lg, [t[1].shape[1] for t in grp])
+            ldg = arr(lg, [t[0].stride(0) for t in grp])
+            ldx = arr(lg, [t[1].stride(0) for t in grp])
+            rps = arr(it_, [t[6] for t in grp])
+            rsa = arr(it_, [t[5] for t in grp])
+            cast = lambda a_: ctypes.cast(a_, vp)  # noqa: E731
+            with on_device(dev):
+                rc = lib.rfn_gemm_tn_grouped(n, cast(G), cast(X), cast(P), cast(Bv), cast(R), cast(T), cast(N), cast(K),
+                                             cast(ldg), cast(ldx), cast(rps), cast(rsa), _DT16[dt], current_stream(dev))
+            _lib.check(rc, "gemm_tn_grouped")
+
+
+class deferred_wgrads:
+    """Context manager around a backward pass: weight gradients of Linear layers are queued and launched in groups (at the
+    block marks, `wgrad_mark`, and on exit).  Re-entrant use keeps the outer queue."""
+
+    def __enter__(self):
+        global _WGRAD_QUEUE
+        self._outer = _WGRAD_QUEUE
+        if GROUP_WGRADS and ENABLED and self._outer is None:
+            _WGRAD_QUEUE = []
+        return self
+
+    def __exit__(self, *exc):
+        global _WGRAD_QUEUE
+        if self._outer is None and _WGRAD_QUEUE is not None:
+            try:
+                if exc[0] is None:
+                    flush_wgrads()
+            finally:
+                _WGRAD_QUEUE = None
+        return False
+
+
+class _WgradMark(torch.autograd.Function):
+    """Identity whose backward flushes the queued weight gradients: placed on a block's INPUT, it runs when the backward pass
+    has left the block."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_wgrads()
+        return g
+
+
+def wgrad_mark(x):
+    return _WgradMark.apply(x) if (GROUP_WGRADS and torch.is_grad_enabled() and x.requires_grad) else x
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -247,6 +247,9 @@ class Block(nn.Module):
                 return _f8.block_forward(self, x, H, W, masks32)      # K5: the block on the fp8 matrix-core kernels
             x = self.attn(self.norm1(x), H, W, res=x, rowscale=None if masks32 is None else masks32[0])
             return self.mlp(self.norm2(x), H, W, res=x, rowscale=None if masks32 is None else masks32[1])
+        # (training: the block's weight gradients are queued during the backward pass and launched as one group when it has left
+        # the block -- mfma.deferred_wgrads / rfn_gemm_tn_grouped)
+        x = mfma.wgrad_mark(x)
         if masks is not None:                       # pre-drawn stochastic-depth masks (MixVisionTransformer)
             if x.is_cuda and masks32 is not None and _linear._FUSED_RESIDUAL:
                 # training (RFN_FUSED_RESIDUAL, on): the same fusion under autograd (linear._LinearFn: residual + per-sample scale in the proj /

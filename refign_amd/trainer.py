@@ -360,8 +360,10 @@ class Trainer:
         capturing = loss.is_cuda and torch.cuda.is_current_stream_capturing()
         overlap = last and self.data_parallel and os.environ.get("RFN_DDP_OVERLAP", "1") != "0"
         seg._GRAD_READY_CB = self.grads.on_ready if overlap else None
+        from . import mfma
         try:
-            loss.backward(retain_graph=retain_graph)
+            with mfma.deferred_wgrads():                 # Linear weight gradients: queued, launched per block in groups
+                loss.backward(retain_graph=retain_graph)
             if capturing and overlap:
                 self.grads.end_capture()
         finally:

@@ -485,11 +485,13 @@ class DomainAdaptationSegmentationModel(nn.Module):
         previous prefetch's buffers)."""
         if not (self.enable_fdist and images_src_next.is_cuda and self._overlap_teacher(images_src_next)):
             return
-        st = self._prefetch_stream_for(images_src_next.device)
+        # (the side stream, behind the teacher branch.  A stream of its own for this -- low priority, so that next step's work only
+        # fills gaps -- was measured in round 5: 191-195 ms/step against 133, also with GPU_MAX_HW_QUEUES=8: a fourth busy stream
+        # costs far more than the priority inversion it removes; profiles/r05_prefetch_stream_ab.txt)
+        self._ensure_side_stream(images_src_next.device)
+        st = self._side_stream
         if after is not None:
             st.wait_event(after)
-        if st is not self._side_stream:
-            st.wait_stream(torch.cuda.current_stream())      # the next batch is resident
         with torch.cuda.stream(st):
             with torch.autocast("cuda", dtype=torch.get_autocast_dtype("cuda"), enabled=torch.is_autocast_enabled("cuda")):
                 feat = self._imnet_forward(images_src_next)[-1]
@@ -763,20 +765,6 @@ class DomainAdaptationSegmentationModel(nn.Module):
         with torch.cuda.stream(self._side_stream):
             return self._target_branch(batch)
 
-    def _prefetch_stream_for(self, device):
-        """The stream the NEXT step's image-only work (ImageNet features, matcher flow) runs on.  Default: the side stream, behind
-        the teacher branch.  RFN_PREFETCH_STREAM=1 (experiment, needs GPU_MAX_HW_QUEUES >= 5 so that a fourth stream gets a
-        hardware queue of its own): a LOW-priority stream -- that work is not on this step's critical path, the side stream's
-        high priority lets it take compute units from the mixed pass's backward, which is."""
-        self._ensure_side_stream(device)
-        if os.environ.get("RFN_PREFETCH_STREAM", "0") != "1":
-            return self._side_stream
-        st = getattr(self, "_pf_stream", None)
-        if st is None or st.device != device:
-            lo = torch.cuda.Stream.priority_range()[0] if hasattr(torch.cuda.Stream, "priority_range") else 0
-            st = self._pf_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("RFN_PREFETCH_PRIORITY", str(max(lo, 0)))))
-        return st
-
     def _ensure_side_stream(self, device):
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
             # high priority: the runtime maps it to a hardware queue of its own.  With the default priority it can
@@ -834,7 +822,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
             return
         # the side stream itself (behind the teacher branch and the ImageNet-feature prefetch): a fourth stream of the
         # process shares a hardware queue with one of the other three and the step goes from 157 to 301 ms (measured)
-        st = self._prefetch_stream_for(images_trg_next.device)
+        self._ensure_side_stream(images_trg_next.device)
+        st = self._side_stream
         if after is not None:
             st.wait_event(after)
         with torch.cuda.stream(st):

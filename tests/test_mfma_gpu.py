@@ -232,6 +232,76 @@ def test_gemm_tn_accumulates_into_gradient_views(dev, T, N, K):
     assert float((gb.double() - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max()) * math.sqrt(T / 1000 + 1) + 1e-3
 
 
+@pytest.mark.parametrize("scaled", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_grouped_weight_gradients_match_fp64(dev, dtype, scaled):
+    """Round 5: the weight gradients of a MiT block's Linear layers (stage-3 shapes at the student's 8 160 tokens, plus a ragged
+    and a 128-multiple one) queued inside mfma.deferred_wgrads() and launched as ONE group (rfn_gemm_tn_grouped: 64 x 64 tiles,
+    fp32 atomics on top of what the gradient views hold, bias column sums; with and without the per-sample stochastic-depth
+    scale) against fp64.  Eleven problems: two launches of at most eight."""
+    from refign_amd import mfma
+    shapes = [(8160, 320, 320), (8160, 640, 320), (8160, 1280, 320), (8160, 320, 1280), (2040, 320, 1280), (4111, 128, 64),
+              (2040, 512, 2048), (8160, 64, 64), (8160, 320, 320), (1000, 64, 256), (8160, 320, 320)]
+    probs = []
+    for i, (T, N, K) in enumerate(shapes):
+        g = _rand((T, N), dev, dtype, 30 + i)
+        x = _rand((T, K), dev, dtype, 60 + i)
+        gw0, gb0 = torch.randn(N, K, device=dev), torch.randn(N, device=dev)
+        rps = T // 4 + 1
+        rs = (torch.rand(4, device=dev) + 0.5) if scaled else None
+        probs.append((g, x, gw0, gb0, gw0.clone(), gb0.clone() if i % 3 else None, rs, rps))
+    with mfma.deferred_wgrads():
+        for g, x, gw0, gb0, gw, gb, rs, rps in probs:
+            assert mfma.defer_gemm_tn(g, x, gw, gb, rs, rps if scaled else 0)
+        assert len(mfma._WGRAD_QUEUE) == len(probs)
+        assert torch.equal(probs[0][4], probs[0][2]), "nothing may be launched before the flush"
+    assert mfma._WGRAD_QUEUE is None
+    for g, x, gw0, gb0, gw, gb, rs, rps in probs:
+        T = g.shape[0]
+        gd = g.double()
+        if rs is not None:
+            gd = gd * rs.double().repeat_interleave(rps)[:T, None]
+        want_w = gw0.double() + gd.t() @ x.double()
+        tol = 2e-5 * math.sqrt(T / 1000 + 1)
+        assert float((gw.double() - want_w).abs().max()) <= tol * float(want_w.abs().max()) + 1e-3
+        if gb is not None:
+            want_b = gb0.double() + gd.sum(0)
+            assert float((gb.double() - want_b).abs().max()) <= tol * float(want_b.abs().max()) + 1e-3
+
+
+def test_deferred_weight_gradients_equal_immediate_ones_through_autograd(dev, monkeypatch):
+    """A MiT block's backward with its Linear weight gradients queued and launched at the block's mark == the same backward with
+    every weight gradient launched where autograd reaches it (gradient views of a flat buffer, bf16): same input gradient bit
+    for bit, parameter gradients to the rounding of the atomics' order."""
+    from refign_amd import mfma, seg
+    from refign_amd.params import mark_grad_sink
+    torch.manual_seed(0)
+    blk = seg.Block(320, 5, sr_ratio=2).to(dev).train()
+    flat = {}
+    for n, p in blk.named_parameters():
+        p.grad = torch.zeros_like(p)
+        mark_grad_sink(p)
+    x0 = torch.randn(2, 34 * 60, 320, device=dev)
+    res = {}
+    for mode in (True, False):
+        for p in blk.parameters():
+            p.grad.zero_()
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(x, 34, 60)
+        loss = (y.float() ** 2).mean()
+        if mode:
+            with mfma.deferred_wgrads():
+                loss.backward()
+        else:
+            loss.backward()
+        res[mode] = (x.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])
+    for n, gdef in res[True][1].items():
+        gimm = res[False][1][n]
+        assert float((gdef - gimm).abs().max()) <= 1e-4 * float(gimm.abs().max()) + 1e-7, n
+
+
 def _ref_attention(q, kv, heads, scale):
     B, N, C = q.shape
     d = C // heads

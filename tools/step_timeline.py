@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""tools/step_timeline.py -- where one bench step's phases sit in time (HIP events on the streams the phases run on, no
+profiler attached): source forward / backward (main stream), teacher branch (side stream), mixed forward / loss + backward (mix
+stream), optimiser + EMA (main stream), and the host time of the step.  Times are ms from the start of the step's EMA update."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+dev = torch.device("cuda:0")
+wl = bench.RefignStep(dev, 2, 1234)
+for _ in range(6):
+    wl.step()
+torch.cuda.synchronize()
+m = wl.model
+ev = {}
+
+
+def mark(key):
+    ev[key] = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
+
+
+def wrap(obj, name, key):
+    f = getattr(obj, name)
+
+    def g(*a, **k):
+        mark(key + "0")
+        out = f(*a, **k)
+        mark(key + "1")
+        return out
+    setattr(obj, name, g)
+
+
+for gname, key in (("source_pass", "S"), ("mixed_pass", "M")):
+    g = m._graphs[gname]
+    wrap(g, "forward", key + "f")
+    wrap(g, "backward", key + "b")
+wrap(m, "_target_branch", "T")
+wrap(m, "update_momentum_encoder", "ema")
+wrap(m._optimizer, "step", "opt")
+if hasattr(m, "prefetch_align_flow"):
+    wrap(m, "prefetch_align_flow", "pfA")
+    wrap(m, "prefetch_imnet_features", "pfI")
+rows = []
+for it in range(5):
+    t0 = time.perf_counter()
+    wl.step()
+    host = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    z = ev["ema0"]
+    rel = lambda k: z.elapsed_time(ev[k])  # noqa: E731
+    parts = [f"{lbl} {rel(k + '0'):6.1f}-{rel(k + '1'):6.1f}" for lbl, k in
+             (("ema", "ema"), ("src fwd", "Sf"), ("src bwd", "Sb"), ("teacher", "T"), ("mix fwd", "Mf"), ("mix bwd", "Mb"), ("opt", "opt"))
+             if k + "0" in ev]
+    print(f"step {it}: host {host:5.1f} ms | " + " | ".join(parts))
+print("(a phase's start is when its first kernel may run on its stream, its end when its last kernel has finished; the prefetches of "
+      "the next batch follow the teacher branch on the side stream)")
