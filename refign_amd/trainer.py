@@ -392,6 +392,8 @@ class Trainer:
                 gc.collect()
             self._steps_done += 1
         try:
+            # (the step's main-stream work on a stream of its own / of another priority: neutral, profiles/r05_main_priority_ab.txt --
+            # HIP offers two priority levels here, (0, -1), and the teacher's stream already has the high one)
             self.model.training_step(batch, batch_idx)
         finally:
             # a crop pre-drawn for a forward that did not happen (exception, mode mismatch) must not leak into the next

@@ -174,6 +174,8 @@ def _logits_for_loss(model, logits, size):
 _ALIGN_PREFETCH = os.environ.get("RFN_ALIGN_PREFETCH", "1") != "0"
 _MERGE_FD_BACKWARD = os.environ.get("RFN_MERGE_FD_BACKWARD", "1") != "0"
 _EARLY_MIXED_FWD = os.environ.get("RFN_EARLY_MIXED_FWD", "1") != "0"
+_PREFETCH_ON = os.environ.get("RFN_PREFETCH_ON", "side")
+_ALIGN_FLOW_ON = os.environ.get("RFN_ALIGN_FLOW_ON", "prefetch")
 
 
 class DomainAdaptationSegmentationModel(nn.Module):
@@ -476,7 +478,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return self._source_bwd(self._source_fwd(images_src, off), images_src, gt_src, feat_imnet_last)
 
     @torch.no_grad()
-    def prefetch_imnet_features(self, images_src_next, after=None):
+    def prefetch_imnet_features(self, images_src_next, after=None, stream=None):
         """Software pipelining across steps (optional; Trainer.step(batch, next_batch=...)): the ImageNet feature of the
         NEXT step's source images depends on nothing that training changes (frozen encoder, :98-105), so it can be
         computed on the side stream while THIS step's mixed pass runs alone on the main stream, instead of inside the
@@ -489,7 +491,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # fills gaps -- was measured in round 5: 191-195 ms/step against 133, also with GPU_MAX_HW_QUEUES=8: a fourth busy stream
         # costs far more than the priority inversion it removes; profiles/r05_prefetch_stream_ab.txt)
         self._ensure_side_stream(images_src_next.device)
-        st = self._side_stream
+        st = self._side_stream if stream is None else stream
         if after is not None:
             st.wait_event(after)
         with torch.cuda.stream(st):
@@ -649,12 +651,34 @@ class DomainAdaptationSegmentationModel(nn.Module):
         else:
             losses = src_graph.backward(images_src, gt_src)
             prefetch_free = cur.record_event()           # (the encoder ran inside the pass: its buffers are busy until then)
+        mix = self._mixed_stream(images_src) if ready is not None else None
+        flow_on_mix = False
+        if mix is not None:
+            mix.wait_event(ready)                        # gradient buffers zeroed, EMA done, batch resident
+            if _ALIGN_FLOW_ON == "mix" and self._align_split(batch['image_trg']) and getattr(self, "_align_prefetch", None) is None:
+                # (RFN_ALIGN_FLOW_ON=mix, experiment) THIS step's matcher flow on the mix stream, which has nothing to do until
+                # the source forward is over; the teacher branch picks it up like a prefetched one (an event, ~80 ms later).  No
+                # cross-step prefetch of the flow then: its ~16 ms leave the tail of the step, where on the high-priority side
+                # stream they run next to the mixed pass's backward, for the head, where they compete at normal priority.
+                with torch.cuda.stream(mix), torch.no_grad():
+                    flow = self._graphs["align_flow"](batch['image_ref'], batch['image_trg'])
+                    done = mix.record_event()
+                self._align_prefetch = (tuple((t, t._version, t.data_ptr()) for t in (batch['image_ref'], batch['image_trg'])),
+                                        flow, done)
+                flow_on_mix = True
         early = None if ready is None else self._start_target_branch(batch, images_src, after=ready)
         self.log("train_loss_src", losses[0])
         if self.enable_fdist:
             self.log("train_loss_featdist_src", losses[1])
-        mix = self._mixed_stream(images_src) if early is not None else None
+        if early is None:
+            mix = None
         run_on = cur if mix is None else mix
+        # where the next batch's image-only work runs: behind the teacher branch on the (high-priority) side stream (at the end of
+        # this function), or (RFN_PREFETCH_ON=main, experiment) HERE, behind the source pass on the main stream, which otherwise
+        # idles until the mixed pass is over -- at normal priority next to the mixed pass's backward, the step's critical tail
+        pf_main = _PREFETCH_ON == "main" and mix is not None
+        if pf_main:
+            self._prefetch_next(batch, prefetch_free, self._side_stream.record_event(), True, cur)
         if mix is not None and getattr(self, "_grad_buffer", None) is not None:
             # data parallelism: the first gradient buffer is final (the mixed pass accumulates into the second one): its
             # all-reduce runs next to the mixed pass (no-op without the two gradient communicators)
@@ -669,7 +693,6 @@ class DomainAdaptationSegmentationModel(nn.Module):
         early_fwd = (_EARLY_MIXED_FWD and mix is not None and self._dacs_kernels_usable(src_nb, early[0], gt_nb))
         if mix is not None:
             self.__dict__["_mixed_concurrent_steps"] = self.__dict__.get("_mixed_concurrent_steps", 0) + 1   # diagnostics
-            mix.wait_event(ready)                        # gradient buffers zeroed, EMA done, batch resident
             if early_fwd:
                 mix.wait_event(src_fwd_done)
                 self.__dict__["_mixed_early_forwards"] = self.__dict__.get("_mixed_early_forwards", 0) + 1   # diagnostics
@@ -717,18 +740,22 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if mix is not None:
             cur.wait_stream(mix)                         # both passes done before the optimiser merges their gradients
             mixed_loss.record_stream(cur)
-        nxt = batch.get("image_src_next")
-        branch_done = self._side_stream.record_event() if early is not None else None
-        if nxt is not None:                              # after the teacher branch the side stream is idle: fill it
-            self.prefetch_imnet_features(nxt, after=prefetch_free)
-        if batch.get("image_trg_next") is not None and batch.get("image_ref_next") is not None and early is not None:
-            # (after this step's warp + refine, which reads the flow buffers the prefetch re-fills)
-            with torch.no_grad():
-                self.prefetch_align_flow(batch["image_ref_next"], batch["image_trg_next"], after=branch_done)
+        if not pf_main:
+            self._prefetch_next(batch, prefetch_free, self._side_stream.record_event() if early is not None else None,
+                                early is not None and not flow_on_mix and _ALIGN_FLOW_ON != "mix", None)
         self.log("train_loss_uda_trg", mixed_loss)
         opt.step()
         sch.step()
         self.global_step += 1
+
+    def _prefetch_next(self, batch, prefetch_free, branch_done, with_flow, stream):
+        nxt = batch.get("image_src_next")
+        if nxt is not None:                              # after the teacher branch the side stream is idle: fill it
+            self.prefetch_imnet_features(nxt, after=prefetch_free, stream=stream)
+        if batch.get("image_trg_next") is not None and batch.get("image_ref_next") is not None and with_flow:
+            # (after this step's warp + refine, which reads the flow buffers the prefetch re-fills)
+            with torch.no_grad():
+                self.prefetch_align_flow(batch["image_ref_next"], batch["image_trg_next"], after=branch_done, stream=stream)
 
     @torch.no_grad()
     def _target_branch(self, batch):
@@ -812,7 +839,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return (_ALIGN_PREFETCH and self.use_refign and self.use_align and not self.adapt_to_ref and x.is_cuda
                 and self._overlap_teacher(x))
 
-    def prefetch_align_flow(self, images_ref_next, images_trg_next, after=None):
+    def prefetch_align_flow(self, images_ref_next, images_trg_next, after=None, stream=None):
         """Software pipelining across steps, like prefetch_imnet_features: the matcher (frozen VGG-16 + flow decoders,
         ~16 ms of the teacher branch at 1080 x 1920) sees the two images only, so the flow of the NEXT batch is computed on the
         side stream while this step's mixed pass runs -- the teacher branch, the head of the critical
@@ -823,7 +850,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # the side stream itself (behind the teacher branch and the ImageNet-feature prefetch): a fourth stream of the
         # process shares a hardware queue with one of the other three and the step goes from 157 to 301 ms (measured)
         self._ensure_side_stream(images_trg_next.device)
-        st = self._side_stream
+        st = self._side_stream if stream is None else stream
         if after is not None:
             st.wait_event(after)
         with torch.cuda.stream(st):

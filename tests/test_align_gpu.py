@@ -360,5 +360,7 @@ def test_align_k4_timed_precision_map_is_bounded_at_1080x1920(dev, tmp_path):
     if out:
         with open(os.path.join(out, "align_amp_1080x1920.txt"), "w") as f:
             f.write(line + "\n")
-    assert mask_mismatch < 1e-3, line
-    assert mean_err < 5e-2 and agree > 0.97 and cert_err < 5e-2, line
+    # measured on MI355X (profiles/r05_align_amp_1080x1920.txt): mask mismatch 0, max |err| 4.5e-3, mean 4.2e-4, agreement 1.00000
+    # on 129 449 decided samples, confidence 1.7e-2
+    assert mask_mismatch < 1e-4, line
+    assert max_err < 2e-2 and mean_err < 2e-3 and agree > 0.999 and cert_err < 4e-2, line
