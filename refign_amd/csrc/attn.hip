@@ -207,6 +207,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) p[kb][r] = sacc[kb][r];
     if (key0 + 64 > Nkv) {                               // wave-uniform: only the last stage has padded keys
+      // (the empty volatile asm keeps this a BRANCH: left to itself hipcc if-converts it -- 32 compares, 32 selects and 38 index
+      // computations in EVERY stage of every wave for a mask that applies to the last stage only; round 5, counted in the ISA)
+      asm volatile("; padded keys" ::: "memory");
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
       for (int r = 0; r < 16; ++r)
         ds[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], c, -ls)) * (dpacc[kb][r] - dl);
     if (key0 + 64 > Nkv) {                               // wave-uniform: padded keys contribute nothing
+      asm volatile("; padded keys" ::: "memory");          // (a branch, not selects in every stage: see attn_fwd_kernel)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

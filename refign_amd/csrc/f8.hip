@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f8_kernel(const unsigned char* _
       for (int r = 0; r < 16; ++r) p[kb][r] = sacc[r];
     }
     if (key0 + 64 > Nkv) {
+      asm volatile("; padded keys" ::: "memory");          // (a branch, not selects in every stage: csrc/attn.hip)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

@@ -343,8 +343,15 @@ class _WgradMark(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        flush_wgrads()
+        global _MARKS_SEEN
+        _MARKS_SEEN += 1
+        if _MARKS_SEEN % _FLUSH_EVERY == 0:
+            flush_wgrads()
         return g
+
+
+_FLUSH_EVERY = max(1, int(os.environ.get("RFN_WGRAD_FLUSH_EVERY", "1")))     # (experiment: flush at every n-th block mark)
+_MARKS_SEEN = 0
 
 
 def wgrad_mark(x):

@@ -174,8 +174,6 @@ def _logits_for_loss(model, logits, size):
 _ALIGN_PREFETCH = os.environ.get("RFN_ALIGN_PREFETCH", "1") != "0"
 _MERGE_FD_BACKWARD = os.environ.get("RFN_MERGE_FD_BACKWARD", "1") != "0"
 _EARLY_MIXED_FWD = os.environ.get("RFN_EARLY_MIXED_FWD", "1") != "0"
-_PREFETCH_ON = os.environ.get("RFN_PREFETCH_ON", "side")
-_ALIGN_FLOW_ON = os.environ.get("RFN_ALIGN_FLOW_ON", "prefetch")
 
 
 class DomainAdaptationSegmentationModel(nn.Module):
@@ -652,20 +650,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
             losses = src_graph.backward(images_src, gt_src)
             prefetch_free = cur.record_event()           # (the encoder ran inside the pass: its buffers are busy until then)
         mix = self._mixed_stream(images_src) if ready is not None else None
-        flow_on_mix = False
         if mix is not None:
             mix.wait_event(ready)                        # gradient buffers zeroed, EMA done, batch resident
-            if _ALIGN_FLOW_ON == "mix" and self._align_split(batch['image_trg']) and getattr(self, "_align_prefetch", None) is None:
-                # (RFN_ALIGN_FLOW_ON=mix, experiment) THIS step's matcher flow on the mix stream, which has nothing to do until
-                # the source forward is over; the teacher branch picks it up like a prefetched one (an event, ~80 ms later).  No
-                # cross-step prefetch of the flow then: its ~16 ms leave the tail of the step, where on the high-priority side
-                # stream they run next to the mixed pass's backward, for the head, where they compete at normal priority.
-                with torch.cuda.stream(mix), torch.no_grad():
-                    flow = self._graphs["align_flow"](batch['image_ref'], batch['image_trg'])
-                    done = mix.record_event()
-                self._align_prefetch = (tuple((t, t._version, t.data_ptr()) for t in (batch['image_ref'], batch['image_trg'])),
-                                        flow, done)
-                flow_on_mix = True
         early = None if ready is None else self._start_target_branch(batch, images_src, after=ready)
         self.log("train_loss_src", losses[0])
         if self.enable_fdist:
@@ -673,12 +659,6 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if early is None:
             mix = None
         run_on = cur if mix is None else mix
-        # where the next batch's image-only work runs: behind the teacher branch on the (high-priority) side stream (at the end of
-        # this function), or (RFN_PREFETCH_ON=main, experiment) HERE, behind the source pass on the main stream, which otherwise
-        # idles until the mixed pass is over -- at normal priority next to the mixed pass's backward, the step's critical tail
-        pf_main = _PREFETCH_ON == "main" and mix is not None
-        if pf_main:
-            self._prefetch_next(batch, prefetch_free, self._side_stream.record_event(), True, cur)
         if mix is not None and getattr(self, "_grad_buffer", None) is not None:
             # data parallelism: the first gradient buffer is final (the mixed pass accumulates into the second one): its
             # all-reduce runs next to the mixed pass (no-op without the two gradient communicators)
@@ -740,9 +720,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if mix is not None:
             cur.wait_stream(mix)                         # both passes done before the optimiser merges their gradients
             mixed_loss.record_stream(cur)
-        if not pf_main:
-            self._prefetch_next(batch, prefetch_free, self._side_stream.record_event() if early is not None else None,
-                                early is not None and not flow_on_mix and _ALIGN_FLOW_ON != "mix", None)
+        # the next batch's image-only work (ImageNet features, matcher flow) behind the teacher branch on the side stream.
+        # (Measured in round 5 and dropped, profiles/r05_flow_placement_ab.txt: the same work behind the source pass on the main
+        # stream, and THIS step's flow on the mix stream while it waits for the source forward -- both within noise.)
+        self._prefetch_next(batch, prefetch_free, self._side_stream.record_event() if early is not None else None,
+                            early is not None, None)
         self.log("train_loss_uda_trg", mixed_loss)
         opt.step()
         sch.step()
