@@ -269,152 +269,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const uint16_t* __restric
   if (g == 0 && q < nqpad) lse2[(long)bh * nqpad + q] = ok ? mrun + log2f(l) : 0.f;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// forward, K / V RESIDENT (round 5).  MiT's spatial reduction leaves at most 510 keys per (image, head) on this path: the
-// whole K R-pack and V T-pack of one (b, head) are 2 x 64 KB -- they fit the LDS of a CU.  The streaming kernel above re-loads
-// them for every 128-query tile (254 tiles per (b, head) at stage 1), pays a DMA round trip in front of every tile and a
-// barrier + DMA hand-off per 64-key stage, and sits at 0.22-0.24 of the MFMA peak with most of its time in waits.  Here a
-// workgroup of NW waves loads K / V of its (b, head) ONCE (one barrier in the whole kernel) and every wave then walks its own
-// 32-query blocks independently: no barrier, no DMA wait and no shared stage in the loop -- the VALU softmax of one wave runs
-// under the MFMAs of the other waves of its SIMD.  grid.x = how many workgroups share a (b, head)'s query blocks (host: enough to
-// fill the chip, few enough to amortise the 128 KB load).  The next block's Q rows are requested before the current block's
-// epilogue.  Same arithmetic in the same order as attn_fwd_kernel: identical results.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kResMaxBlk = 16;              // <= 512 keys: 2 x 16 x 4 KB = 128 KB of LDS
-
-template <int DT, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const uint16_t* __restrict__ Q, long qsb, long qsr,
-                                                              const unsigned char* __restrict__ Kr,
-                                                              const unsigned char* __restrict__ Vt, uint16_t* __restrict__ O,
-                                                              long osb, long osr, float* __restrict__ lse2, int heads, int Nq,
-                                                              int Nkv, int nblk, int nqpad, float scale, int pheads) {
-  using E = Elem<DT>;
-  using vec8 = typename E::vec8;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kResMaxBlk * kPackBlock];
-  constexpr int VOFF = kResMaxBlk * kPackBlock;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), g = lane >> 5, col = lane & 31;
-  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
-  const float c = scale * kLog2e;
-  const long pidx = (long)(b * pheads + hd) * nblk * kPackBlock;
-  {
-    const unsigned char* kbase = Kr + pidx;
-    const unsigned char* vbase = Vt + pidx;
-    const int npiece = 4 * nblk;                         // 1 KB pieces per tensor
-    for (int p = wave; p < 2 * npiece; p += NW) {
-      const bool isv = p >= npiece;
-      const int q = isv ? p - npiece : p;
-      lds_dma16((isv ? vbase : kbase) + (long)q * 1024 + lane * 16, smem + (isv ? VOFF : 0) + q * 1024);
-    }
-    wait_dma_all();
-    wg_barrier();
-  }
-  const int nst = nblk / 2, nqblk = (Nq + 31) / 32;
-  const uint16_t* qbase = Q + (long)b * qsb + hd * 64;
-  int qb = blockIdx.x * NW + wave;
-  const int qstep = gridDim.x * NW;
-  vec8 qf[4];
-  if (qb < nqblk) load_row_frags<DT>(qbase, qsr, qb * 32 + col, Nq, g, qf);
-  for (; qb < nqblk; qb += qstep) {
-    const int q = qb * 32 + col;
-    vec8 qn[4];                                          // the next block's rows, in flight under this block's stages
-    if (qb + qstep < nqblk) load_row_frags<DT>(qbase, qsr, (qb + qstep) * 32 + col, Nq, g, qn);
-    f32x16 oacc[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = 0.f;
-    float mrun = -1e30f, lrun = 0.f;
-    for (int st = 0; st < nst; ++st) {
-      const unsigned char* ks = smem + st * 2 * kPackBlock;
-      const unsigned char* vs = smem + VOFF + st * 2 * kPackBlock;
-      const int key0 = st * 64;
-      f32x16 sacc[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-      {
-        vec8 kfr[4];
-        auto kfrag = [&](int idx) {
-          return *(const vec8*)(ks + (idx >> 2) * kPackBlock + ((2 * (idx & 3) + g) * 32 + col) * 16);
-        };
-#pragma unroll
-        for (int idx = 0; idx < 4; ++idx) kfr[idx] = kfrag(idx);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-          sacc[idx >> 2] = E::mma(kfr[idx & 3], qf[idx & 3], sacc[idx >> 2]);
-          if (idx + 4 < 8) kfr[idx & 3] = kfrag(idx + 4);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      vec8 vfr[4];
-      auto vfrag = [&](int idx) {                        // idx = (key block, m, head-dimension block)
-        const unsigned char* vq = vs + (idx >> 2) * kPackBlock + ((idx & 1) * 32 + col) * 8;
-        const int m = (idx >> 1) & 1;
-        return join8<DT>(*(const u32x2*)(vq + (4 * m + g) * 512), *(const u32x2*)(vq + (4 * m + 2 + g) * 512));
-      };
-#pragma unroll
-      for (int idx = 0; idx < 4; ++idx) vfr[idx] = vfrag(idx);
-      __builtin_amdgcn_sched_barrier(0);
-      float p[2][16];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p[kb][r] = sacc[kb][r];
-      if (key0 + 64 > Nkv) {                             // wave-uniform: only the last stage has padded keys
-        asm volatile("; padded keys" ::: "memory");
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g >= Nkv) p[kb][r] = -1e30f;
-      }
-      float mt = p[0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, p[kb][r]);
-      mt = half_max(mt) * c;
-      const float mnew = fmaxf(mrun, mt);
-      if (__any(mnew > mrun)) {
-        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-        lrun *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          oacc[0][r] *= alpha;
-          oacc[1][r] *= alpha;
-        }
-        mrun = mnew;
-      }
-      float ps = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          p[kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[kb][r], c, -mrun));
-          ps += p[kb][r];
-        }
-      lrun += ps;
-      {
-        vec8 pb[2][2];
-        to_operands<DT>(p[0], pb[0]);
-        to_operands<DT>(p[1], pb[1]);
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-          const int kb = idx >> 2, m = (idx >> 1) & 1, db = idx & 1;
-          oacc[db] = E::mma(vfr[idx & 3], pb[kb][m], oacc[db]);
-          if (idx + 4 < 8) vfr[idx & 3] = vfrag(idx + 4);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    const float l = half_sum(lrun);
-    const bool ok = q < Nq;
-    store_rows64<DT>(oacc, 1.f / l, O + (long)b * osb + (long)(ok ? q : 0) * osr + hd * 64, ok, g);
-    if (g == 0 && q < nqpad) lse2[(long)bh * nqpad + q] = ok ? mrun + log2f(l) : 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
-  }
-}
+// (Round 5 built a K / V-RESIDENT forward -- all <= 512 keys of a (b, head) loaded into LDS once, one barrier per workgroup, 12
+// waves walking their own query blocks with no hand-off in the loop -- and measured it equal to this kernel on every teacher
+// shape (257 vs 262 us at stage 1; profiles/r05_attn_resident_kernel.txt): what a 64-key stage costs a wave is its softmax's
+// VALU work (~177 VALU + 32 v_exp per 16 MFMAs, ~1 700 clocks per wave-stage against 512 of MFMA issue), not the stream's
+// hand-offs.  Removed.)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, dQ.  Same decomposition as the forward; per 32-key block: S^T = K Q^T, dP^T = V dO^T (both with the query
@@ -759,31 +618,6 @@ int rfn_attn_fwd(const void* Q, long q_batch_stride, long q_row_stride, const vo
   RFN_REQUIRE(q_row_stride % 8 == 0 && o_row_stride % 8 == 0 && q_batch_stride % 8 == 0 && o_batch_stride % 8 == 0,
               "attn_fwd: strides must be multiples of 8 elements");
   RFN_REQUIRE(kv_pack_heads >= heads, "attn_fwd: kv_pack_heads");
-  {
-    // K / V resident form (attn_fwd_res_kernel): <= 512 keys and enough query blocks that the 128 KB load per workgroup is
-    // amortised.  grid.x = workgroups per (b, head): the s that minimises rounds(BH s / 256 CUs) x (load + blocks per wave),
-    // the load priced at ~2 blocks.
-    constexpr int NW = 12;
-    const long BH = (long)B * heads, nqblk = cdiv(Nq, 32);
-    static const long res_min = getenv("RFN_ATTN_RES_MIN") ? atol(getenv("RFN_ATTN_RES_MIN")) : 8192;   // (experiment knob)
-    if (nkblk <= kResMaxBlk && BH * nqblk >= res_min) {
-      long best_s = 1, best_cost = -1;
-      for (long sp = 1; sp <= 16 && sp * NW <= nqblk; ++sp) {
-        const long rounds = cdiv(BH * sp, 256L), per_wave = cdiv(nqblk, sp * NW), cost = rounds * (2 + per_wave);
-        if (best_cost < 0 || cost < best_cost) best_cost = cost, best_s = sp;
-      }
-      dim3 rgrid((unsigned)best_s, (unsigned)BH);
-      if (dtype == 1)
-        hipLaunchKernelGGL((attn_fwd_res_kernel<1, NW>), rgrid, dim3(NW * 64), 0, (hipStream_t)stream, (const uint16_t*)Q,
-                           q_batch_stride, q_row_stride, (const unsigned char*)k_rpack, (const unsigned char*)v_tpack, (uint16_t*)O,
-                           o_batch_stride, o_row_stride, lse2, heads, Nq, Nkv, nkblk, nqpad, scale, kv_pack_heads);
-      else
-        hipLaunchKernelGGL((attn_fwd_res_kernel<2, NW>), rgrid, dim3(NW * 64), 0, (hipStream_t)stream, (const uint16_t*)Q,
-                           q_batch_stride, q_row_stride, (const unsigned char*)k_rpack, (const unsigned char*)v_tpack, (uint16_t*)O,
-                           o_batch_stride, o_row_stride, lse2, heads, Nq, Nkv, nkblk, nqpad, scale, kv_pack_heads);
-      return check_launch("attn_fwd_res");
-    }
-  }
   dim3 grid(cdiv(Nq, 128), B * heads);
   if (dtype == 1)
     hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)Q, q_batch_stride,

@@ -22,12 +22,20 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
-#include "gemm2.h"
 #include "mfma.h"
 
 namespace rfn {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. N - 1
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 struct GemmEpi {
   // OUT32 kernels (fp32 result: the split-bf16 parity mode) read bias / res as fp32 through the same pointers
@@ -1157,6 +1165,10 @@ __global__ __launch_bounds__(256) void gemm_tn3_group_kernel(TnGroup grp, const 
 
 __device__ uint4 g_zero_page[4];          // zero-initialised: DMA source of out-of-image / padding pieces
 
+// gemm2.hip (its own translation unit: this file is built with MFMA results in VGPRs, gemm2.h pins its accumulators to AGPRs)
+int launch_nt2(const void* X, const void* W, void* Y, long M, long N, long K, long ldx, long ldw, long ldy, const void* bias,
+               const void* res, const float* rowscale, int rows_per_sample, int bn2, long t2, hipStream_t s);
+
 template <int DT, bool GATHER>
 static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long K, long ldx, long ldw, long ldy,
                      const GemmEpi& epi, ConvGeom cg, hipStream_t s, bool out32 = false) {
@@ -1182,34 +1194,7 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
     if (g2 && bn2 && !out32 && K >= 192 && K % 64 == 0 && (epi.act & 255) == 0 && t2 >= g2_min &&
         (M + 192) * ldy * 2 < (1L << 32) && ldx < (1L << 22) && ldw < (1L << 22) && (((size_t)X | (size_t)W | (size_t)Y) & 15) == 0 &&
         (epi.res == nullptr || ((size_t)epi.res & 15) == 0)) {
-      Gemm2Epi e2{epi.bias, epi.res, epi.rowscale, epi.rows_per_sample, nullptr};
-      const int tn = (int)(N / bn2);
-      // persistent grid: the tiles are dealt round-robin, so the launch takes ceil(t2 / G) rounds whatever G <= 256 is -- the
-      // smallest G with the same round count leaves the other CUs to the streams that run next to the teacher (425 tiles: 213
-      // workgroups of 2 tiles instead of 256 of which 87 run one; RFN_GEMM2_BALANCE=0: always 256)
-      static const int g2_bal = getenv("RFN_GEMM2_BALANCE") ? atoi(getenv("RFN_GEMM2_BALANCE")) : 1;
-      static const long g2_cap = getenv("RFN_GEMM2_GRID_CAP") ? atol(getenv("RFN_GEMM2_GRID_CAP")) : 256;   // (experiment knob)
-      const long rounds = cdiv(t2, g2_cap);
-      dim3 grid((unsigned)(g2_bal ? cdiv(t2, rounds) : std::min<long>(t2, g2_cap))), block(256);
-#define RFN_G2(BN_, NSK_, D3_, BIAS_, RES_)                                                                              \
-  hipLaunchKernelGGL((gemm_nt2_kernel<1, 192, BN_, 2, 2, BIAS_, RES_, 0, NSK_, 4, 4, D3_>), grid, block, 0, s,           \
-                     (const uint16_t*)X, (const uint16_t*)W, (uint16_t*)Y, (int)M, (int)N, (int)K, ldx, ldw, ldy, tn,    \
-                     (int)t2, e2)
-#define RFN_G2E(BN_, NSK_, D3_)                                                                                          \
-  do {                                                                                                                   \
-    if (epi.bias != nullptr) {                                                                                           \
-      if (res2) RFN_G2(BN_, NSK_, D3_, true, true);                                                                      \
-      else RFN_G2(BN_, NSK_, D3_, true, false);                                                                          \
-    } else {                                                                                                             \
-      if (res2) RFN_G2(BN_, NSK_, D3_, false, true);                                                                     \
-      else RFN_G2(BN_, NSK_, D3_, false, false);                                                                         \
-    }                                                                                                                    \
-  } while (0)
-      if (bn2 == 320) RFN_G2E(320, 3, 8);
-      else RFN_G2E(256, 2, 6);
-#undef RFN_G2E
-#undef RFN_G2
-      return check_launch("gemm_nt2");
+      return launch_nt2(X, W, Y, M, N, K, ldx, ldw, ldy, epi.bias, epi.res, epi.rowscale, epi.rows_per_sample, bn2, t2, s);
     }
   }
   // tile: the largest of 128 x 128 (N % 128 == 0), 128 x 64, 64 x 64 that still gives ~1000 tiles (2-4 workgroups per CU

@@ -68,22 +68,6 @@ def test_attention_forward_is_repeatable_under_memory_load():
     assert _repeat(fn, 40, noise) == 0
 
 
-def test_attention_forward_kv_resident_is_repeatable_under_memory_load():
-    """attn_fwd_res_kernel (round 5: K / V resident in LDS behind ONE `vmcnt(0)` + barrier, no hand-off in the loop) on the
-    teacher's stage-3 shape, 40 views x 5 heads: 40 launches."""
-    from refign_amd import mfma
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(12)
-    q = torch.randn(40, 2040, 320, generator=g).to(dev).bfloat16()
-    kv = torch.randn(40, 510, 640, generator=g).to(dev).bfloat16()
-    noise = torch.empty(64 << 20, device=dev, dtype=torch.float32).normal_()
-
-    def fn():
-        with torch.no_grad():
-            return mfma.attention(q, kv, 5, 0.125)
-    assert _repeat(fn, 40, noise) == 0
-
-
 def test_implicit_gemm_convolution_is_repeatable_under_memory_load():
     """gemm_nt_kernel<GATHER> (3 x 3 convolution of the teacher's fusion layer, 4 views here): DMA gather + zero page, ring."""
     from refign_amd import mfma
