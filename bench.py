@@ -203,7 +203,7 @@ REF_CFG = {  # the `model:` / `optimizer:` / `lr_scheduler:` sections of refign_
 }
 
 
-PIPELINE_NEXT_BATCH = os.environ.get("RFN_PREFETCH_NEXT", "1") != "0"
+PIPELINE_NEXT_BATCH = True
 
 
 class RefignStep:
@@ -228,7 +228,7 @@ class RefignStep:
         over = {"backbone.init_args.pretrained": None, "alignment_backbone.init_args.pretrained": None,
                 "alignment_head.init_args.pretrained": None, "adapt_to_ref": False}
         self.model = config.build_model(cfg, over).to(dev).train()
-        self.trainer = Trainer(self.model, sync_batchnorm=sync_bn and os.environ.get("RFN_BENCH_SYNC_BN", "1") != "0")
+        self.trainer = Trainer(self.model, sync_batchnorm=sync_bn)
         self.model.teacher_f8 = precision == "k5"                   # K5: EMA-teacher backbone on the fp8 kernels
         self.precision = precision = "bf16" if precision == "k5" else precision
         self.b, self.H, self.W = b, H, W
@@ -701,7 +701,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (3 x bf16 split products)" if args.precision == "fp32" and args.workload != AlignRefineKernels.name
-                      and os.environ.get("RFN_FP32_SPLIT", "1") != "0" else "f32")
+                      else "f32")
                      if (args.workload == AlignRefineKernels.name or args.precision == "fp32") else
                      ("bf16+fp8(e4m3) teacher" if args.precision == "k5" else
                       ("f16 convolutions, f32 correlation / warp / uncertainty" if args.workload == UAWarpCAlign.name else "bf16")),
@@ -712,7 +712,7 @@ def main():
                                     " + DAFormer head + VGG-16/UAWarpC align (random init)"),
                        "precision_map": (("fp32 storage everywhere; Linear / convolution / attention products as three bf16 "
                                           "products on the MFMA kernels (refign_amd/split32.py, ~2^-16 relative)"
-                                          if os.environ.get("RFN_FP32_SPLIT", "1") != "0" else "fp32 everywhere (library GEMMs)")
+                                          )
                                          if args.precision == "fp32" else
                                          ("K5: as the bf16 map, plus the EMA teacher's MiT blocks (Linear layers and "
                                           "attention core, 40 views) on fp8 e4m3 MFMA kernels; " if args.precision == "k5"

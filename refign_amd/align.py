@@ -215,7 +215,7 @@ _VGG_CFG = {
 }
 
 
-_POOL_KERNEL = os.environ.get("RFN_POOL_KERNEL", "1") != "0"
+_POOL_KERNEL = True
 
 
 def _maxpool2x2(x, m):
@@ -287,11 +287,7 @@ class VGG(nn.Module):
         self.load_state_dict({k: v for k, v in sd.items() if not k.startswith('classifier.')}, strict=True)
 
     def _run(self, x, lo, hi):
-        """features[lo:hi].  RFN_VGG_FUSED=1 routes conv + bias + ReLU through the library's fused entry point; measured
-        SLOWER on this stack (61.6 vs 56.9 ms for align at 1080x1920: it still runs separate add/clamp kernels and
-        loses the Winograd solver for two layers), so it is off by default and kept only as a knob."""
-        fused = (x.is_cuda and not torch.is_grad_enabled() and os.environ.get("RFN_VGG_FUSED", "0") == "1"
-                 and hasattr(torch.ops.aten, "miopen_convolution_relu"))
+        """features[lo:hi] (conv3x3 + bias + ReLU as one launch of the implicit-GEMM kernel)."""
         i = lo
         while i < hi:
             m = self.features[i]
@@ -311,13 +307,8 @@ class VGG(nn.Module):
                     x = y
                     i += 1
                     continue
-            if fused and isinstance(m, nn.Conv2d) and i + 1 < hi and isinstance(self.features[i + 1], nn.ReLU):
-                x = torch.ops.aten.miopen_convolution_relu(x, m.weight, m.bias, m.stride, m.padding, m.dilation,
-                                                           m.groups)
-                i += 2
-            else:
-                x = m(x)
-                i += 1
+            x = m(x)
+            i += 1
         return x
 
     def forward(self, x, extract_only_indices=None):

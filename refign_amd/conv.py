@@ -113,7 +113,7 @@ def _split_ok(*ts):
 # the patch GEMM uses the plain 16-bit copy of the parameter, the input-gradient GEMM its plain transpose, and the weight
 # gradient is added straight into the parameter's .grad by the TN kernel (bias gradient in the same launch) instead of
 # partial sums + a reduction + a permuted add + two bias-reduction launches.  RFN_PATCH_CMAJOR=0: (ry, rx, c) rows.
-_PATCH_CMAJOR = os.environ.get("RFN_PATCH_CMAJOR", "1") != "0"
+_PATCH_CMAJOR = True
 
 
 def _cmajor_ok(x, C, r):
@@ -281,7 +281,7 @@ def patch_conv_tokens(x, H, W, conv):
 import os as _os
 
 _ACT = {None: 0, 'relu': 1, 'leaky': 3}
-_CONV_MFMA = _os.environ.get("RFN_CONV_MFMA", "1") != "0"
+_CONV_MFMA = True
 
 
 def _nhwc_view(p):
@@ -434,8 +434,7 @@ class _ConvMfmaFn(torch.autograd.Function):
 def conv2d_mfma_grad(x, weight, bias, stride, padding, dilation, dtype):
     """conv2d under autograd on the hand-written kernels (see _ConvMfmaFn); None outside their domain (caller takes the
     library path and records it)."""
-    if not (_CONV_MFMA and _mfma.ENABLED and x.is_cuda and x.dim() == 4 and dtype in (torch.float16, torch.bfloat16)
-            and _os.environ.get("RFN_CONV_MFMA_GRAD", "1") != "0"):
+    if not (_CONV_MFMA and _mfma.ENABLED and x.is_cuda and x.dim() == 4 and dtype in (torch.float16, torch.bfloat16)):
         return None
     for v in (stride, padding, dilation):
         if isinstance(v, (tuple, list)) and v[0] != v[1]:

@@ -666,7 +666,7 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
   // (a kernel, not a memset node, when the pass is captured into a hipGraph: capi.hip zero_async)
   if (int rc = zero_async(accT, (size_t)B * heads * 2 * 64 * nkpad * sizeof(float), s)) return rc;
   dim3 grid(cdiv(Nkv, 256), cdiv(nqblk, blocks_per_chunk), B * heads);
-  static const int ring = getenv("RFN_ATTN_DKV_RING") ? atoi(getenv("RFN_ATTN_DKV_RING")) : 2;     // 2 or 4: no difference measured (round 3)
+  static const int ring = 2;     // 2 or 4: no difference measured (round 3)
 #define RFN_DKV_LAUNCH_(D, R)                                                                                           \
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, R>), grid, dim3(512), 0, s, (const uint16_t*)K, (const uint16_t*)V,            \
                      kv_batch_stride, kv_row_stride, (const unsigned char*)q_rpack, (const unsigned char*)q_tpack,      \

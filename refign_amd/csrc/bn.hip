@@ -215,8 +215,8 @@ static int bn_launch(bool bwd, bool apply, const void* x, const void* g, const d
   // instead of 2048 (129 600 x 256 backward statistics 68 -> 37 us, 1 296 000 x 256 forward 142 -> 116 us); the apply passes
   // 2048 in isolation (191 vs 166 us at 512) -- and 1024 in the step, where three streams share the CUs (end of round 4, together
   // with the GEMM tile threshold and the fused GELU backward: -1.5 ms, profiles/r04_knob_ab.txt).  RFN_BN_STATS_WGS / RFN_BN_WGS.
-  static const long wgs_apply = getenv("RFN_BN_WGS") ? atol(getenv("RFN_BN_WGS")) : 1024;
-  static const long wgs_stats = getenv("RFN_BN_STATS_WGS") ? atol(getenv("RFN_BN_STATS_WGS")) : 512;
+  static const long wgs_apply = 1024;
+  static const long wgs_stats = 512;
   const long wgs = apply ? wgs_apply : wgs_stats;
   const int gy = (int)std::max<long>(1, std::min<long>(cdiv(T, (long)pl * 4), std::max<long>(1, wgs / gx)));
   dim3 grid(gx, gy), block(256);

@@ -477,10 +477,10 @@ struct SlicedGeom {
 // 14.4 us; Mix-FFN + GELU 40 x 34 x 60 x 1280: 160 -> 149 us.  NOT for slices under 16 vectors (512 channels: 128-byte runs
 // per pixel, 214 -> 240 us).
 static inline SlicedGeom sliced_geom(int CV, long nslots) {
-  static const int enabled = getenv("RFN_DWCONV_SLICED") ? atoi(getenv("RFN_DWCONV_SLICED")) : 1;
+  static const int enabled = 1;
   // workgroups per XCD: 128 was the optimum of the isolated launches; inside the step (three streams share the CUs) 64 is
   // 0.6 ms per step better (152.8 vs 153.4, twice), 32 is 7 ms worse
-  static const int per_xcd = getenv("RFN_DWCONV_SLICED_BLOCKS") ? atoi(getenv("RFN_DWCONV_SLICED_BLOCKS")) : 64;
+  static const int per_xcd = 64;
   if (!enabled || CV % 8 != 0 || CV / 8 < 16 || CV / 8 > 64) return SlicedGeom{false, 0, 0};
   const int cvb = CV / 8, pl = 256 / cvb;
   const int j = (int)std::max<long>(1, std::min<long>(cdiv(nslots, pl), per_xcd));
@@ -562,7 +562,7 @@ static int launch_bwd_weight(const void* x, const void* gy, float* dw, float* db
   // the channels are split).  Measured (tools/kbench.py --only dw, forward + backward): 40 x 135 x 240 x 256: 1 393 -> 1 070 us;
   // per-call census of the step (tools/abi_census.py): 4 x 68 x 120 x 512: 47 -> 24 us, 4 x 135 x 240 x 256: 78 -> 48 us; the
   // student's stage 3 / 4 maps (4 x 34 x 60 x 1280: 27 vs 26 us) keep the wide blocks.  RFN_DWCONV_WGRAD_CVB forces a width.
-  static const int force_cvb = getenv("RFN_DWCONV_WGRAD_CVB") ? atoi(getenv("RFN_DWCONV_WGRAD_CVB")) : 0;
+  static const int force_cvb = 0;
   const int CV = C / V;
   const long nquads = (long)B * H * (dil * (((W + dil - 1) / dil + kPX - 1) / kPX));
   const int want_cvb = force_cvb ? force_cvb : (nquads >= 8000 ? 16 : 0);
@@ -794,7 +794,7 @@ int rfn_dwconv3x3_tri_stats(const void* x, const float* weight3, const float* bi
   if (int rc = zero_async(sums3, 3 * (2 * (size_t)C + 1) * sizeof(double), st)) return rc;
   TriArgs a{};
   a.w = weight3, a.bias = bias3, a.sums = sums3;
-  a.ablate = getenv("RFN_TRI_ABLATE") ? atoi(getenv("RFN_TRI_ABLATE")) : 0;
+  a.ablate = 0;
   const long nitems = (long)g * g * (C / 64) * B;
   hipLaunchKernelGGL((dwconv3x3_tri_kernel<0>), dim3((unsigned)(16 * cdiv(nitems, 8))), dim3(256), 0, st, (const __hip_bfloat16*)x, a,
                      B, H, W, C, g, (int)nitems);
@@ -810,7 +810,7 @@ int rfn_dwconv3x3_tri_bn_act_fwd(const void* x, const float* weight3, const floa
   RFN_REQUIRE(tri_domain(B, H, W, C, g), "rfn_dwconv3x3_tri_bn_act_fwd: B=%d H=%d W=%d C=%d g=%d outside the kernel's domain", B, H, W, C, g);
   TriArgs a{};
   a.w = weight3, a.bias = bias3, a.sums = const_cast<double*>(sums3), a.relu = relu;
-  a.ablate = getenv("RFN_TRI_ABLATE") ? atoi(getenv("RFN_TRI_ABLATE")) : 0;
+  a.ablate = 0;
   for (int k = 0; k < 3; ++k) {
     RFN_REQUIRE(y3[k], "rfn_dwconv3x3_tri_bn_act_fwd: null output %d", k);
     a.gamma[k] = gamma3[k], a.beta[k] = beta3[k], a.running_mean[k] = running_mean3[k], a.running_var[k] = running_var3[k];

@@ -251,7 +251,7 @@ static int launch_nt_f8(const void* X, const void* W, void* Y, long M, long N, l
   int bn = (N % 128 == 0) ? 128 : 64;
   int bm = ((long)cdiv(M, 128) * cdiv(N, bn) >= 256) ? 128 : 64;
   if (N % 256 == 0 && (long)cdiv(M, 256) * (N / 256) >= 256) bm = bn = 256;
-  static const char* cfg_env = getenv("RFN_GEMM_F8_CFG");       // "bm,bn": tile sweep (tools/f8_bench.py)
+  static const char* cfg_env = nullptr;       // "bm,bn": tile sweep (tools/f8_bench.py)
   if (cfg_env != nullptr) sscanf(cfg_env, "%d,%d", &bm, &bn);
   const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
   const long total = (long)tiles_m * tiles_n;

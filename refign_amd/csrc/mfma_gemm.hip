@@ -1182,15 +1182,14 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   // Linear layers whose column count is a multiple of 320 -- every GEMM of MiT-B5's stage 3 on the teacher's 40 views:
   // 1.2-1.5x on those shapes (profiles/r04_gemm2_v3_probe.txt); bit-identical results -- and, as 192 x 256 tiles, for the
   // other big problems with N % 256 == 0 (stages 2 / 4, the decode heads' 1 x 1 convolutions), which the 8-wave 256 x 256
-  // tile of the first generation served.  RFN_GEMM2=0: the first generation everywhere, 1: the 320-column tiles only.
+  // tile of the first generation served.  
   if constexpr (!GATHER && DT == 1) {
-    static const int g2 = getenv("RFN_GEMM2") ? atoi(getenv("RFN_GEMM2")) : 2;
-    static const long g2_min = getenv("RFN_GEMM2_MIN_TILES") ? atol(getenv("RFN_GEMM2_MIN_TILES")) : 200;
+    constexpr int g2 = 2;
+    constexpr long g2_min = 200;
     // (192 x 256 from K = 256 on: at K = 128 the 8-wave tile is 3-7 % faster, at K >= 512 the new one 1.1-1.45 x --
     // profiles/r04_gemm2_256_ab.txt)
     const int bn2 = N % 320 == 0 ? 320 : (g2 >= 2 && N % 256 == 0 && K >= 256 ? 256 : 0);
     const long t2 = bn2 ? (long)cdiv(M, 192) * (N / bn2) : 0;
-    const bool res2 = epi.res != nullptr || epi.rowscale != nullptr;
     if (g2 && bn2 && !out32 && K >= 192 && K % 64 == 0 && (epi.act & 255) == 0 && t2 >= g2_min &&
         (M + 192) * ldy * 2 < (1L << 32) && ldx < (1L << 22) && ldw < (1L << 22) && (((size_t)X | (size_t)W | (size_t)Y) & 15) == 0 &&
         (epi.res == nullptr || ((size_t)epi.res & 15) == 0)) {
@@ -1202,7 +1201,7 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   // round 3, profiles/r03_gemm_sweep.txt: 8160 x 320 -> 1280: 21.6 -> 18.1 us, 8160 x 1280 -> 320: 19.5 -> 17.5,
   // 2040 x 512 -> 2048: 13.7 -> 11.1).  ~2000 since the end of round 4: in the step, next to two other streams, the smaller
   // tiles of the 1000-2000 band win (profiles/r04_knob_sweep.txt, r04_knob_ab.txt).
-  static const long min_tiles = getenv("RFN_GEMM_NT_MIN_TILES") ? atol(getenv("RFN_GEMM_NT_MIN_TILES")) : 2000;
+  constexpr long min_tiles = 2000;
   int bn = (N % 128 == 0) ? 128 : 64, bm = 128;
   if ((long)cdiv(M, 128) * cdiv(N, bn) < min_tiles) {
     bn = 64;
@@ -1212,18 +1211,15 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
   // big problems whose n extent fills 256-wide tiles: 8 waves on a 256 x 256 tile (1 workgroup per CU); with a long
   // reduction (K >= 1024) already from 128 tiles on (20400 x 2048 -> 512: 74.8 -> 59.7 us)
   if (N % 256 == 0 && (long)cdiv(M, 256) * (N / 256) >= (K >= 1024 ? 128 : 256)) bm = bn = 256;
-  static const char* cfg_env = getenv("RFN_GEMM_CFG");          // "bm,bn,ns": tile sweep of tools/mfma_bench.py
-  if (cfg_env != nullptr) sscanf(cfg_env, "%d,%d,%d", &bm, &bn, &ns);
   const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
   const long total = (long)tiles_m * tiles_n;
   // workgroups per CU by LDS (ns-deep ring of (bm + bn) * 128 bytes; 160 KB per CU), at most 4
   const int ring = ns * (bm + bn) * 128;
   const int per_cu = std::max(1, std::min(160 * 1024 / ring, 4));
-  static const int persist_mode = getenv("RFN_GEMM_PERSIST") ? atoi(getenv("RFN_GEMM_PERSIST")) : -1;
   // persistent (one pipeline across tiles) pays when a tile has only a few K-steps: the next tile's loads hide under the
   // epilogue.  With many K-steps per tile the plain one-tile-per-workgroup launch measured faster (dispatcher refills a CU
-  // the moment a workgroup retires; its stores drain behind it).  RFN_GEMM_PERSIST=0/1 forces either (tools/mfma_bench.py).
-  const bool persistent = persist_mode < 0 ? (K <= 256) : persist_mode != 0;
+  // the moment a workgroup retires; its stores drain behind it).
+  const bool persistent = K <= 256;
   const int slots = persistent ? 256 * per_cu : 0x7fffffff;
   dim3 grid((unsigned)std::min<long>(total, slots)), block(256);
 #define RFN_NT(BM_, BN_, NS_)                                                                                            \
@@ -1250,10 +1246,6 @@ static int launch_nt(const void* X, const void* W, void* Y, long M, long N, long
     case 1280642: RFN_NT(128, 64, 2); break;
     case 641282: RFN_NT(64, 128, 2); break;
     case 640642: RFN_NT(64, 64, 2); break;
-    case 1281283: RFN_NT(128, 128, 3); break;
-    case 1280643: RFN_NT(128, 64, 3); break;
-    case 640644: RFN_NT(64, 64, 4); break;
-    case 640648: RFN_NT(64, 64, 8); break;
     case 2562562:
       grid = dim3((unsigned)std::min<long>(total, persistent ? 256 : 0x7fffffff));
       hipLaunchKernelGGL((gemm_nt_kernel<DT, 256, 256, 64, 2, GATHER, 8>), grid, dim3(512), 0, s, (const uint16_t*)X,
@@ -1272,11 +1264,11 @@ static int launch_tn(const void* G, const void* X, float* P, long T, long N, lon
                      WgradGeom wg = WgradGeom{}) {
   const int S = cdiv(T, R);
   dim3 block(256);
-  static const int tn_xcd = getenv("RFN_GEMM_TN_XCD") ? atoi(getenv("RFN_GEMM_TN_XCD")) : 1;
+  static const int tn_xcd = 1;
   // (first-generation kernel = the fall-back for operands that are not 16-byte aligned; measured on the step: 189.2 ms with
   // it everywhere, 185.8 ms with the second generation)
   const bool vec = (GATHER ? wg.C % 8 == 0 : ldx % 8 == 0) && ((size_t)X & 15) == 0 && ldg % 8 == 0 && ((size_t)G & 15) == 0;
-  static const int tn3 = getenv("RFN_GEMM_TN3") ? atoi(getenv("RFN_GEMM_TN3")) : 1;
+  static const int tn3 = 1;
   if (vec && tn3) {
     // third generation (LDS-DMA + transpose reads); the stochastic-depth scale needs whole samples per 8-row fragment and the
     // slab's scales in 64 LDS floats
@@ -1335,7 +1327,7 @@ int rfn_gemm_nt(const void* X, const void* W, const void* bias, const void* res,
                 rfn_stream_t stream) {
   using namespace rfn;
 #ifdef RFN_GEMM_PROFILE
-  static const int prof = getenv("RFN_GEMM_ABLATE") ? atoi(getenv("RFN_GEMM_ABLATE")) : 0;
+  static const int prof = 0;
   const int act_arg = act;
 #endif
   RFN_REQUIRE(X && W && Y, "gemm_nt: null operand");

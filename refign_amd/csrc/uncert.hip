@@ -220,8 +220,8 @@ int rfn_uncertainty9_frontend_f32(const float* corr, const float* weights, float
   const long ngroups = (npix + kUP - 1) / kUP;
   RFN_REQUIRE(ngroups < 0x7fffffffL, "rfn_uncertainty9_frontend_f32: too many pixels");
   // 2 resident workgroups per CU, grid-stride.  RFN_UNCERT_GRID / RFN_UNCERT_ABLATE: measurement knobs (tools/kbench.py)
-  const char* eg = getenv("RFN_UNCERT_GRID");
-  const char* ea = getenv("RFN_UNCERT_ABLATE");
+  const char* eg = nullptr;
+  const char* ea = nullptr;
   const int grid = (int)std::min<long>(ngroups, eg ? atol(eg) : 256L * 2);
   hipLaunchKernelGGL(uncert9_frontend_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, corr, weights, out, H * W,
                      npix, (int)ngroups, ea ? atoi(ea) : 0);

@@ -14,8 +14,8 @@ import torch.nn.functional as F
 LEAKY_SLOPE = 0.1   # activation_layer = partial(nn.LeakyReLU, negative_slope=0.1)  (modules.py:407,459,498)
 
 
-_DW_BN_STATS = os.environ.get("RFN_DW_BN_STATS", "1") != "0"
-_DW_BN_FUSED = os.environ.get("RFN_DW_BN_FUSED", "1") != "0"
+_DW_BN_STATS = True
+_DW_BN_FUSED = True
 
 
 class ConvBNReLU(nn.Module):

@@ -20,7 +20,7 @@ from . import mfma
 from .params import as_dtype, compute_dtype, grad_sink, linear_param_grads, sum_rows, transposed
 
 
-_FUSED_GRADS = os.environ.get("RFN_LINEAR_FUSED_GRADS", "1") != "0"      # A/B switch (tools)
+_FUSED_GRADS = True
 # residual + stochastic depth in the proj / fc2 GEMMs under autograd (the gradient-free passes always fuse).  Round 2
 # measured it neutral (239.0 / 241.5 vs 237.5 / 240.1 ms per step); with the student passes replayed from graphs and the
 # library kernels gone, the 410 element-wise launches it removes are worth 1.0-1.2 ms per step (181.4 / 181.5 vs 182.4 /

@@ -80,7 +80,7 @@ def l2_normalize_channels(x):
     normalised in one kernel; anything else is made NCHW float32 first."""
     lib = _lib.load_library()
     if x.is_cuda and x.dim() == 4 and x.dtype in _DT16 and x.shape[1] % 8 == 0 and x.shape[1] <= 2048 and \
-            x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("RFN_L2NORM_NHWC16", "1") != "0":
+            x.is_contiguous(memory_format=torch.channels_last):
         B, C, H, W = x.shape
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
         with on_device(x.device):

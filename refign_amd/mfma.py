@@ -16,7 +16,7 @@ from . import _lib
 from ._tensor import current_stream, on_device, ptr
 
 _DT16 = {torch.bfloat16: 1, torch.float16: 2}
-ENABLED = os.environ.get("RFN_MFMA", "1") != "0"            # A/B switch: 0 = library GEMM / SDPA everywhere
+ENABLED = True            # (module switch for tests: False = library GEMM / SDPA everywhere)
 
 # Every dense op of a HIP tensor that ends up in a ROCm LIBRARY (hipBLASLt / MIOpen / fused SDPA behind F.linear, torch.mm,
 # F.conv2d, scaled_dot_product_attention) instead of a hand-written kernel is recorded here by its call site:
@@ -24,7 +24,7 @@ ENABLED = os.environ.get("RFN_MFMA", "1") != "0"            # A/B switch: 0 = li
 # default (reduced-precision) mode the only entries allowed are the ones DESIGN.md lists.  fp32 parity mode runs fp32
 # operands, for which no matrix-core kernel exists -- those calls are recorded too (dtype float32).
 LIBRARY_CALLS = {}
-_NOTE = os.environ.get("RFN_NOTE_LIBRARY", "1") != "0"
+_NOTE = True
 
 
 def note_library(kind, *tensors):
@@ -173,8 +173,8 @@ _TN_WGS = 1024      # target workgroups of a weight-gradient launch (swept in ro
 #                     186.4 / 189.6 ms per step)
 
 
-_TN_ATOMICS = int(os.environ.get("RFN_GEMM_TN_ATOMICS", "2500000"))     # atomic adds per launch (see slab_rows)
-_TN_MIN_WGS = int(os.environ.get("RFN_GEMM_TN_MIN_WGS", "512"))
+_TN_ATOMICS = 2500000     # atomic adds per launch (see slab_rows)
+_TN_MIN_WGS = 512
 
 
 def slab_rows(T, tiles, nk=0):
@@ -343,15 +343,10 @@ class _WgradMark(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        global _MARKS_SEEN
-        _MARKS_SEEN += 1
-        if _MARKS_SEEN % _FLUSH_EVERY == 0:
-            flush_wgrads()
+        # (flushing at every 4th mark or once per pass measured 0.2-0.4 ms better than per block on one box and within noise on
+        # another, profiles/r05_vgpr_form_ab.txt: per block keeps the operands' lifetime short)
+        flush_wgrads()
         return g
-
-
-_FLUSH_EVERY = max(1, int(os.environ.get("RFN_WGRAD_FLUSH_EVERY", "1")))     # (experiment: flush at every n-th block mark)
-_MARKS_SEEN = 0
 
 
 def wgrad_mark(x):
@@ -424,7 +419,7 @@ def _chunk_blocks(nqblk, Nkv, BH):
     device and the L2 atomic units, fewer and longer chunks win: step 154.1 / 153.6 / 153.0 ms at targets of 256 / 192 / 128,
     155.8 at 384; 151.4 / 151.4 / 152.6 / 153.1 at 128 / 96 / 64 / 48 (another box) -- 128 is the default since."""
     kblocks = -(-Nkv // 256)
-    chunks = max(1, int(os.environ.get("RFN_ATTN_DKV_WGS", "128")) // max(1, kblocks * BH))
+    chunks = max(1, 128 // max(1, kblocks * BH))
     return max(4, -(-nqblk // chunks))
 
 

@@ -96,7 +96,7 @@ def _build_plan(params):
           and src[i].dtype == torch.float32 and 1 <= dst[i].dim() <= 4 and dst[i].numel() > 0
           and src[i].shape == dst[i].shape]
     permutes = []
-    if len(pm) >= 4 and os.environ.get("RFN_PERMUTE_REFRESH", "1") != "0":
+    if len(pm) >= 4:
         by_dev = {}
         for i in pm:
             by_dev.setdefault(dst[i].device, []).append(i)

@@ -113,8 +113,7 @@ class Mlp(nn.Module):
 
     def forward(self, x, H, W, res=None, rowscale=None):
         x = self.fc1(x)
-        if x.is_cuda and x.shape[-1] % 8 == 0 and type(self.act) is nn.GELU and self.act.approximate == 'none' \
-                and os.environ.get("RFN_FUSED_DWGELU", "1") != "0":
+        if x.is_cuda and x.shape[-1] % 8 == 0 and type(self.act) is nn.GELU and self.act.approximate == 'none':
             from .dwconv import dwconv3x3_gelu_tokens           # depthwise conv + GELU in one pass (csrc/dwconv.hip)
             dw = self.dwconv.dwconv
             if torch.is_grad_enabled() and x.requires_grad and self.drop.p == 0. and x.dtype in (torch.bfloat16, torch.float16) \
@@ -139,14 +138,14 @@ class Mlp(nn.Module):
 
 _SDPA_BACKEND = None          # (round 2's RFN_SDPA_BACKEND A/B knob is gone: attention never goes to the fused-SDPA library
 #                               on 16-bit or fp32 HIP tensors any more; the branch below is what CPU tensors take)
-_FUSED_UPCAT = os.environ.get("RFN_FUSED_UPCAT", "1") != "0"       # decode heads: up-sampling + concat in one kernel
+_FUSED_UPCAT = True       # decode heads: up-sampling + concat in one kernel
 
 
 def _fused_upcat_here():
     """gradient-free passes always; under autograd with the gather backward kernel (RFN_FUSED_UPCAT_GRAD=0: the unfused
     graph -- the library's bilinear backward on channel slices of the fused gradient was 34 ms/step slower than that)"""
-    return _FUSED_UPCAT and (not torch.is_grad_enabled() or os.environ.get("RFN_FUSED_UPCAT_GRAD", "1") != "0")
-_SR_AS_LINEAR = os.environ.get("RFN_SR_AS_LINEAR", "1") != "0"     # spatial-reduction conv as a Linear over patches
+    return _FUSED_UPCAT
+_SR_AS_LINEAR = True     # spatial-reduction conv as a Linear over patches
 
 
 class Attention(nn.Module):
@@ -210,7 +209,7 @@ def _residual(res, y, rowscale):
     return torch.addcmul(res, y, rowscale.to(y.dtype).view((-1,) + (1,) * (y.dim() - 1)))
 
 
-_LN_PASS = os.environ.get("RFN_LN_PASS", "1") != "0"
+_LN_PASS = True
 
 
 def _norm_pass(norm, x):
@@ -416,7 +415,7 @@ def _up(x, size):
 def _up_logits(x, size):
     """_up for class logits that go straight into the loss: re-laid out to NCHW at the LOW resolution, so that the
     up-sampled tensor is NCHW-contiguous and log_softmax does not copy it (uda._upsample_logits)."""
-    if x.is_cuda and os.environ.get("RFN_LOGITS_NCHW", "1") != "0":
+    if x.is_cuda:
         x = x.contiguous()
     return _up(x, size)
 
@@ -464,12 +463,12 @@ class DepthwiseSeparableASPPModule(nn.ModuleList):
         return [m(x) for m in self]
 
 
-_ASPP_NOCAT = os.environ.get("RFN_ASPP_NOCAT", "1") != "0"
+_ASPP_NOCAT = True
 # the three dilated branches from ONE LDS-resident copy of the input (csrc/dwconv.hip: dwconv3x3_tri_kernel): correct, every
 # input byte fetched once at HBM speed (0.53 ms for the teacher's 2.65 GB), but the passes are VALU-bound (bf16 -> fp32
 # conversions + packed FMAs + zero-padding selects: 2.9 ms of 3.3), so it measures 8.6 ms against 8.1 ms for six single-branch
 # passes (profiles/r04_aspp_try.txt): kept, tested, OFF by default
-_ASPP_TRI = os.environ.get("RFN_ASPP_TRI", "0") != "0"
+_ASPP_TRI = False
 
 
 class ASPPWrapper(nn.Module):
@@ -739,7 +738,7 @@ def hrda_backbone(self, head_os: int, is_teacher: bool = False) -> Callable:
     return deco
 
 
-_REJOIN = os.environ.get("RFN_HRDA_REJOIN", "1") != "0"
+_REJOIN = True
 
 
 def _rejoin(a, b):
@@ -814,7 +813,7 @@ def hrda_head(self, hrda_scale_attention: nn.Module, head_os: int, is_teacher: b
 # ---------------------------------------------------------------------------------------------------------------------
 # loss
 # ---------------------------------------------------------------------------------------------------------------------
-_FUSED_CE = os.environ.get("RFN_FUSED_CE", "1") != "0"
+_FUSED_CE = True
 # Whether the consumer of a head's / model's training logits is PixelWeightedCrossEntropyLoss itself (the only thing that
 # runs a DeferredUpsample as one kernel) is a property of the OWNING MODEL, carried as an attribute on the module
 # (`mark_fused_ce_consumer`): heads used on their own, models with another loss or a subclass that overrides `forward` keep

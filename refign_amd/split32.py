@@ -20,7 +20,7 @@ import torch
 from . import _lib, mfma
 from ._tensor import current_stream, on_device, ptr
 
-ENABLED = os.environ.get("RFN_FP32_SPLIT", "1") != "0"
+ENABLED = True
 BF = torch.bfloat16
 
 

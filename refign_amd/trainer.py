@@ -334,8 +334,7 @@ class Trainer:
         (opt,), (sch,) = model.configure_optimizers()
         self.optimizer, self.scheduler = opt, sch
         self.fast_step = None
-        if fused_optimizer and type(opt) is torch.optim.AdamW and next(model.parameters()).is_cuda and \
-                os.environ.get("RFN_ADAMW_KERNEL", "1") != "0":
+        if fused_optimizer and type(opt) is torch.optim.AdamW and next(model.parameters()).is_cuda:
             from .optim import MultiTensorAdamW
             self.fast_step = MultiTensorAdamW(opt)            # one launch per step; torch's step() where it declines
         groups = model.grad_ready_groups() if hasattr(model, "grad_ready_groups") else None

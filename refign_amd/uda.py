@@ -159,7 +159,7 @@ def _upsample_logits(logits, size):
     refine kernels copy 315 MB per image pair at 1080x1920, 0.95 ms each).  Re-laying-out the LOW-resolution logits first
     (20 MB) makes the up-sampled tensor NCHW-contiguous from the start: same arithmetic, no copy (RFN_LOGITS_NCHW=0: as
     before)."""
-    if logits.is_cuda and os.environ.get("RFN_LOGITS_NCHW", "1") != "0":
+    if logits.is_cuda:
         logits = logits.contiguous()
     return F.interpolate(logits, size, mode='bilinear', align_corners=False)
 
@@ -171,9 +171,9 @@ def _logits_for_loss(model, logits, size):
     return defer_logits(logits, size, _seg.fused_ce_consumer(model))
 
 
-_ALIGN_PREFETCH = os.environ.get("RFN_ALIGN_PREFETCH", "1") != "0"
-_MERGE_FD_BACKWARD = os.environ.get("RFN_MERGE_FD_BACKWARD", "1") != "0"
-_EARLY_MIXED_FWD = os.environ.get("RFN_EARLY_MIXED_FWD", "1") != "0"
+_ALIGN_PREFETCH = True
+_MERGE_FD_BACKWARD = True
+_EARLY_MIXED_FWD = True
 
 
 class DomainAdaptationSegmentationModel(nn.Module):
@@ -755,7 +755,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return images_trg, F.softmax(m_logits_trg, dim=1)
 
     def _overlap_teacher(self, x):
-        return x.is_cuda and os.environ.get("RFN_OVERLAP_TEACHER", "1") != "0"
+        return x.is_cuda
 
     def _start_target_branch(self, batch, images_src, after=None):
         """_target_branch on the side stream.  The adapt_to_ref coin is the THIRD draw of the python `random` stream
@@ -780,7 +780,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
             # share a queue with the main stream once an RCCL communicator has taken its streams (4 hardware queues
             # per process by default), and two streams on one queue do not overlap (measured: 328 vs 299 ms/step)
             self._side_stream = torch.cuda.Stream(device=device,
-                                                  priority=int(os.environ.get("RFN_SIDE_PRIORITY", "-1")))
+                                                  priority=-1)
 
     def _teacher_align_refine(self, images_trg, images_ref):
         """segmentation_model.py:201-213: EMA-teacher logits of (target, reference), warp of the reference logits onto
