@@ -102,9 +102,13 @@ def sync_group(bn):
     return bn.process_group if bn.process_group is not None else dist.group.WORLD
 
 
-def usable(x, bn, dtype):
+def usable(x, bn, dtype, channels=None):
+    """`x`: the tensor BatchNorm is applied to -- or, with `channels`, the INPUT of the convolution in front of it (the caller
+    asks before it convolves; what has to be a multiple of 8 is the normalised tensor's channel count, not the convolution's
+    input: round 4 asked about the wrong one, and layers with 1 or 84 input channels fell to the library's BatchNorm)."""
+    c = x.shape[1] if channels is None else channels
     return (x.is_cuda and dtype in _DT16 and type(bn) in (torch.nn.BatchNorm2d, torch.nn.SyncBatchNorm) and bn.training
-            and bn.affine and bn.track_running_stats and bn.momentum is not None and x.shape[1] % 8 == 0
+            and bn.affine and bn.track_running_stats and bn.momentum is not None and c % 8 == 0 and c == bn.num_features
             and x.shape[0] * x.shape[2] * x.shape[3] > 1)
 
 

@@ -221,6 +221,9 @@ class UDABatchAssembler:
             raise RuntimeError("UDABatchAssembler: one target index per sample of the batch")
         out = self._sets[self._turn]
         self._turn ^= 1
+        # the set being re-filled was handed out two batches ago: the step that read it was queued on the consumer's (the
+        # current) stream -- the crop kernels must not overwrite it while that step may still be running
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
         ctx = torch.cuda.stream(self._stream)
         with ctx:
             for i in range(self.b):                          # the source loader's samples, then the target loader's (two loaders)

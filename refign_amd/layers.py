@@ -158,7 +158,7 @@ class ConvBNReLU(nn.Module):
             return False
         from . import bn as bnk
         from .params import compute_dtype
-        return bnk.usable(x, m.bn, compute_dtype(x))
+        return bnk.usable(x, m.bn, compute_dtype(x), channels=m.conv.out_channels)
 
     def _dw_stats_ok(self, x, cd):
         """depthwise 3x3 -> BatchNorm(train): the convolution kernel leaves the batch statistics of its result behind
@@ -214,7 +214,7 @@ class ConvBNReLU(nn.Module):
                 from . import bn as bnk
                 from .params import compute_dtype
                 cd = compute_dtype(x)
-                if bnk.usable(x, self.bn, cd):
+                if bnk.usable(x, self.bn, cd, channels=c.out_channels):
                     return self._bn_train(x, cd)
             x = self._conv2d(x, c.weight, c.bias)
             if self.use_norm:

@@ -126,8 +126,9 @@ class _RetileFn(torch.autograd.Function):
         ctx.geom = (B, h, w, k, C)
         es = y.element_size()
         out = torch.empty((B, k * h, k * w, C), dtype=y.dtype, device=y.device)
-        rc = _lib.load_library().rfn_retile_copy(ptr(y), ptr(out), B, h, w, k, C * es // 16, y.stride(3) * es // 16, 0,
-                                                 current_stream(y.device))
+        with on_device(y.device):
+            rc = _lib.load_library().rfn_retile_copy(ptr(y), ptr(out), B, h, w, k, C * es // 16, y.stride(3) * es // 16, 0,
+                                                     current_stream(y.device))
         _lib.check(rc, "retile_copy")
         return out.permute(0, 3, 1, 2)
 
@@ -138,7 +139,8 @@ class _RetileFn(torch.autograd.Function):
         gh = go.permute(0, 2, 3, 1).contiguous()
         u = C * gh.element_size() // 16
         gy = torch.empty((B, (k + 2) * h - 2, (k + 2) * w - 2, C), dtype=gh.dtype, device=gh.device)
-        rc = _lib.load_library().rfn_retile_copy(ptr(gh), ptr(gy), B, h, w, k, u, u, 1, current_stream(gh.device))
+        with on_device(gh.device):
+            rc = _lib.load_library().rfn_retile_copy(ptr(gh), ptr(gy), B, h, w, k, u, u, 1, current_stream(gh.device))
         _lib.check(rc, "retile_copy (backward)")
         return gy.permute(0, 3, 1, 2), None, None, None
 

@@ -19,6 +19,17 @@ def build(verbose=False):
     from torch.utils import cpp_extension
     bdir = os.path.join(HERE, "_build")
     os.makedirs(bdir, exist_ok=True)
+    import fcntl
+    with open(os.path.join(bdir, ".lock"), "w") as lock:          # one builder at a time (ranks of one node share the tree)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(src), os.path.getmtime(lib) if os.path.exists(lib) else 0):
+            return SO
+        _compile(cpp_extension, src, bdir, verbose)
+        os.replace(os.path.join(bdir, "correlation.so"), SO)
+    return SO
+
+
+def _compile(cpp_extension, src, bdir, verbose):
     cpp_extension.load(
         name="correlation", sources=[src], build_directory=bdir, verbose=verbose, with_cuda=False, is_python_module=False,
         extra_cflags=["-O2", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1"],
@@ -26,8 +37,6 @@ def build(verbose=False):
         extra_ldflags=[f"-L{LIBDIR}", "-lrefign_hip", "-Wl,-rpath,\\$$ORIGIN/../lib",
                        "-Wl,-rpath,\\$$ORIGIN/../../lib", "-L/opt/rocm/lib", "-lamdhip64",
                        "-lc10_hip", "-ltorch_hip"])
-    os.replace(os.path.join(bdir, "correlation.so"), SO)
-    return SO
 
 
 def load():

@@ -236,7 +236,10 @@ class FlatGradBuffer:
         if bucket_mb is not None:
             self.bucket_mb = bucket_mb
         world = dist.get_world_size()
-        separate = self.flat2 is not None and any(r[0] == 1 or r == (0, 0, self.flat.numel()) for r in self._released)
+        # the second buffer travels on its own as soon as ANY range has been released before this point: adding it into the first
+        # buffer here would race with that range's all-reduce in flight -- and would add un-reduced values to reduced ones
+        # (the whole-first-buffer and second-buffer releases were the cases round 4 handled)
+        separate = self.flat2 is not None and len(self._released) > 0
         if not separate:
             self.merge_second()                       # one sum on the wire: what the second buffer holds goes with the first
         self._reduce_gaps(0)

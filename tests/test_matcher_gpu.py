@@ -195,6 +195,23 @@ def test_matcher_step_under_fp16_autocast_is_bounded(dev):
         assert abs(norm - float(z["gradnorm/" + name])) <= 0.15 * float(z["gradnorm/" + name]), (name, norm)
 
 
+def test_matcher_fp16_step_has_no_library_batch_norm(dev, monkeypatch):
+    """Round 5: every training-mode BatchNorm of the matcher step under the fp16 recipe runs on csrc/bn.hip --
+    round 4 still handed the level-4 uncertainty front end's 1 -> 32 layer and the decoders' first layers (84 input channels) to
+    the library, because the eligibility test looked at the convolution's INPUT channel count."""
+    z = golden("matcher_step_128x160")
+    model = build_matcher(dev)
+    batch = matcher_batch(z, dev)
+    calls = []
+    real = torch.nn.functional.batch_norm
+    monkeypatch.setattr(torch.nn.functional, "batch_norm", lambda *a, **k: (calls.append(tuple(a[0].shape)), real(*a, **k))[1])
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = model.training_step(batch, 0)
+    loss.backward()
+    assert not calls, f"library BatchNorm calls on shapes {sorted(set(calls))}"
+    assert np.isfinite(float(loss))
+
+
 @torch.no_grad()
 def test_matcher_validation_step_feeds_sparse_epe(dev):
     """AlignmentModel.validation_step (alignment_model.py:148-161): flow target -> reference + confidence from forward(),
