@@ -15,7 +15,6 @@ import os
 import sys
 
 os.environ.setdefault("RFN_HIP_GRAPH", "0")
-os.environ.setdefault("RFN_OVERLAP_TEACHER", "0")
 os.environ.setdefault("RFN_MIXED_CONCURRENT", "0")
 
 import torch  # noqa: E402

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/pmc_corr.sh [prof_corr.py target] -- pipe utilisation, LDS behaviour and HBM traffic of the correlation forward
-# selected by RFN_CORR_VARIANT: one kernel-trace pass + separate PMC passes (never combined with tracing domains).
+# one kernel-trace pass + separate PMC passes (never combined with tracing domains).
 export TMPDIR=/tmp
 R=$PWD
 T=${1:-corr_l1_fused}
