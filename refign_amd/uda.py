@@ -622,7 +622,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
         if getattr(self, "_mix_stream", None) is None or self._mix_stream.device != x.device:
             # default priority: a second high-priority stream lands on the side stream's hardware queue and the step
             # goes from 181 to 246 ms (measured, round 3)
-            self._mix_stream = torch.cuda.Stream(device=x.device, priority=int(os.environ.get("RFN_X_MIX_PRIORITY", "0")))   # (experiment)
+            # (round 5, with GPU_MAX_HW_QUEUES=8 so that it gets a queue of its own: -0.6 ms, profiles/r05_mix_priority_ab.txt; not adopted)
+            self._mix_stream = torch.cuda.Stream(device=x.device)
         return self._mix_stream
 
     def _training_step_graphed(self, batch, images_src, gt_src, src_classes, opt, sch):
