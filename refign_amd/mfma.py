@@ -236,7 +236,7 @@ def gemm_tn(g, x, rows_per_slab=None, out=None, bias_out=None, rowscale=None, ro
 # (rfn_gemm_tn_grouped, up to 8 problems per launch, 64 x 64 tiles) at the marks the MiT blocks leave in the autograd graph and
 # at the end of the pass.  Same products, same fp32 atomics into the flat gradient buffer; only the launch structure changes.
 # ---------------------------------------------------------------------------------------------------------------------
-GROUP_WGRADS = os.environ.get("RFN_GROUP_WGRADS", "1") != "0"
+GROUP_WGRADS = True           # (module switch: tests compare the grouped step with the one-launch-per-gradient step)
 _TN_GROUP_MAX = 8
 _WGRAD_QUEUE = None          # None: not deferring; else a list of (g, x, out, bias_out, rowscale, rows_per_sample, rows_per_slab)
 

@@ -855,7 +855,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         return flow
 
     def _teacher_backbone(self, x):
-        # K5 (RFN_TEACHER_F8=1 / bench.py --precision k5): the EMA teacher's MiT blocks on the fp8 matrix-core kernels
+        # K5 (model.teacher_f8 / bench.py --precision k5): the EMA teacher's MiT blocks on the fp8 matrix-core kernels
         # (refign_amd/f8.py); everything else of the step is unchanged
         with _f8.teacher_f8(self.teacher_f8 and x.is_cuda and torch.is_autocast_enabled("cuda")
                             and torch.get_autocast_dtype("cuda") == torch.bfloat16):

@@ -543,3 +543,51 @@ def test_merged_source_backward_equals_the_two_passes(dev, monkeypatch):
     for key, (rows, chk) in out.items():
         np.testing.assert_allclose(rows, ref[0], rtol=2e-3, err_msg=str(key))
         assert abs(chk - ref[1]) < 1e-5 * ref[1], key
+
+
+def test_grouped_weight_gradients_give_the_same_trajectory(dev, monkeypatch):
+    """Round 5: the step with the MiT blocks' weight gradients queued and launched in groups (mfma.deferred_wgrads, on by default)
+    against the step that launches every weight gradient where autograd reaches it: same three losses per step and the same
+    parameters after 5 steps (bf16; the atomics' order is the only difference)."""
+    from refign_amd import mfma
+    from refign_amd.trainer import Trainer
+    out = {}
+    for grouped in (True, False):
+        monkeypatch.setattr(mfma, "GROUP_WGRADS", grouped)
+        model = build(True, dev)
+        trainer = Trainer(model, fused_optimizer=False)
+        random.seed(31); np.random.seed(31); torch.manual_seed(31)
+        rows = []
+        for it in range(5):
+            batch = make_batch(2, 128, 128, 64, dev)
+            batch["image_src"] = batch["image_src"] + 0.1 * it
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                trainer.step(batch, it)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+        out[grouped] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())))
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=3e-2)
+    assert abs(out[True][1] - out[False][1]) < 1e-4 * out[False][1]
+
+
+def test_trainer_diagnostic_switches(dev, monkeypatch, capfd):
+    """RFN_LOG_LOSSES=1: Trainer.step returns the step's logged values as floats (None otherwise: no host synchronisation in the
+    loop); RFN_GC_INTERVAL=0: the trainer leaves Python's cyclic collector alone; RFN_LOG_LIBRARY=1: the first dense call that
+    reaches a ROCm library is printed with its call site and shape (mfma.note_library)."""
+    import gc
+    from refign_amd import mfma
+    from refign_amd.trainer import Trainer
+    model = build(False, dev)
+    monkeypatch.setenv("RFN_GC_INTERVAL", "0")
+    trainer = Trainer(model, fused_optimizer=False)
+    assert trainer.gc_interval == 0
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    batch = make_batch(2, 96, 128, 32, dev)
+    assert trainer.step(batch, 0) is None and gc.isenabled()
+    monkeypatch.setenv("RFN_LOG_LOSSES", "1")
+    logged = trainer.step(batch, 1)
+    assert set(logged) >= {"train_loss_src", "train_loss_uda_trg"} and all(isinstance(v, float) for v in logged.values())
+    monkeypatch.setenv("RFN_LOG_LIBRARY", "1")
+    t = torch.zeros(3, 5, device=dev)
+    mfma.note_library("unit-test", t)
+    assert "library fallback: unit-test float32" in capfd.readouterr().out
+    mfma.LIBRARY_CALLS.pop(("unit-test", "float32", ((3, 5),)), None)

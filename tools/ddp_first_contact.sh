@@ -1,14 +1,13 @@
 #!/bin/bash
 # tools/ddp_first_contact.sh [N=2] [OUT=gpurun_out/first_contact] -- the first minutes on a box with more than one GPU.
-# The N > 1 path has only ever run as one rank (RFN_DDP_REHEARSAL, tools/ddp_rehearsal.sh) and as two gloo ranks on CPU: this runs,
+# The N > 1 path has only ever run as one rank (RFN_DDP_REHEARSAL=1) and as two gloo ranks on CPU: this runs,
 # IN ORDER and each under a wall-clock guard (GUARD seconds, default 180; a step that hangs is killed and the next one still runs),
 #   1. the world-N RCCL SyncBatchNorm worker (tools/micro/syncbn_rccl_worker.py): exchanges over torch's group, over a
 #      communicator of our own, captured in a hipGraph; the bucketed gradient all-reduce;
-#   2. 3 bench steps, conservative configuration: exchanges through torch.distributed, eager student (RFN_RCCL_DIRECT=0 RFN_GRAPH_DDP=0);
-#   3. 3 bench steps with RFN_DDP_MIXED_COMM=0: direct exchanges captured in the student graphs, student passes in stream order,
-#      gradient ranges all-reduced from inside the captured mixed pass;
-#   4. 3 bench steps, the default of N > 1: mixed pass next to the source pass on a communicator of its own (the one-GPU
-#      schedule), the two gradient buffers reduced separately (RFN_BENCH_RETRY=0: no silent second attempt here);
+#   2. 3 bench steps, RFN_DDP_MODE=torch (the N > 1 default): every exchange through torch.distributed, eager student passes;
+#   3. 3 bench steps, RFN_DDP_MODE=direct: RCCL called directly inside the graphed student passes, passes in stream order
+#      (two communicators: student, teacher);
+#   4. 3 bench steps, RFN_DDP_MODE=direct3: the mixed pass next to the source pass on a third communicator (the one-GPU schedule);
 #   5. the one-GPU line for comparison (weak scaling: ms/step should stay put).
 # One line per step in OUT/first_contact.txt: PASS / FAIL(rc) / TIMEOUT, ms per step, pairs/s.  Nothing here kills by pattern: every
 # launch is a process group of its own under `timeout`.
@@ -42,9 +41,9 @@ except Exception:
 launch "1. RCCL SyncBatchNorm worker, $N ranks" worker.log -- tools/micro/syncbn_rccl_worker.py
 grep -E '^(PASS|FAIL)  ' "$O/worker.log" | sed 's/^/      /' >> "$R"
 B="bench.py --gpus $N --steps 3 --warmup 2 --no-cpu --no-roofline"
-launch "2. bench, conservative (torch.distributed exchanges, eager student)" conservative.log RFN_RCCL_DIRECT=0 RFN_GRAPH_DDP=0 -- $B
-launch "3. bench, RFN_DDP_MIXED_COMM=0 (direct exchanges in the student graphs, stream order)" stream_order.log RFN_DDP_MIXED_COMM=0 RFN_BENCH_RETRY=0 -- $B
-launch "4. bench, N > 1 default (mixed pass on its own communicator next to the source pass)" default.log RFN_BENCH_RETRY=0 -- $B
+launch "2. bench, RFN_DDP_MODE=torch (default: torch.distributed exchanges, eager student)" torch.log RFN_DDP_MODE=torch -- $B
+launch "3. bench, RFN_DDP_MODE=direct (direct exchanges in the student graphs, stream order)" direct.log RFN_DDP_MODE=direct -- $B
+launch "4. bench, RFN_DDP_MODE=direct3 (mixed pass on its own communicator next to the source pass)" direct3.log RFN_DDP_MODE=direct3 -- $B
 t0=$(date +%s); timeout -k 10 "$GUARD" python bench.py --gpus 1 --steps 3 --warmup 2 --no-cpu --no-roofline > "$O/one_gpu.log" 2>&1; rc=$?
 printf '%-12s %-78s %s\n' "$([ $rc -eq 0 ] && echo PASS || echo "FAIL(rc=$rc)")" "5. one GPU, no process group" \
   "$(grep '"metric"' "$O/one_gpu.log" | tail -1 | sed 's/.*"ms_per_step": \([0-9.]*\).*/\1 ms\/step/')" | tee -a "$R"
