@@ -368,7 +368,8 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   // CU, a chunk's arithmetic ~1 us): 4 stages.  The small-map instance (one 3-wave workgroup per CU, a chunk's arithmetic ~0.3 us)
   // is bound by chunks-in-flight / DMA latency with 4 (3 chunks per ~2 us = what it measured: 0.67 us per chunk): 8 stages.
   static_assert(NS >= 3 && NS * NTILE * BUF * 4 <= 160 * 1024, "ring fits the LDS");
-  static_assert(!KSPLIT || (NTILE == 2 && NS * NTILE * BUF >= 36 * NT), "channel split: two wave groups, sums exchanged in the rings");
+  static_assert(!KSPLIT || ((NTILE == 2 || NTILE == 4) && NS * NTILE * BUF >= (NTILE - 1) * 36 * NT),
+                "channel split: two or four wave groups, sums exchanged in the rings");
   __shared__ __attribute__((aligned(16))) float rings_all[NS * NTILE * BUF];
   constexpr unsigned RB = NTILE * BUF * 4;             // bytes from one stage to the next
 
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   const int strip = (TW == 64) ? ((q & 1) ? ((j + 14) & 15) : j) : (j ^ ((((q & 3) == 1) || ((q & 3) == 2)) ? 4 : 0));
 
   const size_t plane = (size_t)H * W;
-  const int Cw = KSPLIT ? C / 2 : C;                  // the channels this wave group walks (KSPLIT: group g takes [g C/2, (g+1) C/2))
+  const int Cw = KSPLIT ? C / NTILE : C;              // the channels this wave group walks (KSPLIT: group g takes [g Cw, (g+1) Cw))
   const size_t c0 = (size_t)blockIdx.y * C + (KSPLIT ? (size_t)half * Cw : 0);
   const float* p1 = in1 + ((size_t)n * Ctot + c0) * plane;
   const float* p2 = in2 + ((size_t)n * Ctot + c0) * plane;
@@ -607,15 +608,16 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if constexpr (KSPLIT) {
-    // the second wave group's sums join the first's: [36][NT] floats per round (16 pairs + 4 singles of one vertical shift), lane-
-    // contiguous (no bank conflict), in the rings' memory -- behind a barrier, because a slower wave may still be reading its last chunk
+    // the other wave groups' sums join the first's: [36][NT] floats per group and round (16 pairs + 4 singles of one vertical
+    // shift), lane-contiguous (no bank conflict), in the rings' memory -- behind a barrier, because a slower wave may still be
+    // reading its last chunk.  Group 0 adds groups 1, 2, 3 in that order (deterministic).
     const int t = (int)threadIdx.x - half * NT;
-    f32x2* red2 = reinterpret_cast<f32x2*>(rings_all);
-    float* red1 = rings_all + 32 * NT;
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      if (half == 1) {
+      if (half != 0) {
+        f32x2* red2 = reinterpret_cast<f32x2*>(rings_all + (half - 1) * 36 * NT);
+        float* red1 = rings_all + (half - 1) * 36 * NT + 32 * NT;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -626,10 +628,15 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
       __syncthreads();
       if (half == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int hh = 1; hh < NTILE; ++hh) {
+          const f32x2* red2 = reinterpret_cast<const f32x2*>(rings_all + (hh - 1) * 36 * NT);
+          const float* red1 = rings_all + (hh - 1) * 36 * NT + 32 * NT;
 #pragma unroll
-          for (int p = 0; p < 4; ++p) accp[a][i][p] += red2[(i * 4 + p) * NT + t];
-          accs[a][i] += red1[i * NT + t];
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) accp[a][i][p] += red2[(i * 4 + p) * NT + t];
+            accs[a][i] += red1[i * NT + t];
+          }
         }
       }
       __syncthreads();
@@ -725,15 +732,26 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
       const bool ksplit_ok = C >= 32 && C % 16 == 0;
       const int rem = W % 32;
       const long nreg = (long)B * (W / 32) * tilesY, npair = nreg + (long)(B / 2) * tilesY;
+      // (round 5) FOUR wave groups per tile when the channels allow it (C % 32 == 0: whole ring rounds per group): twelve waves per
+      // CU walk chunks at 9.2 wave-chunks / us against 7.1 with six (level 1 runs twelve) -- K4 level 2 64 -> ~50 us
+      const bool ksplit4 = ksplit_ok && C >= 64 && C % 32 == 0;
       if (ksplit_ok && nt8 > 256 && rem > 0 && rem <= 16 && B % 2 == 0 && npair <= 256 && 2 * sample < (1ull << 32)) {
-        hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 2, 1, 4, true, true>), dim3((unsigned)npair), dim3(8 * 8 * 3 * 2), 0,
-                           st, in1, in2, out, C, H, W, W / 32, tilesY, (int)npair, xcd, (int)nreg, C, 0L);
+        if (ksplit4)
+          hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 4, 1, 4, true, true>), dim3((unsigned)npair), dim3(8 * 8 * 3 * 4), 0,
+                             st, in1, in2, out, C, H, W, W / 32, tilesY, (int)npair, xcd, (int)nreg, C, 0L);
+        else
+          hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 2, 1, 4, true, true>), dim3((unsigned)npair), dim3(8 * 8 * 3 * 2), 0,
+                             st, in1, in2, out, C, H, W, W / 32, tilesY, (int)npair, xcd, (int)nreg, C, 0L);
         return check_launch("corr9_pipe2_kernel");
       }
       if (nt8 > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");
       if (ksplit_ok && nt8 <= 256) {
-        hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 2, 1, 4, true>), dim3((unsigned)nt8), dim3(8 * 8 * 3 * 2), 0, st,
-                           in1, in2, out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L);
+        if (ksplit4)
+          hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 4, 1, 4, true>), dim3((unsigned)nt8), dim3(8 * 8 * 3 * 4), 0, st,
+                             in1, in2, out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L);
+        else
+          hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 2, 1, 4, true>), dim3((unsigned)nt8), dim3(8 * 8 * 3 * 2), 0, st,
+                             in1, in2, out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L);
         return check_launch("corr9_pipe2_kernel");
       }
       hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 1, 1, 4>), dim3((unsigned)nt8), dim3(8 * 8 * 3), 0, st, in1, in2,

@@ -47,7 +47,7 @@ def test_corr_hot_vs_oracle_ragged(dev, oracle, shape):
     np.testing.assert_allclose(tb.grad.cpu().numpy(), w2, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 23, 72), (1, 256, 19, 36), (1, 32, 40, 32), (2, 64, 8, 64), (1, 80, 9, 132), (2, 32, 72, 160)])
+@pytest.mark.parametrize("shape", [(2, 48, 23, 72), (1, 256, 19, 36), (1, 32, 40, 32), (2, 64, 8, 64), (1, 80, 9, 132), (2, 32, 72, 160), (2, 128, 33, 70)])
 def test_corr_channel_split_tiles_vs_oracle(dev, oracle, shape):
     """Maps of up to 256 8 x 32 tiles (at most one workgroup per CU) with C % 16 == 0 run the pipelined kernel with the workgroup's
     two wave groups on the two halves of the channels (KSPLIT: sums joined through the LDS in front of the epilogue): raw volume
@@ -63,12 +63,13 @@ def test_corr_channel_split_tiles_vs_oracle(dev, oracle, shape):
     np.testing.assert_allclose(fused.cpu().numpy(), oracle.local_correlation_layer(b, a), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 135, 240), (2, 48, 130, 236), (2, 32, 129, 228)])
+@pytest.mark.parametrize("shape", [(2, 32, 135, 240), (2, 48, 130, 236), (2, 32, 129, 228), (2, 64, 135, 240), (2, 96, 131, 240)])
 def test_corr_paired_edge_tiles_vs_oracle(dev, oracle, shape):
     """Round 5 (K4 level 2, 2 x C x 135 x 240): a map of MORE than 256 8 x 32 tiles whose width leaves at most half a tile column
     over shares that column band between the two images of a pair (corr9_pipe2_kernel<.., PAIR>: strips 0..3 of an edge tile are
     image n's last columns, strips 4..7 image n + 1's) -- 255 workgroups instead of 272, one per CU, channel split on top.  Raw
-    volume and fused layer against the oracle at the production geometry and with ragged rows and a narrower left-over band."""
+    volume and fused layer against the oracle at the production geometry and with ragged rows and a narrower left-over band; 32 / 48
+    channels take two wave groups per tile, 64 / 96 four (C % 32 == 0: the sums of groups 1-3 join group 0's through LDS)."""
     from refign_amd.correlation import local_correlation_layer, spatial_correlation_sample
     B, C, H, W = shape
     assert B * -(-W // 32) * -(-H // 8) > 256 and 0 < W % 32 <= 16          # the shapes this test is about
