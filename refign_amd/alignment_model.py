@@ -40,6 +40,18 @@ class AlignmentModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, images_i, images_j):
+        """alignment_model.py:55-79.  In eval mode on a GPU the whole forward (frozen VGG-16, head, up-sampling, confidence: ~100
+        launches, no host decision that depends on data) replays from a hipGraph after the first call of a shape
+        (refign_amd/graphs.py; K2 was host-bound without it)."""
+        if images_i.is_cuda and not self.training:
+            g = self.__dict__.get("_fwd_graph")
+            if g is None:
+                from .graphs import GraphedNoGrad
+                g = self.__dict__["_fwd_graph"] = GraphedNoGrad(self._forward_eager, "AlignmentModel.forward")
+            return tuple(o.clone() if torch.is_tensor(o) else o for o in g(images_i, images_j))    # the graph's own outputs are overwritten by the next call
+        return self._forward_eager(images_i, images_j)
+
+    def _forward_eager(self, images_i, images_j):
         return align_mod.alignment_forward(self.alignment_backbone, self.alignment_head, images_i, images_j)
 
     # -- evaluation (alignment_model.py:148-190) -----------------------------------------------------------------------
@@ -73,8 +85,17 @@ class AlignmentModel(nn.Module):
     def test_epoch_end(self, outs=None):
         return self._epoch_end(self.test_metrics)
 
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop("_fwd_graph", None)             # cached derived tensors move with the parameters
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.__dict__.pop("_fwd_graph", None)
+        return super().load_state_dict(*a, **k)
+
     def train(self, mode=True):
         """alignment_model.py:233-238: the frozen backbone's norm layers never leave eval mode."""
+        self.__dict__.pop("_fwd_graph", None)
         super().train(mode)
         for m in self.alignment_backbone.modules():
             if isinstance(m, nn.modules.batchnorm._BatchNorm):

@@ -319,6 +319,13 @@ def test_alignment_forward_k2_golden_512x512(dev):
     cs = float(flow.double().abs().sum())
     assert abs(cs - float(g["flow_abs_checksum"])) < 1e-4 * float(g["flow_abs_checksum"])
     assert abs(float(uncert.double().sum()) - float(g["uncert_checksum"])) < 5e-4 * abs(float(g["uncert_checksum"]))
+    # the forward replays from a hipGraph from the second call of a shape on: other inputs in between, then the golden pair again
+    other = model(T(img_j, dev), T(img_i, dev))
+    flow2, uncert2 = model(T(img_i, dev), T(img_j, dev))
+    assert model.__dict__["_fwd_graph"].states and all(st["graph"] is not None for st in model.__dict__["_fwd_graph"].states.values())
+    assert float((other[0] - flow).abs().max()) > 1e-2                    # not a stale buffer
+    assert float((flow2 - flow).abs().max()) < 1e-4 and float((uncert2 - uncert).abs().max()) < 1e-5
+    assert flow2.data_ptr() != other[0].data_ptr()                         # results are the caller's own tensors
 
 
 @torch.no_grad()
