@@ -85,6 +85,11 @@ class AlignmentModel(nn.Module):
     def test_epoch_end(self, outs=None):
         return self._epoch_end(self.test_metrics)
 
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop("_fwd_graph", None)                         # copies and pickles capture their own
+        return d
+
     def _apply(self, fn, *a, **k):
         self.__dict__.pop("_fwd_graph", None)             # cached derived tensors move with the parameters
         return super()._apply(fn, *a, **k)

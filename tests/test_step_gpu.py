@@ -582,6 +582,7 @@ def test_trainer_diagnostic_switches(dev, monkeypatch, capfd):
     assert trainer.gc_interval == 0
     random.seed(1); np.random.seed(1); torch.manual_seed(1)
     batch = make_batch(2, 96, 128, 32, dev)
+    gc.enable()                                             # (an earlier test's trainer may have left it off: Trainer.close gives it back)
     assert trainer.step(batch, 0) is None and gc.isenabled()
     monkeypatch.setenv("RFN_LOG_LOSSES", "1")
     logged = trainer.step(batch, 1)
