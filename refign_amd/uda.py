@@ -174,6 +174,7 @@ def _logits_for_loss(model, logits, size):
 _ALIGN_PREFETCH = True
 _MERGE_FD_BACKWARD = True
 _EARLY_MIXED_FWD = True
+_SRC_BWD_AFTER_TEACHER = True
 
 
 class DomainAdaptationSegmentationModel(nn.Module):
@@ -643,6 +644,20 @@ class DomainAdaptationSegmentationModel(nn.Module):
         # for -- the decode head's BatchNorm running statistics are updated by both forwards, source first (as in the reference)
         src_graph.forward(images_src, off, variant=feat_next is not None)
         src_fwd_done = cur.record_event()
+        # The source pass's BACKWARD waits for the teacher branch (round 5).  The teacher's 40-view kernels fill the chip: small
+        # student kernels next to them gain little and cost the teacher 10-15 ms, while two student chains next to EACH OTHER
+        # overlap well.  So: teacher + the two student forwards first, then the two backwards side by side (teacher done at
+        # 73 instead of 88 ms, step 129.5 -> 127.2 ms; "after the teacher's backbone" 129.2: profiles/r05_src_bwd_hold_ab.txt).
+        # Host order: the teacher branch is enqueued BEFORE the source backward's replay, which then waits on its stream.
+        mix = early = None
+        hold = _SRC_BWD_AFTER_TEACHER and ready is not None
+        if hold:
+            mix = self._mixed_stream(images_src)
+            if mix is not None:
+                mix.wait_event(ready)                    # gradient buffers zeroed, EMA done, batch resident
+            early = self._start_target_branch(batch, images_src, after=ready)
+            if mix is not None:                          # (no mix stream yet = the passes are not captured yet: stream order)
+                cur.wait_stream(self._side_stream)
         if feat_next is not None:
             feat_next = feat_next.clone()
             prefetch_free = cur.record_event()           # the prefetch buffer is free again from here on
@@ -650,10 +665,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
         else:
             losses = src_graph.backward(images_src, gt_src)
             prefetch_free = cur.record_event()           # (the encoder ran inside the pass: its buffers are busy until then)
-        mix = self._mixed_stream(images_src) if ready is not None else None
-        if mix is not None:
-            mix.wait_event(ready)                        # gradient buffers zeroed, EMA done, batch resident
-        early = None if ready is None else self._start_target_branch(batch, images_src, after=ready)
+        if not hold:
+            mix = self._mixed_stream(images_src) if ready is not None else None
+            if mix is not None:
+                mix.wait_event(ready)                        # gradient buffers zeroed, EMA done, batch resident
+            early = None if ready is None else self._start_target_branch(batch, images_src, after=ready)
         self.log("train_loss_src", losses[0])
         if self.enable_fdist:
             self.log("train_loss_featdist_src", losses[1])

@@ -492,12 +492,16 @@ def test_concurrent_mixed_pass_equals_serial(dev, monkeypatch):
     steps with the passes one after the other: same losses per step, same parameters, same BatchNorm running statistics
     of the student's decode head (they are updated by both passes' forwards) -- and the concurrent path must really
     have been taken."""
+    from refign_amd import uda
     from refign_amd.trainer import Trainer
     monkeypatch.setenv("RFN_GRAPH_STUDENT", "1")
     H, W = 192, 256
     out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("RFN_MIXED_CONCURRENT", mode)
+    # "1": the default (source backward held until the teacher branch is done: the two backwards side by side, round 5);
+    # "1-nohold": the source backward right behind its forward (rounds 3-4); "0": one stream
+    for mode in ("1", "1-nohold", "0"):
+        monkeypatch.setenv("RFN_MIXED_CONCURRENT", mode[0])
+        monkeypatch.setattr(uda, "_SRC_BWD_AFTER_TEACHER", mode != "1-nohold")
         model = build(True, dev)
         trainer = Trainer(model, fused_optimizer=False)
         random.seed(11); np.random.seed(11); torch.manual_seed(11)
@@ -516,6 +520,9 @@ def test_concurrent_mixed_pass_equals_serial(dev, monkeypatch):
     np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=2e-3)
     assert abs(out["1"][1] - out["0"][1]) < 1e-5 * out["0"][1]
     assert float((out["1"][2] - out["0"][2]).abs().max()) < 1e-4 * float(out["0"][2].abs().max())
+    assert out["1-nohold"][3] >= 4 and out["1-nohold"][4] >= 4
+    np.testing.assert_allclose(out["1-nohold"][0], out["0"][0], rtol=2e-3)
+    assert abs(out["1-nohold"][1] - out["0"][1]) < 1e-5 * out["0"][1]
 
 
 def test_merged_source_backward_equals_the_two_passes(dev, monkeypatch):
