@@ -1000,6 +1000,177 @@ __global__ __launch_bounds__(256) void corr9_bwd_tile_kernel(const float* __rest
   }
 }
 
+// Round 5: the same gather on register STRIPS, laid out like the forward.  A thread owns 4 adjacent pixels of a row and the
+// weights of THREE vertical shifts (27 shifts x 4 pixels = 108 registers); the three wave groups of a 192-thread workgroup split
+// the nine vertical shifts of an 8 x 32 tile.  Per channel and vertical shift a thread reads its 12 row values as three
+// ds_read_b128 and does 36 FMAs (the one-pixel kernel above: one ds_read_b32 per FMA -- LDS-bound); the groups' partial sums of
+// a chunk of 8 channels meet in LDS (group 0 adds groups 1, 2 in that order: deterministic) and leave as 16-byte stores.  The
+// next chunk's halo tile is in flight to registers while a chunk is computed (double-buffered LDS, ONE barrier per chunk).
+// Both gradients in ONE launch (blockIdx.y).  W % 4 == 0, C % 8 == 0; anything else takes the one-pixel kernel.
+// K4 level 1 (2 x 128 x 270 x 480, both gradients): 997 us (two launches of the one-pixel kernel) -> 512 (strips, plain float
+// loop) -> 324 (aligned register pairs) -> 308 us (conflict-free lane order) = 0.25 of 8 TB/s on 615 MB; matcher training step
+// 100 -> 91-93 ms (profiles/r05_corr_backward.txt).
+template <int MODE>
+__device__ __forceinline__ void corr9_bwd_strip_body(const float* __restrict__ other, const float* __restrict__ gout,
+                                                     float* __restrict__ grad, int C, int H, int W, int tilesX, int tilesY,
+                                                     float* lds) {
+  constexpr int TH = 8, TW = 32, CC = 8, RH = TH + 8, P4 = (TW + 8) / 4, NT = 192;
+  constexpr int CHUNK4 = CC * RH * P4;                   // float4 pieces of a chunk's halo tile
+  constexpr int NPF = (CHUNK4 + NT - 1) / NT;            // pieces a thread carries
+  float4* tile = reinterpret_cast<float4*>(lds);                                  // [2][CC][RH][P4]
+  constexpr int RP = 10;                                  // slots per row of the exchange buffer (same banking argument)
+  float4* red = reinterpret_cast<float4*>(lds) + 2 * CHUNK4;                      // [2][2][CC][TH][RP]
+  const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+  // lane -> (row, strip): ds_read_b128 is serviced in four groups of 16 lanes (quads {0,3,5,6}, {1,2,4,7} of each half wave),
+  // and a group must touch 16 distinct 16-byte slots of the 256-byte bank row.  With rows of 10 slots the half rows start at
+  // slot (10 r + 4 h) mod 16; the quads of a group get {(0,0),(0,1),(2,1),(4,1)}, {(2,0),(4,0),(6,0),(6,1)} and the same on the
+  // odd rows -- start slots {0,4,8,12} + const for every vertical shift, channel and read of a row: conflict-free.
+  const int quad = lane >> 2, q7 = quad & 7;
+  const int ly = 2 * ((0x32130210u >> (4 * q7)) & 3) + (quad >> 3);
+  const int strip = 4 * ((0xE8u >> q7) & 1) + (lane & 3);
+  int bid = blockIdx.x;
+  {                                                      // XCD-local tile order (neighbours share halo rows in one L2)
+    const int nwg = gridDim.x, qq = nwg / 8, rr = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+  }
+  const int tx = bid % tilesX; bid /= tilesX;
+  const int ty = bid % tilesY;
+  const int n = bid / tilesY;
+  const int h0 = ty * TH, w0 = tx * TW;
+  const int qy = h0 + ly, qx0 = w0 + 4 * strip;
+  const bool inq = qy < H && qx0 < W;                    // W % 4 == 0: a strip is all in or all out
+  const size_t plane = (size_t)H * W;
+  const float* go = gout + (size_t)n * 81 * plane;
+  // Weights as REGISTER PAIRS for v_pk_fma_f32 (64-bit operands are even-aligned register pairs): a tap at an EVEN offset into the
+  // 12 row values pairs pixels (0, 1) and (2, 3) with the natural halves of the three 16-byte reads; at an ODD offset pixels
+  // (1, 2) pair up and pixels 0 and 3 go as single FMAs -- 22 VALU instructions per 36 FMAs, no register shuffling, no
+  // unaligned LDS reads (the compiler's own pairing of a plain float loop: ~19 moves + 8 small LDS reads per row).
+  f32x2 we[3][5][2];                                     // even horizontal shifts 0, 2, ..., 8: pixels (0, 1), (2, 3)
+  f32x2 wo[3][4];                                        // odd shifts 1, 3, 5, 7: pixels (1, 2)
+  float wo0[3][4], wo3[3][4];                            //                        pixels 0 and 3
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int dy = 3 * grp + a;
+#pragma unroll
+    for (int dx = 0; dx < 9; ++dx) {
+      const int d = dy * 9 + dx;
+      float wv[4];
+      if (MODE == 1) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inq) v = *reinterpret_cast<const float4*>(go + (size_t)d * plane + (size_t)qy * W + qx0);
+        wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
+      } else {
+        const int py = qy - (dy - 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int px = qx0 + i - (dx - 4);
+          wv[i] = (inq && py >= 0 && py < H && px >= 0 && px < W) ? go[(size_t)d * plane + (size_t)py * W + px] : 0.0f;
+        }
+      }
+      if (dx % 2 == 0) {
+        we[a][dx / 2][0] = f32x2{wv[0], wv[1]};
+        we[a][dx / 2][1] = f32x2{wv[2], wv[3]};
+      } else {
+        wo[a][dx / 2] = f32x2{wv[1], wv[2]};
+        wo0[a][dx / 2] = wv[0];
+        wo3[a][dx / 2] = wv[3];
+      }
+    }
+  }
+  const float* src = other + (size_t)n * C * plane;
+  float* dst = grad + (size_t)n * C * plane;
+  // this thread's pieces of a chunk's halo tile: (channel, row, 16-byte column) -- the same for every chunk
+  int poff[NPF];                                         // offset of the piece within a channel chunk, or -1 (outside the image)
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    const int idx = tid + NT * k;
+    const int x4 = idx % P4, r = (idx / P4) % RH, c = idx / (P4 * RH);
+    const int gy = h0 - 4 + r, gx = w0 - 4 + 4 * x4;
+    poff[k] = (idx < CHUNK4 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (int)((size_t)c * plane + (size_t)gy * W + gx) : -1;
+  }
+  float4 pf[NPF];
+  auto fetch = [&](int c0) {
+    const float* s0 = src + (size_t)c0 * plane;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      pf[k] = poff[k] >= 0 ? *reinterpret_cast<const float4*>(s0 + poff[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      if (tid + NT * k < CHUNK4) tile[buf * CHUNK4 + tid + NT * k] = pf[k];
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  const int nchunks = C / CC;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nchunks) fetch((kc + 1) * CC);
+    float4 part[CC];
+    const float4* tb = tile + buf * CHUNK4;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      f32x2 e01 = {0.f, 0.f}, e23 = {0.f, 0.f}, o12 = {0.f, 0.f};
+      float o0 = 0.f, o3 = 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int dy = 3 * grp + a;
+        const int r = (MODE == 1) ? ly + dy : ly + 8 - dy;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f* rowp = reinterpret_cast<const v4f*>(tb + (c * RH + r) * P4 + strip);
+        const v4f q0 = rowp[0], q1 = rowp[1], q2 = rowp[2];
+        const f32x2 v2[6] = {f32x2{q0[0], q0[1]}, f32x2{q0[2], q0[3]}, f32x2{q1[0], q1[1]},
+                             f32x2{q1[2], q1[3]}, f32x2{q2[0], q2[1]}, f32x2{q2[2], q2[3]}};
+        const float v1[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) {
+          const int o = (MODE == 1) ? dx : 8 - dx;       // pixel i reads row value i + o (same parity as dx)
+          if (dx % 2 == 0) {
+            e01 = __builtin_elementwise_fma(we[a][dx / 2][0], v2[o / 2], e01);
+            e23 = __builtin_elementwise_fma(we[a][dx / 2][1], v2[o / 2 + 1], e23);
+          } else {
+            o12 = __builtin_elementwise_fma(wo[a][dx / 2], v2[(o + 1) / 2], o12);
+            o0 = fmaf(wo0[a][dx / 2], v1[o], o0);
+            o3 = fmaf(wo3[a][dx / 2], v1[o + 3], o3);
+          }
+        }
+      }
+      part[c] = make_float4(e01[0] + o0, e01[1] + o12[0], e23[0] + o12[1], e23[1] + o3);
+    }
+    float4* rb = red + buf * (2 * CC * TH * RP);
+    if (grp != 0) {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) rb[((grp - 1) * CC + c) * (TH * RP) + ly * RP + strip] = part[c];
+    }
+    if (kc + 1 < nchunks) stage(buf ^ 1);
+    __syncthreads();
+    if (grp == 0 && inq) {
+      float* d0 = dst + (size_t)(kc * CC) * plane + (size_t)qy * W + qx0;
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        const float4 p1 = rb[(0 * CC + c) * (TH * RP) + ly * RP + strip];
+        const float4 p2 = rb[(1 * CC + c) * (TH * RP) + ly * RP + strip];
+        float4 o;
+        o.x = (part[c].x + p1.x) + p2.x;
+        o.y = (part[c].y + p1.y) + p2.y;
+        o.z = (part[c].z + p1.z) + p2.z;
+        o.w = (part[c].w + p1.w) + p2.w;
+        *reinterpret_cast<float4*>(d0 + (size_t)c * plane) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(192) void corr9_bwd_strip_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
+                                                              const float* __restrict__ gout, float* __restrict__ g1,
+                                                              float* __restrict__ g2, int C, int H, int W, int tilesX,
+                                                              int tilesY) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 8 * 16 * 40 + 2 * 2 * 8 * 8 * 40];
+  if (blockIdx.y == 0) corr9_bwd_strip_body<1>(in2, gout, g1, C, H, W, tilesX, tilesY, lds);
+  else corr9_bwd_strip_body<2>(in1, gout, g2, C, H, W, tilesX, tilesY, lds);
+}
+
 // Generic backward: scatter with hardware atomics, one thread per gout element (grads pre-zeroed by the caller).
 template <typename T>
 __global__ __launch_bounds__(256) void corr_generic_bwd_kernel(const T* __restrict__ in1,
@@ -1130,6 +1301,12 @@ static int corr_bwd_any(const T* in1, const T* in2, const T* gout, T* g1, T* g2,
       const int tilesX = cdiv(p.iW, 32), tilesY = cdiv(p.iH, 8);
       const long blocks = (long)p.B * tilesX * tilesY;
       if (blocks > 0x7fffffffL) return fail(RFN_EINVAL, "corr bwd: grid too large");
+      if (p.iW % 4 == 0 && p.C % 8 == 0 && (size_t)p.C * p.iH * p.iW < (1ull << 31) &&
+          (((size_t)in1 | (size_t)in2 | (size_t)gout | (size_t)g1 | (size_t)g2) & 15) == 0) {
+        hipLaunchKernelGGL(corr9_bwd_strip_kernel, dim3((unsigned)blocks, 2), dim3(192), 0, st, in1, in2, gout, g1, g2, p.C, p.iH,
+                           p.iW, tilesX, tilesY);
+        return check_launch("corr9_bwd_strip_kernel");
+      }
       hipLaunchKernelGGL((corr9_bwd_tile_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, in2, gout, g1, p.C,
                          p.iH, p.iW, tilesX, tilesY);
       if (int rc = check_launch("corr9_bwd_tile_kernel<1>")) return rc;

@@ -47,6 +47,26 @@ def test_corr_hot_vs_oracle_ragged(dev, oracle, shape):
     np.testing.assert_allclose(tb.grad.cpu().numpy(), w2, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 8, 32), (2, 16, 19, 36), (2, 24, 33, 68), (1, 128, 17, 100), (3, 8, 5, 4), (2, 40, 70, 132)])
+def test_corr_backward_strip_kernel_vs_oracle(dev, oracle, shape):
+    """Round 5: the hot parameterisation's backward on register strips (corr9_bwd_strip_kernel: W % 4 == 0, C % 8 == 0, both
+    gradients in one launch) against the oracle's backward: ragged rows, partial column tiles, maps smaller than the halo, more
+    than one chunk of 8 channels; run twice (deterministic: bit-identical)."""
+    from refign_amd import correlation
+    rng = np.random.default_rng(sum(shape) + 7)
+    a = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape).astype(np.float32)
+    B, C, H, W = shape
+    go = rng.standard_normal((B, 9, 9, H, W)).astype(np.float32)
+    args = (1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)
+    g1, g2 = correlation.backward(T(a, dev), T(b, dev), T(go, dev), *args)
+    w1, w2 = oracle.corr_backward(a, b, go, patch_size=9)
+    np.testing.assert_allclose(g1.cpu().numpy(), w1, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(g2.cpu().numpy(), w2, rtol=1e-4, atol=1e-4)
+    h1, h2 = correlation.backward(T(a, dev), T(b, dev), T(go, dev), *args)
+    assert torch.equal(g1, h1) and torch.equal(g2, h2)
+
+
 @pytest.mark.parametrize("shape", [(2, 48, 23, 72), (1, 256, 19, 36), (1, 32, 40, 32), (2, 64, 8, 64), (1, 80, 9, 132), (2, 32, 72, 160), (2, 128, 33, 70)])
 def test_corr_channel_split_tiles_vs_oracle(dev, oracle, shape):
     """Maps of up to 256 8 x 32 tiles (at most one workgroup per CU) with C % 16 == 0 run the pipelined kernel with the workgroup's
