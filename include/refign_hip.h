@@ -27,7 +27,7 @@ extern "C" {
 #define RFN_ELAUNCH (-2)   /* hipLaunchKernel / runtime error, see rfn_last_error() */
 #define RFN_ENOTSUP (-3)   /* valid in the reference but not built here (documented per function) */
 
-#define RFN_ABI_VERSION 2
+#define RFN_ABI_VERSION 3
 
 typedef void* rfn_stream_t; /* hipStream_t */
 
@@ -306,9 +306,10 @@ int rfn_multi_cast_f32_bf16(const void* table, int nchunks, rfn_stream_t stream)
  * has a bf16 copy pointer, the rounded new value is written there in the same pass (the teacher's cached 16-bit weight). */
 int rfn_multi_ema_f32(const void* table, int nchunks, float momentum, rfn_stream_t stream);
 /* (Same purpose as rfn_multi_cast_f32_bf16.)  Transposed bf16 copies of a set of fp32 matrices in ONE launch: dst (K, N) = bf16(src (N, K)^T), both row-major and
- * contiguous; table = ntiles x {const float* src, bf16* dst, int N, int K, int n0, int k0} (one 32 x 32 tile each) in device
- * memory.  (The cached W^T operands of the input-gradient GEMMs, refreshed after optimiser / EMA updates.) */
+ * contiguous; table = ntiles x {const float* src, bf16* dst, int N, int K, int n0, int k0} (one T x T tile each, T = rfn_multi_transpose_tile(): 64
+ * since ABI 3, 32 before) in device memory.  (The cached W^T operands of the input-gradient GEMMs, refreshed after optimiser / EMA updates.) */
 int rfn_multi_transpose_cast_f32_bf16(const void* table, int ntiles, rfn_stream_t stream);
+int rfn_multi_transpose_tile(void);
 /* AdamW step of a whole parameter set in ONE launch (what the reference's optimizer section instantiates --
  * configs/cityscapes_darkzurich/refign_hrda_star.yaml:176-180, stepped by models/segmentation_model.py:252 --
  * torch.optim.AdamW, decoupled weight decay, no amsgrad / maximize; fp32 state).  table = nchunks x {float* p,

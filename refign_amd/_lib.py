@@ -66,6 +66,7 @@ SIGNATURES = {
     "rfn_patchify_tokens": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rfn_patchify_tokens_cmajor": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rfn_multi_cast_chunk_elems": (c_int, []),
+    "rfn_multi_transpose_tile": (c_int, []),
     "rfn_multi_permute_chunk_elems": (c_int, []),
     "rfn_multi_permute_cast_f32": (c_int, [c_void_p, c_int, c_void_p]),
     "rfn_multi_cast_f32_bf16": (c_int, [c_void_p, c_int, c_void_p]),
@@ -119,8 +120,8 @@ SIGNATURES = {
 
 
 # RFN_ABI_VERSION of include/refign_hip.h this table was written against (2: rfn_global_corr_layer_f32 takes a workspace,
-# rfn_dacs_mix_jitter accepts one half of the mix)
-ABI_VERSION = 2
+# rfn_dacs_mix_jitter accepts one half of the mix; 3: the transpose-cast table holds 64 x 64 tiles, rfn_multi_transpose_tile)
+ABI_VERSION = 3
 
 
 def library_path():

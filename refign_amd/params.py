@@ -147,11 +147,12 @@ def _transpose_table(dst, src, dev):
     fp32 parameters, dst the contiguous (K, N) bf16 copies."""
     import numpy as np
     rows = []
+    T = _lib.load_library().rfn_multi_transpose_tile()
     for s_, d in zip(src, dst):
         K, N = s_.shape                                   # view (K, N) of a parameter stored (N, K)
         sp, dp = s_.data_ptr(), d.data_ptr()
-        for n0 in range(0, N, 32):
-            for k0 in range(0, K, 32):
+        for n0 in range(0, N, T):
+            for k0 in range(0, K, T):
                 rows.append((sp, dp, N | (K << 32), n0 | (k0 << 32)))
     return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows)
 

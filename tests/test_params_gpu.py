@@ -145,6 +145,32 @@ def test_refresh_multi_tensor_cast_is_torch_rounding(dev):
             torch.equal(torch.nan_to_num(c.float(), nan=0.0), torch.nan_to_num(want.float(), nan=0.0))
 
 
+def test_refresh_transposed_copies_multi_tensor(dev):
+    """refresh() of the cached W^T bf16 operands (params.transposed: the input-gradient GEMMs' weights) = one multi-tensor
+    transpose + cast launch over 64 x 64 tiles (ABI 3): bit-identical to p.t().to(bfloat16) for shapes that are / are not
+    multiples of the tile or of the 16-byte pieces, and for a storage that is only 4-byte aligned."""
+    from refign_amd.params import refresh, transposed
+    g = torch.Generator().manual_seed(2)
+    shapes = [(320, 320), (1280, 320), (320, 1280), (64, 64), (72, 40), (19, 150), (8, 8), (130, 67), (1, 5)]
+    flat = torch.randn(sum(a * b for a, b in shapes) + 3, generator=g).to(dev)
+    ps, off = [], 0
+    for k, (a, b) in enumerate(shapes):
+        if k == 5:
+            off += 1                                             # from here on: odd element offset
+        ps.append(nn.Parameter(flat[off:off + a * b].view(a, b)))
+        off += a * b
+    copies = [transposed(p, torch.bfloat16) for p in ps]
+    for p, c in zip(ps, copies):
+        assert tuple(c.shape) == (p.shape[1], p.shape[0]) and c.is_contiguous()
+    with torch.no_grad():
+        for p in ps:
+            p.data.mul_(-0.7).add_(0.321)                        # through .data: version counters do not move
+    refresh(ps)
+    for p, c in zip(ps, copies):
+        assert transposed(p, torch.bfloat16) is c
+        assert torch.equal(c, p.detach().t().to(torch.bfloat16)), tuple(p.shape)
+
+
 def test_python_side_workspace_sizes_match_the_abi(dev):
     """layernorm.py / dwconv.py size their scratch buffers without an ABI round trip: same numbers as the library."""
     from refign_amd import _lib, dwconv, layernorm
