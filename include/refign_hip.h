@@ -90,10 +90,14 @@ int rfn_local_corr_layer_f32(const float* feature_target, const float* feature_s
                              float* out, int B, int C, int H, int W, rfn_stream_t stream);
 
 /* The same for SMALL maps (no flow): the channels are split into `splits` chunks that run as separate workgroups (a
- * 2 x 256 x 32 x 32 level is 8 tiles -- 8 workgroups walking 256 channels serially, ~100 us of latency), partial sums go
- * to `workspace` (splits * B * 81 * H * W floats) and a second kernel adds them in chunk order and applies ReLU +
- * L2 norm.  Deterministic; differs from the one-kernel path by the rounding of the chunked channel sum only.
- * W % 4 == 0, C % splits == 0, (C / splits) % 8 == 0, 2 <= splits <= 64. */
+ * 2 x 256 x 32 x 32 level is 8 tiles -- 8 workgroups walking 256 channels serially, ~100 us of latency); partial sums go
+ * to `workspace` and are added in chunk order, then ReLU + L2 norm.  ABI 3: ONE launch when the chunks are multiples of 32
+ * channels and at least 64 (the tile's last workgroup joins the chunks; tickets live behind the partial volumes), a second
+ * kernel otherwise.  workspace: rfn_local_corr_layer_split_workspace_bytes(B, H, W, splits) bytes (splits * B * 81 * H * W floats
+ * + one unsigned per 8 x 32 tile -- the tickets: ZERO before the first call with a workspace; every call leaves them zero),
+ * 16-byte aligned.  Deterministic; differs from the one-kernel path by the rounding of the
+ * chunked channel sum only.  W % 4 == 0, C % splits == 0, (C / splits) % 8 == 0, 2 <= splits <= 64. */
+long rfn_local_corr_layer_split_workspace_bytes(int B, int H, int W, int splits);
 int rfn_local_corr_layer_split_f32(const float* feature_target, const float* feature_source, float* out,
                                    float* workspace, int B, int C, int H, int W, int splits, rfn_stream_t stream);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     "rfn_corr_bwd_f16": (c_int, [c_void_p] * 5 + [c_int] * 4 + _CORR12 + [c_void_p]),
     "rfn_local_corr_layer_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "rfn_local_corr_layer_split_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "rfn_local_corr_layer_split_workspace_bytes": (ctypes.c_long, [c_int] * 4),
     "rfn_global_corr_layer_f32": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "rfn_warp_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "rfn_warp_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),

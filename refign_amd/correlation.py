@@ -143,7 +143,7 @@ def local_correlation_layer(feature_source, feature_target, flow=None, single_ke
     splits = _channel_splits(B, C, H, W) if flow is None else 1
     with on_device(dev):
         if splits > 1:
-            ws = torch.empty((splits, B, 81, H, W), dtype=torch.float32, device=dev)
+            ws = _split_workspace(lib.rfn_local_corr_layer_split_workspace_bytes(B, H, W, splits), dev)
             rc = lib.rfn_local_corr_layer_split_f32(ptr(feature_target), ptr(feature_source), ptr(out), ptr(ws), B, C, H, W,
                                                     splits, current_stream(dev))
         else:
@@ -151,6 +151,22 @@ def local_correlation_layer(feature_source, feature_target, flow=None, single_ke
                                               current_stream(dev))
     _lib.check(rc, "local_correlation_layer")
     return out
+
+
+_SPLIT_WS = {}
+
+
+def _split_workspace(nbytes, dev):
+    """Workspace of the channel-split path, one per (device, stream, size), kept: its tail holds the tickets of the one-launch
+    form, which must be zero before the first call and are left zero by every call (include/refign_hip.h).  Per stream: two
+    streams may run the same level side by side."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, nbytes)
+    ws = _SPLIT_WS.get(key)
+    if ws is None:
+        if len(_SPLIT_WS) >= 64:
+            _SPLIT_WS.clear()
+        ws = _SPLIT_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    return ws
 
 
 def _channel_splits(B, C, H, W):
@@ -165,10 +181,15 @@ def _channel_splits(B, C, H, W):
     forced = int(os.environ.get("RFN_CORR_SPLITS", "0"))                # tuning knob
     if forced:
         return forced if (forced > 1 and C % forced == 0 and (C // forced) % 8 == 0) else 1
-    tiles = B * -(-W // 64) * -(-H // 8)
-    if tiles > 32:
+    tiles = B * -(-W // 32) * -(-H // 8)
+    if tiles > 64:
         return 1
-    s = 1
-    while tiles * s < 64 and s < 8 and C % (2 * s) == 0 and (C // (2 * s)) % 8 == 0 and C // (2 * s) >= 16:
-        s *= 2
-    return s
+    # chunks of >= 64 channels in multiples of 32 take the one-launch form (four wave groups per workgroup, joined by the
+    # tile's last workgroup): split down to 64 channels; where that gives no split, the two-launch form down to 16
+    def grow(floor_c, mult):
+        s = 1
+        while tiles * s < 64 and s < 8 and C % (2 * s) == 0 and (C // (2 * s)) % mult == 0 and C // (2 * s) >= floor_c:
+            s *= 2
+        return s
+    s = grow(64, 32)
+    return s if s > 1 else grow(16, 8)

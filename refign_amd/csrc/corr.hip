@@ -341,10 +341,20 @@ __device__ __forceinline__ void lds_dma16_masked(const void* sbase, unsigned vof
 //     the source-row base, the store address); the LDS image, the products and the hand-offs are the same.  `tilesX` then
 //     counts the FULL tile columns, tiles [0, nreg) are regular and tiles [nreg, ntiles) are the (image pair, row band) edge
 //     tiles: 2 x 17 x 7 + 17 = 255 workgroups -- one per CU, which also lets the channel split (KSPLIT) apply.
-template <int TH, int TW, bool FUSE, int MINW, int NTILE, int DEPTH = 1, int NS = 4, bool KSPLIT = false, bool PAIR = false>
+//   * JOIN (cross-workgroup channel split of tiny maps, launch_corr9_split; 1 = raw sums, 2 = ReLU + L2 norm): gridDim.y workgroups
+//     share a tile, each writes the raw partial volume of its channel slice, takes a ticket, and the LAST arriver adds the slices in
+//     slice order (deterministic), applies the epilogue and writes the result: the level in ONE launch (round 5; before: a second
+//     kernel, 14 + 18 us for K4 level 3).  Publication across XCDs: slab stores, vmcnt(0), barrier, agent-scope release fence,
+//     relaxed agent-scope ticket; the reducer takes an agent-scope acquire fence before it reads (the L2s of the XCDs are not
+//     coherent with each other).  The tickets are zero on entry and the joining workgroup puts its ticket back to zero: the
+//     caller zeroes them once per workspace (a memset node in front of every launch was tried first: under hipGraph replay the
+//     level came out stale -- tests/test_align_gpu.py K2 golden -- while eager launches were right).
+template <int TH, int TW, bool FUSE, int MINW, int NTILE, int DEPTH = 1, int NS = 4, bool KSPLIT = false, bool PAIR = false,
+          int JOIN = 0>
 __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_kernel(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C, int H, int W,
-    int tilesX, int tilesY, int ntiles, int xcd_remap, int nreg, int Ctot, long part_stride) {
+    int tilesX, int tilesY, int ntiles, int xcd_remap, int nreg, int Ctot, long part_stride, float* __restrict__ joined,
+    unsigned* __restrict__ tickets) {
   // (C = the channels THIS workgroup walks, Ctot = the tensors' channel count: equal except in the cross-workgroup channel
   // split of tiny maps, launch_corr9_split, where blockIdx.y picks the slice [blockIdx.y C, (blockIdx.y + 1) C) and the raw
   // partial sums go to out + blockIdx.y * part_stride)
@@ -410,6 +420,7 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
   const size_t c0 = (size_t)blockIdx.y * C + (KSPLIT ? (size_t)half * Cw : 0);
   const float* p1 = in1 + ((size_t)n * Ctot + c0) * plane;
   const float* p2 = in2 + ((size_t)n * Ctot + c0) * plane;
+  const float* const slab0 = out;                      // (JOIN) slice 0 of the partial volumes
   out += (size_t)blockIdx.y * part_stride;
 
   // LDS image of a chunk (differs from corr9_pipe_kernel's): the TARGET rows of both channels first, then the source rows --
@@ -697,6 +708,81 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
         o += plane;                                    // (a running pointer: one 64-bit add per store instead of a 64-bit multiply-add)
       }
   }
+  if constexpr (JOIN != 0) {
+    static_assert(!FUSE && !PAIR && KSPLIT, "JOIN: raw partial sums of one tile per workgroup");
+    constexpr int PX = TH * TW, NTH = NT * NTILE;
+    static_assert((81 * PX + PX) <= NS * NTILE * BUF, "JOIN: the tile's volume fits the rings");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // every wave's slab stores have left; the rings are free
+    int* flag = reinterpret_cast<int*>(rings_all);
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned prev = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == gridDim.y - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // nobody else touches this ticket in this launch: back to zero for the next one (the caller zeroes the tickets ONCE)
+        __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      flag[0] = last;
+    }
+    __syncthreads();
+    const int last = flag[0];
+    __syncthreads();
+    if (!last) return;
+    float* acc = rings_all;                            // [81][PX]
+    float* scl = rings_all + 81 * PX;                  // [PX]
+    const int S = (int)gridDim.y;
+    const float* pbase = slab0 + (size_t)n * 81 * plane;
+    for (int idx = threadIdx.x; idx < 81 * (PX / 4); idx += NTH) {
+      const int d = idx / (PX / 4), sp = idx % (PX / 4), rr = sp / STRIPS, st = sp % STRIPS;
+      const int hh = h0 + rr, ww = w0 + 4 * st;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (hh < H && ww < W) {
+        const float* q = pbase + (size_t)d * plane + (size_t)hh * W + ww;
+        v = *reinterpret_cast<const float4*>(q);
+#pragma unroll 4
+        for (int sl = 1; sl < S; ++sl) {               // slice order: the same sum for every launch geometry
+          const float4 t = *reinterpret_cast<const float4*>(q + (size_t)sl * part_stride);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+      }
+      if (JOIN == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(&acc[d * PX + 4 * sp]) = v;
+    }
+    __syncthreads();
+    if (JOIN == 2) {
+      for (int px = threadIdx.x; px < PX; px += NTH) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                  // the three vertical-shift groups of the one-kernel epilogue, in its order
+          float ss = 0.f;
+#pragma unroll
+          for (int d = 0; d < 27; ++d) {
+            const float r = acc[(k * 27 + d) * PX + px];
+            ss = fmaf(r, r, ss);
+          }
+          tot = k == 0 ? ss : tot + ss;
+        }
+        scl[px] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+      }
+      __syncthreads();
+    }
+    float* obase = joined + (size_t)n * 81 * plane;
+    for (int idx = threadIdx.x; idx < 81 * (PX / 4); idx += NTH) {
+      const int d = idx / (PX / 4), sp = idx % (PX / 4), rr = sp / STRIPS, st = sp % STRIPS;
+      const int hh = h0 + rr, ww = w0 + 4 * st;
+      if (hh < H && ww < W) {
+        float4 v = *reinterpret_cast<const float4*>(&acc[d * PX + 4 * sp]);
+        if (JOIN == 2) {
+          const float4 sc = *reinterpret_cast<const float4*>(&scl[4 * sp]);
+          v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+        }
+        *reinterpret_cast<float4*>(obase + (size_t)d * plane + (size_t)hh * W + ww) = v;
+      }
+    }
+  }
 }
 
 // (The fp32-matrix-pipe formulation of this forward -- exact, measured slower: 166-171 vs 139 us, profiles/r02_corr_mfma_*.txt,
@@ -719,7 +805,7 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
         const long ntiles = (long)B * tilesX * tilesY, blocks = (ntiles + 1) / 2;
         if (ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");
         hipLaunchKernelGGL((corr9_pipe2_kernel<16, 32, FUSE, 3, 2, 1, 4>), dim3((unsigned)blocks), dim3(16 * 8 * 3 * 2), 0, st,
-                           in1, in2, out, C, H, W, tilesX, tilesY, (int)ntiles, xcd, 0, C, 0L);
+                           in1, in2, out, C, H, W, tilesX, tilesY, (int)ntiles, xcd, 0, C, 0L, nullptr, nullptr);
         return check_launch("corr9_pipe2_kernel");
       }
       // Smaller maps: single 8 x 32 tiles, 3-wave workgroups.  Up to 256 of them (one workgroup per CU) the workgroup's second
@@ -738,24 +824,24 @@ static int launch_corr9(const float* in1, const float* in2, const float* flow, f
       if (ksplit_ok && nt8 > 256 && rem > 0 && rem <= 16 && B % 2 == 0 && npair <= 256 && 2 * sample < (1ull << 32)) {
         if (ksplit4)
           hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 4, 1, 4, true, true>), dim3((unsigned)npair), dim3(8 * 8 * 3 * 4), 0,
-                             st, in1, in2, out, C, H, W, W / 32, tilesY, (int)npair, xcd, (int)nreg, C, 0L);
+                             st, in1, in2, out, C, H, W, W / 32, tilesY, (int)npair, xcd, (int)nreg, C, 0L, nullptr, nullptr);
         else
           hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 2, 1, 4, true, true>), dim3((unsigned)npair), dim3(8 * 8 * 3 * 2), 0,
-                             st, in1, in2, out, C, H, W, W / 32, tilesY, (int)npair, xcd, (int)nreg, C, 0L);
+                             st, in1, in2, out, C, H, W, W / 32, tilesY, (int)npair, xcd, (int)nreg, C, 0L, nullptr, nullptr);
         return check_launch("corr9_pipe2_kernel");
       }
       if (nt8 > 0x7fffffffL) return fail(RFN_EINVAL, "corr9: grid too large");
       if (ksplit_ok && nt8 <= 256) {
         if (ksplit4)
           hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 4, 1, 4, true>), dim3((unsigned)nt8), dim3(8 * 8 * 3 * 4), 0, st,
-                             in1, in2, out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L);
+                             in1, in2, out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L, nullptr, nullptr);
         else
           hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 2, 1, 4, true>), dim3((unsigned)nt8), dim3(8 * 8 * 3 * 2), 0, st,
-                             in1, in2, out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L);
+                             in1, in2, out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L, nullptr, nullptr);
         return check_launch("corr9_pipe2_kernel");
       }
       hipLaunchKernelGGL((corr9_pipe2_kernel<8, 32, FUSE, 3, 1, 1, 4>), dim3((unsigned)nt8), dim3(8 * 8 * 3), 0, st, in1, in2,
-                         out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L);
+                         out, C, H, W, cdiv(W, 32), tilesY, (int)nt8, xcd, 0, C, 0L, nullptr, nullptr);
       return check_launch("corr9_pipe2_kernel");
     }
   }
@@ -835,9 +921,18 @@ static int launch_corr9_split(const float* in1, const float* in2, float* out, fl
   if (ntiles <= 0 || ntiles > 0x7fffffffL) return fail(RFN_EINVAL, "corr9 split: grid too large");
   if ((size_t)C * H * W * sizeof(float) >= (1ull << 32)) return fail(RFN_EINVAL, "corr9 split: samples of 4 GB and more are not tiny maps");
   const long plane = (long)H * W, part_stride = (long)B * 81 * plane;
+  if (Cc >= 64 && Cc % 32 == 0 && (W & 3) == 0) {
+    // ONE launch: four wave groups per workgroup on the quarters of its slice, the tile's last workgroup joins the slices.
+    // Tickets: the ntiles unsigned ints behind the partial volumes (rfn_local_corr_layer_split_workspace_bytes).
+    unsigned* tickets = reinterpret_cast<unsigned*>(workspace + (size_t)S * part_stride);
+    hipLaunchKernelGGL((corr9_pipe2_kernel<TH, TW, false, 3, 4, 1, 4, true, false, FUSE ? 2 : 1>), dim3((unsigned)ntiles, (unsigned)S),
+                       dim3(TH * (TW / 4) * 3 * 4), 0, st, in1, in2, workspace, Cc, H, W, tilesX, tilesY, (int)ntiles, 0, 0, C,
+                       part_stride, out, tickets);
+    return check_launch("corr9_pipe2_kernel (channel split, joined in the launch)");
+  }
   // slice blockIdx.y of the channels per workgroup (Cc % 8 == 0: whole rounds of the 4-stage ring), raw partial volumes
   hipLaunchKernelGGL((corr9_pipe2_kernel<TH, TW, false, 3, 1, 1, 4>), dim3((unsigned)ntiles, (unsigned)S), dim3(TH * (TW / 4) * 3),
-                     0, st, in1, in2, workspace, Cc, H, W, tilesX, tilesY, (int)ntiles, 0, 0, C, part_stride);
+                     0, st, in1, in2, workspace, Cc, H, W, tilesX, tilesY, (int)ntiles, 0, 0, C, part_stride, nullptr, nullptr);
   if (int rc = check_launch("corr9_pipe2_kernel (channel split)")) return rc;
   const long total = (long)B * plane;
   hipLaunchKernelGGL((corr9_split_reduce_kernel<FUSE>), dim3(cdiv(total, 32)), dim3(256), 0, st, workspace, out, S,
@@ -1416,6 +1511,12 @@ int rfn_local_corr_layer_f32(const float* feature_target, const float* feature_s
   hipStream_t st = (hipStream_t)stream;
   if (flow) return launch_corr9<true, true>(feature_target, feature_source, flow, out, B, C, H, W, st);
   return launch_corr9<true, false>(feature_target, feature_source, nullptr, out, B, C, H, W, st);
+}
+
+long rfn_local_corr_layer_split_workspace_bytes(int B, int H, int W, int splits) {
+  if (B <= 0 || H <= 0 || W <= 0 || splits <= 0) return 0;
+  const long tickets = (long)B * rfn::cdiv(W, 32) * rfn::cdiv(H, 8);
+  return ((long)splits * B * 81 * H * W + tickets) * 4;
 }
 
 int rfn_local_corr_layer_split_f32(const float* feature_target, const float* feature_source, float* out,

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const AdamChunk* __res
   const AdamChunk c = table[blockIdx.x];
   const int gi = (int)((unsigned long)c.n >> 56);
   const long n = c.n & ((1L << 56) - 1);
-  const float lr = gr.lr[gi], b1 = gr.beta1[gi], b2 = gr.beta2[gi], eps = gr.eps[gi], wd = gr.wd[gi];
+  const float lr = gr.lr[gi], b2 = gr.beta2[gi], eps = gr.eps[gi], wd = gr.wd[gi];
   const float step_size = lr / gr.bc1[gi], bc2s = gr.bc2_sqrt[gi], omb1 = gr.omb1[gi], omb2 = gr.omb2[gi];
   auto upd = [&](float& p, float g, float& m, float& v) {
     p -= lr * wd * p;

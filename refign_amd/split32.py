@@ -122,7 +122,7 @@ def attention(q, k, v, scale):
     """softmax(scale q k^T) v for (B, h, N, d) fp32 tensors as explicit products on the matrix-core kernels + a torch softmax
     (mix_transformer.py:150-160 materialises the same score matrix)."""
     B, h, N, d = q.shape
-    if B * h > 64 and torch.cuda.is_current_stream_capturing():
+    if B * h > 128 and torch.cuda.is_current_stream_capturing():
         # the EMA teacher's 40 views: ~10^5 nodes in one hipGraph (hipStreamEndCapture does not survive that, seen in round 5);
         # refign_amd.graphs catches this and keeps the pass eager -- the parity mode is the correctness mode, not the fast one
         raise RuntimeError(f"split32.attention: {B * h} per-head products under a stream capture; this pass runs eagerly")

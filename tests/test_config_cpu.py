@@ -122,7 +122,8 @@ def test_correlation_channel_split_heuristic(monkeypatch):
     from refign_amd.correlation import _channel_splits as f
     monkeypatch.delenv("RFN_CORR_SPLIT", raising=False)
     monkeypatch.delenv("RFN_CORR_SPLITS", raising=False)
-    assert f(2, 256, 32, 32) == 8                      # K4 level 3
+    assert f(2, 256, 32, 32) == 4                      # K4 level 3: chunks of 64 channels, joined inside the launch (round 5)
+    assert f(2, 512, 32, 32) == 8 and f(2, 256, 64, 64) == 2 and f(2, 48, 16, 32) == 2   # (48: two-launch form, chunks of 24)
     assert f(2, 128, 270, 480) == 1 and f(2, 256, 135, 240) == 1
     assert f(2, 256, 32, 30) == 1                      # W % 4
     assert f(1, 20, 16, 16) == 1                       # C % 8

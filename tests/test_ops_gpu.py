@@ -323,11 +323,14 @@ def test_l2_normalize_channels_from_channels_last_16bit(dev, B, C, H, W, dt):
     assert torch.allclose(got, composite, rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 256, 32, 32), (1, 128, 9, 12), (2, 64, 17, 64), (1, 512, 16, 16), (3, 32, 8, 4)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 32, 32), (1, 128, 9, 12), (2, 64, 17, 64), (1, 512, 16, 16), (3, 32, 8, 4),
+                                     (2, 512, 32, 32), (2, 256, 64, 64), (1, 192, 20, 40)])
 def test_local_correlation_layer_channel_split_matches_one_kernel_path(dev, oracle, B, C, H, W, monkeypatch):
-    """Small maps split their channels over several workgroups (csrc/corr.hip launch_corr9_split: partial sums + a
-    reduce kernel with the fused ReLU + L2-norm epilogue): same result as the one-kernel path up to the rounding of the
-    chunked channel sum, equal to the CPU oracle within the correlation tolerance, deterministic, ragged sizes."""
+    """Small maps split their channels over several workgroups (csrc/corr.hip launch_corr9_split: partial sums, joined with the
+    fused ReLU + L2-norm epilogue by the tile's last workgroup inside the launch when the chunks are >= 64 channels in multiples
+    of 32 -- shapes 1, 2, 4, 6, 7, 8 --, by a reduce kernel otherwise): same result as the one-kernel path up to the rounding of
+    the chunked channel sum, equal to the CPU oracle within the correlation tolerance, deterministic (also across the 20
+    back-to-back calls that re-use the tickets), ragged sizes."""
     from refign_amd import correlation
     rng = np.random.default_rng(B * C + H * W)
     src = rng.standard_normal((B, C, H, W)).astype(np.float32)
@@ -335,7 +338,9 @@ def test_local_correlation_layer_channel_split_matches_one_kernel_path(dev, orac
     s = correlation._channel_splits(B, C, H, W)
     assert s > 1, "this size is supposed to take the split path"
     got = correlation.local_correlation_layer(T(src, dev), T(trg, dev))
-    again = correlation.local_correlation_layer(T(src, dev), T(trg, dev))
+    ts, tt = T(src, dev), T(trg, dev)
+    for _ in range(20):
+        again = correlation.local_correlation_layer(ts, tt)
     assert torch.equal(got, again)
     monkeypatch.setenv("RFN_CORR_SPLIT", "0")
     one = correlation.local_correlation_layer(T(src, dev), T(trg, dev))
