@@ -23,6 +23,7 @@ bash tools/pmc_corr.sh corr_l1_fused > $O/pmc_corr9.txt 2>&1
 python tools/pmc_corr_json.py $O/pmc_corr9.txt $O/pmc_traffic_corr9.json > /dev/null 2>&1
 timeout 300 python tools/kbench.py --only L1,L2,L3,K2-L1 2>&1 | grep -v "amdgpu.ids\|MIOpen" > $O/kbench_corr.txt
 timeout 300 python tools/kbench.py --only tail 2>&1 | grep -v "amdgpu.ids\|MIOpen" >> $O/kbench_corr.txt
+timeout 300 python tools/corr_small_maps.py 2>&1 | grep -v "amdgpu.ids" > $O/corr_small_maps.txt
 timeout 300 python tools/attn_bench.py 2>&1 | grep -v "amdgpu.ids" > $O/attn_bench.txt
 for t in gemm_fc1_s3:gemm_nt gemm_fc2_s3:gemm_nt conv_bottleneck:gemm_nt attn_fwd_s3:attn_fwd wgrad_s3:gemm_tn; do
   echo "== ${t%%:*}"; bash tools/pmc_mfma.sh ${t%%:*} ${t##*:}; done > $O/pmc_mfma_kernels.txt 2>&1
