@@ -38,6 +38,37 @@ def test_local_correlation_is_repeatable_under_memory_load(B, C, H, W, reps):
     assert _repeat(lambda: correlation.local_correlation_layer(f2, f1), reps, noise) == 0
 
 
+@pytest.mark.parametrize("B,C,H,W,reps", [(2, 256, 32, 32, 300), (2, 512, 32, 32, 200), (2, 256, 64, 64, 200), (1, 128, 9, 12, 100)])
+def test_joined_channel_split_is_repeatable_under_memory_load(B, C, H, W, reps):
+    """Round 5: tiny maps in ONE launch -- the slices of a tile meet through global memory inside the launch (slab stores, agent-scope
+    release fence, ticket; the last workgroup's acquire fence, then plain loads; tickets put back to zero for the next launch).  A
+    hand-off that publishes the ticket before the slabs, or a ticket that is not back at zero, shows up as a launch that differs:
+    identical results for hundreds of back-to-back launches on one workspace, with a copy stream keeping the memory system busy."""
+    from refign_amd import correlation
+    dev = torch.device("cuda:0")
+    assert correlation._channel_splits(B, C, H, W) > 1 and (C // correlation._channel_splits(B, C, H, W)) % 32 == 0
+    g = torch.Generator().manual_seed(3)
+    f1 = torch.nn.functional.normalize(torch.relu(torch.randn(B, C, H, W, generator=g)), dim=1).to(dev)
+    f2 = torch.nn.functional.normalize(torch.relu(torch.randn(B, C, H, W, generator=g)), dim=1).to(dev)
+    noise = torch.empty(48 << 20, device=dev, dtype=torch.float32).normal_()
+    assert _repeat(lambda: correlation.local_correlation_layer(f2, f1), reps, noise) == 0
+
+
+@pytest.mark.parametrize("B,C,H,W,reps", [(2, 128, 270, 480, 30), (6, 128, 65, 68, 100), (1, 64, 33, 72, 100)])
+def test_correlation_backward_is_repeatable_under_memory_load(B, C, H, W, reps):
+    """Round 5: corr9_bwd_strip_kernel (double-buffered halo tiles, one barrier per chunk of 8 channels, the three wave groups' sums
+    exchanged through double-buffered LDS): both gradients identical, launch after launch."""
+    from refign_amd import correlation
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    f1 = torch.randn(B, C, H, W, generator=g).to(dev)
+    f2 = torch.randn(B, C, H, W, generator=g).to(dev)
+    go = torch.randn(B, 9, 9, H, W, generator=g).to(dev)
+    noise = torch.empty(48 << 20, device=dev, dtype=torch.float32).normal_()
+    args = (1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)
+    assert _repeat(lambda: torch.cat([t.flatten() for t in correlation.backward(f1, f2, go, *args)]), reps, noise) == 0
+
+
 @pytest.mark.parametrize("M,N,K,res", [(81600, 320, 320, True), (81600, 320, 1280, True), (20400, 512, 2048, False),
                                        (8160, 1280, 320, False)])
 def test_gemm_nt_is_repeatable_under_memory_load(M, N, K, res):
