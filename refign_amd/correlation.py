@@ -163,8 +163,7 @@ def _split_workspace(nbytes, dev):
     key = (dev, torch.cuda.current_stream(dev).cuda_stream, nbytes)
     ws = _SPLIT_WS.get(key)
     if ws is None:
-        if len(_SPLIT_WS) >= 64:
-            _SPLIT_WS.clear()
+        # never evicted: a captured hipGraph may hold this address (a few MB per distinct (stream, level size))
         ws = _SPLIT_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     return ws
 
