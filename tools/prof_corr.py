@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/prof_corr.py -- run ONE kernel of the hot path a few times (for rocprofv3 --kernel-trace / --pmc).
-usage: prof_corr.py [corr_l1|corr_l1_fused|corr_l1_warp|corr_l2_fused|uncert_l1|tail|refine] [reps]"""
+usage: prof_corr.py [corr_l1|corr_l1_fused|corr_l1_warp|corr_l1_bwd|corr_l2_fused|uncert_l1|tail|refine] [reps]"""
 import os
 import sys
 
@@ -34,6 +34,9 @@ if what == "uncert_l1":
     def fn():
         with torch.no_grad():
             return um.patch_statistics(corr)
+elif what == "corr_l1_bwd":
+    go = torch.randn(b, 9, 9, 270, 480, generator=g).to(dev)
+    fn = lambda: correlation.backward(f1, f2, go, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)  # noqa: E731
 elif what in ("corr_l1", "corr_l2"):
     fn = lambda: correlation.forward(f1, f2, 1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)  # noqa: E731
 elif what.endswith("_fused"):
