@@ -27,6 +27,9 @@ extern "C" {
 #define RFN_ELAUNCH (-2)   /* hipLaunchKernel / runtime error, see rfn_last_error() */
 #define RFN_ENOTSUP (-3)   /* valid in the reference but not built here (documented per function) */
 
+/* 2: rfn_global_corr_layer_f32 takes a workspace; rfn_dacs_mix_jitter accepts one half of the mix.
+ * 3: rfn_local_corr_layer_split_f32's workspace carries tickets (rfn_local_corr_layer_split_workspace_bytes; zero before first use);
+ *    the transpose-cast table holds rfn_multi_transpose_tile() x rfn_multi_transpose_tile() tiles (64; 32 before). */
 #define RFN_ABI_VERSION 3
 
 typedef void* rfn_stream_t; /* hipStream_t */
