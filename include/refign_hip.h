@@ -271,6 +271,11 @@ int rfn_layernorm_bwd_add(const void* x, const void* grad_y, const void* add, co
 int rfn_uncertainty9_weights_len(void);
 int rfn_uncertainty9_frontend_f32(const float* corr, const float* weights, float* out, int B, int H, int W,
                                   rfn_stream_t stream);
+/* The same with the two matrix layers (32 -> 32, 32 -> 16) on the f16 matrix pipe, fp32 accumulation, f16 activations in between --
+ * the precision the reference's AMP recipe runs these convolutions in (autocast; modules.py:529-551 forces nothing).  Same packed
+ * fp32 weights, fp32 input and result.  (ABI 3.) */
+int rfn_uncertainty9_frontend_f16mm(const float* corr, const float* weights, float* out, int B, int H, int W,
+                                    rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * out[i] (+)= sum_{s < S} x[s*n + i]: sum over the leading dimension of a row-major (S, n) matrix into float32.

@@ -117,6 +117,7 @@ SIGNATURES = {
                         + [c_int] * 5 + [c_float] * 5 + [c_void_p]),
     "rfn_uncertainty9_weights_len": (c_int, []),
     "rfn_uncertainty9_frontend_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
+    "rfn_uncertainty9_frontend_f16mm": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
 }
 
 

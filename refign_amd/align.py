@@ -148,7 +148,8 @@ class UncertaintyModule(nn.Module):
         if (s == 9 and corr.is_cuda and not self.training and not torch.is_grad_enabled()
                 and self.conv_0.use_norm and corr.dtype == torch.float32
                 and os.environ.get("RFN_UNCERT_FUSED", "1") != "0"):
-            return matching.uncertainty9_frontend(corr, self.packed_frontend_weights())
+            return matching.uncertainty9_frontend(corr, self.packed_frontend_weights(),
+                                                  half_matrix=align_compute_dtype() != torch.float32)
         if s == 9 and (self.training or torch.is_grad_enabled()):
             return self._patch_statistics_tiled(corr)
         x = corr.permute(0, 2, 3, 1).reshape(b * h * w, 1, s, s)

@@ -97,7 +97,7 @@ def l2_normalize_channels(x):
     return out
 
 
-def uncertainty9_frontend(corr, packed_weights):
+def uncertainty9_frontend(corr, packed_weights, half_matrix=False):
     """Front end of UncertaintyModule (search size 9, eval mode; models/modules.py:529-551): (B,81,H,W) correlation
     volume -> (B,6,H,W), the 9x9 -> 7x7 -> 5x5 -> 3x3 -> 1x1 micro-conv chain of every pixel in one HIP kernel.
     `packed_weights`: UncertaintyModule.packed_frontend_weights() (BatchNorm folded, layout in refign_hip.h)."""
@@ -111,7 +111,9 @@ def uncertainty9_frontend(corr, packed_weights):
     same_device(corr, w)
     out = torch.empty((B, 6, H, W), dtype=torch.float32, device=corr.device)
     with on_device(corr.device):
-        rc = lib.rfn_uncertainty9_frontend_f32(ptr(corr), ptr(w), ptr(out), B, H, W, current_stream(corr.device))
+        # half_matrix: the 32 -> 32 and 32 -> 16 layers on the f16 matrix pipe (the reference's AMP precision for these convolutions)
+        fn = lib.rfn_uncertainty9_frontend_f16mm if half_matrix else lib.rfn_uncertainty9_frontend_f32
+        rc = fn(ptr(corr), ptr(w), ptr(out), B, H, W, current_stream(corr.device))
     _lib.check(rc, "uncertainty9_frontend")
     return out
 

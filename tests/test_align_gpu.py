@@ -59,6 +59,31 @@ def test_uncertainty9_frontend_fused_vs_library_chain(dev, monkeypatch, B, H, W)
     np.testing.assert_allclose(fused.cpu().numpy(), chain.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(scale, 1.0))
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 5, 7), (2, 33, 20), (2, 64, 64)])
+@torch.no_grad()
+def test_uncertainty9_frontend_half_matrix_layers(dev, B, H, W):
+    """Round 5: under autocast (the timed mode) the 32 -> 32 and 32 -> 16 layers of the front end run on the f16 matrix pipe with
+    f16 activations in between -- what the reference's AMP recipe does with these convolutions.  Against the fp32 kernel on the
+    same weights: within fp16 rounding of O(1) activations through two layers (1e-2 of the output scale, mean error 10x lower);
+    without autocast the fp32 kernel is what runs (bit-identical to a direct call)."""
+    from refign_amd import align as A, matching
+    um = closed_form_fill(A.UncertaintyModule(1, search_size=9, feed_in_previous=True),
+                          "estimate_uncertainty_components2.").to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(B * 77 + W)
+    corr = torch.rand((B, 81, H, W), generator=g).to(dev)
+    corr = corr / corr.norm(dim=1, keepdim=True)                           # what the fused correlation layer hands over
+    full = um.patch_statistics(corr)
+    assert torch.equal(full, matching.uncertainty9_frontend(corr, um.packed_frontend_weights()))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        half = um.patch_statistics(corr)
+    assert torch.equal(half, matching.uncertainty9_frontend(corr, um.packed_frontend_weights(), half_matrix=True))
+    assert half.dtype == torch.float32 and not torch.equal(half, full)
+    scale = float(full.abs().max())
+    err = (half - full).abs()
+    print(f"\nuncertainty front end, f16 matrix layers vs fp32: max {float(err.max()):.2e}, mean {float(err.mean()):.2e}, scale {scale:.2e}")
+    assert float(err.max()) < 1e-2 * max(scale, 1.0) and float(err.mean()) < 1e-3 * max(scale, 1.0)
+
+
 def _pyramids(name, H, W):
     pyr = {
         "trg": [unit((1, 128, H // 4, W // 4), f"g5/{name}/t1"), unit((1, 256, H // 8, W // 8), f"g5/{name}/t2")],
