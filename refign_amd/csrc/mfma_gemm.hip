@@ -164,11 +164,51 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(const uint16_t* __rest
       wsrc[q] = (const unsigned char*)(W + (long)n * ldw) + 16 * dpiece;
     }
   };
+  // (round 5) C % 64 == 0, forward gather: the 8 pieces of a K-step are 64 channels of ONE tap, and a tap lasts C / 64 K-steps --
+  // the tap's source pointers (image bounds, row / column arithmetic: ~12 VALU per DMA piece, 4 VALU per MFMA on the 1024-channel
+  // bottleneck convolution) are computed when the tap changes and ADVANCED by 128 bytes per K-step in between.  Measured: the
+  // 40 x 135 x 240 x 1024 -> 256 bottleneck 6 520 -> 6 358 us (min 6 124 -> 5 966): the index arithmetic was mostly hidden under the
+  // LDS-DMA issue that paces this kernel (8 DMA instructions per wave and K-step against 32 MFMAs).
+  const bool fastc = GATHER && cg.transposed == 0 && (cg.C8 & 7) == 0;
+  int f_tap = 0, f_cb = 0;
+  const unsigned char* psrc[GATHER ? XI : 1];
+  auto tap_sources = [&]() {
+    if constexpr (GATHER) {
+      const unsigned ky = cg.KW == 1 ? (unsigned)f_tap : __umulhi((unsigned)f_tap, cg.kw_magic), kx = (unsigned)f_tap - ky * cg.KW;
+      const bool tap_ok = (int)ky < cg.KH;
+      const int dy = (int)ky * cg.dil, dx = (int)kx * cg.dil;
+#pragma unroll
+      for (int q = 0; q < XI; ++q) {
+        const int iy = iy0[q] + dy, ix = ix0[q] + dx;
+        const bool ok = tap_ok && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
+        psrc[q] = ok ? xsrc[q] + (long)(iy * cg.W + ix) * cg.C * 2 + 16 * dpiece : nullptr;
+      }
+    }
+  };
   auto issue = [&](int kt, int buf) {
     unsigned char* xs = smem + buf * STAGE;
     unsigned char* ws = xs + XBYTES;
     if (ablate & 1) return;
     if constexpr (GATHER) {
+      if (fastc) {
+        if (kt == 0) {
+          f_tap = 0;
+          f_cb = 0;
+          tap_sources();
+        }
+#pragma unroll
+        for (int q = 0; q < XI; ++q)
+          lds_dma16(psrc[q] != nullptr ? psrc[q] + (long)f_cb * 16 : (const unsigned char*)cg.zero, xs + 1024 * (NW * q + wave));
+        f_cb += 8;
+        if (f_cb == cg.C8) {
+          f_cb = 0;
+          ++f_tap;
+          tap_sources();
+        }
+#pragma unroll
+        for (int q = 0; q < WI; ++q) lds_dma16(wsrc[q] + (long)kt * ROWB, ws + 1024 * (NW * q + wave));
+        return;
+      }
       const unsigned j = (unsigned)(kt * PPR + dpiece);                     // 16-byte piece index along k
       const unsigned tap = cg.C8 == 1 ? j : __umulhi(j, cg.c8_magic), c8 = j - tap * cg.C8;
       const unsigned ky = cg.KW == 1 ? tap : __umulhi(tap, cg.kw_magic), kx = tap - ky * cg.KW;
