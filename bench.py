@@ -666,6 +666,11 @@ def main():
                 "traffic": pmc_traffic() if (rh, rw, rb) == (270, 480, 2) else None, "avg_launch_us": round(us, 2),
                 "avg_launch_us_back_to_back": round(us_b2b, 2),
                 "frac_back_to_back": round(wl.roofline_bytes() / (us_b2b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                # the same launch against the fp32 vector peak: the kernel is a dot per pixel pair (2 x 81 x C flop per pixel, no matrix
+                # pipe) and its packed FMAs, not its bytes, are what it issues most of the launch
+                "second_bound": {"bound": "fp32 valu", "achieved": round(2.0 * 81 * rc * rb * rh * rw / (us * 1e-6) / 1e12, 1),
+                                 "peak": 157.3, "unit": "TFLOP/s",
+                                 "frac": round(2.0 * 81 * rc * rb * rh * rw / (us * 1e-6) / 1e12 / 157.3, 4)},
                 "algorithmic_bytes_per_launch": wl.roofline_bytes(), "rocprofv3_in_step": rocprof_in_step_us() if (rh, rw, rb) == (270, 480, 2) else None}
 
     cpu = None
