@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--pairs-per-gpu", type=int, default=2)
+    ap.add_argument("--adapt-to-ref", action="store_true",
+                    help="adapt_to_ref: True as refign_hrda_star.yaml:92 writes it: a coin per step, on heads the teacher sees "
+                         "the reference image alone (no align, no refine).  Default off = every step aligns and refines (the "
+                         "more expensive side of the coin, every step)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", default="full", choices=["full", "small"],
@@ -213,7 +217,7 @@ class RefignStep:
     # constant caches, the second one captures the hipGraphs of the gradient-free half (refign_amd/graphs.py)
     prime_steps = 2
 
-    def __init__(self, dev, b, seed, H=1080, W=1920, precision="bf16", sync_bn=True):
+    def __init__(self, dev, b, seed, H=1080, W=1920, precision="bf16", sync_bn=True, adapt_to_ref=False):
         import copy
         import random
         import numpy as np
@@ -226,8 +230,9 @@ class RefignStep:
             cfg["model"]["init_args"].pop("hrda_scale_attention")
         # offline: no checkpoints -> random init of the same architectures; pin the Refign branch
         over = {"backbone.init_args.pretrained": None, "alignment_backbone.init_args.pretrained": None,
-                "alignment_head.init_args.pretrained": None, "adapt_to_ref": False}
+                "alignment_head.init_args.pretrained": None, "adapt_to_ref": bool(adapt_to_ref)}
         self.model = config.build_model(cfg, over).to(dev).train()
+        self.adapt_to_ref = bool(adapt_to_ref)
         self.trainer = Trainer(self.model, sync_batchnorm=sync_bn)
         self.model.teacher_f8 = precision == "k5"                   # K5: EMA-teacher backbone on the fp8 kernels
         self.precision = precision = "bf16" if precision == "k5" else precision
@@ -603,7 +608,8 @@ def main():
         if args.workload == AlignRefineKernels.name:
             wl = AlignRefineKernels(dev, args.pairs_per_gpu, seed=1234 + rank)
         else:
-            wl = WORKLOADS[args.workload](dev, args.pairs_per_gpu, 1234 + rank, args.height, args.width, args.precision)
+            kw = {"adapt_to_ref": True} if args.adapt_to_ref else {}
+            wl = WORKLOADS[args.workload](dev, args.pairs_per_gpu, 1234 + rank, args.height, args.width, args.precision, **kw)
 
     def sync():
         if dev.type == "cuda":
@@ -622,6 +628,16 @@ def main():
         if world > 1:                                  # (N > 1 only: keeps the guard's clock honest, off the N=1 path)
             sync()
         tick(f"prime step {i}")
+    if getattr(wl, "adapt_to_ref", False):
+        # both sides of the coin have to be past their eager warm-up calls and captured before the timed region (untimed
+        # set-up like the prime steps; the coin is the step's own draw from python's `random`, seeded per rank above)
+        for i in range(24):
+            tb = wl.model._graphs["teacher_backbone"].states.values()
+            if len(tb) == 2 and all(s_["graph"] is not None or s_["failed"] for s_ in tb) and \
+                    all(s_["graph"] is not None or s_["failed"] for s_ in wl.model._graphs["tail_refine"].states.values()):
+                break
+            wl.step()
+            tick(f"adapt_to_ref prime step {i}")
     for i in range(args.warmup):
         wl.step()
         if world > 1:
@@ -629,11 +645,13 @@ def main():
         tick(f"warm-up step {i}")
     barrier()
     tick("timed region")
+    a0 = getattr(getattr(wl, "model", None), "_adapted_to_ref_steps", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
     barrier()
     dt = time.perf_counter() - t0
+    adapted_in_timed = getattr(getattr(wl, "model", None), "_adapted_to_ref_steps", 0) - a0
     tick("after the timed region")
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -730,6 +748,12 @@ def main():
                                       f"dp{world}: pairs sharded, gradient-free, no collective in the timed region"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if step_kind:
+            line["config"]["adapt_to_ref"] = (
+                f"True (refign_hrda_star.yaml:92): {adapted_in_timed} of the {args.steps} timed steps fell on heads (teacher on the "
+                f"reference image alone, no align / refine), {args.steps - adapted_in_timed} aligned and refined"
+                if getattr(wl, "adapt_to_ref", False) else
+                "False: every step aligns and refines (the YAML's coin would skip that on half of the steps)")
         if step_kind and (world > 1 or "RANK" in os.environ):
             from refign_amd import bn as _bn
             tr = getattr(wl, "trainer", None)
@@ -764,8 +788,8 @@ def main():
         if isinstance(wl, RefignStep) and type(wl) is not RefignAlignRefine:
             line["config"]["next_batch_prefetch"] = (
                 "frozen ImageNet-encoder features of the next step's source images and the frozen matcher's flow of the next "
-                "(reference, target) pair computed during this step's mixed pass (same work per step, same numbers; "
-                "RFN_PREFETCH_NEXT=0 computes both inside the step, RFN_ALIGN_PREFETCH=0 the flow only)") if PIPELINE_NEXT_BATCH \
+                "(reference, target) pair computed during this step's mixed pass (same work per step, same numbers: "
+                "tests/test_step_gpu.py::test_prefetched_imnet_features_give_the_same_trajectory)") if PIPELINE_NEXT_BATCH \
                 else "off"
         print(json.dumps(line))
 

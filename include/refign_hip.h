@@ -435,6 +435,35 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
                      int nkpad, int blocks_per_chunk, float scale, int dtype, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * The same attention core for FLOAT32 tensors (the fp32 parity mode; mix_transformer.py:150-160 materialises the score
+ * matrix in fp32): every product on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), softmax in fp32, one launch per pass.
+ * Q (B, Nq, heads*64) and KV (B, Nkv, 2, heads, 64) are used in place through their strides (in floats, multiples of 4;
+ * 16-byte aligned bases); lse2 / delta: fp32 [B*heads][nqpad].
+ *   rfn_attn32_fwd   O and lse2 (base-2 log-sum-exp of the scaled scores).
+ *   rfn_attn32_bwd   dQ, dKV and delta = rowsum(dO o O), two launches.  dK / dV: the query dimension is split into
+ *                    `query_chunks` chunks per 128-key tile whose partial sums are ADDED with fp32 atomics -- dKV must be
+ *                    ZERO on entry when query_chunks > 1 (one chunk: plain stores, any contents).
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_attn32_fwd(const float* Q, long q_batch_stride, long q_row_stride, const float* KV, long kv_batch_stride,
+                   long kv_row_stride, float* O, long o_batch_stride, long o_row_stride, float* lse2, int B, int heads, int Nq,
+                   int Nkv, int nqpad, float scale, rfn_stream_t stream);
+int rfn_attn32_bwd(const float* Q, long q_batch_stride, long q_row_stride, const float* KV, long kv_batch_stride,
+                   long kv_row_stride, const float* dO, const float* O, long o_batch_stride, long o_row_stride,
+                   const float* lse2, float* delta, float* dQ, long dq_batch_stride, long dq_row_stride, float* dKV,
+                   long dkv_batch_stride, long dkv_row_stride, int B, int heads, int Nq, int Nkv, int nqpad, int query_chunks,
+                   float scale, rfn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Operand preparation of the split-bf16 products (an fp32 product as three bf16 MFMA products, refign_amd/split32.py):
+ * x (rows, K) fp32 with row stride x_row_stride -> hi = bf16(x), lo = bf16(x - hi), written as three terms
+ *   term i, row r, column k -> out[i * term_stride + r * out_row_stride + k]  (bf16; columns K .. Kp-1 zero; Kp % 4 == 0)
+ * order 0: (hi, hi, lo) -- activations / gradients; order 1: (hi, lo, hi) -- weights.  term_stride = Kp with
+ * out_row_stride = 3 Kp puts the terms side by side along the reduction index; term_stride = rows * out_row_stride stacks them.
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_split3_bf16(const float* x, long x_row_stride, void* out, long out_row_stride, long term_stride, long rows, int K,
+                    int Kp, int order, rfn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ ReLU) on channels-last 16-bit tensors viewed as (T = B*H*W, C): the norm + activation of
  * the decode heads' ConvBNReLU blocks (models/modules.py:16-56), which use BATCH statistics in the student and in the EMA
  * teacher.  dtype 1 = bf16, 2 = f16; statistics, affine parameters and running buffers fp32; C % 8 == 0.

@@ -149,7 +149,7 @@ class UncertaintyModule(nn.Module):
                 and self.conv_0.use_norm and corr.dtype == torch.float32
                 and os.environ.get("RFN_UNCERT_FUSED", "1") != "0"):
             return matching.uncertainty9_frontend(corr, self.packed_frontend_weights(),
-                                                  half_matrix=align_compute_dtype() != torch.float32)
+                                                  half_matrix=_HEAD_IN_TIMED_MAP[0] or align_compute_dtype() != torch.float32)
         if s == 9 and (self.training or torch.is_grad_enabled()):
             return self._patch_statistics_tiled(corr)
         x = corr.permute(0, 2, 3, 1).reshape(b * h * w, 1, s, s)
@@ -518,8 +518,35 @@ def align(alignment_backbone, alignment_head, logits_ref, images_ref, images_trg
     dt = align_compute_dtype()
     with torch.autocast("cuda", enabled=dt != torch.float32, dtype=dt if dt != torch.float32 else None):
         pyr = extract_pyramids(alignment_backbone, images_ref.float(), images_trg.float())
-        flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
+        flow_q, logvar_q = run_head(alignment_head, pyr, (h, w))[-1]
         return matching.align_tail(logits_ref, flow_q.float(), logvar_q.float())
+
+
+# The timed precision map of the matcher (round 6).  Inside the step's 16-bit autocast region the VGG-16 pyramid runs in fp16
+# (the reference's own AMP dtype) and is accurate enough: with the head in fp32 the warped logits at 1080 x 1920 sit within 8e-5 of
+# the reference's fp32 CPU path.  The HEAD is where fp16 loses the north star's 1e-3: its decoders take the flow itself as input
+# channels -- hundreds of pixels at full resolution, where fp16 resolves 0.125-0.25 px -- and carry activations of that
+# magnitude through 14 layers; input, weight and output rounding contribute alike (profiles/r06_align_precision_layers.txt:
+# flow error 0.07 / 0.11 / 0.11 / 0.19 px after levels 4 / 3 / 2 / 1, warped logits 5.6e-3).  So the head's convolutions run as
+# split-bf16 products (three MFMA products per convolution, fp32 activations between the layers; refign_amd/split32.py) --
+# 2^-16 relative instead of 2^-11 -- while the per-pixel 9 x 9 micro-image front end of the uncertainty module keeps its f16
+# matrix layers (inputs in [0, 1], fp32 elsewhere; 5e-4).  HEAD_SPLIT = False: the head in the autocast dtype (round 5).
+HEAD_SPLIT = True
+_HEAD_IN_TIMED_MAP = [False]
+
+
+def run_head(alignment_head, pyr, size):
+    """alignment_head(*pyr, size) under the precision map above."""
+    dt = align_compute_dtype()
+    if HEAD_SPLIT and dt != torch.float32 and pyr[0][0].is_cuda and not torch.is_grad_enabled():
+        was = _HEAD_IN_TIMED_MAP[0]
+        _HEAD_IN_TIMED_MAP[0] = True
+        try:
+            with torch.autocast("cuda", enabled=False):
+                return alignment_head(*[[f.float() for f in p] for p in pyr], size)
+        finally:
+            _HEAD_IN_TIMED_MAP[0] = was
+    return alignment_head(*pyr, size)
 
 
 def align_flow(alignment_backbone, alignment_head, images_ref, images_trg):
@@ -530,7 +557,7 @@ def align_flow(alignment_backbone, alignment_head, images_ref, images_trg):
     dt = align_compute_dtype()
     with torch.autocast("cuda", enabled=dt != torch.float32, dtype=dt if dt != torch.float32 else None):
         pyr = extract_pyramids(alignment_backbone, images_ref.float(), images_trg.float())
-        flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
+        flow_q, logvar_q = run_head(alignment_head, pyr, (h, w))[-1]
     return flow_q.float(), logvar_q.float()
 
 
@@ -554,7 +581,7 @@ def alignment_forward(alignment_backbone, alignment_head, images_i, images_j):
     """AlignmentModel.forward (alignment_model.py:55-79): flow i->j at full resolution and 1 - P_R."""
     h, w = images_i.shape[-2:]
     pyr = extract_pyramids(alignment_backbone, images_j, images_i)
-    flow_q, logvar_q = alignment_head(*pyr, (h, w))[-1]
+    flow_q, logvar_q = run_head(alignment_head, pyr, (h, w))[-1]
     flow = _up(flow_q, (h, w))
     uncert = _up(logvar_q, (h, w))
     return flow, 1.0 - matching.estimate_probability_of_confidence_interval_of_mixture_density(uncert, R=1.0)

@@ -112,7 +112,7 @@ def _split_ok(*ts):
 # Patch rows in (c, ry, rx) order -- the layout of the convolution weight itself (csrc/upcat.hip patchify_cmajor_kernel):
 # the patch GEMM uses the plain 16-bit copy of the parameter, the input-gradient GEMM its plain transpose, and the weight
 # gradient is added straight into the parameter's .grad by the TN kernel (bias gradient in the same launch) instead of
-# partial sums + a reduction + a permuted add + two bias-reduction launches.  RFN_PATCH_CMAJOR=0: (ry, rx, c) rows.
+# partial sums + a reduction + a permuted add + two bias-reduction launches.  (Module constant; False: (ry, rx, c) rows.)
 _PATCH_CMAJOR = True
 
 

@@ -135,8 +135,9 @@ class GraphedStep:
     rank whose capture throws runs the same collectives eagerly, so the ranks stay matched either way.  Under data
     parallelism the capture is ON when the exchanges are RCCL calls of our own on the pass's stream (refign_amd/rccl.py:
     plain kernel nodes, and the mixed pass runs next to the source pass on a communicator of its own -- rehearsal
-    192.3 ms/step) and OFF when they go through torch's process group (RFN_RCCL_DIRECT=0: a captured collective is then
-    a cross-stream branch of the graph; 216.4 ms graphed, 214-231 ms eager, no gain).  RFN_GRAPH_DDP=0 / 1 overrides.
+    192.3 ms/step: RFN_DDP_MODE=direct / direct3) and OFF when they go through torch's process group (RFN_DDP_MODE=torch, the
+    default for N > 1: a captured collective is then a cross-stream branch of the graph; 216.4 ms graphed, 214-231 ms eager,
+    no gain) -- see usable().
     The first `warmup` calls run eagerly (they create every lazily cached constant / derived tensor); a capture that
     throws leaves the pass eager for good, like GraphedNoGrad."""
 
@@ -248,9 +249,14 @@ class GraphedSplitStep(GraphedStep):
     Every call of forward() must be followed by exactly one backward() before the next forward().  Warm-up calls and a
     failed capture run both functions eagerly, like GraphedStep."""
 
-    def __init__(self, fwd_fn, bwd_fn, name, **kw):
+    def __init__(self, fwd_fn, bwd_fn, name, forward_state=None, agree=None, **kw):
+        """`forward_state()` -> the tensors the forward updates in place as a SIDE EFFECT (BatchNorm running statistics and
+        batch counters): kept as they are across the one eager re-run of the forward that a failed backward capture needs.
+        `agree(failed) -> failed on ANY rank` (data parallelism, called once, on the step the backward is captured): every
+        rank then takes the same way out, so the statistics exchanges of the re-run forward are issued on all ranks or on none."""
         super().__init__(None, name, **kw)
         self.fwd_fn, self.bwd_fn = fwd_fn, bwd_fn
+        self.forward_state, self.agree = forward_state, agree
         self._held = None            # (state, held, fwd inputs) of the forward that awaits its backward
 
     def reset(self):
@@ -333,14 +339,31 @@ class GraphedSplitStep(GraphedStep):
                 st["graph_bwd"], st["inputs_bwd"], st["outputs"] = g, inputs, outputs
                 st["held"] = None                 # the autograd graph has been consumed; its buffers live in the pool
                 st["extra"] = self.after_capture() if self.after_capture is not None else None
+                failure = None
             except Exception as e:
-                # the forward of this step has only run as a replay whose autograd graph the failed capture may have consumed:
-                # run the whole pass again eagerly (its forward kernels twice in this one step), eager for good afterwards
-                st["failed"], st["graph"], st["held"] = True, None, None
-                warnings.warn(f"refign_amd.graphs: capture of '{self.name}' (backward) failed ({type(e).__name__}: {e}); "
+                failure = e
+            failed = failure is not None
+            if self.agree is not None:
+                failed = bool(self.agree(failed))        # one tiny collective, on this step only: all ranks go the same way
+            if failed:
+                # The forward of this step has only run as a replay, and the failed capture may have consumed its autograd graph:
+                # the pass is run again eagerly, and is eager for good afterwards.  The replayed forward has ALREADY made the
+                # forward's in-place side effects (BatchNorm running statistics, num_batches_tracked): the re-run's second
+                # update is undone from a snapshot, so the step leaves the state a single forward leaves.  Its statistics
+                # exchanges (data parallelism) are issued a second time by EVERY rank (agree), never by one rank alone.  The
+                # device generator advances twice (drop-path masks of the re-run differ from the replay's: the re-run's
+                # forward and backward are consistent with each other, which is what the gradients need).
+                st["failed"], st["graph"], st["held"], st["graph_bwd"] = True, None, None, None
+                warnings.warn(f"refign_amd.graphs: capture of '{self.name}' (backward) failed "
+                              f"({type(failure).__name__ if failure is not None else 'on another rank'}: {failure}); "
                               f"running it eagerly")
                 torch.cuda.synchronize()
-                return self.bwd_fn(self.fwd_fn(*fwd_tensors), *tensors)
+                keep = [(t, t.clone()) for t in (self.forward_state() if self.forward_state is not None else [])]
+                out = self.bwd_fn(self.fwd_fn(*fwd_tensors), *tensors)
+                with torch.no_grad():                    # (after the backward: autograd has saved the running buffers)
+                    for t, saved in keep:
+                        t.copy_(saved)
+                return out
         for s, t in zip(st["inputs_bwd"], tensors):
             if s.data_ptr() != t.data_ptr():
                 s.copy_(t)

@@ -162,7 +162,7 @@ class ConvBNReLU(nn.Module):
 
     def _dw_stats_ok(self, x, cd):
         """depthwise 3x3 -> BatchNorm(train): the convolution kernel leaves the batch statistics of its result behind
-        (csrc/dwconv.hip STATS), the BatchNorm skips its statistics pass.  RFN_DW_BN_STATS=0: two passes, as before."""
+        (csrc/dwconv.hip STATS), the BatchNorm skips its statistics pass.  (_DW_BN_STATS = False: two passes.)"""
         c = self.conv
         return (_DW_BN_STATS and x.is_cuda and x.dtype == torch.bfloat16 and cd == torch.bfloat16
                 and c.groups == c.in_channels == c.out_channels and c.kernel_size == (3, 3) and c.stride == (1, 1)
@@ -203,6 +203,16 @@ class ConvBNReLU(nn.Module):
             y = conv2d_mfma(x, w, b, c.stride, c.padding, c.dilation, act=self.act, dtype=compute_dtype(x))
             if y is not None:
                 return y
+        if x.is_cuda and c.groups == 1 and not torch.is_grad_enabled() and (not self.use_norm or not self.training) \
+                and self.act_slope in (0.0, LEAKY_SLOPE) and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda"):
+            # the same block on fp32 tensors (parity mode; the matcher's head inside the timed step, align.HEAD_SPLIT): split-bf16
+            # products, folded norm, bias and activation in the epilogue of the one launch
+            from . import split32
+            if split32.usable(x):
+                w, b = self.folded() if self.use_norm else (c.weight, c.bias)
+                y = split32.conv2d(x, w, b, c.stride, c.padding, c.dilation, act={None: 0, 'relu': 1, 'leaky': 3}[self.act])
+                if y is not None:
+                    return y
         if self.use_norm and not self.training and not torch.is_grad_enabled():
             x = self._conv2d(x, *self.folded())
         else:

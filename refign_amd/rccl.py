@@ -12,8 +12,8 @@ kernel node: the captured pass stays a linear graph.
 calls ncclCommInitRank.  One DirectComm per stream that may run collectives concurrently (same rule as everywhere: two
 streams must not issue collectives of one communicator in a rank-dependent order).
 
-ON under data parallelism with the RCCL backend (RFN_RCCL_DIRECT=0: every exchange through torch's process group, and
-then eager student passes).  It could only be run with a 1-rank communicator on the one-GPU development boxes
+Used under data parallelism with RFN_DDP_MODE=direct / direct3 (bn.ddp_mode; the default `torch` sends every exchange
+through torch's process group and keeps the student passes eager).  It could only be run with a 1-rank communicator on the one-GPU development boxes
 (tests/test_syncbn_gpu.py; RFN_DDP_REHEARSAL): 192.3 ms/step for one rank of N with graphed student passes, against
 216.4 ms with the same graphs over torch's process group and 214-231 ms with the eager student
 (profiles/r02_ddp_rehearsal.txt).

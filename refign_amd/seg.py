@@ -121,7 +121,7 @@ class Mlp(nn.Module):
                 # the activation + its pre-activation; fc2's input-gradient GEMM applies gelu' in its epilogue instead of a
                 # gelu_backward pass over the 4C-wide hidden tensor (test_mix_ffn_gelu_backward_in_the_fc2_dgrad_epilogue).
                 # Neutral on the step in rounds 2-3 (182.4 / 183.0 vs 182.4 / 182.5 ms); on the round-4 kernels -0.5 ms alone and
-                # -1.5 ms together with RFN_BN_WGS=1024 and RFN_GEMM_NT_MIN_TILES=2000 (three alternating runs each,
+                # -1.5 ms together with 1 024 BatchNorm workgroups and the 2 000-tile GEMM threshold, both constants now (three alternating runs each,
                 # profiles/r04_knob_ab.txt): on since the end of round 4.  RFN_FUSED_GELU_BWD=0: the separate pass.
                 a, z = dwconv3x3_gelu_tokens(x, dw.weight, dw.bias, H, W, with_z=True)
                 if res is not None:
@@ -136,13 +136,13 @@ class Mlp(nn.Module):
         return y if res is None else _residual(res, y, rowscale)
 
 
-_SDPA_BACKEND = None          # (round 2's RFN_SDPA_BACKEND A/B knob is gone: attention never goes to the fused-SDPA library
-#                               on 16-bit or fp32 HIP tensors any more; the branch below is what CPU tensors take)
+_SDPA_BACKEND = None          # (attention never goes to the fused-SDPA library on 16-bit or fp32 HIP tensors; the branch below is
+#                               what CPU tensors take -- checkpoint / config tests on the host)
 _FUSED_UPCAT = True       # decode heads: up-sampling + concat in one kernel
 
 
 def _fused_upcat_here():
-    """gradient-free passes always; under autograd with the gather backward kernel (RFN_FUSED_UPCAT_GRAD=0: the unfused
+    """gradient-free passes always; under autograd with the gather backward kernel (_FUSED_UPCAT = False: the unfused
     graph -- the library's bilinear backward on channel slices of the fused gradient was 34 ms/step slower than that)"""
     return _FUSED_UPCAT
 _SR_AS_LINEAR = True     # spatial-reduction conv as a Linear over patches
@@ -181,10 +181,8 @@ class Attention(nn.Module):
         o = mfma.attention(q, kv, h, self.scale) if (d == 64 and p == 0.0 and _SDPA_BACKEND is None) else None
         if o is None and q.is_cuda and q.dtype == torch.float32 and p == 0.0 and _SDPA_BACKEND is None:
             from . import split32
-            if split32.usable(q, kv):                  # fp32 parity mode: explicit products on the matrix-core kernels
-                kk, vv = kv.view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4).unbind(0)
-                o = split32.attention(q.view(B, N, h, d).transpose(1, 2), kk, vv, self.scale)
-                o = o.transpose(1, 2).reshape(B, N, C)
+            if split32.usable(q, kv) and d == 64:      # fp32 parity mode: the fp32 matrix-pipe attention kernel (csrc/attn32.hip)
+                o = split32.attention(q, kv, h, self.scale)
         if o is None:
             mfma.note_library("sdpa", q, kv)
             q = q.view(B, N, h, d).transpose(1, 2)                           # (B,h,N,d)
@@ -193,7 +191,7 @@ class Attention(nn.Module):
             k, v = kv.view(B, -1, 2, h, d).permute(2, 0, 3, 1, 4).unbind(0)  # (B,h,Nkv,d) each
             if _SDPA_BACKEND is None:
                 o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
-            else:                                      # measurement knob: RFN_SDPA_BACKEND=flash|efficient|math
+            else:                                      # (module constant: a torch.nn.attention.SDPBackend)
                 with torch.nn.attention.sdpa_kernel([_SDPA_BACKEND]):
                     o = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
             o = o.transpose(1, 2).reshape(B, N, C)
@@ -500,7 +498,7 @@ class ASPPWrapper(nn.Module):
                 cat = torch.empty((B, H, W, sum(ch)), dtype=compute_dtype(x), device=x.device)
                 # round 4: the three dilated depthwise branches (6 / 12 / 18 = g, 2 g, 3 g) of the same input from ONE statistics
                 # pass and ONE convolution + BatchNorm + ReLU pass over it (csrc/dwconv.hip dwconv3x3_tri_kernel) instead of
-                # three of each; RFN_ASPP_TRI=0: branch by branch
+                # three of each
                 dw_out = {}
                 sep = [m for m in mods if m.depthwise_separable]
                 if _ASPP_TRI and len(sep) == 3 and compute_dtype(x) == torch.bfloat16:

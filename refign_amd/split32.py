@@ -10,8 +10,8 @@ along the reduction index:
     weight gradient                        [gh ; gh ; gl]^T . [xh ; xl ; xh]      (rows T -> 3T; conv: batch -> 3B)
 on csrc/mfma_gemm.hip's kernels with an fp32-result epilogue (rfn_gemm_nt_o32 / rfn_conv2d_nhwc_o32; the weight-gradient
 kernel's result is fp32 anyway).  The dropped lo.lo' term and the second rounding leave ~2^-16 relative error per product
-(fp32: 2^-24): far inside the 1e-3 parity bar of the goldens.  A correctness path, not a fast one (the splits are torch
-element-wise ops, three times the MFMA work).  RFN_FP32_SPLIT=0 switches back to the library calls.
+(fp32: 2^-24): far inside the 1e-3 parity bar of the goldens.  Three times the MFMA work of the 16-bit path; the operand
+splits are one launch each (csrc/split3.hip), and attention runs on the fp32 matrix pipe itself (csrc/attn32.hip).
 """
 import os
 
@@ -33,15 +33,26 @@ def split2(x):
     return hi, (x - hi.float()).to(BF)
 
 
+_ORDER = {"hhl": 0, "hlh": 1}
+
+
+def split3(x2, order, Kp, stack=False):
+    """(rows, K) fp32, unit column stride -> the three bf16 terms `order` of its (hi, lo) split in ONE launch (csrc/split3.hip):
+    side by side as (rows, 3 Kp), or stacked as (3 rows, Kp); columns K .. Kp - 1 are zero."""
+    rows, K = x2.shape
+    if x2.stride(1) != 1 or x2.stride(0) < K:
+        x2 = x2.contiguous()
+    out = torch.empty((3 * rows, Kp) if stack else (rows, 3 * Kp), dtype=BF, device=x2.device)
+    with on_device(x2.device):
+        rc = _lib.load_library().rfn_split3_bf16(ptr(x2), x2.stride(0), ptr(out), out.stride(0), rows * Kp if stack else Kp,
+                                                 rows, K, Kp, _ORDER[order], current_stream(x2.device))
+    _lib.check(rc, "split3_bf16")
+    return out
+
+
 def _cat_k(x, order, pad_to=64):
     """(rows, K) fp32 -> (rows, 3 Kp) bf16 = terms `order` of (hi, lo) side by side, each zero-padded to Kp = roundup(K, pad_to)."""
-    hi, lo = split2(x)
-    K = x.shape[1]
-    Kp = -(-K // pad_to) * pad_to
-    out = torch.zeros((x.shape[0], 3 * Kp), dtype=BF, device=x.device)
-    for i, which in enumerate(order):
-        out[:, i * Kp:i * Kp + K] = hi if which == "h" else lo
-    return out
+    return split3(x, order, -(-x.shape[1] // pad_to) * pad_to)
 
 
 def gemm_nt(x, w, bias=None, res=None, act=0):
@@ -49,8 +60,8 @@ def gemm_nt(x, w, bias=None, res=None, act=0):
     M, K = x.shape
     N = w.shape[0]
     Np = -(-N // 8) * 8
-    x3 = _cat_k(x.contiguous(), "hhl")
-    w3 = _cat_k(w.contiguous(), "hlh")
+    x3 = _cat_k(x, "hhl")
+    w3 = _cat_k(w, "hlh")
     if Np != N:
         w3 = torch.cat([w3, w3.new_zeros((Np - N, w3.shape[1]))])
         if bias is not None:
@@ -69,16 +80,9 @@ def gemm_nt(x, w, bias=None, res=None, act=0):
 
 def gemm_tn(g, x):
     """fp32 (N, K) = g[T, N]^T @ x[T, K]: the three products stacked along T on the split-T weight-gradient kernel."""
-    gh, gl = split2(g.contiguous())
-    xh, xl = split2(x.contiguous())
     N, K = g.shape[1], x.shape[1]
-    Np, Kp = -(-N // 64) * 64, -(-K // 64) * 64
-    g3 = torch.zeros((3 * g.shape[0], Np), dtype=BF, device=g.device)
-    x3 = torch.zeros((3 * x.shape[0], Kp), dtype=BF, device=g.device)
-    T = g.shape[0]
-    for i, (a, b) in enumerate(((gh, xh), (gh, xl), (gl, xh))):
-        g3[i * T:(i + 1) * T, :N] = a
-        x3[i * T:(i + 1) * T, :K] = b
+    g3 = split3(g, "hhl", -(-N // 64) * 64, stack=True)              # [gh ; gh ; gl]
+    x3 = split3(x, "hlh", -(-K // 64) * 64, stack=True)              # [xh ; xl ; xh]
     part = mfma.gemm_tn(g3, x3)
     if part is None:
         raise RuntimeError("split32.gemm_tn: outside the weight-gradient kernel's domain")
@@ -118,21 +122,59 @@ def matmul_nt(a, b):
     return _LinearFn.apply(a, b, None)
 
 
-def attention(q, k, v, scale):
-    """softmax(scale q k^T) v for (B, h, N, d) fp32 tensors as explicit products on the matrix-core kernels + a torch softmax
-    (mix_transformer.py:150-160 materialises the same score matrix)."""
-    B, h, N, d = q.shape
-    if B * h > 128 and torch.cuda.is_current_stream_capturing():
-        # the EMA teacher's 40 views: ~10^5 nodes in one hipGraph (hipStreamEndCapture does not survive that, seen in round 5);
-        # refign_amd.graphs catches this and keeps the pass eager -- the parity mode is the correctness mode, not the fast one
-        raise RuntimeError(f"split32.attention: {B * h} per-head products under a stream capture; this pass runs eagerly")
-    out = []
-    for b in range(B):
-        for hd in range(h):
-            s = matmul_nt(q[b, hd].contiguous(), k[b, hd].contiguous()) * scale
-            p = torch.softmax(s, dim=-1)
-            out.append(matmul_nt(p, v[b, hd].t().contiguous()))
-    return torch.stack(out).view(B, h, N, d)
+class _Attn32Fn(torch.autograd.Function):
+    """softmax(scale q k^T) v per head of 64 on the fp32 matrix pipe (csrc/attn32.hip): one launch forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        B, N, C = q.shape
+        Nkv = kv.shape[1]
+        nqpad = -(-N // 128) * 128
+        o = torch.empty_like(q)
+        lse2 = torch.empty((B * heads, nqpad), dtype=torch.float32, device=q.device)
+        with on_device(q.device):
+            rc = _lib.load_library().rfn_attn32_fwd(ptr(q), q.stride(0), q.stride(1), ptr(kv), kv.stride(0), kv.stride(1), ptr(o),
+                                                    o.stride(0), o.stride(1), ptr(lse2), B, heads, N, Nkv, nqpad, float(scale),
+                                                    current_stream(q.device))
+        _lib.check(rc, "attn32_fwd")
+        if q.requires_grad or kv.requires_grad:
+            ctx.save_for_backward(q, kv, o, lse2)
+            ctx.heads, ctx.scale = heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse2 = ctx.saved_tensors
+        heads, scale = ctx.heads, ctx.scale
+        B, N, C = q.shape
+        Nkv = kv.shape[1]
+        do = do.float()
+        if do.stride() != o.stride():
+            do = do.contiguous()
+        dq = torch.empty_like(q)
+        delta = torch.empty_like(lse2)
+        # enough (key tile, query chunk) workgroups for 256 CUs; the chunks of a key tile add their partial sums with atomics
+        tiles = -(-Nkv // 128) * B * heads
+        chunks = max(1, min(-(-N // 32), -(-1024 // tiles)))
+        dkv = (torch.zeros_like if chunks > 1 else torch.empty_like)(kv)
+        with on_device(q.device):
+            rc = _lib.load_library().rfn_attn32_bwd(ptr(q), q.stride(0), q.stride(1), ptr(kv), kv.stride(0), kv.stride(1), ptr(do),
+                                                    ptr(o), o.stride(0), o.stride(1), ptr(lse2), ptr(delta), ptr(dq), dq.stride(0),
+                                                    dq.stride(1), ptr(dkv), dkv.stride(0), dkv.stride(1), B, heads, N, Nkv,
+                                                    lse2.shape[1], chunks, float(scale), current_stream(q.device))
+        _lib.check(rc, "attn32_bwd")
+        return dq, dkv, None, None
+
+
+def attention(q, kv, heads, scale):
+    """q: (B, N, heads * 64) fp32, kv: (B, Nkv, 2 * heads * 64) fp32 (K then V, each (heads, 64) per token: the layout of
+    mix_transformer.py:147-149) -> (B, N, heads * 64) = `(softmax(scale q k^T) v).transpose(1, 2).reshape(B, N, C)`; None
+    outside the kernel's domain (head dimension 64, contiguous rows)."""
+    B, N, C = q.shape
+    if C != heads * 64 or kv.shape[2] != 2 * C or q.stride(2) != 1 or kv.stride(2) != 1 or q.stride(1) % 4 or kv.stride(1) % 4 \
+            or q.stride(0) % 4 or kv.stride(0) % 4 or q.data_ptr() % 16 or kv.data_ptr() % 16:
+        return None
+    return _Attn32Fn.apply(q, kv, heads, scale)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -141,13 +183,13 @@ def attention(q, k, v, scale):
 def _nhwc3(x, order):
     """NCHW-shaped fp32 -> (B, H, W, 3 Cp) bf16: the split terms `order` concatenated along the channels (Cp = C to 8)."""
     xh = x.permute(0, 2, 3, 1)
-    hi, lo = split2(xh)
-    C = xh.shape[-1]
+    B, H, W, C = xh.shape
     Cp = -(-C // 8) * 8
-    out = torch.zeros(xh.shape[:3] + (3 * Cp,), dtype=BF, device=x.device)
-    for i, which in enumerate(order):
-        out[..., i * Cp:i * Cp + C] = hi if which == "h" else lo
-    return out, Cp
+    # rows = pixels; a channels-last tensor (also a channel slice of one) has uniformly strided rows: no copy
+    if not (xh.stride(3) == 1 and xh.stride(2) >= C and xh.stride(1) == W * xh.stride(2) and xh.stride(0) == H * xh.stride(1)):
+        xh = xh.contiguous()
+    rows = xh.as_strided((B * H * W, C), (xh.stride(2), 1))
+    return split3(rows, order, Cp).view(B, H, W, 3 * Cp), Cp
 
 
 def _w3(w, order):
@@ -162,6 +204,22 @@ def _w3(w, order):
     Np = -(-N // 8) * 8
     if Np != N:
         packed = torch.cat([packed, packed.new_zeros((Np - N, packed.shape[1]))])
+    return packed
+
+
+def _w3_frozen(w, order):
+    """_w3 with the result kept on the weight tensor for gradient-free calls (the frozen matcher's decoders run ~60 of these per
+    align()): valid while the tensor's version counter stands; never created inside a stream capture (a tensor allocated there
+    holds no data until the first replay)."""
+    if torch.is_grad_enabled():
+        return _w3(w, order)
+    key = (w._version, order)
+    ent = w.__dict__.get("_rfn_w3")
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    packed = _w3(w, order)
+    if not torch.cuda.is_current_stream_capturing():
+        w.__dict__["_rfn_w3"] = (key, packed)
     return packed
 
 
@@ -188,7 +246,7 @@ class _Conv2dFn(torch.autograd.Function):
         b = None if bias is None else torch.nn.functional.pad(bias, (0, Np - N)).contiguous()
         OH = (H + 2 * p - d * (KH - 1) - 1) // s + 1
         OW = (W + 2 * p - d * (KW - 1) - 1) // s + 1
-        y = _conv_o32(x3, _w3(weight, "hlh"), b, B, H, W, 3 * Cp, Np, KH, KW, s, p, d, act, False, (OH, OW))
+        y = _conv_o32(x3, _w3_frozen(weight, "hlh"), b, B, H, W, 3 * Cp, Np, KH, KW, s, p, d, act, False, (OH, OW))
         ctx.save_for_backward(x, weight)
         ctx.conf, ctx.has_bias = (s, p, d), bias is not None
         assert act == 0 or not any(ctx.needs_input_grad), "activation epilogue: gradient-free callers only"

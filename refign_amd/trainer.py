@@ -283,7 +283,7 @@ class Trainer:
                 group = dist.new_group()
                 for m in teacher:
                     m.process_group = group
-        # RCCL called directly for the statistics exchanges (refign_amd/rccl.py; RFN_RCCL_DIRECT=0: off): a collective of torch's
+        # RCCL called directly for the statistics exchanges (refign_amd/rccl.py; RFN_DDP_MODE=direct / direct3): a collective of torch's
         # process group hops to the group's own stream and back, and with three compute streams on four hardware queues
         # that stream shares a queue with a busy one -- in the 1-rank rehearsal the teacher branch takes 138 ms instead
         # of 116.  One communicator per stream that exchanges: the student's passes on the main stream, the teacher
@@ -313,7 +313,7 @@ class Trainer:
                     # profiles/r04_ddp_rehearsal.txt; the reduce itself is 343 MB: ~1-5 ms of link time on 8..2 GPUs).
                     # RFN_DDP_DIRECT_REDUCE=1: a communicator and a stream of its own (FlatGradBuffer.use_direct) -- the
                     # finished ranges then travel from inside the last backward pass, eagerly and inside the captured mixed
-                    # pass alike (meant for RFN_DDP_MIXED_COMM=0, passes in stream order).
+                    # pass alike (meant for RFN_DDP_MODE=direct: passes in stream order).
                     if os.environ.get("RFN_DDP_DIRECT_REDUCE", "0") == "1":
                         self._grad_comm = rccl.DirectComm(dev)
                         # (second buffer reduced on its own -- FlatGradBuffer.use_direct -- only on request: its in-graph

@@ -157,8 +157,7 @@ def _upsample_logits(logits, size):
     (segmentation_model.py:163, :169, :206, :220, :230, :239).  The decode heads hand over channels-last logits; up-sampled
     in that layout, the 19 x H x W result is channels-last too and everything after it wants NCHW (log_softmax / the
     refine kernels copy 315 MB per image pair at 1080x1920, 0.95 ms each).  Re-laying-out the LOW-resolution logits first
-    (20 MB) makes the up-sampled tensor NCHW-contiguous from the start: same arithmetic, no copy (RFN_LOGITS_NCHW=0: as
-    before)."""
+    (20 MB) makes the up-sampled tensor NCHW-contiguous from the start: same arithmetic, no copy."""
     if logits.is_cuda:
         logits = logits.contiguous()
     return F.interpolate(logits, size, mode='bilinear', align_corners=False)
@@ -279,15 +278,34 @@ class DomainAdaptationSegmentationModel(nn.Module):
             self._graphs["imnet_features"] = GraphedNoGrad(self._imnet_features, "ImageNet features")
         # forward + backward of the student passes (single process; eager under DDP: SyncBatchNorm collectives)
         shared = {}
-        self._graphs["source_pass"] = GraphedSplitStep(self._source_fwd, self._source_bwd, "student source pass", shared=shared)
+        self._graphs["source_pass"] = GraphedSplitStep(self._source_fwd, self._source_bwd, "student source pass", shared=shared,
+                                                       forward_state=self._student_forward_state, agree=self._any_rank)
         # the mixed pass may run NEXT TO the tail of the source pass (see _training_step_graphed): a memory pool of its own,
         # and its captured backward kernels accumulate into the second flat gradient buffer
         self._graphs["mixed_pass"] = GraphedSplitStep(self._mixed_fwd, self._mixed_bwd, "student mixed pass", shared=None,
+                                                      forward_state=self._student_forward_state, agree=self._any_rank,
                                                       capture_context=self._mixed_capture_context,
                                                       after_capture=self._mixed_captured_reduce,
                                                       on_replay=self._mixed_replayed_reduce)
         self.teacher_f8 = _f8.ENV_DEFAULT                # K5: EMA-teacher backbone in fp8 (no reference analogue)
         self.load_weights(pretrained)
+
+    def _student_forward_state(self):
+        """What a student forward updates in place besides computing its outputs: the BatchNorm running statistics and batch
+        counters of the decode heads (graphs.GraphedSplitStep keeps them across the eager re-run after a failed capture)."""
+        return [b for m in (self.backbone, self.head, self.hrda_scale_attention) if m is not None
+                for n, b in m.named_buffers() if n.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+
+    @staticmethod
+    def _any_rank(flag):
+        """`flag` on any rank of the data-parallel group (a world of one: the flag itself)."""
+        from .bn import data_parallel
+        if not data_parallel():
+            return flag
+        import torch.distributed as dist
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=torch.cuda.current_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
 
     # -- trainer hooks (what Lightning provides in the reference) ---------------------------------------------------
     @property
@@ -455,7 +473,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         manual_backward(loss_featdist_src), :179-186), both accumulating into `.grad`: that sum of two gradients is the
         gradient of the sum of the two losses, so ONE backward pass of `loss_src + loss_fd` gives every parameter the same
         gradient (up to the rounding order of the additions) and walks the low-resolution MiT-B5 backbone once instead of
-        twice.  RFN_MERGE_FD_BACKWARD=0: the two passes."""
+        twice.  (uda._MERGE_FD_BACKWARD = False: the two passes; tests/test_step_gpu.py flips it.)"""
         logits_src = _logits_for_loss(self, held["logits"], held["size"])
         if self.use_hrda:
             loss_src = (1 - self.hr_loss_weight) * self.loss(logits_src, gt_src) + \
@@ -588,7 +606,7 @@ class DomainAdaptationSegmentationModel(nn.Module):
         in stream order -- torch runs a collective on a stream of its own, so a captured one is a cross-stream branch
         of the graph, hipGraph replays those with a synchronisation per edge, and two replays running next to each
         other pay for it.  So under data parallelism the passes stay in stream order, UNLESS the exchanges are RCCL
-        calls of our own on the capture stream (refign_amd/rccl.py, RFN_RCCL_DIRECT=1: plain kernel nodes) -- then the
+        calls of our own on the capture stream (refign_amd/rccl.py, RFN_DDP_MODE=direct3: plain kernel nodes) -- then the
         mixed pass gets its own communicator (trainer: model._mixed_comm) and runs next to the source pass."""
         import contextlib
         from .bn import data_parallel, direct_comm
@@ -751,7 +769,8 @@ class DomainAdaptationSegmentationModel(nn.Module):
         nxt = batch.get("image_src_next")
         if nxt is not None:                              # after the teacher branch the side stream is idle: fill it
             self.prefetch_imnet_features(nxt, after=prefetch_free, stream=stream)
-        if batch.get("image_trg_next") is not None and batch.get("image_ref_next") is not None and with_flow:
+        if batch.get("image_trg_next") is not None and batch.get("image_ref_next") is not None and with_flow \
+                and self._next_step_aligns(batch["image_src"]):
             # (after this step's warp + refine, which reads the flow buffers the prefetch re-fills)
             with torch.no_grad():
                 self.prefetch_align_flow(batch["image_ref_next"], batch["image_trg_next"], after=branch_done, stream=stream)
@@ -767,8 +786,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
             # teacher forward on (target, reference) + align + refine: gradient-free and shape-static, mostly
             # replayed from hipGraphs after the first eager call (refign_amd/graphs.py)
             return images_trg, self._teacher_align_refine(images_trg, batch['image_ref'])
-        m_logits_trg = self.m_head(self.m_backbone(images_trg))
+        # (:210-213) the coin fell on the reference image (or Refign is off): the teacher alone, plain softmax.  The backbone
+        # replays from a hipGraph of its own input signature (b images instead of 2b), like the aligned branch's
+        m_logits_trg = self.m_head(self._graphs["teacher_backbone"](images_trg))
         m_logits_trg = _upsample_logits(m_logits_trg, images_trg.shape[-2:])
+        self.__dict__["_adapted_to_ref_steps"] = self.__dict__.get("_adapted_to_ref_steps", 0) + int(adapt_to_ref)   # diagnostics
         return images_trg, F.softmax(m_logits_trg, dim=1)
 
     def _overlap_teacher(self, x):
@@ -834,9 +856,28 @@ class DomainAdaptationSegmentationModel(nn.Module):
 
     def _align_split(self, x):
         """align() as flow + (warp, refine): whenever the flow of the next batch may be computed ahead, i.e. the target
-        branch always aligns (no adapt_to_ref coin) and runs on the side stream.  RFN_ALIGN_PREFETCH=0: one piece."""
-        return (_ALIGN_PREFETCH and self.use_refign and self.use_align and not self.adapt_to_ref and x.is_cuda
-                and self._overlap_teacher(x))
+        branch runs on the side stream.  With `adapt_to_ref` (refign_hrda_star.yaml:92) the branch aligns on tails only: the
+        prefetch then goes by a PEEK at the next step's coin (_next_step_aligns); a flow that was not prefetched is computed
+        in the step by the same graph, an unused one is dropped -- the numbers never depend on the prediction.
+        (module constant _ALIGN_PREFETCH = False: align() in one piece.)"""
+        return _ALIGN_PREFETCH and self.use_refign and self.use_align and x.is_cuda and self._overlap_teacher(x)
+
+    def _next_step_aligns(self, images_src):
+        """Will the NEXT training_step take the Refign branch?  Without `adapt_to_ref`: always.  With it, the coin is the next
+        step's third draw from python's `random` stream, after the two HRDA crop offsets of its source forward (the order
+        the reference draws in: hrda.py:22-27, then segmentation_model.py:195): those draws are made here on a COPY of the
+        generator state, which is put back -- a prediction that consumes nothing.  (A loader that draws from `random`
+        between the steps only makes it a worse prediction.)"""
+        if not self.adapt_to_ref:
+            return True
+        state = random.getstate()
+        try:
+            if self.use_hrda:
+                H, W = images_src.shape[-2:]
+                draw_crop_offsets(H, W, (int(H * 0.5), int(W * 0.5)), self.hrda_output_stride * 2.0)
+            return not random.random() < 0.5
+        finally:
+            random.setstate(state)
 
     def prefetch_align_flow(self, images_ref_next, images_trg_next, after=None, stream=None):
         """Software pipelining across steps, like prefetch_imnet_features: the matcher (frozen VGG-16 + flow decoders,

@@ -51,7 +51,7 @@ class Recorder:
         self.opt.step()
 
 
-def run_reference(use_hrda, model_type="mit_b0", dims=DIMS):
+def run_reference(use_hrda, model_type="mit_b0", dims=DIMS, adapt_to_ref=False, enable_fdist=True):
     sm = R.ref_module("models.segmentation_model")
     mt = R.ref_module("models.backbones.mix_transformer")
     df = R.ref_module("models.heads.daformer")
@@ -88,7 +88,7 @@ def run_reference(use_hrda, model_type="mit_b0", dims=DIMS):
         loss=ls.PixelWeightedCrossEntropyLoss(),
         alignment_backbone=vg.VGG('vgg16', out_indices=[2, 3, 4]),
         alignment_head=ua.UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True),
-        backbone_lr_factor=0.1, use_refign=True, adapt_to_ref=False, gamma=0.25, enable_fdist=True,
+        backbone_lr_factor=0.1, use_refign=True, adapt_to_ref=adapt_to_ref, gamma=0.25, enable_fdist=enable_fdist,
         color_jitter_p=1.0, blur=False, use_hrda=use_hrda, hrda_output_stride=4,
         hrda_scale_attention=sf.SegFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0))
     closed_form_fill(model)
@@ -183,4 +183,126 @@ def g13_k3():
     torch.set_grad_enabled(False)
 
 
-GROUPS = {"G13": g13, "G13B5": g13_b5, "G13K3": g13_k3}
+def g13_k4(H=1080, W=1920, enable_fdist=False, name="step_hrda_b5_1080x1920", seed=80, blk=120):
+    """G13-K4: BASELINE config 4 as a STEP at the size the metric is quoted on -- one reference training_step of the HRDA
+    MiT-B5 model (refign_hrda_star.yaml's networks) on ONE 1080 x 1920 (source, target, reference) triple, fp32, closed-form
+    weights, augmentation off: the student's 540 x 960 low-resolution view + 540 x 960 detail crop, the teacher's 2 x (1 + 9)
+    views with the 3 x 3 slide fusion on non-square crops, align at 1080 x 1920, refine, the DACS mix and the fused CE at
+    the full size.  Captured as in G13-B5, plus strided samples of the refined target probabilities (what get_dacs_mix
+    receives, segmentation_model.py:214), their arg-max / max, and of the mixed label and weight.
+    `enable_fdist=False` at 1080 x 1920: the REFERENCE ITSELF cannot compute the feature distance at this size -- the label
+    down-scaling pools 1080 rows by 64 into 16 (segmentation_model.py:655-667) while MiT's stage-4 map has 17, and
+    masked_feat_dist fails with an IndexError (:634); it trains on 1024 x 1024 crops (refign_hrda_star.yaml:17-20).  The
+    feature distance at the K4 scale is pinned by the second fixture, G13-K4F: the same step WITH it at 1088 x 1920
+    (17 x 64 rows, the nearest size the reference accepts)."""
+    torch.set_grad_enabled(True)
+    dims = [64, 128, 320, 512]
+    model = run_reference(True, "mit_b5", dims, enable_fdist=enable_fdist)
+    model.logged = {}
+    batch = make_batch(1, H, W, blk)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    model.global_step = 3
+    grads, seen = {}, {}
+    real, real_mix = model._rec.step, model.get_dacs_mix
+
+    def step():
+        grads["conv_seg"] = model.head.conv_seg.weight.grad.detach().flatten()[::37].clone().numpy()
+        grads["fc1"] = model.backbone.block3[20].mlp.fc1.weight.grad.detach().flatten()[::997].clone().numpy()
+        real()
+
+    def mix(images_trg, probs_trg, images_src, gt_src):
+        p = probs_trg.detach()
+        seen["probs"] = p[:, :, ::12, ::12].clone().numpy()
+        mx, am = p.max(1)
+        srt = torch.sort(p, dim=1)[0]
+        seen["argmax"] = am[:, ::4, ::4].to(torch.uint8).numpy()
+        seen["margin"] = (srt[:, -1] - srt[:, -2])[:, ::4, ::4].to(torch.float16).numpy()
+        seen["confident"] = float((mx >= 0.968).double().mean())
+        out = real_mix(images_trg, probs_trg, images_src, gt_src)
+        seen["mixed_lbl"] = out[1][:, ::4, ::4].to(torch.uint8).numpy()
+        seen["mixed_weight"] = out[2][:, ::8, ::8].clone().numpy()
+        return out
+    real_refine = model.refine
+
+    def refine(logits_trg, logits_ref, warp_mask, certs):
+        # refine() is discontinuous where an INPUT's arg-max is a tie: the static-class mask M follows the arg-max of the target's
+        # and of the warped reference's probabilities (segmentation_model.py:446-460); keep both top-2 margins for the test
+        mg = []
+        for lg in (logits_trg, logits_ref):
+            srt = torch.sort(torch.softmax(lg, dim=1), dim=1)[0]
+            mg.append(srt[:, -1] - srt[:, -2])
+        seen["in_margin"] = torch.minimum(*mg)[:, ::4, ::4].to(torch.float16).numpy()
+        return real_refine(logits_trg, logits_ref, warp_mask, certs)
+    model._rec.step, model.get_dacs_mix, model.refine = step, mix, refine
+    import time
+    t0 = time.perf_counter()
+    model.training_step(batch, 0)
+    dt = time.perf_counter() - t0
+    print(f"    reference step at {H}x{W}: {dt:.1f} s on {torch.get_num_threads()} threads")
+    ema = float(sum(p.double().abs().sum() for p in model.ema_parameters()))
+    live = float(sum(p.double().abs().sum() for p in model.live_parameters()))
+    save(name, losses=np.array([model.logged["train_loss_src"], model.logged.get("train_loss_featdist_src", 0.0),
+                                model.logged["train_loss_uda_trg"]]), enable_fdist=np.bool_(enable_fdist),
+         grad_norms=np.array(model._rec.norms), ema_abs_sum=ema, live_abs_sum=live, size=np.array([H, W]), blk=np.int64(blk),
+         cpu_seconds=np.float32(dt), grad_conv_seg=grads["conv_seg"], grad_fc1=grads["fc1"],
+         w_q=model.backbone.block1[0].attn.q.weight.detach().flatten()[::61].numpy(),
+         w_fuse=model.head.fuse_layer.bottleneck.conv.weight.detach().flatten()[::9973].numpy(),
+         probs_sample=seen["probs"], probs_argmax=seen["argmax"], probs_margin=seen["margin"], in_margin=seen["in_margin"],
+         confident=np.float64(seen["confident"]), mixed_lbl=seen["mixed_lbl"], mixed_weight=seen["mixed_weight"])
+    print("   ", model.logged, model._rec.norms, "confident", seen["confident"])
+    torch.set_grad_enabled(False)
+
+
+def g13_adapt():
+    """G13-A: the `adapt_to_ref: True` branch (refign_hrda_star.yaml:92, segmentation_model.py:194-213): with the coin on
+    heads the teacher sees the reference image alone -- no align, no refine, pseudo-labels from its plain softmax.  THREE
+    consecutive reference steps of the HRDA mit_b0 model (128 x 128, b = 2) from one seed chosen so that both sides of the coin
+    occur; per step: which side, the three losses, the group gradient norms; after the last step the EMA / student
+    checksums.  The draws of a step: two crop offsets, the coin, the DACS parameters, two crop offsets (python `random`),
+    the class choice (torch)."""
+    torch.set_grad_enabled(True)
+    sm = R.ref_module("models.segmentation_model")
+    for seed in range(81, 200):
+        random.seed(seed)
+        coins = []
+        for _ in range(3):                     # a dry run of the python stream: 2 crop draws, coin, jitter, 2 crop draws
+            random.randrange(0, 8); random.randrange(0, 8)
+            coins.append(random.random() < 0.5)
+            random.uniform(0, 1)
+            random.randrange(0, 8); random.randrange(0, 8)
+        if coins == [True, False, True]:
+            break
+    model = run_reference(True, adapt_to_ref=True)
+    H = W = 128
+    batch = make_batch(2, H, W, 64)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    model.global_step = 3
+    aligned = []
+    real_align = model.align
+
+    def align(*a, **k):
+        aligned[-1] = True
+        return real_align(*a, **k)
+    model.align = align
+    losses, norms = [], []
+    for _ in range(3):
+        aligned.append(False)
+        model.training_step(batch, 0)
+        model.global_step += 1
+        losses.append([model.logged["train_loss_src"], model.logged["train_loss_featdist_src"], model.logged["train_loss_uda_trg"]])
+        norms.append(list(model._rec.norms))
+    took_ref = [not a for a in aligned]
+    assert took_ref == coins, (took_ref, coins)
+    ema = float(sum(p.double().abs().sum() for p in model.ema_parameters()))
+    live = float(sum(p.double().abs().sum() for p in model.live_parameters()))
+    save("step_hrda_adapt_to_ref", seed=np.int64(seed), adapted_to_ref=np.array(took_ref), losses=np.array(losses),
+         grad_norms=np.array(norms), ema_abs_sum=ema, live_abs_sum=live, size=np.array([H, W]))
+    print("    seed", seed, "adapted to ref:", took_ref, losses)
+    torch.set_grad_enabled(False)
+
+
+def g13_k4f():
+    g13_k4(1088, 1920, True, "step_hrda_b5_1088x1920", 81, 64)
+
+
+GROUPS = {"G13": g13, "G13B5": g13_b5, "G13K3": g13_k3, "G13K4": g13_k4, "G13K4F": g13_k4f, "G13A": g13_adapt}

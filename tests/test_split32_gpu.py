@@ -51,18 +51,64 @@ def test_conv2d_fp32_split_forward_backward(B, H, W, C, N, k, stride, pad, dil):
         assert float((got.double() - want).abs().max()) <= TOL * float(want.abs().max()) + 1e-6
 
 
-def test_attention_fp32_split_matches_fp64():
+ATTN = [  # B, heads, Nq, Nkv  (head dimension 64; ragged query / key tails, one / several query chunks in dK / dV)
+    (2, 2, 130, 70), (1, 5, 2040, 510), (3, 1, 517, 33), (1, 8, 510, 510), (2, 1, 4100, 480), (1, 2, 31, 5),
+]
+
+
+@pytest.mark.parametrize("B,h,N,Nkv", ATTN)
+def test_attention_fp32_kernel_matches_fp64(B, h, N, Nkv):
+    """csrc/attn32.hip (fp32 matrix pipe, fp32 softmax) against the fp64 formulation of mix_transformer.py:147-160 on the
+    tensors as the Linears hand them over -- q (B, N, h 64), kv (B, Nkv, 2 h 64) -- forward and the three gradients; the
+    forward twice, bit-identical (no atomics there)."""
     from refign_amd import split32
-    q, k, v = _r((2, 2, 130, 32), 9).requires_grad_(True), _r((2, 2, 70, 32), 10).requires_grad_(True), \
-        _r((2, 2, 70, 32), 11).requires_grad_(True)
-    o = split32.attention(q, k, v, 0.17)
-    go = _r(tuple(o.shape), 12)
+    C = h * 64
+    q, kv = _r((B, N, C), 9).requires_grad_(True), _r((B, Nkv, 2 * C), 10).requires_grad_(True)
+    scale = 0.125
+    o = split32.attention(q, kv, h, scale)
+    assert o is not None and tuple(o.shape) == (B, N, C)
+    assert torch.equal(o, split32.attention(q.detach(), kv.detach(), h, scale))
+    go = _r((B, N, C), 12)
     o.backward(go)
-    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
-    od = torch.softmax(qd @ kd.transpose(-1, -2) * 0.17, -1) @ vd
+    qd, kvd = (t.detach().double().requires_grad_(True) for t in (q, kv))
+    k, v = kvd.view(B, Nkv, 2, h, 64).permute(2, 0, 3, 1, 4).unbind(0)
+    od = (torch.softmax(qd.view(B, N, h, 64).transpose(1, 2) @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, N, C)
     od.backward(go.double())
-    for got, want in ((o, od), (q.grad, qd.grad), (k.grad, kd.grad), (v.grad, vd.grad)):
-        assert float((got.double() - want).abs().max()) <= 4 * TOL * float(want.abs().max()) + 1e-6
+    for name, got, want in (("o", o, od), ("dq", q.grad, qd.grad), ("dkv", kv.grad, kvd.grad)):
+        err = float((got.double() - want).abs().max())
+        assert err <= 2e-5 * float(want.abs().max()) + 1e-7, (name, err, float(want.abs().max()))
+
+
+def test_attention_fp32_kernel_strided_operands_and_large_scores():
+    """q / kv as channel slices of wider tensors (row stride > heads * 64) and scores of +-60 (the running maximum has to carry
+    the softmax): still the fp64 result."""
+    from refign_amd import split32
+    B, h, N, Nkv, C = 2, 2, 300, 96, 128
+    qw, kvw = _r((B, N, C + 64), 21, 3.0), _r((B, Nkv, 2 * C + 32), 22, 3.0)
+    q, kv = qw[:, :, 64:], kvw[:, :, :2 * C]
+    o = split32.attention(q, kv, h, 0.5)
+    qd, kvd = q.double(), kv.double()
+    k, v = kvd.reshape(B, Nkv, 2, h, 64).permute(2, 0, 3, 1, 4).unbind(0)
+    od = (torch.softmax(qd.reshape(B, N, h, 64).transpose(1, 2) @ k.transpose(-1, -2) * 0.5, -1) @ v).transpose(1, 2).reshape(B, N, C)
+    assert float((o.double() - od).abs().max()) <= 2e-5 * float(od.abs().max())
+
+
+@pytest.mark.parametrize("rows,K,pad", [(300, 64, 64), (77, 100, 64), (1000, 86, 8), (5, 3, 8), (4096, 320, 64)])
+def test_split3_kernel_equals_the_two_term_split(rows, K, pad):
+    """csrc/split3.hip: hi = bf16(x), lo = bf16(x - hi) as three terms in one launch == the torch formulation, bit for bit, side by
+    side and stacked, from a row-strided view too; pad columns zero."""
+    from refign_amd import split32
+    wide = _r((rows, K + 12), 30, 7.0)
+    for x in (wide[:, :K].contiguous(), wide[:, 4:K + 4]):
+        hi, lo = split32.split2(x)
+        Kp = -(-K // pad) * pad
+        for order, terms in (("hhl", (hi, hi, lo)), ("hlh", (hi, lo, hi))):
+            side = split32.split3(x, order, Kp)
+            stack = split32.split3(x, order, Kp, stack=True)
+            assert tuple(side.shape) == (rows, 3 * Kp) and tuple(stack.shape) == (3 * rows, Kp)
+            for i, t in enumerate(terms):
+                assert torch.equal(side[:, i * Kp:i * Kp + K], t) and torch.equal(stack[i * rows:(i + 1) * rows, :K], t)
+                assert not side[:, i * Kp + K:(i + 1) * Kp].any() and not stack[i * rows:(i + 1) * rows, K:].any()
 
 
 def test_fp32_goldens_stay_off_the_libraries():

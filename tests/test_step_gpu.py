@@ -26,7 +26,7 @@ def make_batch(b, H, W, blk, dev):
     return {"image_src": t(img("g13/src")), "semantic_src": t(lbl), "image_trg": t(trg), "image_ref": t(ref)}
 
 
-def build(use_hrda, dev, model_type="mit_b0", dims=None):
+def build(use_hrda, dev, model_type="mit_b0", dims=None, adapt_to_ref=False, enable_fdist=True):
     dims = dims or DIMS
     from refign_amd.align import VGG, UAWarpCHead
     from refign_amd.seg import DAFormerHead, MixVisionTransformer, PixelWeightedCrossEntropyLoss, SegFormerHead
@@ -38,7 +38,7 @@ def build(use_hrda, dev, model_type="mit_b0", dims=None):
         loss=PixelWeightedCrossEntropyLoss(),
         alignment_backbone=VGG('vgg16', out_indices=[2, 3, 4]),
         alignment_head=UAWarpCHead(in_index=[0, 1], input_transform='multiple_select', estimate_uncertainty=True),
-        backbone_lr_factor=0.1, use_refign=True, adapt_to_ref=False, gamma=0.25, enable_fdist=True,
+        backbone_lr_factor=0.1, use_refign=True, adapt_to_ref=adapt_to_ref, gamma=0.25, enable_fdist=enable_fdist,
         color_jitter_p=1.0, blur=False, use_hrda=use_hrda, hrda_output_stride=4,
         hrda_scale_attention=SegFormerHead(dims, [0, 1, 2, 3], 19, 'multiple_select', dropout_ratio=0.0))
     closed_form_fill(model)
@@ -89,14 +89,102 @@ def test_training_step_mit_b5_hrda_512_matches_reference(dev):
     assert np.abs(w_q - g["w_q"]).max() <= 1e-4 and np.abs(w_fuse - g["w_fuse"]).max() <= 1e-4
 
 
-def _b5_step(dev, use_hrda, b, H, W, seed, autocast):
-    """one training_step of the MiT-B5 model on the G13 batch; returns what the goldens hold (+ the pseudo-label probs)"""
+def test_training_step_adapt_to_ref_both_sides_of_the_coin_match_reference(dev):
+    """G13-A: `adapt_to_ref: True` (refign_hrda_star.yaml:92; segmentation_model.py:194-213) -- on heads the teacher sees the
+    reference image alone: no align, no refine, pseudo-labels from its plain softmax.  THREE consecutive steps of the HRDA
+    mit_b0 model from the golden's seed, on which the reference's coin fell heads, tails, heads
+    (tests/golden/make_golden_step.py::g13_adapt): the same side is taken every step (i.e. the python `random` stream is
+    consumed in the reference's order: crop, crop, coin, jitter, crop, crop), and losses / gradient norms per step and the
+    EMA / student checksums after the third step match.  fp32 parity mode; the third step is the one the student passes are
+    captured on (graphs.GraphedSplitStep, warm-up 2), so both the eager and the captured schedule are on the path."""
     from refign_amd.trainer import Trainer
-    model = build(use_hrda, dev, "mit_b5", [64, 128, 320, 512])
+    g = golden("step_hrda_adapt_to_ref")
+    seed = int(g["seed"])
+    H, W = [int(v) for v in g["size"]]
+    model = build(True, dev, adapt_to_ref=True)
     trainer = Trainer(model, fused_optimizer=False)
     trainer.scheduler = torch.optim.lr_scheduler.LambdaLR(trainer.optimizer, lambda s: 1.0)
     model._scheduler = trainer.scheduler
-    batch = make_batch(b, H, W, 64, dev)
+    batch = make_batch(2, H, W, 64, dev)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    model.global_step = 3
+    norms, sides, losses = [], [], []
+    real_step, real_tar = trainer.optimizer.step, model._teacher_align_refine
+
+    def recording_step(*a, **k):
+        norms.append([float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in grp["params"])))
+                      for grp in trainer.optimizer.param_groups])
+        return real_step(*a, **k)
+
+    def recording_tar(*a, **k):
+        sides[-1] = False
+        return real_tar(*a, **k)
+
+    trainer.optimizer.step, model._teacher_align_refine = recording_step, recording_tar
+    for it in range(3):
+        sides.append(True)
+        model.training_step(batch, it)
+        losses.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+    assert sides == [bool(v) for v in g["adapted_to_ref"]] == [True, False, True]
+    assert model.__dict__.get("_adapted_to_ref_steps", 0) == 2
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=2e-3)
+    np.testing.assert_allclose(np.array(norms), g["grad_norms"], rtol=2e-2)
+    ema = float(sum(p.double().abs().sum() for p in model.ema_parameters()))
+    live = float(sum(p.double().abs().sum() for p in model.live_parameters()))
+    assert abs(ema - float(g["ema_abs_sum"])) < 1e-5 * float(g["ema_abs_sum"])
+    assert abs(live - float(g["live_abs_sum"])) < 1e-5 * float(g["live_abs_sum"])
+    assert model.global_step == 6
+
+
+def test_adapt_to_ref_graphed_schedule_equals_eager_and_prefetch_follows_the_coin(dev, monkeypatch):
+    """The schedule the YAML's `adapt_to_ref: True` actually builds: 10 bf16 steps with every graph on and the next batch handed
+    over (Trainer.step(next_batch=...)) against 10 steps with the student passes eager and no prefetch, same seed: the same side
+    of the coin every step, the same three losses per step, the same parameters.  The matcher's flow of the next batch is
+    prefetched exactly when the NEXT step's coin falls on tails (uda._next_step_aligns peeks at a copy of the generator state)."""
+    from refign_amd.trainer import Trainer
+    out = {}
+    for mode in ("graphs", "eager"):
+        monkeypatch.setenv("RFN_GRAPH_STUDENT", "1" if mode == "graphs" else "0")
+        model = build(True, dev, adapt_to_ref=True)
+        trainer = Trainer(model, fused_optimizer=False)
+        random.seed(12); np.random.seed(12); torch.manual_seed(12)
+        batches = []
+        for it in range(11):
+            bt = make_batch(2, 128, 128, 64, dev)
+            bt["image_src"] = bt["image_src"] + 0.1 * it
+            bt["image_trg"] = bt["image_trg"] + 0.05 * it
+            batches.append(bt)
+        rows, sides = [], []
+        real_tar = model._teacher_align_refine
+
+        def recording_tar(*a, _real=real_tar, **k):
+            sides[-1] = False
+            return _real(*a, **k)
+        model._teacher_align_refine = recording_tar
+        for it in range(10):
+            sides.append(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                trainer.step(batches[it], it, next_batch=batches[it + 1] if mode == "graphs" else None)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+        out[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), sides,
+                     model.__dict__.get("_align_prefetch_used", 0))
+    assert out["graphs"][2] == out["eager"][2] and 0 < sum(out["graphs"][2]) < 10, out["graphs"][2]
+    # every aligned step after the first found its flow prefetched by the step before it (the prefetch is part of the schedule from
+    # the first step on, also while the student passes still run their eager warm-up calls), and no other step asked for one
+    want = sum(1 for it in range(1, 10) if not out["graphs"][2][it])
+    assert out["graphs"][3] == want and out["eager"][3] == 0, (out["graphs"][3], want, out["graphs"][2])
+    np.testing.assert_allclose(out["graphs"][0], out["eager"][0], rtol=3e-2)
+    assert abs(out["graphs"][1] - out["eager"][1]) < 1e-4 * out["eager"][1]
+
+
+def _b5_step(dev, use_hrda, b, H, W, seed, autocast, blk=64, enable_fdist=True):
+    """one training_step of the MiT-B5 model on the G13 batch; returns what the goldens hold (+ the pseudo-label probs)"""
+    from refign_amd.trainer import Trainer
+    model = build(use_hrda, dev, "mit_b5", [64, 128, 320, 512], enable_fdist=enable_fdist)
+    trainer = Trainer(model, fused_optimizer=False)
+    trainer.scheduler = torch.optim.lr_scheduler.LambdaLR(trainer.optimizer, lambda s: 1.0)
+    model._scheduler = trainer.scheduler
+    batch = make_batch(b, H, W, blk, dev)
     random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
     model.global_step = 3
     seen = {}
@@ -111,12 +199,14 @@ def _b5_step(dev, use_hrda, b, H, W, seed, autocast):
 
     def recording_mix(images_trg, probs_trg, *a, **k):
         seen["probs"] = probs_trg.detach().float().clone()
-        return real_mix(images_trg, probs_trg, *a, **k)
+        out = real_mix(images_trg, probs_trg, *a, **k)
+        seen["mixed_lbl"], seen["mixed_weight"] = out[1].detach().clone(), out[2].detach().float().clone()
+        return out
 
     trainer.optimizer.step, model.get_dacs_mix = recording_step, recording_mix
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
         model.training_step(batch, 0)
-    seen["losses"] = np.array([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+    seen["losses"] = np.array([float(model.logged.get(k, 0.0)) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
     seen["ema"] = float(sum(p.double().abs().sum() for p in model.ema_parameters()))
     seen["live"] = float(sum(p.double().abs().sum() for p in model.live_parameters()))
     seen["w_q"] = model.backbone.block1[0].attn.q.weight.detach().flatten()[::61].cpu().numpy()
@@ -140,6 +230,54 @@ def test_training_step_daformer_mit_b5_k3_matches_reference(dev):
     assert abs(seen["ema"] - float(g["ema_abs_sum"])) < 1e-5 * float(g["ema_abs_sum"])
     assert abs(seen["live"] - float(g["live_abs_sum"])) < 1e-5 * float(g["live_abs_sum"])
     assert np.abs(seen["w_q"] - g["w_q"]).max() <= 1e-4 and np.abs(seen["w_fuse"] - g["w_fuse"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["step_hrda_b5_1080x1920", "step_hrda_b5_1088x1920"])
+def test_training_step_hrda_b5_k4_matches_reference(dev, name):
+    """G13-K4 / G13-K4F: BASELINE config 4 as a STEP at the size the metric is quoted on -- HRDA MiT-B5 (the bench's networks), one
+    (source, target, reference) triple, fp32 parity mode on the hand-written kernels, against one reference training_step
+    (tests/golden/make_golden_step.py::g13_k4, ~105 s of reference CPU time): the student's 540 x 960 view + detail crop, the
+    teacher's 2 x (1 + 9) views with the 3 x 3 slide fusion on non-square crops, align at the full size, refine, DACS, the fused
+    CE.  1080 x 1920 runs WITHOUT the feature distance because the reference cannot compute it there (IndexError at
+    segmentation_model.py:634: 1080 rows pool into 16 by 64, MiT's stage-4 map has 17); 1088 x 1920 (17 x 64) runs WITH it.
+    Bounds as G13-B5, plus what the refine stage hands to DACS: refined target probabilities within 1e-3 (the north star's
+    tolerance; strided sample), their arg-max exact wherever the reference's top-2 margin exceeds 2e-3, the mixed label
+    equal wherever it is a source label or a decided pseudo-label, the mixed weight exact."""
+    from refign_amd import mfma
+    g = golden(name)
+    H, W = [int(v) for v in g["size"]]
+    fd = bool(g["enable_fdist"])
+    mfma.LIBRARY_CALLS.clear()
+    seen = _b5_step(dev, True, 1, H, W, 80 if not fd else 81, autocast=False, blk=int(g["blk"]), enable_fdist=fd)
+    assert not mfma.LIBRARY_CALLS, mfma.library_summary()
+    keep = [0, 2] if not fd else [0, 1, 2]
+    np.testing.assert_allclose(seen["losses"][keep], g["losses"][keep], rtol=2e-3)
+    np.testing.assert_allclose(seen["norms"], g["grad_norms"], rtol=2e-2)
+    for key, ref in (("conv_seg", g["grad_conv_seg"]), ("fc1", g["grad_fc1"])):
+        assert np.abs(seen[key] - ref).max() <= 2e-2 * np.abs(ref).max(), key
+    assert abs(seen["ema"] - float(g["ema_abs_sum"])) < 1e-5 * float(g["ema_abs_sum"])
+    assert abs(seen["live"] - float(g["live_abs_sum"])) < 1e-5 * float(g["live_abs_sum"])
+    assert np.abs(seen["w_q"] - g["w_q"]).max() <= 1e-4 and np.abs(seen["w_fuse"] - g["w_fuse"]).max() <= 1e-4
+    probs = seen["probs"]
+    err = float(np.abs(probs[:, :, ::12, ::12].cpu().numpy() - g["probs_sample"]).max())
+    am = probs.argmax(1)[:, ::4, ::4].cpu().numpy()
+    # decided pixels: the reference's own top-2 margin exceeds 2e-3 AND neither input of refine() is near an arg-max tie -- the
+    # static-class mask M follows the arg-max of the target's and of the warped reference's probabilities
+    # (segmentation_model.py:446-460), so refine() itself jumps there
+    decided = (g["probs_margin"].astype(np.float32) > 2e-3) & (g["in_margin"].astype(np.float32) > 1e-3)
+    print(f"\n{name}: refined probabilities max |err| {err:.2e}; arg-max checked on {int(decided.sum())} of {decided.size} "
+          f"sampled pixels; losses {seen['losses']} vs {g['losses']}")
+    assert err <= 1e-3
+    wrong = int((am[decided] != g["probs_argmax"][decided]).sum())
+    print(f"    arg-max mismatches on decided pixels: {wrong}; on all sampled pixels: {int((am != g['probs_argmax']).sum())}")
+    assert decided.mean() > 0.5 and wrong == 0
+    conf = float((probs.max(1)[0] >= 0.968).double().mean())
+    assert abs(conf - float(g["confident"])) <= 1e-4
+    lbl = seen["mixed_lbl"][:, ::4, ::4].cpu().numpy().astype(np.uint8)
+    same = lbl == g["mixed_lbl"]
+    from_target = g["mixed_lbl"] == g["probs_argmax"]          # (source labels that equal the pseudo-label count as decided too)
+    assert same[decided | ~from_target].all() and same.mean() > 0.99
+    np.testing.assert_allclose(seen["mixed_weight"][:, ::8, ::8].cpu().numpy(), g["mixed_weight"], atol=1e-4)
 
 
 def test_training_step_mit_b5_hrda_512_bench_mode_is_bounded(dev):
@@ -431,6 +569,49 @@ def test_failed_graph_capture_falls_back_to_eager(dev, monkeypatch):
     torch.cuda.synchronize()
     assert float(z.sum()) == 8.0
     assert all(s["failed"] for s in g.states.values())
+
+
+def test_failed_backward_capture_leaves_one_forwards_side_effects(dev, monkeypatch):
+    """ADVICE r5 (graphs.GraphedSplitStep.backward): when the BACKWARD capture of a student pass fails, the forward of that step
+    has already run as a graph replay, and the pass is run once more eagerly to get an autograd graph -- the decode heads'
+    BatchNorm running statistics and batch counters must still move ONCE per forward.  4 steps with the source pass's backward
+    capture made to fail (a host synchronisation inside the captured region) against 4 steps with the student passes eager: same
+    losses, same parameters, the same running statistics, counters equal; a warning, and the pass eager from then on."""
+    from refign_amd.trainer import Trainer
+    out = {}
+    for mode in ("fail", "eager"):
+        monkeypatch.setenv("RFN_GRAPH_STUDENT", "1" if mode == "fail" else "0")
+        model = build(True, dev)
+        trainer = Trainer(model, fused_optimizer=False)
+        if mode == "fail":
+            sp = model._graphs["source_pass"]
+            real_bwd = sp.bwd_fn
+
+            def bwd(held, *tensors):
+                if torch.cuda.is_current_stream_capturing():
+                    float(tensors[0].float().sum())          # .item(): illegal while capturing
+                return real_bwd(held, *tensors)
+            sp.bwd_fn = bwd
+        random.seed(41); np.random.seed(41); torch.manual_seed(41)
+        rows = []
+        for it in range(4):
+            batch = make_batch(2, 128, 128, 64, dev)
+            batch["image_src"] = batch["image_src"] + 0.1 * it
+            if mode == "fail" and it == 2:
+                with pytest.warns(UserWarning, match=r"student source pass' \(backward\) failed"):
+                    trainer.step(batch, it)
+            else:
+                trainer.step(batch, it)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+        stats = torch.cat([b.flatten().double() for n, b in model.head.named_buffers() if "running" in n]).cpu()
+        counts = [int(b) for n, b in model.head.named_buffers() if n.endswith("num_batches_tracked")]
+        out[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), stats, counts)
+        if mode == "fail":
+            assert all(s_["failed"] for s_ in sp.states.values())
+    assert out["fail"][3] == out["eager"][3] and max(out["eager"][3]) == 8          # two forwards per step, four steps
+    np.testing.assert_allclose(out["fail"][0], out["eager"][0], rtol=2e-3)
+    assert abs(out["fail"][1] - out["eager"][1]) < 1e-5 * out["eager"][1]
+    assert float((out["fail"][2] - out["eager"][2]).abs().max()) < 1e-4 * float(out["eager"][2].abs().max())
 
 
 def test_checkpoint_round_trip_on_gpu(dev, tmp_path):

@@ -4,7 +4,7 @@
   * the same with two real processes sharing the one GPU of the box, exchanging over gloo (RCCL refuses two ranks on
     one device: "Duplicate GPU detected");
   * a 1-rank RCCL group: the student passes WITH the statistics exchanges inside are captured into hipGraphs and replay
-    to the eager trajectory (what N > 1 runs with RFN_GRAPH_DDP=1; exchanges forced on for the 1-rank group)."""
+    to the eager trajectory (what N > 1 runs with RFN_DDP_MODE=direct / direct3; exchanges forced on for the 1-rank group)."""
 import os
 import socket
 import sys
