@@ -437,21 +437,21 @@ int rfn_attn_bwd_dkv(const void* K, const void* V, long kv_batch_stride, long kv
 /* ------------------------------------------------------------------------------------------------------------
  * The same attention core for FLOAT32 tensors (the fp32 parity mode; mix_transformer.py:150-160 materialises the score
  * matrix in fp32): every product on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), softmax in fp32, one launch per pass.
- * Q (B, Nq, heads*64) and KV (B, Nkv, 2, heads, 64) are used in place through their strides (in floats, multiples of 4;
- * 16-byte aligned bases); lse2 / delta: fp32 [B*heads][nqpad].
+ * Q (B, Nq, heads*D) and KV (B, Nkv, 2, heads, D), head_dim D = 64 or 32 (MiT-B0), are used in place through their strides
+ * (in floats, multiples of 4; 16-byte aligned bases); lse2 / delta: fp32 [B*heads][nqpad].
  *   rfn_attn32_fwd   O and lse2 (base-2 log-sum-exp of the scaled scores).
  *   rfn_attn32_bwd   dQ, dKV and delta = rowsum(dO o O), two launches.  dK / dV: the query dimension is split into
  *                    `query_chunks` chunks per 128-key tile whose partial sums are ADDED with fp32 atomics -- dKV must be
  *                    ZERO on entry when query_chunks > 1 (one chunk: plain stores, any contents).
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_attn32_fwd(const float* Q, long q_batch_stride, long q_row_stride, const float* KV, long kv_batch_stride,
-                   long kv_row_stride, float* O, long o_batch_stride, long o_row_stride, float* lse2, int B, int heads, int Nq,
-                   int Nkv, int nqpad, float scale, rfn_stream_t stream);
+                   long kv_row_stride, float* O, long o_batch_stride, long o_row_stride, float* lse2, int B, int heads,
+                   int head_dim, int Nq, int Nkv, int nqpad, float scale, rfn_stream_t stream);
 int rfn_attn32_bwd(const float* Q, long q_batch_stride, long q_row_stride, const float* KV, long kv_batch_stride,
                    long kv_row_stride, const float* dO, const float* O, long o_batch_stride, long o_row_stride,
                    const float* lse2, float* delta, float* dQ, long dq_batch_stride, long dq_row_stride, float* dKV,
-                   long dkv_batch_stride, long dkv_row_stride, int B, int heads, int Nq, int Nkv, int nqpad, int query_chunks,
-                   float scale, rfn_stream_t stream);
+                   long dkv_batch_stride, long dkv_row_stride, int B, int heads, int head_dim, int Nq, int Nkv, int nqpad,
+                   int query_chunks, float scale, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Operand preparation of the split-bf16 products (an fp32 product as three bf16 MFMA products, refign_amd/split32.py):

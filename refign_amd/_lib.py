@@ -94,10 +94,10 @@ SIGNATURES = {
                                                                                          c_void_p]),
     "rfn_attn_bwd_dkv": (c_int, [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long] + [c_void_p] * 8 + [c_int] * 8
                          + [c_float, c_int, c_void_p]),
-    "rfn_attn32_fwd": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] * 3 + [c_void_p] + [c_int] * 5 + [c_float, c_void_p]),
+    "rfn_attn32_fwd": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] * 3 + [c_void_p] + [c_int] * 6 + [c_float, c_void_p]),
     "rfn_attn32_bwd": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long] * 2 + [c_void_p, c_void_p, ctypes.c_long, ctypes.c_long,
                                                                                 c_void_p, c_void_p]
-                       + [c_void_p, ctypes.c_long, ctypes.c_long] * 2 + [c_int] * 6 + [c_float, c_void_p]),
+                       + [c_void_p, ctypes.c_long, ctypes.c_long] * 2 + [c_int] * 7 + [c_float, c_void_p]),
     "rfn_split3_bf16": (c_int, [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, c_int, c_int,
                                 c_int, c_void_p]),
     "rfn_upsample_ce": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),

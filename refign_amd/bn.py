@@ -102,14 +102,18 @@ def sync_group(bn):
     return bn.process_group if bn.process_group is not None else dist.group.WORLD
 
 
-def usable(x, bn, dtype, channels=None):
+def usable(x, bn, dtype, channels=None, count=None):
     """`x`: the tensor BatchNorm is applied to -- or, with `channels`, the INPUT of the convolution in front of it (the caller
     asks before it convolves; what has to be a multiple of 8 is the normalised tensor's channel count, not the convolution's
-    input: round 4 asked about the wrong one, and layers with 1 or 84 input channels fell to the library's BatchNorm)."""
+    input: round 4 asked about the wrong one, and layers with 1 or 84 input channels fell to the library's BatchNorm).
+    `count`: values per channel of the NORMALISED tensor (the convolution's output: batch x OH x OW) when x is the input --
+    one value per channel has no variance, and torch raises there ('Expected more than 1 value per channel'); so do we,
+    by leaving the call to torch."""
     c = x.shape[1] if channels is None else channels
+    n = x.shape[0] * x.shape[2] * x.shape[3] if count is None else count
     return (x.is_cuda and dtype in _DT16 and type(bn) in (torch.nn.BatchNorm2d, torch.nn.SyncBatchNorm) and bn.training
             and bn.affine and bn.track_running_stats and bn.momentum is not None and c % 8 == 0 and c == bn.num_features
-            and x.shape[0] * x.shape[2] * x.shape[3] > 1)
+            and n > 1)
 
 
 # The four kernel passes (csrc/bn.hip) on (B, H, W, C) 16-bit tensors; module-level so that tests/test_ddp_cpu.py can put

@@ -157,9 +157,14 @@ _SPLIT_WS = {}
 
 
 def _split_workspace(nbytes, dev):
-    """Workspace of the channel-split path, one per (device, stream, size), kept: its tail holds the tickets of the one-launch
-    form, which must be zero before the first call and are left zero by every call (include/refign_hip.h).  Per stream: two
-    streams may run the same level side by side."""
+    """Workspace of the channel-split path: its tail holds the tickets of the one-launch form, which must be zero before the first
+    call and are left zero by every call (include/refign_hip.h).  Eager calls: one per (device, stream, size), kept -- two
+    streams may run the same level side by side.  Captured calls: one per call (below)."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture the current stream is torch's capture stream whichever stream will replay the graph: a cached
+        # workspace would be shared by every captured graph, and two graphs replaying side by side would race on its tickets and
+        # partial sums (ADVICE r5).  One workspace per captured call, from the graph's own pool, zeroed by a fill KERNEL node.
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(0)
     key = (dev, torch.cuda.current_stream(dev).cuda_stream, nbytes)
     ws = _SPLIT_WS.get(key)
     if ws is None:

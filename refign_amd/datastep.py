@@ -214,16 +214,22 @@ class UDABatchAssembler:
                        "image_ref": torch.empty((self.b, 3, *pairs.size), dtype=torch.float32, device=self.device)} for _ in range(2)]
         self._turn = 0
         self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._read_done = [None, None]       # per buffer set: event behind the last step that read it (consumed())
 
     def assemble(self, pair_indices):
         """-> (batch dict, event): the batch is complete once `event` has fired (wait on it from the consuming stream)"""
         if len(pair_indices) != self.b:
             raise RuntimeError("UDABatchAssembler: one target index per sample of the batch")
         out = self._sets[self._turn]
+        done, self._read_done[self._turn] = self._read_done[self._turn], None
         self._turn ^= 1
-        # the set being re-filled was handed out two batches ago: the step that read it was queued on the consumer's (the
-        # current) stream -- the crop kernels must not overwrite it while that step may still be running (ADVICE r4)
-        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        # the set being re-filled was handed out two batches ago: the crop kernels must not overwrite it while the step that
+        # read it may still be running (ADVICE r4).  If the consumer marked that step (consumed()), wait for exactly it -- batch
+        # n + 1 is then built NEXT TO step n (ADVICE r5); otherwise for everything queued on the consumer's stream so far
+        if done is not None:
+            self._stream.wait_event(done)
+        else:
+            self._stream.wait_stream(torch.cuda.current_stream(self.device))
         ctx = torch.cuda.stream(self._stream)
         with ctx:
             for i in range(self.b):                          # the source loader's samples, then the target loader's (two loaders)
@@ -232,3 +238,12 @@ class UDABatchAssembler:
                 self.pairs.sample(idx, out["image_trg"][i], out["image_ref"][i])
             ev = self._stream.record_event()
         return out, ev
+
+    def consumed(self, batch):
+        """Call on the consuming stream right after queueing the last work that reads `batch` (a dict assemble() returned): the
+        set may be re-filled as soon as that work is done."""
+        for i, st in enumerate(self._sets):
+            if batch is st or batch.get("image_src") is st["image_src"]:
+                self._read_done[i] = torch.cuda.current_stream(self.device).record_event()
+                return
+        raise RuntimeError("UDABatchAssembler.consumed: not a batch of this assembler")

@@ -375,5 +375,18 @@ class GraphedSplitStep(GraphedStep):
     def captured(self):
         return self._last is not None and self._last["graph"] is not None and self._last.get("graph_bwd") is not None
 
+    def any_failed(self):
+        return any(st["failed"] for st in self.states.values())
+
+    def give_up(self):
+        """Eager from now on, for every input signature seen so far and for new ones of this generation (the owner calls this on
+        the passes of a model when ONE of them could not be captured: the passes then all run eagerly, the one combination every
+        configuration is tested in -- a replayed pass next to an eagerly run one is not)."""
+        if self._held is not None and self._held[0] is not None:
+            raise RuntimeError("GraphedSplitStep.give_up between forward() and backward()")
+        for st in self.states.values():
+            st["failed"], st["graph"], st["graph_bwd"], st["held"] = True, None, None, None
+        self.warmup = 1 << 60
+
     def __call__(self, *a, **k):
         raise TypeError("GraphedSplitStep: call forward() and backward()")

@@ -80,6 +80,15 @@ class ConvBNReLU(nn.Module):
         self._folded = None
         return super()._apply(fn, *a, **k)
 
+    def _out_count(self, x):
+        """values per channel of this block's convolution result on `x` (batch x OH x OW)"""
+        c = self.conv
+        n = x.shape[0]
+        for i in (0, 1):
+            pad = c.padding[i] if not isinstance(c.padding, str) else (c.dilation[i] * (c.kernel_size[i] - 1) // 2 if c.padding == "same" else 0)
+            n *= max(0, (x.shape[2 + i] + 2 * pad - c.dilation[i] * (c.kernel_size[i] - 1) - 1) // c.stride[i] + 1)
+        return n
+
     def _conv2d(self, x, w, b, stats=None):
         """The convolution itself.  Depthwise 3x3 (the DAFormer ASPP branches) goes to the hand-written channels-last
         HIP kernel on the GPU -- the library's grouped-conv path for group size 1 is ~50x off the HBM roofline; every
@@ -158,7 +167,7 @@ class ConvBNReLU(nn.Module):
             return False
         from . import bn as bnk
         from .params import compute_dtype
-        return bnk.usable(x, m.bn, compute_dtype(x), channels=m.conv.out_channels)
+        return bnk.usable(x, m.bn, compute_dtype(x), channels=m.conv.out_channels, count=m._out_count(x))
 
     def _dw_stats_ok(self, x, cd):
         """depthwise 3x3 -> BatchNorm(train): the convolution kernel leaves the batch statistics of its result behind
@@ -224,7 +233,7 @@ class ConvBNReLU(nn.Module):
                 from . import bn as bnk
                 from .params import compute_dtype
                 cd = compute_dtype(x)
-                if bnk.usable(x, self.bn, cd, channels=c.out_channels):
+                if bnk.usable(x, self.bn, cd, channels=c.out_channels, count=self._out_count(x)):
                     return self._bn_train(x, cd)
             x = self._conv2d(x, c.weight, c.bias)
             if self.use_norm:

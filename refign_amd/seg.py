@@ -181,7 +181,7 @@ class Attention(nn.Module):
         o = mfma.attention(q, kv, h, self.scale) if (d == 64 and p == 0.0 and _SDPA_BACKEND is None) else None
         if o is None and q.is_cuda and q.dtype == torch.float32 and p == 0.0 and _SDPA_BACKEND is None:
             from . import split32
-            if split32.usable(q, kv) and d == 64:      # fp32 parity mode: the fp32 matrix-pipe attention kernel (csrc/attn32.hip)
+            if split32.usable(q, kv) and d in (32, 64):    # fp32 parity mode: the fp32 matrix-pipe attention kernel (csrc/attn32.hip)
                 o = split32.attention(q, kv, h, self.scale)
         if o is None:
             mfma.note_library("sdpa", q, kv)

@@ -134,7 +134,8 @@ class _Attn32Fn(torch.autograd.Function):
         lse2 = torch.empty((B * heads, nqpad), dtype=torch.float32, device=q.device)
         with on_device(q.device):
             rc = _lib.load_library().rfn_attn32_fwd(ptr(q), q.stride(0), q.stride(1), ptr(kv), kv.stride(0), kv.stride(1), ptr(o),
-                                                    o.stride(0), o.stride(1), ptr(lse2), B, heads, N, Nkv, nqpad, float(scale),
+                                                    o.stride(0), o.stride(1), ptr(lse2), B, heads, C // heads, N, Nkv, nqpad,
+                                                    float(scale),
                                                     current_stream(q.device))
         _lib.check(rc, "attn32_fwd")
         if q.requires_grad or kv.requires_grad:
@@ -160,18 +161,18 @@ class _Attn32Fn(torch.autograd.Function):
         with on_device(q.device):
             rc = _lib.load_library().rfn_attn32_bwd(ptr(q), q.stride(0), q.stride(1), ptr(kv), kv.stride(0), kv.stride(1), ptr(do),
                                                     ptr(o), o.stride(0), o.stride(1), ptr(lse2), ptr(delta), ptr(dq), dq.stride(0),
-                                                    dq.stride(1), ptr(dkv), dkv.stride(0), dkv.stride(1), B, heads, N, Nkv,
-                                                    lse2.shape[1], chunks, float(scale), current_stream(q.device))
+                                                    dq.stride(1), ptr(dkv), dkv.stride(0), dkv.stride(1), B, heads, C // heads, N,
+                                                    Nkv, lse2.shape[1], chunks, float(scale), current_stream(q.device))
         _lib.check(rc, "attn32_bwd")
         return dq, dkv, None, None
 
 
 def attention(q, kv, heads, scale):
-    """q: (B, N, heads * 64) fp32, kv: (B, Nkv, 2 * heads * 64) fp32 (K then V, each (heads, 64) per token: the layout of
-    mix_transformer.py:147-149) -> (B, N, heads * 64) = `(softmax(scale q k^T) v).transpose(1, 2).reshape(B, N, C)`; None
-    outside the kernel's domain (head dimension 64, contiguous rows)."""
+    """q: (B, N, heads * D) fp32, kv: (B, Nkv, 2 * heads * D) fp32 (K then V, each (heads, D) per token: the layout of
+    mix_transformer.py:147-149) -> (B, N, heads * D) = `(softmax(scale q k^T) v).transpose(1, 2).reshape(B, N, C)`; None
+    outside the kernel's domain (head dimension 64 or 32, contiguous rows)."""
     B, N, C = q.shape
-    if C != heads * 64 or kv.shape[2] != 2 * C or q.stride(2) != 1 or kv.stride(2) != 1 or q.stride(1) % 4 or kv.stride(1) % 4 \
+    if C not in (heads * 64, heads * 32) or kv.shape[2] != 2 * C or q.stride(2) != 1 or kv.stride(2) != 1 or q.stride(1) % 4 or kv.stride(1) % 4 \
             or q.stride(0) % 4 or kv.stride(0) % 4 or q.data_ptr() % 16 or kv.data_ptr() % 16:
         return None
     return _Attn32Fn.apply(q, kv, heads, scale)

@@ -761,6 +761,9 @@ class DomainAdaptationSegmentationModel(nn.Module):
         self._prefetch_next(batch, prefetch_free, self._side_stream.record_event() if early is not None else None,
                             early is not None, None)
         self.log("train_loss_uda_trg", mixed_loss)
+        if src_graph.any_failed() != mix_graph.any_failed():
+            # one student pass could not be captured: the other one goes back to eager launches too (graphs.GraphedSplitStep.give_up)
+            (mix_graph if src_graph.any_failed() else src_graph).give_up()
         opt.step()
         sch.step()
         self.global_step += 1

@@ -355,9 +355,10 @@ def test_alignment_forward_k2_golden_512x512(dev):
 
 @torch.no_grad()
 def test_align_k4_timed_precision_map_is_bounded_at_1080x1920(dev, tmp_path):
-    """bound the TIMED precision map where the metric is quoted.  align() under the autocast region bench.py times
-    (convolutions fp16 -- the reference's own AMP dtype, README.md:262 -- correlation / warp / L2 norm / uncertainty fp32, which
-    the reference forces too: correlation_function.py:51, matching_utils.py:40-43) against the reference CPU path's fp32 output
+    """the TIMED precision map holds the north star's tolerance where the metric is quoted.  align() under the
+    autocast region bench.py times (VGG-16 convolutions fp16 -- the reference's own AMP dtype, README.md:262 -- the UAWarpC head's
+    convolutions as split-bf16 products (align.HEAD_SPLIT), correlation / warp / L2 norm / uncertainty fp32, which the reference
+    forces too: correlation_function.py:51, matching_utils.py:40-43) against the reference CPU path's fp32 output
     at 1080 x 1920 (G7-K4, tests/golden/make_golden_k4.py).  The deviation is WRITTEN DOWN (printed, and kept in
     profiles/r05_align_amp_1080x1920.txt from the round's GPU run) and bounded: warp-mask mismatch fraction, warped-logit error
     inside the mask, argmax agreement on the pixels the reference decides by a margin."""
@@ -383,7 +384,7 @@ def test_align_k4_timed_precision_map_is_bounded_at_1080x1920(dev, tmp_path):
     decided = (g["warped_margin"].astype(np.float32) > 1e-2) & (want_mask & m)[:, ::4, ::4]
     agree = float((am == g["warped_argmax"])[decided].mean())
     cert_err = float(np.abs(cert.cpu().numpy()[:, :, ::8, ::8] - g["cert_sample"]).max())
-    line = (f"align() at {H}x{W}, timed precision map (fp16 convolutions) vs reference fp32 CPU path: warp-mask mismatch "
+    line = (f"align() at {H}x{W}, timed precision map (VGG fp16, head split-bf16) vs reference fp32 CPU path: warp-mask mismatch "
             f"{mask_mismatch:.2e} of the pixels, warped logits inside the mask max |err| {max_err:.3e} mean {mean_err:.3e}, "
             f"argmax agreement on decided pixels {agree:.5f} ({int(decided.sum())} sampled), confidence max |err| {cert_err:.3e}")
     print("\n" + line)
@@ -392,7 +393,8 @@ def test_align_k4_timed_precision_map_is_bounded_at_1080x1920(dev, tmp_path):
     if out:
         with open(os.path.join(out, "align_amp_1080x1920.txt"), "w") as f:
             f.write(line + "\n")
-    # measured on MI355X (profiles/r05_align_amp_1080x1920.txt): mask mismatch 0, max |err| 4.5e-3, mean 4.2e-4, agreement 1.00000
-    # on 129 449 decided samples, confidence 1.7e-2
+    # Round 6 (align.HEAD_SPLIT: VGG-16 fp16, the head's convolutions as split-bf16 products), measured on MI355X
+    # (profiles/r06_align_amp_1080x1920.txt): mask mismatch 0, max |err| 7.4e-5, mean 6.3e-6, agreement 1.00000 on 129 449 decided
+    # samples, confidence 4.1e-4 -- the north star's 1e-3 holds in the TIMED map.  (Round 5, everything fp16: 5.6e-3 / 1.2e-2.)
     assert mask_mismatch < 1e-4, line
-    assert max_err < 2e-2 and mean_err < 2e-3 and agree > 0.999 and cert_err < 4e-2, line
+    assert max_err <= 1e-3 and mean_err < 1e-4 and agree > 0.999 and cert_err <= 1e-3, line

@@ -51,18 +51,19 @@ def test_conv2d_fp32_split_forward_backward(B, H, W, C, N, k, stride, pad, dil):
         assert float((got.double() - want).abs().max()) <= TOL * float(want.abs().max()) + 1e-6
 
 
-ATTN = [  # B, heads, Nq, Nkv  (head dimension 64; ragged query / key tails, one / several query chunks in dK / dV)
-    (2, 2, 130, 70), (1, 5, 2040, 510), (3, 1, 517, 33), (1, 8, 510, 510), (2, 1, 4100, 480), (1, 2, 31, 5),
+ATTN = [  # B, heads, Nq, Nkv, head dimension  (ragged query / key tails, one / several query chunks in dK / dV)
+    (2, 2, 130, 70, 64), (1, 5, 2040, 510, 64), (3, 1, 517, 33, 64), (1, 8, 510, 510, 64), (2, 1, 4100, 480, 64), (1, 2, 31, 5, 64),
+    (2, 2, 130, 70, 32), (2, 1, 1536, 24, 32), (1, 8, 96, 96, 32),
 ]
 
 
-@pytest.mark.parametrize("B,h,N,Nkv", ATTN)
-def test_attention_fp32_kernel_matches_fp64(B, h, N, Nkv):
+@pytest.mark.parametrize("B,h,N,Nkv,D", ATTN)
+def test_attention_fp32_kernel_matches_fp64(B, h, N, Nkv, D):
     """csrc/attn32.hip (fp32 matrix pipe, fp32 softmax) against the fp64 formulation of mix_transformer.py:147-160 on the
     tensors as the Linears hand them over -- q (B, N, h 64), kv (B, Nkv, 2 h 64) -- forward and the three gradients; the
     forward twice, bit-identical (no atomics there)."""
     from refign_amd import split32
-    C = h * 64
+    C = h * D
     q, kv = _r((B, N, C), 9).requires_grad_(True), _r((B, Nkv, 2 * C), 10).requires_grad_(True)
     scale = 0.125
     o = split32.attention(q, kv, h, scale)
@@ -71,8 +72,8 @@ def test_attention_fp32_kernel_matches_fp64(B, h, N, Nkv):
     go = _r((B, N, C), 12)
     o.backward(go)
     qd, kvd = (t.detach().double().requires_grad_(True) for t in (q, kv))
-    k, v = kvd.view(B, Nkv, 2, h, 64).permute(2, 0, 3, 1, 4).unbind(0)
-    od = (torch.softmax(qd.view(B, N, h, 64).transpose(1, 2) @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, N, C)
+    k, v = kvd.view(B, Nkv, 2, h, D).permute(2, 0, 3, 1, 4).unbind(0)
+    od = (torch.softmax(qd.view(B, N, h, D).transpose(1, 2) @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, N, C)
     od.backward(go.double())
     for name, got, want in (("o", o, od), ("dq", q.grad, qd.grad), ("dkv", kv.grad, kvd.grad)):
         err = float((got.double() - want).abs().max())

@@ -576,7 +576,9 @@ def test_failed_backward_capture_leaves_one_forwards_side_effects(dev, monkeypat
     has already run as a graph replay, and the pass is run once more eagerly to get an autograd graph -- the decode heads'
     BatchNorm running statistics and batch counters must still move ONCE per forward.  4 steps with the source pass's backward
     capture made to fail (a host synchronisation inside the captured region) against 4 steps with the student passes eager: same
-    losses, same parameters, the same running statistics, counters equal; a warning, and the pass eager from then on."""
+    losses, same parameters, the same running statistics, counters equal; a warning, and BOTH student passes eager from then on
+    (a replayed pass next to an eagerly run one is a combination nothing else exercises).  In the step's own precision map (bf16
+    autocast: BatchNorm on csrc/bn.hip)."""
     from refign_amd.trainer import Trainer
     out = {}
     for mode in ("fail", "eager"):
@@ -597,21 +599,23 @@ def test_failed_backward_capture_leaves_one_forwards_side_effects(dev, monkeypat
         for it in range(4):
             batch = make_batch(2, 128, 128, 64, dev)
             batch["image_src"] = batch["image_src"] + 0.1 * it
-            if mode == "fail" and it == 2:
-                with pytest.warns(UserWarning, match=r"student source pass' \(backward\) failed"):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                if mode == "fail" and it == 2:
+                    with pytest.warns(UserWarning, match=r"student source pass' \(backward\) failed"):
+                        trainer.step(batch, it)
+                else:
                     trainer.step(batch, it)
-            else:
-                trainer.step(batch, it)
             rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
         stats = torch.cat([b.flatten().double() for n, b in model.head.named_buffers() if "running" in n]).cpu()
         counts = [int(b) for n, b in model.head.named_buffers() if n.endswith("num_batches_tracked")]
         out[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), stats, counts)
         if mode == "fail":
             assert all(s_["failed"] for s_ in sp.states.values())
+            assert all(s_["failed"] and s_["graph"] is None for s_ in model._graphs["mixed_pass"].states.values())
     assert out["fail"][3] == out["eager"][3] and max(out["eager"][3]) == 8          # two forwards per step, four steps
-    np.testing.assert_allclose(out["fail"][0], out["eager"][0], rtol=2e-3)
-    assert abs(out["fail"][1] - out["eager"][1]) < 1e-5 * out["eager"][1]
-    assert float((out["fail"][2] - out["eager"][2]).abs().max()) < 1e-4 * float(out["eager"][2].abs().max())
+    np.testing.assert_allclose(out["fail"][0], out["eager"][0], rtol=3e-2)
+    assert abs(out["fail"][1] - out["eager"][1]) < 1e-4 * out["eager"][1]
+    assert float((out["fail"][2] - out["eager"][2]).abs().max()) < 2e-3 * float(out["eager"][2].abs().max())
 
 
 def test_checkpoint_round_trip_on_gpu(dev, tmp_path):
