@@ -462,6 +462,12 @@ int rfn_attn32_bwd(const float* Q, long q_batch_stride, long q_row_stride, const
  * ---------------------------------------------------------------------------------------------------------- */
 int rfn_split3_bf16(const float* x, long x_row_stride, void* out, long out_row_stride, long term_stride, long rows, int K,
                     int Kp, int order, rfn_stream_t stream);
+/* The (hi, hi, lo) split of the channel CONCATENATION of 1..4 fp32 maps of one (B, H, W), each addressed through its own
+ * strides[4 i .. 4 i + 3] = (batch, channel, row, column) in floats (NCHW and channels-last parts mix freely), written as the
+ * (B, H, W, 3 Cp) bf16 operand of rfn_conv2d_nhwc_o32; sum of channels <= Cp <= 96, Cp % 4 == 0 (uawarpc.py:136-160: the decoder
+ * inputs cat(correlation, flow, ...)).  `parts`, `strides`, `channels` are HOST arrays. */
+int rfn_split3_cat_bf16(const float* const* parts, const long* strides, const int* channels, int nparts, void* out, int B, int H,
+                        int W, int Cp, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ ReLU) on channels-last 16-bit tensors viewed as (T = B*H*W, C): the norm + activation of

@@ -201,7 +201,7 @@ class UncertaintyModule(nn.Module):
         parts = [self.patch_statistics(corr), feat]
         if self.feed_in_previous:
             parts += [up_previous_uncertainty, up_previous_flow]
-        u = self.pred_conv_1(self.pred_conv_0(torch.cat(parts, 1)))
+        u = self.pred_conv_1(self.pred_conv_0(parts))
         return self.predict_uncertainty_final(u)
 
 
@@ -398,7 +398,7 @@ class UAWarpCHead(BaseHead):
         parts = [corr, flow_prev] + ([extra] if extra is not None else [])
         if self.estimate_uncertainty:
             parts.append(uncert_prev)
-        res, x = getattr(self, f"decoder{lvl}")(torch.cat(parts, 1))
+        res, x = getattr(self, f"decoder{lvl}")(parts)        # (the concatenation as its parts: layers.ConvBNReLU.forward)
         refine = {3: self.refinement_at_adaptive_res and 'refinement_module_adaptive',
                   1: self.refinement_at_finest_level and 'refinement_module_finest'}.get(lvl)
         if refine:
@@ -543,7 +543,9 @@ def run_head(alignment_head, pyr, size):
         _HEAD_IN_TIMED_MAP[0] = True
         try:
             with torch.autocast("cuda", enabled=False):
-                return alignment_head(*[[f.float() for f in p] for p in pyr], size)
+                # (the fp16 pyramid as it is: the head's first step is the L2 normalisation, whose kernel takes channels-last 16-bit
+                # maps and writes fp32 NCHW in one pass -- everything after it is fp32)
+                return alignment_head(*pyr, size)
         finally:
             _HEAD_IN_TIMED_MAP[0] = was
     return alignment_head(*pyr, size)

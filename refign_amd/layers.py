@@ -196,6 +196,22 @@ class ConvBNReLU(nn.Module):
         return bnk.bn_act_train(self._conv_train(x, cd), self.bn, act, cd, out=out)
 
     def forward(self, x, out=None):
+        if isinstance(x, (list, tuple)):
+            # a channel concatenation handed over as its parts (the matcher's decoders: cat(correlation, flow, ...)): on the
+            # gradient-free split-bf16 path the parts go straight into the convolution's operand (split32.conv2d_parts)
+            c = getattr(self, "conv", None)
+            if c is not None and out is None and x[0].is_cuda and c.groups == 1 and not torch.is_grad_enabled() \
+                    and (not self.use_norm or not self.training) and self.act_slope in (0.0, LEAKY_SLOPE) \
+                    and all(t.dtype == torch.float32 for t in x) and not torch.is_autocast_enabled("cuda") \
+                    and c.stride[0] == c.stride[1] and c.padding[0] == c.padding[1] and c.dilation[0] == c.dilation[1]:
+                from . import split32
+                if split32.usable(*x):
+                    w, b = self.folded() if self.use_norm else (c.weight, c.bias)
+                    y = split32.conv2d_parts(list(x), w, b, c.stride[0], c.padding[0], c.dilation[0],
+                                             act={None: 0, 'relu': 1, 'leaky': 3}[self.act])
+                    if y is not None:
+                        return y
+            x = torch.cat(list(x), 1)
         if self.depthwise_separable:
             return self.pointwise_conv(self.depthwise_conv(x), out=out)
         c = self.conv

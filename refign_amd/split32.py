@@ -224,6 +224,70 @@ def _w3_frozen(w, order):
     return packed
 
 
+def _wb_frozen(weight, bias):
+    """(packed split weight, bias padded to the packed row count) of a gradient-free convolution, kept like _w3_frozen."""
+    wp = _w3_frozen(weight, "hlh")
+    if bias is None:
+        return wp, None
+    N, Np = bias.shape[0], wp.shape[0]
+    if Np == N and bias.is_contiguous():
+        return wp, bias
+    if torch.is_grad_enabled():
+        return wp, torch.nn.functional.pad(bias, (0, Np - N)).contiguous()
+    key = (bias._version, Np)
+    ent = bias.__dict__.get("_rfn_bpad")
+    if ent is not None and ent[0] == key:
+        return wp, ent[1]
+    bp = torch.nn.functional.pad(bias.detach(), (0, Np - N)).contiguous()
+    if not torch.cuda.is_current_stream_capturing():
+        bias.__dict__["_rfn_bpad"] = (key, bp)
+    return wp, bp
+
+
+def cat_split(parts):
+    """[(B, c_i, H, W) fp32 maps, any strides] -> ((B, H, W, 3 Cp) bf16 (hi, hi, lo) split of their channel concatenation, Cp, C) in
+    one launch (csrc/split3.hip split3_cat_kernel); None outside its domain (more than 4 parts, more than 96 channels)."""
+    import ctypes
+    B, _, H, W = parts[0].shape
+    C = sum(p.shape[1] for p in parts)
+    Cp = -(-C // 8) * 8
+    if not (1 <= len(parts) <= 4 and Cp <= 96 and all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 4
+                                                      and p.shape[0] == B and tuple(p.shape[2:]) == (H, W) for p in parts)):
+        return None
+    n = len(parts)
+    out = torch.empty((B, H, W, 3 * Cp), dtype=BF, device=parts[0].device)
+    ptrs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts])
+    strides = (ctypes.c_long * (4 * n))(*[v for p in parts for v in p.stride()])
+    chans = (ctypes.c_int * n)(*[p.shape[1] for p in parts])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
+    with on_device(out.device):
+        rc = _lib.load_library().rfn_split3_cat_bf16(cast(ptrs), cast(strides), cast(chans), n, ptr(out), B, H, W, Cp,
+                                                     current_stream(out.device))
+    _lib.check(rc, "split3_cat_bf16")
+    return out, Cp, C
+
+
+def conv2d_parts(parts, weight, bias=None, stride=1, padding=0, dilation=1, act=0):
+    """conv2d(torch.cat(parts, 1), ...) for gradient-free fp32 HIP maps without materialising the concatenation: the parts are
+    gathered, split and laid out channels-last in one pass (cat_split), then the one-launch split-bf16 convolution.  None outside
+    the domain (the caller concatenates)."""
+    if torch.is_grad_enabled() or not isinstance(stride, int) or not isinstance(padding, int) or not isinstance(dilation, int):
+        return None
+    N, C, KH, KW = weight.shape
+    if sum(p.shape[1] for p in parts) != C or 3 * (-(-C // 8) * 8) * KH * KW // 8 >= 65536:
+        return None
+    got = cat_split(parts)
+    if got is None:
+        return None
+    x3, Cp, _ = got
+    B, H, W = x3.shape[:3]
+    wp, b = _wb_frozen(weight, bias)
+    OH = (H + 2 * padding - dilation * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * padding - dilation * (KW - 1) - 1) // stride + 1
+    y = _conv_o32(x3, wp, b, B, H, W, 3 * Cp, wp.shape[0], KH, KW, stride, padding, dilation, act, False, (OH, OW))
+    return y[..., :N].permute(0, 3, 1, 2)
+
+
 def _conv_o32(x3, wp, bias, B, H, W, C, N, KH, KW, s, p, d, act, transposed, out_hw):
     """(H, W, C) = the convolution's INPUT side, N its output channels (C ABI of rfn_conv2d_nhwc_o32); the result has N
     channels (forward) or C channels (transposed = data gradient)."""
@@ -244,10 +308,10 @@ class _Conv2dFn(torch.autograd.Function):
         B, _, H, W = x.shape
         x3, Cp = _nhwc3(x, "hhl")
         Np = -(-N // 8) * 8
-        b = None if bias is None else torch.nn.functional.pad(bias, (0, Np - N)).contiguous()
+        wp, b = _wb_frozen(weight, bias)
         OH = (H + 2 * p - d * (KH - 1) - 1) // s + 1
         OW = (W + 2 * p - d * (KW - 1) - 1) // s + 1
-        y = _conv_o32(x3, _w3_frozen(weight, "hlh"), b, B, H, W, 3 * Cp, Np, KH, KW, s, p, d, act, False, (OH, OW))
+        y = _conv_o32(x3, wp, b, B, H, W, 3 * Cp, Np, KH, KW, s, p, d, act, False, (OH, OW))
         ctx.save_for_backward(x, weight)
         ctx.conf, ctx.has_bias = (s, p, d), bias is not None
         assert act == 0 or not any(ctx.needs_input_grad), "activation epilogue: gradient-free callers only"

@@ -112,6 +112,32 @@ def test_split3_kernel_equals_the_two_term_split(rows, K, pad):
                 assert not side[:, i * Kp + K:(i + 1) * Kp].any() and not stack[i * rows:(i + 1) * rows, K:].any()
 
 
+@pytest.mark.parametrize("B,H,W,chans", [(2, 19, 37, (81, 2, 2, 1)), (1, 16, 64, (6, 32, 1, 2)), (1, 5, 7, (3,)), (2, 33, 65, (81, 2, 1))])
+def test_conv2d_on_parts_equals_conv2d_on_the_concatenation(B, H, W, chans):
+    """split32.conv2d_parts (csrc/split3.hip split3_cat_kernel): the decoders' cat(correlation, flow, [feature,] log-variance)
+    handed over as parts in MIXED layouts (NCHW, channels-last, a channel slice of a wider channels-last tensor) -- the split
+    operand is bit-identical to the one made from torch.cat, so the convolution is too."""
+    from refign_amd import split32
+    parts = []
+    for i, c in enumerate(chans):
+        t = _r((B, c, H, W), 40 + i, 50.0)
+        if i % 3 == 1:
+            t = t.contiguous(memory_format=torch.channels_last)
+        elif i % 3 == 2:
+            wide = _r((B, H, W, c + 5), 50 + i, 50.0)
+            t = wide[..., 2:2 + c].permute(0, 3, 1, 2)
+        parts.append(t)
+    C, N = sum(chans), 24
+    w, b = _r((N, C, 3, 3), 60, (9 * C) ** -0.5), _r((N,), 61)
+    with torch.no_grad():
+        x3, Cp, Cc = split32.cat_split(parts)
+        want3, _ = split32._nhwc3(torch.cat(parts, 1), "hhl")
+        assert Cc == C and torch.equal(x3, want3)
+        y = split32.conv2d_parts(parts, w, b, 1, 1, 1, act=3)
+        want = split32.conv2d(torch.cat(parts, 1), w, b, 1, 1, 1, act=3)
+    assert y is not None and torch.equal(y, want)
+
+
 def test_fp32_goldens_stay_off_the_libraries():
     """One fp32 forward + backward of MiT-b0 + DAFormer head + HRDA scale attention on HIP tensors records no dense library
     call (F.linear / torch.mm / F.conv2d / scaled_dot_product_attention): the fp32 parity mode the golden-vector tests run
