@@ -470,6 +470,16 @@ int rfn_split3_cat_bf16(const float* const* parts, const long* strides, const in
                         int W, int Cp, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Mix-FFN front half of the gradient-free MiT passes (mix_transformer.py:79-103) in one kernel:
+ *   a = gelu(dwconv3x3(x W1^T + b1) + bdw)      x (views, H*W, C) bf16 tokens, a (views, H*W, HID) bf16
+ * W1 (HID, C) bf16 row-major, b1 (HID) bf16, wdw_tap (9, HID) fp32 tap-major (tap = ky * 3 + kx), bdw (HID) fp32;
+ * C % 64 == 0, HID % 128 == 0.  The hidden pre-activation is rounded to bf16 (as the fc1 kernel stores it) and is zero
+ * outside the image (the convolution pads the hidden map).
+ * ---------------------------------------------------------------------------------------------------------- */
+int rfn_ffn_fc1_dw_gelu_bf16(const void* x, const void* w1, const void* b1, const float* wdw_tap, const float* bdw, void* a,
+                             int views, int H, int W, int C, int HID, rfn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Training-mode BatchNorm2d (+ ReLU) on channels-last 16-bit tensors viewed as (T = B*H*W, C): the norm + activation of
  * the decode heads' ConvBNReLU blocks (models/modules.py:16-56), which use BATCH statistics in the student and in the EMA
  * teacher.  dtype 1 = bf16, 2 = f16; statistics, affine parameters and running buffers fp32; C % 8 == 0.

@@ -100,6 +100,7 @@ SIGNATURES = {
                        + [c_void_p, ctypes.c_long, ctypes.c_long] * 2 + [c_int] * 7 + [c_float, c_void_p]),
     "rfn_split3_bf16": (c_int, [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, c_int, c_int,
                                 c_int, c_void_p]),
+    "rfn_ffn_fc1_dw_gelu_bf16": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "rfn_split3_cat_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rfn_upsample_ce": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     "rfn_bn_stats_fwd": (c_int, [c_void_p] * 2 + [ctypes.c_long, c_int, c_int, c_void_p]),

@@ -5,6 +5,8 @@ NCHW transposes of the reference: x is (B, N=H*W, C) and stays that way.  `dwcon
 is the same on (B, H, W, C) maps with dilation (DAFormer ASPP branches, daformer.py:46-62).  `weight` is the reference
 parameter itself, shape (C, 1, 3, 3); activations float32 or bfloat16, accumulation fp32, weight grads fp32.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -142,6 +144,31 @@ def dwconv3x3_gelu_tokens(x, weight, bias, H, W, with_z=False):
     if isinstance(out, tuple):
         return out[0].reshape(B, N, C), out[1].reshape(B, N, C)
     return (out.reshape(B, N, C), None) if with_z else out.reshape(B, N, C)
+
+
+FUSED_FFN = os.environ.get("RFN_FUSED_FFN", "1") != "0"      # (tests flip the attribute; the variable is for A/B runs of bench.py)
+
+
+@torch.no_grad()
+def ffn_fc1_dw_gelu(x, fc1, dw, H, W):
+    """gelu(dw(fc1(x))) of a Mix-FFN (mix_transformer.py:99-101) on gradient-free bf16 tokens (views, H*W, C) in ONE kernel
+    (csrc/mixffn.hip): the 4C-wide pre-activation never reaches HBM.  `fc1`: the Linear, `dw`: the depthwise nn.Conv2d.  None
+    outside the kernel's domain (the caller runs fc1, then dwconv3x3_gelu_tokens)."""
+    B, N, C = x.shape
+    HID = fc1.weight.shape[0]
+    if not (FUSED_FFN and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and N == H * W and C % 64 == 0
+            and HID % 128 == 0 and fc1.bias is not None and dw.bias is not None and dw.weight.shape == (HID, 1, 3, 3)
+            and dw.padding == (1, 1) and dw.stride == (1, 1) and dw.dilation == (1, 1)):
+        return None
+    w1, b1 = as_dtype(fc1.weight, torch.bfloat16), as_dtype(fc1.bias, torch.bfloat16)
+    w_tap = derived(dw.weight, "tap_major_f32", lambda t: t.float().reshape(HID, 9).t().contiguous(), lambda t: t.reshape(HID, 9).t())
+    bdw = as_dtype(dw.bias, torch.float32).detach().contiguous()
+    a = torch.empty((B, N, HID), dtype=torch.bfloat16, device=x.device)
+    with on_device(x.device):
+        rc = _lib.load_library().rfn_ffn_fc1_dw_gelu_bf16(ptr(x), ptr(w1), ptr(b1), ptr(w_tap), ptr(bdw), ptr(a), B, H, W, C, HID,
+                                                          current_stream(x.device))
+    _lib.check(rc, "ffn_fc1_dw_gelu")
+    return a
 
 
 def dwconv3x3_nhwc(x, weight, bias=None, dilation=1, stats=None):

@@ -112,6 +112,14 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x, H, W, res=None, rowscale=None):
+        if x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and type(self.act) is nn.GELU \
+                and self.act.approximate == 'none' and self.drop.p == 0. and type(self.fc1) is Linear and not _f8.active():
+            # gradient-free passes (EMA teacher's 40 views, ImageNet encoder): fc1 + depthwise 3x3 + GELU in ONE kernel, the 4C-wide
+            # pre-activation never reaches HBM (csrc/mixffn.hip); fc2 (+ residual) follows as before
+            from .dwconv import ffn_fc1_dw_gelu
+            a = ffn_fc1_dw_gelu(x, self.fc1, self.dwconv.dwconv, H, W)
+            if a is not None:
+                return self.fc2(a, res=res, rowscale=rowscale) if res is not None else self.fc2(a)
         x = self.fc1(x)
         if x.is_cuda and x.shape[-1] % 8 == 0 and type(self.act) is nn.GELU and self.act.approximate == 'none':
             from .dwconv import dwconv3x3_gelu_tokens           # depthwise conv + GELU in one pass (csrc/dwconv.hip)

@@ -167,3 +167,46 @@ def test_three_dilations_of_one_input_in_two_passes(dev, B, H, W, C, g, relu, bi
         assert torch.allclose(bns_a[k].running_mean, bns_b[k].running_mean, rtol=1e-6, atol=1e-7)
         assert torch.allclose(bns_a[k].running_var, bns_b[k].running_var, rtol=1e-6, atol=1e-7)
         assert int(bns_a[k].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("views,H,W,C", [(3, 17, 30, 512), (2, 34, 60, 320), (2, 7, 45, 128), (1, 135, 240, 64), (2, 13, 31, 320),
+                                         (1, 6, 30, 64), (1, 1, 1, 128), (2, 68, 120, 128)])
+def test_fused_mix_ffn_front_half_equals_the_three_kernels(dev, views, H, W, C):
+    """Round 6, csrc/mixffn.hip: gelu(dw3x3(fc1(x))) of a Mix-FFN (mix_transformer.py:99-101) in ONE kernel for the gradient-free
+    passes -- all four MiT-B5 stage widths, token maps that are not multiples of the 6 x 30 interior tile (ragged right / bottom
+    tiles, maps smaller than one tile), several views (no halo leaks across views) -- against the three-kernel formulation
+    (GEMM with bf16 store, depthwise + GELU kernel) on the same modules: the same roundings, so at most one bf16 step apart; and
+    against the fp32 torch formulation; twice, bit-identical."""
+    from refign_amd import dwconv
+    from refign_amd.seg import Mlp
+    torch.manual_seed(C + H)
+    mlp = Mlp(C, 4 * C).to(dev).eval()
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.mul_(2.0)
+        mlp.dwconv.dwconv.bias.normal_(0, 0.5)
+        mlp.fc1.bias.normal_(0, 0.5)
+    x = torch.randn(views, H * W, C, device=dev).to(torch.bfloat16)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a = dwconv.ffn_fc1_dw_gelu(x, mlp.fc1, mlp.dwconv.dwconv, H, W)
+        assert a is not None and tuple(a.shape) == (views, H * W, 4 * C)
+        assert torch.equal(a, dwconv.ffn_fc1_dw_gelu(x, mlp.fc1, mlp.dwconv.dwconv, H, W))
+        h = mlp.fc1(x)
+        want = dwconv.dwconv3x3_gelu_tokens(h, mlp.dwconv.dwconv.weight, mlp.dwconv.dwconv.bias, H, W)
+        y_fused = mlp(x, H, W)
+        dwconv.FUSED_FFN = False
+        try:
+            y_plain = mlp(x, H, W)
+        finally:
+            dwconv.FUSED_FFN = True
+    d = (a.float() - want.float()).abs()
+    scale = float(want.float().abs().max())
+    assert float(d.max()) <= 2.0 ** -6 * scale and float(d.mean()) <= 2e-4 * scale, (float(d.max()), float(d.mean()), scale)
+    assert float((y_fused.float() - y_plain.float()).abs().max()) <= 2.0 ** -5 * float(y_plain.float().abs().max())
+    # fp32 formulation (the reference's ops)
+    xf = x.float()
+    hf = torch.nn.functional.linear(xf, mlp.fc1.weight, mlp.fc1.bias).to(torch.bfloat16).float()
+    hf = hf.transpose(1, 2).reshape(views, 4 * C, H, W)
+    ref = torch.nn.functional.gelu(torch.nn.functional.conv2d(hf, mlp.dwconv.dwconv.weight, mlp.dwconv.dwconv.bias, padding=1,
+                                                              groups=4 * C)).flatten(2).transpose(1, 2)
+    assert float((a.float() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())

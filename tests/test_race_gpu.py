@@ -150,3 +150,18 @@ def test_attention_input_gradients_are_repeatable_under_memory_load():
         assert torch.equal(gq, rq), f"query gradient differs in launch {i}"
         torch.testing.assert_close(gkv.float(), rkv.float(), rtol=2e-2, atol=2e-2)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("views,H,W,C,reps", [(8, 34, 60, 320, 100), (2, 135, 240, 64, 60)])
+def test_fused_mix_ffn_front_half_is_repeatable_under_memory_load(views, H, W, C, reps):
+    """Round 6: csrc/mixffn.hip lays its hidden tile over the operand ring after the last chunk and hands chunks over through
+    registers and two LDS stages with one barrier each: identical activations, launch after launch."""
+    from refign_amd import dwconv
+    from refign_amd.seg import Mlp
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    mlp = Mlp(C, 4 * C).to(dev).eval()
+    x = torch.randn(views, H * W, C, device=dev).to(torch.bfloat16)
+    noise = torch.empty(48 << 20, device=dev, dtype=torch.float32).normal_()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        assert _repeat(lambda: dwconv.ffn_fc1_dw_gelu(x, mlp.fc1, mlp.dwconv.dwconv, H, W), reps, noise) == 0

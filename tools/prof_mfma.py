@@ -34,6 +34,17 @@ elif what == "f8attn_s3":
     q8, kv8 = f8.quantize(r(B, Nq, h * 64)), f8.quantize(r(B, Nkv, 2 * h * 64))
     fn = lambda: f8.attention(q8, kv8, h, 0.125)  # noqa: E731
     print(f"{what}: B={B} heads={h} Nq={Nq} Nkv={Nkv} fwd flops={4.0 * B * h * Nq * Nkv * 64:.4g}")
+elif what.startswith("ffn_"):
+    from refign_amd import dwconv
+    from refign_amd.seg import Mlp
+    H, W, C = {"ffn_s1": (135, 240, 64), "ffn_s2": (68, 120, 128), "ffn_s3": (34, 60, 320)}[what]
+    mlp = Mlp(C, 4 * C).to(dev).eval()
+    x = r(40, H * W, C)
+    print(f"{what}: 40 x {H}x{W} tokens, C={C}: fc1 flops={2.0 * 40 * H * W * C * 4 * C:.4g} hidden bytes={2.0 * 40 * H * W * 4 * C:.4g}")
+
+    def fn():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return dwconv.ffn_fc1_dw_gelu(x, mlp.fc1, mlp.dwconv.dwconv, H, W)
 elif what == "wgrad_s3":
     T, N, K = 8160, 1280, 320
     g, x = r(T, N), r(T, K)
