@@ -15,6 +15,14 @@
 //      x), into an LDS tile [256 tokens][128 + 8 channels] laid over the ring.
 //   3. the 3 x 3 stencil + bias + exact-erf GELU on the interior from LDS in strips of 6 outputs (3 x 8 halo values per strip; a
 //      thread keeps its 8 channels' 72 weights in registers; packed fp32 math), 16-byte stores of the activation.
+// Where the launch stands (profiles/r06_ffn_bench.txt, r06_pmc_ffn.txt; stage 3, 40 views: 215-230 us against 47 + 160 us for the
+// fc1 GEMM + depthwise kernel back to back, 100 + 205 us each on its own): vector instructions 42 % of the launch, matrix pipe 20 %,
+// the rest stalls -- each 64-channel chunk's operands arrive from L2 in ~1 us while its products take 0.5 us, and LDS (two
+// workgroups per CU) has no room for a deeper ring.  Built, measured and removed this round: an fp32 hidden tile in LDS (no bf16
+// unpacking in the stencil, one workgroup per CU: 341 us), a persistent grid with the CU's two workgroups started one phase apart
+// (no change: they do not march in lockstep), an eight-wave workgroup at <= 128 registers (four waves per SIMD: 226 us, no change --
+// occupancy is not what is missing).  In the step the kernel is worth 3.5 ms (same-box A/B, profiles/r06_fused_ffn_ab.txt): the
+// hidden tensor's three trips through HBM were taken from the other two streams.
 // fc2 (+ residual) stays the second-generation GEMM.  Numerics: the same roundings as the three-kernel path (bf16 hidden map, fp32
 // stencil, bf16 activation); only the fp32 summation order of the stencil differs.
 #include "common.h"
