@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "librefign_hip.so")
+# (RFN_LIB: another build of the same library, for A/B runs of kernel variants -- tools/ab_build.sh)
+_LIB_PATH = os.environ.get("RFN_LIB") or os.path.join(_HERE, "lib", "librefign_hip.so")
 _lock = threading.Lock()
 _lib = None
 

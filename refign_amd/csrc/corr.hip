@@ -703,8 +703,9 @@ __global__ __launch_bounds__(TH * (TW / 4) * 3 * NTILE, MINW) void corr9_pipe2_k
     for (int dyi = 0; dyi < 3; ++dyi)
 #pragma unroll
       for (int dx = 0; dx < 9; ++dx) {
-        *reinterpret_cast<float4*>(o) = make_float4(get(dyi, dx, 0) * scale[0], get(dyi, dx, 1) * scale[1],
-                                                    get(dyi, dx, 2) * scale[2], get(dyi, dx, 3) * scale[3]);
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v val = {get(dyi, dx, 0) * scale[0], get(dyi, dx, 1) * scale[1], get(dyi, dx, 2) * scale[2], get(dyi, dx, 3) * scale[3]};
+        *reinterpret_cast<f4v*>(o) = val;               // (non-temporal stores: measured, no change -- profiles/r06_corr_nt_store_ab.txt)
         o += plane;                                    // (a running pointer: one 64-bit add per store instead of a 64-bit multiply-add)
       }
   }
