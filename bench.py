@@ -528,22 +528,13 @@ def launch_series_us(launch, spaced, reps=20):
 
 
 def _stall_guard(rank, world, progress):
-    """N > 1 only: if a multi-rank run makes no progress for RFN_BENCH_STALL_S seconds (default 600), say where it stopped and
-    exit non-zero instead of hanging the node.  (Round 4 re-executed every rank in another configuration here; the multi-rank
-    default is now the configuration that needs no second chance -- refign_amd/trainer.py -- and a stalled run is an error.)"""
-    import threading
-    limit = float(os.environ.get("RFN_BENCH_STALL_S", "600"))
-
-    def watch():
-        while True:
-            time.sleep(5.0)
-            idle = time.monotonic() - progress[0]
-            if idle > limit:
-                print(f"bench.py rank {rank}/{world}: no progress for {idle:.0f} s after '{progress[1]}'; giving up",
-                      file=sys.stderr, flush=True)
-                os._exit(17)
-
-    threading.Thread(target=watch, daemon=True, name="bench-stall-guard").start()
+    """N > 1 only: if a multi-rank run makes no progress for RFN_STALL_S (RFN_BENCH_STALL_S) seconds (default 600), say where it
+    stopped and exit non-zero instead of hanging the node.  The guard itself lives in the trainer (refign_amd.trainer.StallGuard,
+    which also watches Trainer.step in any other driver); `progress` is its [time, phase] heartbeat, updated by tick()."""
+    from refign_amd.trainer import StallGuard
+    g = StallGuard(rank, world)
+    g.progress = progress
+    return g
 
 
 def _self_launch(args):

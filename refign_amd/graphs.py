@@ -390,3 +390,119 @@ class GraphedSplitStep(GraphedStep):
 
     def __call__(self, *a, **k):
         raise TypeError("GraphedSplitStep: call forward() and backward()")
+
+
+def _leaves(out, acc):
+    """the tensors of a nested tuple / list structure, in order"""
+    if torch.is_tensor(out):
+        acc.append(out)
+    elif isinstance(out, (list, tuple)):
+        for o in out:
+            _leaves(o, acc)
+    return acc
+
+
+def _rebuild(out, it):
+    if torch.is_tensor(out):
+        return next(it)
+    if isinstance(out, (list, tuple)):
+        return type(out)(_rebuild(o, it) for o in out)
+    return out
+
+
+class _SegmentSplice(torch.autograd.Function):
+    """The captured sub-network as ONE node of the surrounding (eager) autograd graph: forward hands out the static outputs of the
+    replayed forward graph, backward copies the incoming gradients into the static gradient buffers and replays the backward
+    graph (which accumulates the parameters' gradients where the captured kernels put them: the flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, st, _anchor, *outs):
+        ctx.st = st
+        return tuple(o.view_as(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        st = ctx.st
+        for buf, g in zip(st["grads"], grads):
+            if g is None:
+                buf.zero_()
+            else:
+                buf.copy_(g)
+        st["graph_bwd"].replay()
+        return (None, None) + (None,) * len(grads)
+
+
+class GraphedSegment:
+    """A collective-free PART of a student pass (the MiT backbone: 52 blocks, ~90 % of the pass's launches) as a forward and a
+    backward hipGraph spliced into an otherwise eager pass -- the form for data parallelism through torch.distributed
+    (RFN_DDP_MODE=torch, the N > 1 default): the decode heads' SyncBatchNorm exchanges stay ordinary torch.distributed calls, issued
+    eagerly from one host thread in program order, BETWEEN the replays (graph -> collectives -> graph), and the launch-bound bulk of
+    the pass stops costing host time (round 5: eager student passes alone cost 12.8 ms of the step).  The layout of torch's
+    make_graphed_callables, driven by hand because the captured kernels accumulate parameter gradients in place (no gradient
+    tensors to hand back).  `fn(*tensors)` -> nested tuples / lists of tensors (other objects pass through, e.g. the crop box).
+    Warm-up calls and a failed capture run `fn` eagerly; every call's forward must be followed by its backward before the next call."""
+
+    def __init__(self, fn, name, warmup=2):
+        self.fn, self.name, self.warmup = fn, name, warmup
+        self.generation = 0
+        self.states = {}
+        self._anchor = None
+
+    def reset(self):
+        self.generation += 1
+        self.states.clear()
+
+    def captured(self):
+        return any(st["graph"] is not None for st in self.states.values())
+
+    def __call__(self, *tensors):
+        if not (tensors[0].is_cuda and enabled() and torch.is_grad_enabled()) or torch.cuda.is_current_stream_capturing():
+            return self.fn(*tensors)
+        key = (tuple((tuple(t.shape), t.dtype, t.device) for t in tensors), torch.is_autocast_enabled("cuda"),
+               torch.get_autocast_dtype("cuda"), self.generation)
+        st = self.states.get(key)
+        if st is None:
+            st = self.states[key] = {"calls": 0, "graph": None, "failed": False}
+        if st["failed"]:
+            return self.fn(*tensors)
+        if st["graph"] is None:
+            st["calls"] += 1
+            if st["calls"] <= self.warmup:
+                return self.fn(*tensors)
+            try:
+                self._capture(st, tensors)
+            except Exception as e:
+                st["failed"], st["graph"] = True, None
+                warnings.warn(f"refign_amd.graphs: capture of '{self.name}' failed ({type(e).__name__}: {e}); running it eagerly")
+                torch.cuda.synchronize()
+                return self.fn(*tensors)
+        for s_, t in zip(st["inputs"], tensors):
+            if s_.data_ptr() != t.data_ptr():
+                s_.copy_(t)
+        st["graph"].replay()
+        if self._anchor is None or self._anchor.device != tensors[0].device:
+            self._anchor = torch.zeros(1, device=tensors[0].device, requires_grad=True)
+        outs = _SegmentSplice.apply(st, self._anchor, *st["outs"])
+        return _rebuild(st["structure"], iter(outs))
+
+    def _capture(self, st, tensors):
+        inputs = [t.clone() for t in tensors]
+        cur = torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        try:
+            with _no_cyclic_gc():
+                with torch.cuda.graph(fwd, capture_error_mode="thread_local"):
+                    structure = self.fn(*inputs)
+                outs = [o for o in _leaves(structure, []) if o.requires_grad]
+                if len(outs) != len(_leaves(structure, [])):
+                    raise RuntimeError("every tensor a graphed segment returns must carry a gradient")
+                grads = [torch.empty_like(o) for o in outs]
+                with torch.cuda.graph(bwd, pool=fwd.pool(), capture_error_mode="thread_local"):
+                    torch.autograd.backward(outs, grad_tensors=grads)
+        except BaseException:
+            torch.cuda.set_stream(cur)
+            raise
+        st["graph"], st["graph_bwd"], st["inputs"] = fwd, bwd, inputs
+        st["outs"], st["grads"] = [o.detach() for o in outs], grads
+        st["structure"] = structure

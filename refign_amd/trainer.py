@@ -258,6 +258,35 @@ class FlatGradBuffer:
         self.flat.div_(world)
 
 
+class StallGuard:
+    """A multi-rank run that makes no progress for `limit` seconds (RFN_STALL_S, default 600; RFN_BENCH_STALL_S is still read) says
+    where it stopped on stderr and exits with code 17 instead of hanging the node in a collective.  `note(what)` is the heartbeat:
+    Trainer.step calls it around every step; bench.py adds its own phases.  One daemon thread per process."""
+
+    def __init__(self, rank, world, limit=None):
+        import threading
+        import time
+        self.rank, self.world = rank, world
+        self.limit = float(os.environ.get("RFN_STALL_S", os.environ.get("RFN_BENCH_STALL_S", "600"))) if limit is None else float(limit)
+        self.progress = [time.monotonic(), "start"]
+        threading.Thread(target=self._watch, daemon=True, name="refign-stall-guard").start()
+
+    def note(self, what):
+        import time
+        self.progress[0], self.progress[1] = time.monotonic(), what
+
+    def _watch(self):
+        import sys
+        import time
+        while True:
+            time.sleep(min(5.0, max(0.2, self.limit / 4)))
+            idle = time.monotonic() - self.progress[0]
+            if idle > self.limit:
+                print(f"refign_amd rank {self.rank}/{self.world}: no progress for {idle:.0f} s after '{self.progress[1]}'; giving up",
+                      file=sys.stderr, flush=True)
+                os._exit(17)
+
+
 class Trainer:
     """fit-loop subset: `step(batch)` = one reference training_step including EMA, three backward passes, the single
     gradient all-reduce and the optimiser/scheduler step."""
@@ -350,8 +379,11 @@ class Trainer:
         model._grad_buffer = self.grads                      # uda: second buffer for the concurrently running mixed pass
         model._scheduler = sch
         model._backward = self._backward
+        self.guard = None
         if dist.is_available() and dist.is_initialized():
             self.broadcast_parameters()
+            if dist.get_world_size() > 1:                    # a rank that never arrives must not hang the others for ever
+                self.guard = StallGuard(dist.get_rank(), dist.get_world_size())
 
     def _backward(self, loss, retain_graph=False, last=False):
         """What Lightning's manual_backward does, plus: during the LAST backward pass of a step under data parallelism
@@ -393,10 +425,14 @@ class Trainer:
             elif self._steps_done % self.gc_interval == 0:
                 gc.collect()
             self._steps_done += 1
+        if self.guard is not None:
+            self.guard.note(f"entering step {self._steps_done}")
         try:
             # (the step's main-stream work on a stream of its own / of another priority: neutral, profiles/r05_main_priority_ab.txt --
             # HIP offers two priority levels here, (0, -1), and the teacher's stream already has the high one)
             self.model.training_step(batch, batch_idx)
+            if self.guard is not None:
+                self.guard.note(f"step {self._steps_done} queued")
         finally:
             # a crop pre-drawn for a forward that did not happen (exception, mode mismatch) must not leak into the next
             # unrelated extract_crop call

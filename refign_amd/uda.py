@@ -34,7 +34,7 @@ from . import refine as refine_mod
 from ._tensor import const_tensor, upload_async
 from . import dacs as _dacs
 from . import f8 as _f8
-from .graphs import GraphedNoGrad, GraphedSplitStep, GraphedStep
+from .graphs import GraphedNoGrad, GraphedSegment, GraphedSplitStep, GraphedStep
 from .params import ema_update
 from .config import instantiate_class
 from . import seg as _seg
@@ -287,6 +287,10 @@ class DomainAdaptationSegmentationModel(nn.Module):
                                                       capture_context=self._mixed_capture_context,
                                                       after_capture=self._mixed_captured_reduce,
                                                       on_replay=self._mixed_replayed_reduce)
+        # data parallelism through torch.distributed (RFN_DDP_MODE=torch): the passes stay eager around the decode heads' statistics
+        # exchanges, their collective-free backbones replay from graphs (graphs.GraphedSegment)
+        self._graphs["source_backbone"] = GraphedSegment(self._backbone_fn, "student backbone (source pass)")
+        self._graphs["mixed_backbone"] = GraphedSegment(self._backbone_fn, "student backbone (mixed pass)")
         self.teacher_f8 = _f8.ENV_DEFAULT                # K5: EMA-teacher backbone in fp8 (no reference analogue)
         self.load_weights(pretrained)
 
@@ -428,7 +432,29 @@ class DomainAdaptationSegmentationModel(nn.Module):
         """Graph replay of the student passes: training on a GPU (see GraphedStep.usable).  HRDA and, since the end of round 4,
         the single-scale DAFormer / SegFormer configurations too (K3: the eager passes kept the host busy for most of a 115 ms
         step, and the line moved with the box's other tenants: profiles/r04_k3_host_sensitivity.txt)."""
-        return self.training and GraphedStep.usable(x) and torch.is_grad_enabled()
+        return self.training and torch.is_grad_enabled() and (GraphedStep.usable(x) or self._backbone_segments(x))
+
+    def _backbone_segments(self, x):
+        """Data parallelism with every exchange through torch.distributed (bn.ddp_mode() == "torch", the N > 1 default): whole-pass
+        graphs are off (a captured torch.distributed collective is a cross-stream branch of the graph: no gain, round 4), so the
+        passes run eagerly -- except their backbones, which hold ~90 % of the launches and no collective.  The step then takes the
+        same route as the graphed one (device-side HRDA crops, teacher branch queued first); RFN_GRAPH_SEGMENTS=0: all eager."""
+        if not (x.is_cuda and os.environ.get("RFN_GRAPH_SEGMENTS", "1") != "0"):
+            return False
+        from . import graphs
+        from .bn import data_parallel, ddp_mode
+        return graphs.enabled() and data_parallel() and ddp_mode() == "torch"
+
+    def _backbone_fn(self, images, off):
+        if self.use_hrda:
+            push_device_crop(off, self.hrda_output_stride * 2.0)
+        return self.backbone(images)
+
+    def _backbone(self, slot, images, off):
+        """the student backbone of a pass: a replayed segment under torch-mode data parallelism, else the call itself"""
+        if self._backbone_segments(images) and not torch.cuda.is_current_stream_capturing():
+            return self._graphs[slot + "_backbone"](images, off)
+        return self._backbone_fn(images, off)
 
     def _crop_offsets(self, images, slot):
         """Draw the HRDA crop offsets of the next student forward on the host (python `random`, the reference's stream
@@ -457,12 +483,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def _source_fwd(self, images_src, off):
         """SOURCE (:156-163), forward half: backbone + decode head up to the low-resolution class logits."""
         if self.use_hrda:
-            push_device_crop(off, self.hrda_output_stride * 2.0)
-            feats_src = self.backbone(images_src)
+            feats_src = self._backbone("source", images_src, off)
             logits_src, hr_logits_src, crop_box_src = self.head(feats_src)
             return {"feat": feats_src[0], "logits": logits_src, "hr": hr_logits_src, "box": crop_box_src,
                     "size": tuple(images_src.shape[-2:])}
-        feats_src = self.backbone(images_src)              # single scale (:171-173): `off` is unused
+        feats_src = self._backbone("source", images_src, off)     # single scale (:171-173): `off` is unused
         return {"feat": feats_src, "logits": self.head(feats_src), "size": tuple(images_src.shape[-2:])}
 
     def _source_bwd(self, held, images_src, gt_src, feat_imnet_last=None):
@@ -559,10 +584,9 @@ class DomainAdaptationSegmentationModel(nn.Module):
     def _mixed_fwd(self, mixed_img, off):
         """MIXED (:226-231), forward half."""
         if self.use_hrda:
-            push_device_crop(off, self.hrda_output_stride * 2.0)
-            mixed_pred, hr_mixed_pred, box = self.head(self.backbone(mixed_img))
+            mixed_pred, hr_mixed_pred, box = self.head(self._backbone("mixed", mixed_img, off))
             return {"logits": mixed_pred, "hr": hr_mixed_pred, "box": box, "size": tuple(mixed_img.shape[-2:])}
-        return {"logits": self.head(self.backbone(mixed_img)), "size": tuple(mixed_img.shape[-2:])}
+        return {"logits": self.head(self._backbone("mixed", mixed_img, off)), "size": tuple(mixed_img.shape[-2:])}
 
     def _mixed_bwd(self, held, mixed_lbl, mixed_weight):
         """MIXED (:232-250), loss half: pixel-weighted cross-entropy against the (refined) pseudo-labels + backward."""

@@ -100,6 +100,24 @@ def test_bench_stall_guard_exits_and_says_where(tmp_path):
     assert "no progress" in r.stderr and "warm-up step 1" in r.stderr and "rank 1/2" in r.stderr
 
 
+def test_trainer_stall_guard_watches_the_step():
+    """The same guard inside the trainer (not only in bench.py): refign_amd.trainer.StallGuard, started by Trainer for a
+    world of more than one rank, with Trainer.step as its heartbeat -- here driven directly: a heartbeat that stops ends the process
+    with code 17 and names the last phase."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from refign_amd.trainer import StallGuard\n"
+            "g = StallGuard(3, 8)\n"
+            "g.note('step 41 queued')\n"
+            "time.sleep(30)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RFN_STALL_S="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 17, r.stderr
+    assert "rank 3/8" in r.stderr and "step 41 queued" in r.stderr
+
+
 def test_ddp_mode_selector(monkeypatch):
     """RFN_DDP_MODE: the N > 1 default is `torch` (every exchange through torch.distributed); the direct-RCCL modes are opt-in;
     anything else is refused."""

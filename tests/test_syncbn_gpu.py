@@ -183,7 +183,12 @@ def _rccl_step_worker(rank, world, port, out):
     # the gradient all-reduce of the finished ranges INSIDE the captured mixed pass on a communicator / stream of its own);
     # "direct3" = + the mixed pass next to the source pass on a third communicator (here with the two gradient buffers reduced
     # separately)
-    for mode in ("torch", "direct3", "direct"):
+    for mode in ("torch-eager", "torch", "direct3", "direct"):
+        # "torch" = the default as it runs since round 6: eager passes around the statistics exchanges, their backbones replayed
+        # from graphs (graphs.GraphedSegment); "torch-eager": RFN_GRAPH_SEGMENTS=0, everything eager (the round-5 default)
+        os.environ["RFN_GRAPH_SEGMENTS"] = "0" if mode == "torch-eager" else "1"
+        mode = "torch" if mode == "torch-eager" else mode
+        key = "torch-eager" if os.environ["RFN_GRAPH_SEGMENTS"] == "0" else mode
         os.environ["RFN_DDP_MODE"] = mode
         os.environ["RFN_DDP_DIRECT_REDUCE"] = "1" if mode != "torch" else "0"   # gradient reduce on our own comm
         os.environ["RFN_DDP_TWO_BUFFER"] = "1" if mode == "direct3" else "0"
@@ -208,7 +213,9 @@ def _rccl_step_worker(rank, world, port, out):
         captured = all(g.captured() for n, g in model._graphs.items() if n in ("source_pass", "mixed_pass")) \
             if mode != "torch" else None
         bn = torch.cat([b.flatten().double() for n, b in model.head.named_buffers() if "running" in n]).cpu()
-        traj[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), captured, n_sync,
+        if key == "torch":
+            captured = all(model._graphs[n].captured() for n in ("source_backbone", "mixed_backbone"))
+        traj[key] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), captured, n_sync,
                       calls["n"], len(calls["groups"]), model.__dict__.get("_mixed_concurrent_steps", 0), bn,
                       getattr(trainer.grads, "overlapped_fraction", 0.0),
                       trainer.grads._comm is not None)
@@ -223,13 +230,22 @@ def _rccl_step_worker(rank, world, port, out):
 
 def test_student_graphs_with_rccl_statistics_exchange_inside(dev, tmp_path):
     """What one rank of N > 1 runs, on a 1-rank RCCL group (RFN_DDP_REHEARSAL=1): 5 eager steps with every exchange through
-    torch.distributed (RFN_DDP_MODE=torch, the N > 1 default) against 5 steps with the student passes captured into hipGraphs
+    torch.distributed (RFN_DDP_MODE=torch, RFN_GRAPH_SEGMENTS=0) against the N > 1 default (the same exchanges, backbones replayed
+    from graph segments) and against 5 steps with the student passes captured into hipGraphs
     WITH the SyncBatchNorm exchanges inside as RCCL calls of our own (direct: passes in stream order; direct3: a communicator
     per pass, mixed pass next to the source pass)."""
     port, out = _free_port(), str(tmp_path)
     mp.spawn(_rccl_step_worker, args=(1, port, out), nprocs=1, join=True)
     traj = torch.load(f"{out}/traj.pt", weights_only=False)
-    e = traj["torch"]
+    e = traj["torch-eager"]
+    # round 6, the N > 1 default: passes eager around the exchanges (the same torch.distributed calls, the same two groups), the
+    # collective-free backbones of both passes replayed from graphs -- same trajectory
+    t = traj["torch"]
+    assert t[2], "the backbone segments of the student passes were not captured"
+    assert t[4] == e[4] and t[5] == 2 and t[6] == 0, (t[4:7], e[4:7])
+    np.testing.assert_allclose(t[0], e[0], rtol=3e-2)
+    assert abs(t[1] - e[1]) < 1e-4 * e[1]
+    assert float((t[7] - e[7]).abs().max()) < 5e-2 * float(e[7].abs().max())
     assert e[3] > 0, "no SyncBatchNorm module in the model: nothing was exchanged"
     # eager: every exchange goes through dist.all_reduce each step, over two communicators (student, teacher)
     assert e[4] > 5 * 4 and e[5] == 2, e[4:6]
