@@ -659,8 +659,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
         which is why this is limited to the Refign configuration (teacher + align + refine before the mix)."""
         if not (self.use_refign and self.use_align):
             return None
-        if not (getattr(self, "_mixed_on_second", False) and self._graphs["mixed_pass"].captured()
-                and self._graphs["source_pass"].captured() and self._overlap_teacher(x)):
+        whole = self._graphs["mixed_pass"].captured() and self._graphs["source_pass"].captured()
+        # (torch-mode data parallelism: the passes are eager around their exchanges -- torch.distributed keeps the collectives of the
+        # two streams in the host's issue order, the same on every rank -- with their backbones replayed from segments)
+        segs = self._backbone_segments(x) and self._graphs["mixed_backbone"].captured() and self._graphs["source_backbone"].captured()
+        if not (getattr(self, "_mixed_on_second", False) and (whole or segs) and self._overlap_teacher(x)):
             return None
         if getattr(self, "_mix_stream", None) is None or self._mix_stream.device != x.device:
             # default priority: a second high-priority stream lands on the side stream's hardware queue and the step
@@ -739,7 +742,16 @@ class DomainAdaptationSegmentationModel(nn.Module):
                 mix.wait_stream(self._side_stream)       # pseudo-labels
         from .bn import direct_comm
         comm = getattr(self, "_mixed_comm", None)
-        with torch.cuda.stream(run_on):
+        seg_second = contextlib.nullcontext
+        if self._backbone_segments(images_src) and getattr(self, "_grad_buffer", None) is not None \
+                and os.environ.get("RFN_MIXED_CONCURRENT", "1") != "0":
+            # torch-mode data parallelism (eager passes, backbone segments): the WHOLE mixed pass -- the capture of its backbone
+            # segment, every replay's eager head -- accumulates into the second flat gradient buffer, so that it may run next to the
+            # source pass (the host enqueues the two backward passes one after the other: `.grad` points where the pass being
+            # enqueued wants it; the optimiser's proxy adds the buffers)
+            seg_second = self._grad_buffer.into_second
+            self._mixed_on_second = True
+        with torch.cuda.stream(run_on), seg_second():
             if early_fwd:
                 images_trg, m_probs_trg = early
                 with torch.no_grad():

@@ -242,14 +242,17 @@ def test_student_graphs_with_rccl_statistics_exchange_inside(dev, tmp_path):
     # collective-free backbones of both passes replayed from graphs -- same trajectory
     t = traj["torch"]
     assert t[2], "the backbone segments of the student passes were not captured"
-    assert t[4] == e[4] and t[5] == 2 and t[6] == 0, (t[4:7], e[4:7])
+    assert t[4] == e[4] and t[5] == 2, (t[4:6], e[4:6])
+    # ... and once both segments replay, the mixed pass runs on its own stream next to the source pass (its gradients in the second
+    # flat buffer; torch.distributed keeps the two streams' collectives in the host's issue order, the same on every rank)
+    assert t[6] >= 2, "the mixed pass did not run next to the source pass under torch-mode data parallelism"
     np.testing.assert_allclose(t[0], e[0], rtol=3e-2)
     assert abs(t[1] - e[1]) < 1e-4 * e[1]
     assert float((t[7] - e[7]).abs().max()) < 5e-2 * float(e[7].abs().max())
     assert e[3] > 0, "no SyncBatchNorm module in the model: nothing was exchanged"
     # eager: every exchange goes through dist.all_reduce each step, over two communicators (student, teacher)
     assert e[4] > 5 * 4 and e[5] == 2, e[4:6]
-    assert e[6] == 0, "two passes with exchanges on one communicator must stay in stream order"
+    assert e[6] == 0, "all-eager passes stay in stream order"
     # exchanges as direct RCCL calls (student passes AND teacher): nothing goes through torch's process group any more,
     # both passes captured, and the mixed pass runs next to the source pass once both replay
     # (bf16 passes with atomics in the weight-gradient kernels: the trajectories agree to rounding, not to the bit)
