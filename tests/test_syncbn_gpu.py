@@ -271,3 +271,56 @@ def test_student_graphs_with_rccl_statistics_exchange_inside(dev, tmp_path):
     np.testing.assert_allclose(f[0], e[0], rtol=3e-2)
     assert abs(f[1] - e[1]) < 1e-4 * e[1]
     assert float((f[7] - e[7]).abs().max()) < 5e-2 * float(e[7].abs().max())
+
+
+def _two_rank_segment_worker(rank, world, port, out):
+    # two REAL ranks sharing the box's one GPU, exchanging over gloo (RCCL refuses two ranks on one device): the N > 1 default
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RFN_DDP_MODE="torch")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import random
+    import test_step_gpu as T
+    from refign_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    res = {}
+    for seg in ("1", "0"):
+        os.environ["RFN_GRAPH_SEGMENTS"] = seg
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        model = T.build(True, dev)
+        trainer = Trainer(model, sync_batchnorm=True, fused_optimizer=False)
+        assert trainer.data_parallel and trainer.ddp_mode == "torch" and trainer.guard is not None
+        random.seed(7 + rank); np.random.seed(7 + rank); torch.manual_seed(7 + rank)       # each rank its own pairs and draws
+        rows = []
+        for it in range(5):
+            batch = T.make_batch(2, 128, 128, 64, dev)
+            batch["image_src"] = batch["image_src"] + 0.1 * it + 0.05 * rank
+            batch["image_trg"] = batch["image_trg"] - 0.03 * rank
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                trainer.step(batch, it)
+            rows.append([float(model.logged[k]) for k in ("train_loss_src", "train_loss_featdist_src", "train_loss_uda_trg")])
+        res[seg] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())),
+                    all(model._graphs[n].captured() for n in ("source_backbone", "mixed_backbone")),
+                    model.__dict__.get("_mixed_concurrent_steps", 0))
+        trainer.close()
+    torch.save(res, f"{out}/seg{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_backbone_segments_equal_eager_passes_on_two_ranks(dev, tmp_path):
+    """Round 6, the N > 1 default with TWO real ranks (one GPU, gloo): 5 steps with the student backbones replayed from graph segments
+    and the mixed pass next to the source pass (graphs.GraphedSegment; capture on the third step) against 5 all-eager steps
+    (RFN_GRAPH_SEGMENTS=0), per rank: the same losses, the same parameters -- and the two ranks, fed different pairs, end with the SAME
+    parameters (one mean gradient, SyncBatchNorm statistics of the global batch)."""
+    port, out = _free_port(), str(tmp_path)
+    mp.spawn(_two_rank_segment_worker, args=(2, port, out), nprocs=2, join=True)
+    r = [torch.load(f"{out}/seg{k}.pt", weights_only=False) for k in range(2)]
+    for k in range(2):
+        seg, eag = r[k]["1"], r[k]["0"]
+        assert seg[2] and not eag[2], "segments not captured / captured with RFN_GRAPH_SEGMENTS=0"
+        assert seg[3] >= 2 and eag[3] == 0
+        np.testing.assert_allclose(seg[0], eag[0], rtol=3e-2)
+        assert abs(seg[1] - eag[1]) < 1e-4 * eag[1]
+    assert abs(r[0]["1"][1] - r[1]["1"][1]) < 1e-6 * r[0]["1"][1], "the replicas drifted apart"
+    assert float(np.abs(r[0]["1"][0] - r[1]["1"][0]).max()) > 1e-4, "the ranks saw the same data: the test would not see a missing exchange"
