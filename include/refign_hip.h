@@ -29,8 +29,10 @@ extern "C" {
 
 /* 2: rfn_global_corr_layer_f32 takes a workspace; rfn_dacs_mix_jitter accepts one half of the mix.
  * 3: rfn_local_corr_layer_split_f32's workspace carries tickets (rfn_local_corr_layer_split_workspace_bytes; zero before first use);
- *    the transpose-cast table holds rfn_multi_transpose_tile() x rfn_multi_transpose_tile() tiles (64; 32 before). */
-#define RFN_ABI_VERSION 3
+ *    the transpose-cast table holds rfn_multi_transpose_tile() x rfn_multi_transpose_tile() tiles (64; 32 before).
+ * 4: new entry points, none changed: rfn_attn32_fwd / rfn_attn32_bwd (fp32 attention), rfn_split3_bf16 / rfn_split3_cat_bf16
+ *    (operands of the split-bf16 products), rfn_ffn_fc1_dw_gelu_bf16 (fused Mix-FFN front half). */
+#define RFN_ABI_VERSION 4
 
 typedef void* rfn_stream_t; /* hipStream_t */
 

@@ -130,9 +130,10 @@ SIGNATURES = {
 }
 
 
-# RFN_ABI_VERSION of include/refign_hip.h this table was written against (2: rfn_global_corr_layer_f32 takes a workspace,
+# RFN_ABI_VERSION of include/refign_hip.h this table was written against (4: round 6 added rfn_attn32_fwd / _bwd, rfn_split3_bf16,
+# rfn_split3_cat_bf16, rfn_ffn_fc1_dw_gelu_bf16; 2: rfn_global_corr_layer_f32 takes a workspace,
 # rfn_dacs_mix_jitter accepts one half of the mix; 3: the transpose-cast table holds 64 x 64 tiles, rfn_multi_transpose_tile)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def library_path():

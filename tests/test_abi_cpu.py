@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"librefign_hip.so does not export {s}"
         assert s in _lib.SIGNATURES, f"refign_amd/_lib.py has no ctypes signature for {s}"
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert refign_amd.abi_version() == 3
+    assert refign_amd.abi_version() == 4
 
 
 def test_no_cpu_fallback():

@@ -10,6 +10,7 @@ timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_n1.json
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --no-cpu --no-roofline 2>/dev/null | grep '^{"metric"' > $O/bench_torchrun_n1.json
 timeout 900 python bench.py --precision fp32 --no-cpu --steps 10 2>/dev/null | tail -1 > $O/bench_fp32_n1.json
 timeout 600 python bench.py --precision k5 --no-cpu 2>/dev/null | tail -1 > $O/bench_k5_n1.json
+timeout 600 python bench.py --adapt-to-ref --no-cpu 2>/dev/null | tail -1 > $O/bench_adapt_to_ref_n1.json
 timeout 600 python bench.py --workload uawarpc_align_512x512 --steps 50 --warmup 5 2>/dev/null | tail -1 > $O/bench_k2.json
 timeout 600 python bench.py --workload refign_daformer_step_1080x1920 --height 512 --width 1024 --no-cpu --no-roofline 2>/dev/null | tail -1 > $O/bench_k3_daformer_512x1024.json
 timeout 300 python tools/step_timeline.py 2>&1 | grep "^step\|^(" > $O/step_timeline.txt
@@ -25,7 +26,11 @@ timeout 300 python tools/kbench.py --only L1,L2,L3,K2-L1 2>&1 | grep -v "amdgpu.
 timeout 300 python tools/kbench.py --only tail 2>&1 | grep -v "amdgpu.ids\|MIOpen" >> $O/kbench_corr.txt
 timeout 300 python tools/corr_small_maps.py 2>&1 | grep -v "amdgpu.ids" > $O/corr_small_maps.txt
 timeout 300 python tools/attn_bench.py 2>&1 | grep -v "amdgpu.ids" > $O/attn_bench.txt
-for t in gemm_fc1_s3:gemm_nt gemm_fc2_s3:gemm_nt conv_bottleneck:gemm_nt attn_fwd_s3:attn_fwd wgrad_s3:gemm_tn; do
+timeout 300 python tools/ffn_bench.py 2>&1 | grep stage > $O/ffn_bench_final.txt
+timeout 400 python tools/align_precision_layers.py "timed map" "fp32 everything" 2>&1 | grep -v "amdgpu.ids" > $O/align_precision_timed_map.txt
+bash tools/prof_teacher.sh final_teacher_half > /dev/null 2>&1; cp $R/gpurun_out/final_teacher_half_timed_region.csv $O/teacher_half_kernel_stats_timed_region.csv
+bash tools/ddp_rehearsal.sh > $O/ddp_rehearsal_final.txt 2>&1
+for t in gemm_fc1_s3:gemm_nt gemm_fc2_s3:gemm_nt conv_bottleneck:gemm_nt attn_fwd_s3:attn_fwd wgrad_s3:gemm_tn ffn_s3:ffn_fc1; do
   echo "== ${t%%:*}"; bash tools/pmc_mfma.sh ${t%%:*} ${t##*:}; done > $O/pmc_mfma_kernels.txt 2>&1
 { timeout 300 python tools/matcher_bench.py --precision fp16 2>&1 | tail -2; } > $O/matcher_bench.txt
 timeout 300 python tools/aten_census.py 2>&1 | grep -v "amdgpu.ids\|Warn\|_warn" > $O/aten_census.txt
