@@ -6,8 +6,11 @@ Host side mirrors the reference's operator/module interface for this path (brdav
   refign_amd.modules       <-> models/modules.py (Local/GlobalFeatureCorrelationLayer, decoders, uncertainty)
   refign_amd.refine        <-> DomainAdaptationSegmentationModel.refine / .eta / .align tail
 
-All compute goes through the C ABI of lib/librefign_hip.so (include/refign_hip.h).  There is NO CPU fallback:
-calling an op without the HIP library or with CPU tensors raises.
+All compute of the hot path goes through the C ABI of lib/librefign_hip.so (include/refign_hip.h).  The kernel-backed operators
+(correlation, warp, align tail, refine, L2 norm, uncertainty front end) have NO CPU form: they raise on CPU tensors or a missing
+library.  The nn.Module mirrors of the segmentation networks (Linear, Conv2d, LayerNorm, attention ...) DO run on CPU tensors --
+through ATen, for the host-side tests (configs, checkpoints, gloo data parallelism) -- and on a GPU hand any call outside their
+kernels' domain to ATen too, recorded by mfma.note_library (bench.py prints `library_fallbacks`; the step goldens assert it empty).
 """
 # GPU_MAX_HW_QUEUES (how many hardware queues ROCm multiplexes a process's streams onto; default 4) is left alone.
 # Round 1 raised it to 8 for the eager step next to an RCCL communicator (328 -> 300 ms/step); with the student passes

@@ -1,10 +1,12 @@
 """nn.Conv2d for the MiT patch-embedding / spatial-reduction convolutions, with the parameter plumbing of params.py.
 
-The convolution itself (forward, data gradient, weight gradient) is the ROCm library's; what changes is how the
-parameters enter and leave it: the weight is used through its cached bf16 copy instead of being re-cast by autocast at
-every call (80 spatial-reduction convs x 7 uses per step), and the weight / bias gradients are added straight into
-the fp32 views of the flat gradient buffer (no bf16 -> fp32 cast kernel + AccumulateGrad add per use).
-Same parameters / state_dict keys as nn.Conv2d; CPU tensors take the stock path.
+On a GPU the convolution runs on the hand-written kernels: the implicit-GEMM MFMA kernel (conv2d_mfma: forward; conv2d_mfma_grad:
+forward + data gradient + weight gradient under autograd), the patch GEMM for kernel == stride (patch_conv_tokens), split-bf16
+products for fp32 tensors (split32.conv2d).  Weights are used through cached 16-bit copies (params.derived) refreshed in place after
+optimiser / EMA updates; weight / bias gradients are added straight into the fp32 views of the flat gradient buffer.  What is left
+to ATen: CPU tensors (host-side tests) and geometries outside the kernels' domain (unequal strides / paddings, grouped
+convolutions other than depthwise) -- each such GPU call is recorded by mfma.note_library.
+Same parameters / state_dict keys as nn.Conv2d.
 """
 import os
 

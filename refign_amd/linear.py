@@ -7,7 +7,9 @@ split-K for it, i.e. 25-400 workgroups each walking the whole T: measured 24 TF/
 S independent slabs turns it into a batched GEMM with S x more workgroups; the (S, N, K) partials are reduced by
 csrc/reduce.hip, which ADDS the result straight into the parameter's .grad view of the flat gradient buffer; the bias
 gradient (column sum of dY) goes through the same kernel.  Weights are used through their cached bf16 copies
-(params.derived) instead of being re-cast at every call.  Forward and the input gradient stay ordinary library GEMMs.
+(params.derived) instead of being re-cast at every call.  Forward and the input gradient run on the hand-written MFMA GEMMs
+(mfma.gemm_nt: first- and second-generation kernels, bias / activation / residual in the epilogue; fp32 tensors: split32.linear);
+CPU tensors and shapes outside the kernels' domain go to ATen (F.linear), recorded on a GPU by mfma.note_library.
 Same parameters / state_dict keys as nn.Linear.
 """
 import os
