@@ -776,6 +776,11 @@ def main():
                 line["config"]["mixed_pass"] = (("own stream; forward queued before the pseudo-labels exist, loss + backward behind "
                                                  "the teacher branch" if early else "own stream next to the tail of the source pass")
                                                 if steps_m else "in stream order after the source pass")
+                probe = getattr(wl.model, "_mix_stream_probe", None)
+                if probe is not None:
+                    # slow-down of a spin kernel on the candidate stream next to one on the main / side stream, per candidate tried
+                    # (~1 = own hardware queue, ~2 = shares one): the last one is the stream in use (graphs.concurrent_stream)
+                    line["config"]["mixed_pass_stream_probe"] = probe
         if isinstance(wl, RefignStep) and type(wl) is not RefignAlignRefine:
             line["config"]["next_batch_prefetch"] = (
                 "frozen ImageNet-encoder features of the next step's source images and the frozen matcher's flow of the next "

@@ -33,6 +33,57 @@ def enabled():
     return os.environ.get("RFN_HIP_GRAPH", "1") != "0"
 
 
+def concurrent_stream(device, peers, priority=0, tries=8, spin_cycles=4_000_000):
+    """A new stream whose kernels really run NEXT TO those of `peers`.  The runtime multiplexes a process's streams onto a few
+    hardware queues (4 by default) in creation order, and two streams that land on ONE queue do not overlap -- their kernels
+    and graph replays run back to back.  Which queue a new stream gets depends on everything created before it (capture
+    streams, RCCL's streams, the streams of an earlier model), so a fixed recipe breaks when the step's history changes:
+    round 6 found the mixed pass of the `adapt_to_ref` configuration (one more capture before the stream is made) sharing the
+    main stream's queue -- every pass at its stand-alone duration, one after the other (profiles/r06_stream_priority_ab.txt:
+    121.9 ms per step, 106.9 with probed streams).
+    So the stream is PROBED: a ~1.7 ms spin kernel on each peer and on the candidate, timed with events; a candidate that
+    serialises with a peer is kept alive (so that the next one lands elsewhere) and the next one is tried.  Costs ~10-30 ms, once per stream.
+    Returns (stream, report)."""
+    cur = torch.cuda.current_stream(device)
+
+    def span(streams):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(cur)
+        for st in streams:
+            if st != cur:
+                st.wait_event(start)
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(spin_cycles)
+        for st in streams:
+            if st != cur:
+                cur.wait_stream(st)
+        end.record(cur)
+        end.synchronize()
+        return start.elapsed_time(end)
+
+    peers = [p for p in peers if p is not None]
+    span(peers[:1] or [cur])
+    one = min(span([p]) for p in (peers or [cur]))
+    rejected, report = [], []
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device, priority=priority)
+        span([cand])
+        worst = max([span([p, cand]) for p in peers] or [one])
+        report.append(round(worst / one, 2))
+        if worst < 1.5 * one:
+            break
+        rejected.append(cand)
+    else:
+        warnings.warn(f"refign_amd: no stream found that overlaps with its peers (slow-down factors {report}); "
+                      "GPU_MAX_HW_QUEUES may be too small")
+        cand = rejected[0]
+    _KEPT_STREAMS.extend(rejected)
+    return cand, report
+
+
+_KEPT_STREAMS = []
+
+
 @contextlib.contextmanager
 def _no_cyclic_gc():
     """No cyclic garbage collection while a capture is open: a collection that happens to run inside the captured region

@@ -174,6 +174,7 @@ _ALIGN_PREFETCH = True
 _MERGE_FD_BACKWARD = True
 _EARLY_MIXED_FWD = True
 _SRC_BWD_AFTER_TEACHER = True
+_SIDE_PRIORITY = 0          # priority of the teacher branch's stream (0: probed for concurrency, -1: rounds 2-5's high-priority stream)
 
 
 class DomainAdaptationSegmentationModel(nn.Module):
@@ -669,7 +670,11 @@ class DomainAdaptationSegmentationModel(nn.Module):
             # default priority: a second high-priority stream lands on the side stream's hardware queue and the step
             # goes from 181 to 246 ms (measured, round 3)
             # (round 5, with GPU_MAX_HW_QUEUES=8 so that it gets a queue of its own: -0.6 ms, profiles/r05_mix_priority_ab.txt; not adopted)
-            self._mix_stream = torch.cuda.Stream(device=x.device)
+            # (round 6: the stream is probed for real concurrency with the other two -- graphs.concurrent_stream)
+            from .graphs import concurrent_stream
+            with torch.cuda.device(x.device):
+                self._mix_stream, self._mix_stream_probe = concurrent_stream(
+                    x.device, [torch.cuda.current_stream(x.device), getattr(self, "_side_stream", None)])
         return self._mix_stream
 
     def _training_step_graphed(self, batch, images_src, gt_src, src_classes, opt, sch):
@@ -854,11 +859,19 @@ class DomainAdaptationSegmentationModel(nn.Module):
 
     def _ensure_side_stream(self, device):
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
-            # high priority: the runtime maps it to a hardware queue of its own.  With the default priority it can
-            # share a queue with the main stream once an RCCL communicator has taken its streams (4 hardware queues
-            # per process by default), and two streams on one queue do not overlap (measured: 328 vs 299 ms/step)
-            self._side_stream = torch.cuda.Stream(device=device,
-                                                  priority=-1)
+            # Rounds 2-5: a HIGH-priority stream, because the runtime keeps those in a hardware-queue pool of their own (with the
+            # default priority the stream could land on the main stream's queue once an RCCL communicator had taken its streams,
+            # and two streams on one queue do not overlap: 328 vs 299 ms/step).  Round 6: default priority and a stream PROBED
+            # for concurrency with the main stream (graphs.concurrent_stream).  Same step time in the headline configuration and
+            # in the data-parallel rehearsals, and the `adapt_to_ref` configuration goes from 157 to 107 ms per step: there the
+            # high-priority teacher starved the source forward (it ended WITH the teacher) once the mixed pass had a queue of
+            # its own (profiles/r06_stream_priority_ab.txt).
+            if _SIDE_PRIORITY == 0:
+                from .graphs import concurrent_stream
+                with torch.cuda.device(device):
+                    self._side_stream, self._side_stream_probe = concurrent_stream(device, [torch.cuda.current_stream(device)])
+                return
+            self._side_stream = torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY)
 
     def _teacher_align_refine(self, images_trg, images_ref):
         """segmentation_model.py:201-213: EMA-teacher logits of (target, reference), warp of the reference logits onto

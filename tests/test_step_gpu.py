@@ -169,12 +169,45 @@ def test_adapt_to_ref_graphed_schedule_equals_eager_and_prefetch_follows_the_coi
         out[mode] = (np.array(rows), float(sum(p.double().abs().sum() for p in model.live_parameters())), sides,
                      model.__dict__.get("_align_prefetch_used", 0))
     assert out["graphs"][2] == out["eager"][2] and 0 < sum(out["graphs"][2]) < 10, out["graphs"][2]
+    # (the last model is the eager one: its teacher branch still runs on a probed stream of its own)
+    assert model._side_stream_probe[-1] < 1.5, model._side_stream_probe
     # every aligned step after the first found its flow prefetched by the step before it (the prefetch is part of the schedule from
     # the first step on, also while the student passes still run their eager warm-up calls), and no other step asked for one
     want = sum(1 for it in range(1, 10) if not out["graphs"][2][it])
     assert out["graphs"][3] == want and out["eager"][3] == 0, (out["graphs"][3], want, out["graphs"][2])
     np.testing.assert_allclose(out["graphs"][0], out["eager"][0], rtol=3e-2)
     assert abs(out["graphs"][1] - out["eager"][1]) < 1e-4 * out["eager"][1]
+
+
+def test_probed_streams_run_next_to_their_peers(dev):
+    """graphs.concurrent_stream: the stream handed back overlaps with every peer (spin kernels side by side take the time of
+    one), candidates that shared a hardware queue with a peer were passed over (slow-down ~2 in the report, the last entry is
+    the stream in use), and a training step uses such streams for the teacher branch and the mixed pass."""
+    from refign_amd.graphs import concurrent_stream
+    main = torch.cuda.current_stream(dev)
+    with torch.cuda.device(dev):
+        side, rep1 = concurrent_stream(dev, [main])
+        mix, rep2 = concurrent_stream(dev, [main, side])
+    assert rep1 and rep2 and rep1[-1] < 1.5 and rep2[-1] < 1.5, (rep1, rep2)
+    assert all(r >= 1.5 for r in rep1[:-1] + rep2[:-1]), (rep1, rep2)
+    assert len({main.cuda_stream, side.cuda_stream, mix.cuda_stream}) == 3
+
+    def spin_ms(streams):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(main)
+        for st in streams:
+            st.wait_event(e0)
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(6_000_000)
+        for st in streams:
+            main.wait_stream(st)
+        e1.record(main)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    spin_ms([main])
+    one, three = spin_ms([main]), spin_ms([main, side, mix])
+    assert three < 1.5 * one, (one, three)
 
 
 def _b5_step(dev, use_hrda, b, H, W, seed, autocast, blk=64, enable_fdist=True):

@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
-wl = bench.RefignStep(dev, 2, 1234)
-for _ in range(6):
+wl = bench.RefignStep(dev, 2, 1234, adapt_to_ref="--adapt-to-ref" in sys.argv)
+for _ in range(12 if "--adapt-to-ref" in sys.argv else 6):
     wl.step()
 torch.cuda.synchronize()
 m = wl.model
@@ -24,10 +24,21 @@ def mark(key):
     ev[key] = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
 
 
+ALONE = "--alone" in sys.argv          # every phase with the device to itself (synchronize on both sides): its stand-alone time
+alone = {}
+
+
 def wrap(obj, name, key):
     f = getattr(obj, name)
 
     def g(*a, **k):
+        if ALONE:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = f(*a, **k)
+            torch.cuda.synchronize()
+            alone.setdefault(key, []).append((time.perf_counter() - t) * 1e3)
+            return out
         mark(key + "0")
         out = f(*a, **k)
         mark(key + "1")
@@ -46,11 +57,18 @@ if hasattr(m, "prefetch_align_flow"):
     wrap(m, "prefetch_align_flow", "pfA")
     wrap(m, "prefetch_imnet_features", "pfI")
 rows = []
-for it in range(5):
+for it in range(10 if "--adapt-to-ref" in sys.argv else 5):
+    ev.clear()
     t0 = time.perf_counter()
     wl.step()
     host = (time.perf_counter() - t0) * 1e3
     torch.cuda.synchronize()
+    if ALONE:
+        names = (("ema", "ema"), ("src fwd", "Sf"), ("teacher", "T"), ("mix fwd", "Mf"), ("mix bwd", "Mb"), ("src bwd", "Sb"),
+                 ("next imnet", "pfI"), ("next flow", "pfA"), ("opt", "opt"))
+        print(f"step {it} (phases one at a time): wall {host:6.1f} ms | " +
+              " | ".join(f"{lbl} {sum(alone.pop(k)):6.2f}" for lbl, k in names if k in alone))
+        continue
     z = ev["ema0"]
     rel = lambda k: z.elapsed_time(ev[k])  # noqa: E731
     parts = [f"{lbl} {rel(k + '0'):6.1f}-{rel(k + '1'):6.1f}" for lbl, k in
