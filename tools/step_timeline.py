@@ -13,7 +13,7 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
 wl = bench.RefignStep(dev, 2, 1234, adapt_to_ref="--adapt-to-ref" in sys.argv)
-for _ in range(12 if "--adapt-to-ref" in sys.argv else 6):
+for _ in range(14 if "--adapt-to-ref" in sys.argv else 8):
     wl.step()
 torch.cuda.synchronize()
 m = wl.model
@@ -50,6 +50,9 @@ for gname, key in (("source_pass", "S"), ("mixed_pass", "M")):
     g = m._graphs[gname]
     wrap(g, "forward", key + "f")
     wrap(g, "backward", key + "b")
+if "student_backbone" in m._graphs:
+    wrap(m._graphs["student_backbone"], "forward", "Bf")
+    wrap(m._graphs["student_backbone"], "backward", "Bb")
 wrap(m, "_target_branch", "T")
 wrap(m, "update_momentum_encoder", "ema")
 wrap(m._optimizer, "step", "opt")
@@ -64,7 +67,7 @@ for it in range(10 if "--adapt-to-ref" in sys.argv else 5):
     host = (time.perf_counter() - t0) * 1e3
     torch.cuda.synchronize()
     if ALONE:
-        names = (("ema", "ema"), ("src fwd", "Sf"), ("teacher", "T"), ("mix fwd", "Mf"), ("mix bwd", "Mb"), ("src bwd", "Sb"),
+        names = (("ema", "ema"), ("bb fwd", "Bf"), ("bb bwd", "Bb"), ("src fwd", "Sf"), ("teacher", "T"), ("mix fwd", "Mf"), ("mix bwd", "Mb"), ("src bwd", "Sb"),
                  ("next imnet", "pfI"), ("next flow", "pfA"), ("opt", "opt"))
         print(f"step {it} (phases one at a time): wall {host:6.1f} ms | " +
               " | ".join(f"{lbl} {sum(alone.pop(k)):6.2f}" for lbl, k in names if k in alone))
@@ -72,7 +75,8 @@ for it in range(10 if "--adapt-to-ref" in sys.argv else 5):
     z = ev["ema0"]
     rel = lambda k: z.elapsed_time(ev[k])  # noqa: E731
     parts = [f"{lbl} {rel(k + '0'):6.1f}-{rel(k + '1'):6.1f}" for lbl, k in
-             (("ema", "ema"), ("src fwd", "Sf"), ("src bwd", "Sb"), ("teacher", "T"), ("mix fwd", "Mf"), ("mix bwd", "Mb"), ("opt", "opt"))
+             (("ema", "ema"), ("bb fwd", "Bf"), ("src fwd", "Sf"), ("src bwd", "Sb"), ("teacher", "T"), ("mix fwd", "Mf"), ("mix bwd", "Mb"),
+              ("bb bwd", "Bb"), ("opt", "opt"))
              if k + "0" in ev]
     print(f"step {it}: host {host:5.1f} ms | " + " | ".join(parts))
 print("(a phase's start is when its first kernel may run on its stream, its end when its last kernel has finished; the prefetches of "
