@@ -718,7 +718,8 @@ def main():
                       else "f32")
                      if (args.workload == AlignRefineKernels.name or args.precision == "fp32") else
                      ("bf16+fp8(e4m3) teacher" if args.precision == "k5" else
-                      ("f16 convolutions, f32 correlation / warp / uncertainty" if args.workload == UAWarpCAlign.name else "bf16")),
+                      ("f16 VGG-16, split-bf16 (fp32-class) head convolutions, f32 correlation / warp / uncertainty"
+                       if args.workload == UAWarpCAlign.name else "bf16")),
             "data": "synthetic",
             "config": {"workload": wl.name, "pairs_per_gpu": args.pairs_per_gpu, "image": size,
                        "networks": ("VGG-16 + UAWarpC head (random init)" if args.workload == UAWarpCAlign.name else
@@ -732,8 +733,10 @@ def main():
                                           "attention core, 40 views) on fp8 e4m3 MFMA kernels; " if args.precision == "k5"
                                           else "") +
                                          "reference AMP recipe: seg nets bf16 autocast (fp32 master weights, grads, "
-                                         "norm statistics, losses); align convolutions fp16 autocast; correlation, "
-                                         "warp, L2-norm, uncertainty and refine kernels fp32"),
+                                         "norm statistics, losses); matcher: VGG-16 fp16 autocast, UAWarpC head "
+                                         "convolutions as three bf16 split products on fp32 storage (align.HEAD_SPLIT: the "
+                                         "1e-3 parity bound holds inside the timed map; plain fp16 there: 5.6e-3), "
+                                         "correlation, warp, L2-norm, uncertainty and refine kernels fp32"),
                        "parallelism": (f"dp{world}: pairs sharded, align/refine/teacher replica-local, one flat "
                                        f"gradient all-reduce per step over RCCL") if step_kind else
                                       f"dp{world}: pairs sharded, gradient-free, no collective in the timed region"},
