@@ -36,10 +36,16 @@ def smooth_logits(C, H, W, key):
 def fp32ify(mod):
     orig = mod.forward
 
+    def f32(t):
+        if torch.is_tensor(t):
+            return t.float()
+        if isinstance(t, (list, tuple)):
+            return type(t)(f32(u) for u in t)
+        return t
+
     def fwd(*a, **k):
         with torch.autocast("cuda", enabled=False):
-            return orig(*[t.float() if torch.is_tensor(t) else t for t in a],
-                        **{n: (t.float() if torch.is_tensor(t) else t) for n, t in k.items()})
+            return orig(*[f32(t) for t in a], **{n: f32(t) for n, t in k.items()})
     mod.forward = fwd
     return lambda: setattr(mod, "forward", orig)
 
@@ -75,6 +81,18 @@ def main():
             head.decoder4.predict_mapping, head.decoder3.predict_mapping, head.decoder2.predict_mapping,
             head.decoder1.predict_mapping, head.refinement_module_adaptive.dc_convs[-1], head.refinement_module_finest.dc_convs[-1]],
         "level-1 flow regressors fp32": lambda: [head.decoder1.predict_mapping, head.refinement_module_finest.dc_convs[-1]],
+        "first convolutions of decoders 3 / 2 / 1 fp32 (the ones that see the flow)": lambda: [head.decoder3.conv_0, head.decoder2.conv_0,
+                                                                                              head.decoder1.conv_0],
+        "first convolutions + uncertainty pred_conv_0 x3 fp32": lambda: [
+            head.decoder3.conv_0, head.decoder2.conv_0, head.decoder1.conv_0] + [
+            getattr(head, f"estimate_uncertainty_components{l}").pred_conv_0 for l in (3, 2, 1)],
+        "first convolutions + flow regressors fp32": lambda: [
+            head.decoder3.conv_0, head.decoder2.conv_0, head.decoder1.conv_0,
+            head.decoder4.predict_mapping, head.decoder3.predict_mapping, head.decoder2.predict_mapping,
+            head.decoder1.predict_mapping, head.refinement_module_adaptive.dc_convs[-1], head.refinement_module_finest.dc_convs[-1]],
+        "decoders fp32, refinement + uncertainty fp16": lambda: [head.decoder4, head.decoder3, head.decoder2, head.decoder1, head.reduce],
+        "decoders + refinement fp32, uncertainty fp16": lambda: [head.decoder4, head.decoder3, head.decoder2, head.decoder1, head.reduce,
+                                                                 head.refinement_module_adaptive, head.refinement_module_finest],
         "decoder1 fp32": lambda: [head.decoder1],
         "finest refinement fp32": lambda: [head.refinement_module_finest],
         "uncertainty back ends fp32": lambda: [getattr(head, f"estimate_uncertainty_components{l}") for l in (4, 3, 2, 1)],
