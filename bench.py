@@ -649,6 +649,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    small_ar_us = None
+    if dist is not None and not selftest and dev.type == "cuda" and args.backend == "nccl":
+        # EVERY rank: what one small exchange costs from the step's stream (reported in config.data_parallel)
+        probe_t = torch.zeros(512, device=dev)
+        for _ in range(5):
+            dist.all_reduce(probe_t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(50):
+            dist.all_reduce(probe_t)
+        e1.record()
+        e1.synchronize()
+        small_ar_us = round(e0.elapsed_time(e1) * 1e3 / 50, 1)
+
     roof = None
     if not args.no_roofline and rank == 0 and not selftest:
         # HIP events around EACH launch of the dominant kernel, on the stream it is launched on.  Two series of 20:
@@ -762,6 +777,11 @@ def main():
                                     if gb is not None and gb._comm is not None else "torch.distributed buckets"),
                 "reduced_inside_last_backward": (round(getattr(gb, "overlapped_elements", 0) / gb.flat.numel(), 3)
                                                  if gb is not None else None)}
+            if small_ar_us is not None:
+                # device time of one tiny all-reduce issued from the step's stream (50 in a row, after the timed region): torch.distributed
+                # runs a collective on a stream of its own, and when that stream does not share the issuing stream's hardware queue
+                # every exchange is two cross-queue hand-overs (profiles/r06_stream_priority_ab.txt)
+                line["config"]["data_parallel"]["small_all_reduce_us"] = small_ar_us
         from refign_amd import mfma as _mfma
         # dense ops that ended up in a ROCm library (hipBLASLt / MIOpen / fused SDPA) instead of a hand-written kernel,
         # by call site and dtype, over the whole run (refign_amd/mfma.py: note_library)
