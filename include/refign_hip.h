@@ -260,6 +260,11 @@ int rfn_layernorm_bwd(const void* x, const void* grad_y, const float* gamma, con
 int rfn_layernorm_bwd_add(const void* x, const void* grad_y, const void* add, const float* gamma, const float* mean,
                           const float* rstd, void* grad_x, float* grad_gamma, float* grad_beta, void* workspace, long rows, int C,
                           int x_dtype, int gy_dtype, int accumulate, rfn_stream_t stream);
+/* the same with a SECOND gradient of the LayerNorm output summed in (either of grad_y2 / add may be null): in a MiT attention block
+   norm1(x) feeds the q projection and the spatial-reduction convolution (mix_transformer.py:142-150) */
+int rfn_layernorm_bwd_add2(const void* x, const void* grad_y, const void* grad_y2, const void* add, const float* gamma,
+                           const float* mean, const float* rstd, void* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
+                           long rows, int C, int x_dtype, int gy_dtype, int accumulate, rfn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Front end of the UAWarpC UncertaintyModule for search size 9 (models/modules.py:529-551, eval mode): every pixel's

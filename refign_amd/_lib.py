@@ -56,6 +56,7 @@ SIGNATURES = {
     "rfn_layernorm_bwd_workspace_bytes": (ctypes.c_ulong, [c_int]),
     "rfn_layernorm_bwd": (c_int, [c_void_p] * 9 + [ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "rfn_layernorm_bwd_add": (c_int, [c_void_p] * 10 + [ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p]),
+    "rfn_layernorm_bwd_add2": (c_int, [c_void_p] * 11 + [ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "rfn_dwconv3x3_bwd_weight_workspace_bytes": (ctypes.c_ulong, [c_int]),
     "rfn_dwconv3x3_nhwc_bwd_weight": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "rfn_sum_rows_workspace_bytes": (ctypes.c_ulong, [ctypes.c_long, ctypes.c_long]),

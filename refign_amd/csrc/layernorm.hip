@@ -260,7 +260,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TX* __rest
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, TX* __restrict__ dx,
                                                                 float* __restrict__ ws, long rows, int C,
-                                                                const TX* __restrict__ add) {
+                                                                const TX* __restrict__ add, const TG* __restrict__ gy2) {
+  // gy2 (may be null): a second gradient of the LayerNorm's OUTPUT -- in a MiT attention block norm1(x) feeds the q projection AND
+  // the spatial-reduction convolution (mix_transformer.py:142-150), two edges of the autograd graph whose gradients the engine
+  // used to sum with an element-wise launch per block and backward pass -- summed in fp32 as the rows are loaded
   // add (may be null): a second gradient of x that arrives by another edge of the autograd graph -- the residual stream
   // x feeds the LayerNorm AND the residual add of the block (mix_transformer.py:203-207) -- summed here instead of in an
   // element-wise kernel of its own (2 per block and backward pass)
@@ -292,6 +295,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TX* __rest
       if (valid && act[j]) {
         ld8<TX>(x + r * C + (sub + LPR * j) * 8, xv);
         ld8<TG>(gy + r * C + (sub + LPR * j) * 8, gv);
+        if (gy2 != nullptr) {
+          float g2[8];
+          ld8<TG>(gy2 + r * C + (sub + LPR * j) * 8, g2);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) gv[i] += g2[i];
+        }
         // the residual gradient is requested WITH the row, not after the two row reductions (a second exposed load latency
         // per row: the launch is a chain of <= 8 row iterations per wave)
         if (add != nullptr) ld8<TX>(add + r * C + (sub + LPR * j) * 8, av[j]);
@@ -409,15 +418,15 @@ static int ln_fwd_dispatch(const void* x, const float* g, const float* b, void* 
 template <typename TX, typename TG>
 static int ln_bwd_dispatch(const void* x, const void* gy, const float* g, const float* mean, const float* rstd,
                            void* dx, float* dgamma, float* dbeta, float* ws, long rows, int C, int accumulate,
-                           hipStream_t st, const void* add = nullptr) {
-  if (add != nullptr && C % 8 != 0) return fail(RFN_EINVAL, "rfn_layernorm_bwd_add: C %% 8 != 0");
+                           hipStream_t st, const void* add = nullptr, const void* gy2 = nullptr) {
+  if ((add != nullptr || gy2 != nullptr) && C % 8 != 0) return fail(RFN_EINVAL, "rfn_layernorm_bwd_add: C %% 8 != 0");
   int grid = ln_grid(rows, kLnMaxBlocks);
   const int npl = cdiv(C, 64);
   if (C % 8 == 0) {
 #define RFN_LN_BWDV(LPR, NV)                                                                                        \
   grid = (int)std::max<long>(1, std::min<long>(cdiv(rows, 4 * (64 / LPR)), kLnMaxBlocks));                         \
   hipLaunchKernelGGL((layernorm_bwd_vec_kernel<TX, TG, LPR, NV>), dim3(grid), dim3(256), 0, st, (const TX*)x,      \
-                     (const TG*)gy, g, mean, rstd, (TX*)dx, ws, rows, C, (const TX*)add)
+                     (const TG*)gy, g, mean, rstd, (TX*)dx, ws, rows, C, (const TX*)add, (const TG*)gy2)
     if (C <= 64) { RFN_LN_BWDV(8, 1); }
     else if (C <= 128) { RFN_LN_BWDV(16, 1); }
     else if (C <= 256) { RFN_LN_BWDV(32, 1); }
@@ -484,6 +493,26 @@ int rfn_layernorm_bwd_add(const void* x, const void* grad_y, const void* add, co
   if (x_dtype == 1 && gy_dtype == 0)
     return ln_bwd_dispatch<__hip_bfloat16, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st, add);
   return fail(RFN_EINVAL, "rfn_layernorm_bwd_add: dtype codes must be 0 (f32) or 1 (bf16)");
+}
+
+// grad_y2 / add: either may be null
+int rfn_layernorm_bwd_add2(const void* x, const void* grad_y, const void* grad_y2, const void* add, const float* gamma,
+                           const float* mean, const float* rstd, void* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
+                           long rows, int C, int x_dtype, int gy_dtype, int accumulate, rfn_stream_t stream) {
+  RFN_REQUIRE(x && grad_y && gamma && mean && rstd && grad_x && grad_gamma && grad_beta && workspace,
+              "rfn_layernorm_bwd_add2: null pointer");
+  RFN_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * kLnMaxPerLane, "rfn_layernorm_bwd_add2: need C %% 8 == 0, C <= 1024 (got %d)", C);
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  if (x_dtype == 0 && gy_dtype == 0)
+    return ln_bwd_dispatch<float, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st, add, grad_y2);
+  if (x_dtype == 0 && gy_dtype == 1)
+    return ln_bwd_dispatch<float, __hip_bfloat16>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st, add, grad_y2);
+  if (x_dtype == 1 && gy_dtype == 1)
+    return ln_bwd_dispatch<__hip_bfloat16, __hip_bfloat16>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st, add, grad_y2);
+  if (x_dtype == 1 && gy_dtype == 0)
+    return ln_bwd_dispatch<__hip_bfloat16, float>(x, grad_y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, ws, rows, C, accumulate, st, add, grad_y2);
+  return fail(RFN_EINVAL, "rfn_layernorm_bwd_add2: dtype codes must be 0 (f32) or 1 (bf16)");
 }
 
 int rfn_layernorm_fwd_f8(const void* x_bf16, const float* gamma, const float* beta, void* y8, long rows, int C, float eps,

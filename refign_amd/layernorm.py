@@ -43,14 +43,21 @@ class _LayerNormFn(torch.autograd.Function):
         return _ln_backward(ctx, gy, None)
 
 
-def _ln_backward(ctx, gy, add):
+def _ln_backward(ctx, gy, add, gy_b=None):
         x2, w32, mean, rstd = ctx.saved_tensors
         rows, C = x2.shape
+        if gy is None:
+            gy, gy_b = gy_b, None
         if gy is None:                                     # only the pass-through output was used
             return (add, None, None, None, None)
         if gy.dtype not in _DT:
             gy = gy.float()
         gy2 = gy.contiguous().view(rows, C)
+        if gy_b is not None:                               # a second consumer of the LayerNorm output (layer_norm_pass2)
+            if C % 8 == 0:
+                gy_b = gy_b.to(gy2.dtype).contiguous().view(rows, C)
+            else:
+                gy2, gy_b = gy2 + gy_b.to(gy2.dtype).contiguous().view(rows, C), None
         dx = torch.empty_like(x2)
         if add is not None:
             add = add.to(x2.dtype).contiguous().view(rows, C)
@@ -62,7 +69,12 @@ def _ln_backward(ctx, gy, add):
         lib = _lib.load_library()
         ws = workspace(_LN_WS_ROWS * 2 * C * 4, x2.device)     # == rfn_layernorm_bwd_workspace_bytes(C)
         with on_device(x2.device):
-            if add is not None and C % 8 == 0:
+            if gy_b is not None:
+                rc = lib.rfn_layernorm_bwd_add2(ptr(x2), ptr(gy2), ptr(gy_b), ptr(add) if add is not None else None, ptr(w32),
+                                                ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db), ptr(ws), rows, C, _DT[x2.dtype],
+                                                _DT[gy2.dtype], 1 if direct else 0, current_stream(x2.device))
+                add = None
+            elif add is not None and C % 8 == 0:
                 rc = lib.rfn_layernorm_bwd_add(ptr(x2), ptr(gy2), ptr(add), ptr(w32), ptr(mean), ptr(rstd), ptr(dx), ptr(dg),
                                                ptr(db), ptr(ws), rows, C, _DT[x2.dtype], _DT[gy2.dtype], 1 if direct else 0,
                                                current_stream(x2.device))
@@ -92,6 +104,29 @@ class _LayerNormPassFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gx_res):
         return _ln_backward(ctx, gy, gx_res)
+
+
+class _LayerNormPass2Fn(torch.autograd.Function):
+    """(LayerNorm(x), LayerNorm(x) again, x) -- the LayerNorm output for TWO consumers (in a MiT attention block norm1(x) feeds the
+    q projection and the spatial-reduction convolution, mix_transformer.py:142-150) plus the pass-through of _LayerNormPassFn:
+    all three gradients arrive here and are summed inside the LayerNorm-backward kernel (rfn_layernorm_bwd_add2)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        y = _LayerNormFn.forward(ctx, x, weight, bias, eps, out_dtype)
+        return y, y.view_as(y), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gy_b, gx_res):
+        return _ln_backward(ctx, gy, gx_res, gy_b)
+
+
+def layer_norm_pass2(x, weight, bias, eps=1e-5):
+    """-> (LayerNorm(x), LayerNorm(x), x): two handles on the output for two consumers, and the residual pass-through."""
+    out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    if out_dtype not in _DT:
+        out_dtype = x.dtype
+    return _LayerNormPass2Fn.apply(x, weight, bias, eps, out_dtype)
 
 
 def layer_norm_pass(x, weight, bias, eps=1e-5):

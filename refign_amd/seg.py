@@ -174,10 +174,14 @@ class Attention(nn.Module):
             self.sr = Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = LayerNorm(dim)
 
-    def forward(self, x, H, W, res=None, rowscale=None):
+    def forward(self, x, H, W, res=None, rowscale=None, x_kv=None):
+        """`x_kv`: a second handle on the same tensor for the key / value path (_norm_pass(..., fan=2): the two gradients of the
+        block's LayerNorm output are then summed inside its backward kernel, not by an element-wise launch of the engine)."""
         B, N, C = x.shape
         h, d = self.num_heads, C // self.num_heads
         q = self.q(x)                                                        # (B,N,C) = (B,N,h,d)
+        if x_kv is not None:
+            x = x_kv
         if self.sr_ratio > 1:
             r = patch_conv_tokens(x, H, W, self.sr) if _SR_AS_LINEAR else None   # (B, N/sr^2, C) tokens directly
             if r is None:
@@ -218,15 +222,25 @@ def _residual(res, y, rowscale):
 _LN_PASS = True
 
 
-def _norm_pass(norm, x):
+_LN_FAN2 = True
+
+
+def _norm_pass(norm, x, fan=1):
     """(norm(x), x') where x' is x to be used as the residual operand of the branch: under autograd on the GPU the two
     gradients of x (through the LayerNorm and through the residual add) are then summed inside the LayerNorm-backward kernel
-    (layernorm.layer_norm_pass) instead of by an element-wise launch of the autograd engine."""
+    (layernorm.layer_norm_pass) instead of by an element-wise launch of the autograd engine.
+    fan=2: ((n, n'), x') -- two handles on norm(x) for the two consumers inside the attention module (q projection, key / value
+    path), whose gradients meet in the same kernel (layernorm.layer_norm_pass2)."""
     if _LN_PASS and x.is_cuda and torch.is_grad_enabled() and x.requires_grad and type(norm) is LayerNorm and x.shape[-1] % 8 == 0 \
             and x.shape[-1] <= 1024 and x.dtype in (torch.float32, torch.bfloat16) and len(norm.normalized_shape) == 1:
-        from .layernorm import layer_norm_pass
-        return layer_norm_pass(x, norm.weight, norm.bias, norm.eps)
-    return norm(x), x
+        from .layernorm import layer_norm_pass, layer_norm_pass2
+        if fan == 2 and _LN_FAN2:
+            n, nb, xa = layer_norm_pass2(x, norm.weight, norm.bias, norm.eps)
+            return (n, nb), xa
+        n, xa = layer_norm_pass(x, norm.weight, norm.bias, norm.eps)
+        return ((n, None), xa) if fan == 2 else (n, xa)
+    n = norm(x)
+    return ((n, None), x) if fan == 2 else (n, x)
 
 
 class Block(nn.Module):
@@ -259,16 +273,16 @@ class Block(nn.Module):
             if x.is_cuda and masks32 is not None and _linear._FUSED_RESIDUAL:
                 # training (RFN_FUSED_RESIDUAL, on): the same fusion under autograd (linear._LinearFn: residual + per-sample scale in the proj /
                 # fc2 GEMM epilogue; in the backward the scale rides in the input- and weight-gradient kernels)
-                n, xa = _norm_pass(self.norm1, x)
-                x = self.attn(n, H, W, res=xa, rowscale=masks32[0])
+                (n, nb), xa = _norm_pass(self.norm1, x, fan=2)
+                x = self.attn(n, H, W, res=xa, rowscale=masks32[0], x_kv=nb)
                 n, xa = _norm_pass(self.norm2, x)
                 return self.mlp(n, H, W, res=xa, rowscale=masks32[1])
             x = torch.addcmul(x, self.attn(self.norm1(x), H, W), masks[0])
             return torch.addcmul(x, self.mlp(self.norm2(x), H, W), masks[1])
         dp = self.drop_path
         if x.is_cuda and _linear._FUSED_RESIDUAL and not (self.training and isinstance(dp, DropPath) and dp.drop_prob > 0.):
-            n, xa = _norm_pass(self.norm1, x)
-            x = self.attn(n, H, W, res=xa)
+            (n, nb), xa = _norm_pass(self.norm1, x, fan=2)
+            x = self.attn(n, H, W, res=xa, x_kv=nb)
             n, xa = _norm_pass(self.norm2, x)
             return self.mlp(n, H, W, res=xa)
         res = dp.residual if isinstance(dp, DropPath) else torch.add

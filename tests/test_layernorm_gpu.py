@@ -91,3 +91,33 @@ def test_layernorm_pass_through_sums_both_gradients(dev, dtype, C):
     _, xp = layer_norm_pass(xc, ln.weight, ln.bias, ln.eps)
     xp.backward(g2)
     assert torch.equal(xc.grad, g2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 320, 512])
+def test_layernorm_two_consumers_and_pass_through_sum_in_the_kernel(dev, dtype, C):
+    """layernorm.layer_norm_pass2: two handles on LayerNorm(x) (q projection and key / value path of a MiT attention block) and
+    the pass-through of x; the three gradients meet in ONE kernel (rfn_layernorm_bwd_add2) == autograd's own sums, also when a
+    consumer or the pass-through is not differentiated."""
+    from refign_amd.layernorm import LayerNorm, layer_norm_pass2
+    torch.manual_seed(C + 1)
+    ln = LayerNorm(C, eps=1e-6).to(dev)
+    x = torch.randn(2, 301, C, device=dev).to(dtype)
+    g1, g2, g3 = torch.randn_like(x), torch.randn_like(x), torch.randn_like(x)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    for use in ((1, 1, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1)):
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        ln.zero_grad()
+        y, y2, xp = layer_norm_pass2(xa, ln.weight, ln.bias, ln.eps)
+        assert y2.data_ptr() == y.data_ptr() and xp.data_ptr() == xa.data_ptr()
+        outs, grads = zip(*[(o, g) for o, g, u in zip((y, y2, xp), (g1, g2, g3), use) if u])
+        torch.autograd.backward(outs, grads)
+        wg, bg = ln.weight.grad.clone(), ln.bias.grad.clone()
+        ln.zero_grad()
+        yb = ln(xb)
+        gsum = (g1.float() * use[0] + g2.float() * use[1]).to(dtype)
+        torch.autograd.backward([yb] + ([xb * 1.0] if use[2] else []), [gsum] + ([g3] if use[2] else []))
+        assert torch.equal(y, yb)
+        assert float((xa.grad.float() - xb.grad.float()).abs().max()) <= tol * float(xb.grad.float().abs().max()), use
+        assert torch.allclose(wg, ln.weight.grad, rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=0.3 if dtype == torch.bfloat16 else 1e-3), use
+        assert torch.allclose(bg, ln.bias.grad, rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=0.3 if dtype == torch.bfloat16 else 1e-3), use
