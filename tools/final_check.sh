@@ -14,6 +14,8 @@ timeout 600 python bench.py --adapt-to-ref --no-cpu 2>/dev/null | tail -1 > $O/b
 timeout 600 python bench.py --workload uawarpc_align_512x512 --steps 50 --warmup 5 2>/dev/null | tail -1 > $O/bench_k2.json
 timeout 600 python bench.py --workload refign_daformer_step_1080x1920 --height 512 --width 1024 --no-cpu --no-roofline 2>/dev/null | tail -1 > $O/bench_k3_daformer_512x1024.json
 timeout 300 python tools/step_timeline.py 2>&1 | grep "^step\|^(" > $O/step_timeline.txt
+timeout 300 python tools/step_timeline.py --adapt-to-ref 2>&1 | grep "^step\|^(" > $O/step_timeline_adapt_to_ref.txt
+{ timeout 300 python tools/step_timeline.py --alone 2>&1 | grep "^step"; timeout 300 python tools/step_timeline.py --alone --adapt-to-ref 2>&1 | grep "^step"; } > $O/phases_alone_final.txt
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench --output-format csv -- python $R/bench.py --no-cpu --steps 6 --warmup 3 > /tmp/prof_bench.log 2>&1
 cd $R
 grep '^{"metric"' /tmp/prof_bench.log > $O/bench_under_rocprof.json
