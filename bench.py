@@ -744,8 +744,9 @@ def main():
                                           "products on the MFMA kernels (refign_amd/split32.py, ~2^-16 relative)"
                                           )
                                          if args.precision == "fp32" else
-                                         ("K5: as the bf16 map, plus the EMA teacher's MiT blocks (Linear layers and "
-                                          "attention core, 40 views) on fp8 e4m3 MFMA kernels; " if args.precision == "k5"
+                                         ("K5: as the bf16 map, plus the attention half of the EMA teacher's MiT blocks (q / kv / "
+                                          "spatial-reduction / proj Linear layers and the attention core, 40 views) on fp8 e4m3 MFMA "
+                                          "kernels, the Mix-FFN half on the bf16 kernels (f8.HYBRID_FFN); " if args.precision == "k5"
                                           else "") +
                                          "reference AMP recipe: seg nets bf16 autocast (fp32 master weights, grads, "
                                          "norm statistics, losses); matcher: VGG-16 fp16 autocast, UAWarpC head "
