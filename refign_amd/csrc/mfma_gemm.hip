@@ -70,6 +70,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //   Y[m, n] = sum_{tap, c} X[b, oy s - p + ky d, ox s - p + kx d, c] * W[n, (tap, c)],   m = (b, oy, ox), zero padding.
 // The reduction index k = tap * C + c is walked in 64-wide steps; a 16-byte DMA piece is 8 channels of ONE tap, so C % 8
 // == 0 and the weight rows are [tap][c] zero-padded to a multiple of 64 (pieces past the last tap read the zero page).
+// conv3x3.hip: RFN_OK / an error, or 1 = outside its domain
+int launch_conv3x3_halo(const void* X, const void* W, const void* bias, void* Y, int B, int H, int Wd, int C, int N, long ldw,
+                        long ldy, int act, int dtype, hipStream_t s);
+
 struct ConvGeom {
   int H, W, C, OH, OW, KH, KW, stride, pad, dil;
   int C8;                  // C / 8
@@ -1410,6 +1414,11 @@ int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* 
   ConvGeom cg{H, Wd, C, OH, OW, KH, KW, stride, pad, dil, C / 8, (unsigned)((0x100000000ULL + C / 8 - 1) / (C / 8)),
               (unsigned)((0x100000000ULL + KW - 1) / KW), nullptr, 0, 0};
   hipStream_t s = (hipStream_t)stream;
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1 && res == nullptr) {
+    // halo-tiled form (conv3x3.hip): the input tile staged once per 64 channels instead of once per tap
+    const int rc = launch_conv3x3_halo(X, W, bias, Y, B, H, Wd, C, N, ldw, ldy, act, dtype, s);
+    if (rc != 1) return rc;
+  }
   return dtype == 1 ? launch_nt<1, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s)
                     : launch_nt<2, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s);
 }
