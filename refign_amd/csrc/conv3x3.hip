@@ -63,21 +63,26 @@ template <int I, int N, typename F> __device__ __forceinline__ void c3_static_fo
   }
 }
 
-template <int DT, int BN>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+// NA = halo stages: 2, or 1 for C == 64 (a single chunk per tile: nothing to prefetch) -- with BN = 64 that is 76 KB of LDS and
+// <= 128 registers, so TWO workgroups share a CU and one's prologue / epilogue runs under the other's taps
+template <int DT, int BN, int NA>
+__global__ __launch_bounds__(NA == 1 ? 256 : 512) void conv3x3_halo_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                            const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y, int H,
                                                            int W, int C, int N, long ldw, long ldy, int tiles_y, int tiles_x,
                                                            int act, const void* __restrict__ zero) {
   using E = Elem<DT>;
   using vec8 = typename E::vec8;
-  // 8 waves = 4 (pixel rows 2 pw, 2 pw + 1) x 2 (channel halves): two waves per SIMD, one's fragment reads under the other's MFMAs
-  constexpr int WC = BN / 2;                  // channels of a wave
+  // 8 waves = 4 (pixel rows 2 pw, 2 pw + 1) x 2 (channel halves): two waves per SIMD, one's fragment reads under the other's MFMAs.
+  // NA == 1: 4 waves (all channels each), two such workgroups per CU.
+  constexpr int NWV = NA == 1 ? 4 : 8;
+  constexpr int WC = BN / (NWV / 4);          // channels of a wave
   constexpr int CB = WC / 32;                 // its 32-channel blocks (2 or 1)
-  constexpr int NBI = BN / 64;                // weight DMA instructions per wave and step (BN rows, 8 per instruction, 8 waves)
+  constexpr int NBI = BN / (8 * NWV);         // weight DMA instructions per wave and step (BN rows, 8 per instruction)
+  constexpr int NAI = (kC3AI + NWV - 1) / NWV;   // halo DMA instructions of a wave: 6 (5 for waves 4-7) / 11
   constexpr int BSTAGE = BN * 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kC3AB + kC3NB * BSTAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NA * kC3AB + kC3NB * BSTAGE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, j = lane & 31;
-  const int pw = wave & 3, cw = wave >> 2;
+  const int pw = wave & 3, cw = NWV == 8 ? wave >> 2 : 0;
 
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int NT = N / BN;
@@ -92,11 +97,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const uint16_t* __res
   // ---- DMA sources: lane = (row of the instruction's 8, 16-byte piece); source piece = piece ^ swizzle(row) ----------------------
   // halo instructions wave + 8 k: waves 0-3 carry six of the 44, waves 4-7 five
   const int drow = lane >> 3, piece = lane & 7;
-  const int na = wave < 4 ? 6 : 5;            // (scalar)
-  unsigned aoff[6];
+  const int na = NWV == 8 ? (wave < 4 ? 6 : 5) : 11;            // (scalar)
+  unsigned aoff[NAI];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int row = 8 * (wave + 8 * k) + drow;
+  for (int k = 0; k < NAI; ++k) {
+    const int row = 8 * (wave + NWV * k) + drow;
     const int hy = row / kC3HW, hx = row - hy * kC3HW;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = row < kC3HP && y >= 0 && y < H && x >= 0 && x < W;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const uint16_t* __res
   unsigned boff[NBI];
 #pragma unroll
   for (int k = 0; k < NBI; ++k) {
-    const int n = 8 * (wave + 8 * k) + drow;
+    const int n = 8 * (wave + NWV * k) + drow;
     const int sp = piece ^ ((n >> 1) & 7);
     boff[k] = (unsigned)(((long)(n0 + n) * ldw) * 2 + sp * 16);
   }
@@ -114,14 +119,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const uint16_t* __res
   const unsigned char* Wb = (const unsigned char*)Wt;
   auto issue_a = [&](int k, int chunk) {
     const void* src = aoff[k] != 0xffffffffu ? (const void*)(Xb + aoff[k] + (long)chunk * 128) : zero;
-    lds_dma16(src, smem + (chunk & 1) * kC3AB + (wave + 8 * k) * 1024);
+    lds_dma16(src, smem + (chunk & (NA - 1)) * kC3AB + (wave + NWV * k) * 1024);
   };
   auto issue_b = [&](int s) {                // step s = 9 chunk + tap
     const int c = s / 9, t = s - 9 * c;
     const long koff = ((long)t * C + (long)c * 64) * 2;
-    unsigned char* dst = smem + 2 * kC3AB + (s & (kC3NB - 1)) * BSTAGE;
+    unsigned char* dst = smem + NA * kC3AB + (s & (kC3NB - 1)) * BSTAGE;
 #pragma unroll
-    for (int k = 0; k < NBI; ++k) lds_dma16(Wb + boff[k] + koff, dst + (wave + 8 * k) * 1024);
+    for (int k = 0; k < NBI; ++k) lds_dma16(Wb + boff[k] + koff, dst + (wave + NWV * k) * 1024);
   };
 
   f32x16 acc[CB][2];
@@ -134,8 +139,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const uint16_t* __res
 
   // ---- prologue: halo tile of chunk 0, weight stages of steps 0, 1, 2 ---------------------------------------------------------------
 #pragma unroll
-  for (int k = 0; k < 5; ++k) issue_a(k, 0);
-  if (na == 6) issue_a(5, 0);
+  for (int k = 0; k < NAI - 1; ++k) issue_a(k, 0);
+  if (NWV == 4 || na == 6) issue_a(NAI - 1, 0);
   issue_b(0);
   issue_b(1);
   issue_b(2);
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const uint16_t* __res
   const int swzw = (j >> 1) & 7;
   for (int c = 0; c < nchunks; ++c) {
     const bool notlast = c + 1 < nchunks;
-    const unsigned char* as = smem + (c & 1) * kC3AB;
+    const unsigned char* as = smem + (c & (NA - 1)) * kC3AB;
     c3_static_for<0, 9>([&](auto tt) {
       constexpr int t = decltype(tt)::value;
       constexpr int dy = t / 3, dx = t % 3;
@@ -157,17 +162,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const uint16_t* __res
         int en = t == 0 ? 0 : (t == 1 ? 1 : (t <= 5 ? 2 : 0));
         if (t == 6) en = 1 + (na == 6 ? 1 : 0);
         if (t == 7) en = na == 6 ? 1 : 0;
-        wait_dma_rt(2 * NBI + (notlast ? en : 0));
+        wait_dma_rt(2 * NBI + ((NA == 2 && notlast) ? en : 0));
       }
       wg_barrier();
-      if (notlast) {
-        if constexpr (t < 5) issue_a(t, c + 1);
-        else if constexpr (t == 5) {
-          if (na == 6) issue_a(5, c + 1);
+      if constexpr (NA == 2) {
+        if (notlast) {
+          if constexpr (t < 5) issue_a(t, c + 1);
+          else if constexpr (t == 5) {
+            if (na == 6) issue_a(5, c + 1);
+          }
         }
       }
       if (s + 3 < S) issue_b(s + 3);
-      const unsigned char* bs = smem + 2 * kC3AB + (s & (kC3NB - 1)) * BSTAGE;
+      const unsigned char* bs = smem + NA * kC3AB + (s & (kC3NB - 1)) * BSTAGE;
       const int hr0 = (2 * pw + dy) * kC3HW + j + dx, hr1 = hr0 + kC3HW;
       const int sw0 = (hr0 >> 1) & 7, sw1 = (hr1 >> 1) & 7;
       const unsigned char* x0p = as + hr0 * 128;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const uint16_t* __res
 
   // ---- epilogue: + bias, activation, 16-bit rounding -> LDS [pixel][channel] -> 16-byte row-contiguous stores ----------------------
   constexpr int PITCH = WC + 8;              // halfs
-  static_assert(8 * 64 * PITCH * 2 <= 2 * kC3AB, "staging block fits the halo stages");
+  static_assert(NWV * 64 * PITCH * 2 <= NA * kC3AB + kC3NB * BSTAGE, "staging block fits the stages");
   uint16_t* stg = (uint16_t*)smem + wave * 64 * PITCH;
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -251,20 +258,21 @@ int launch_conv3x3_halo(const void* X, const void* W, const void* bias, void* Y,
   // where it wins (tools/experiments/conv3x3_check.py time, profiles/r06_conv3x3_halo.txt): few input channels (the halo tile is most
   // of a step's traffic) or many pixels; at C >= 256 on <= 130 000 pixels the 256 x 256 implicit-GEMM tile is 2-5 % ahead
   if (C > 128 && (long)B * H * Wd < 400000) return 1;
-  const int BN = N % 128 == 0 ? 128 : 64;
+  const bool one_chunk = C == 64;                       // single halo stage, 64-channel tiles, two workgroups per CU
+  const int BN = (N % 128 == 0 && !one_chunk) ? 128 : 64;
   const long blocks = (long)B * tiles_y * tiles_x * (N / BN);
   if (blocks >= (1L << 31)) return 1;
   static void* zero_page = nullptr;          // looked up once (first call is an eager warm-up, never inside a capture)
   if (zero_page == nullptr && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero_page_c3)) != hipSuccess)
     return fail(RFN_ELAUNCH, "conv3x3_halo: zero page symbol");
-#define RFN_C3(DT_, BN_)                                                                                                         \
-  hipLaunchKernelGGL((conv3x3_halo_kernel<DT_, BN_>), dim3((unsigned)blocks), dim3(512), 0, s, (const uint16_t*)X,                \
+#define RFN_C3(DT_, BN_, NA_)                                                                                                    \
+  hipLaunchKernelGGL((conv3x3_halo_kernel<DT_, BN_, NA_>), dim3((unsigned)blocks), dim3(NA_ == 1 ? 256 : 512), 0, s, (const uint16_t*)X,           \
                      (const uint16_t*)W, (const uint16_t*)bias, (uint16_t*)Y, H, Wd, C, N, ldw, ldy, tiles_y, tiles_x, act,       \
                      (const void*)zero_page)
   if (dtype == 1) {
-    if (BN == 128) RFN_C3(1, 128); else RFN_C3(1, 64);
+    if (one_chunk) RFN_C3(1, 64, 1); else if (BN == 128) RFN_C3(1, 128, 2); else RFN_C3(1, 64, 2);
   } else {
-    if (BN == 128) RFN_C3(2, 128); else RFN_C3(2, 64);
+    if (one_chunk) RFN_C3(2, 64, 1); else if (BN == 128) RFN_C3(2, 128, 2); else RFN_C3(2, 64, 2);
   }
 #undef RFN_C3
   return check_launch("conv3x3_halo_kernel");
