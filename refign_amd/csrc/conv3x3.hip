@@ -156,7 +156,14 @@ __global__ __launch_bounds__(NA == 1 ? 256 : 512) void conv3x3_halo_kernel(const
       // everything older than what the two previous steps issued has landed (loads retire in order): this step's weight stage,
       // and on tap 0 the chunk's halo tile (its last piece went out on tap 5 of the previous chunk, before that stage).
       // Halo pieces of the next chunk: one per wave on taps 0-4, a sixth on tap 5 for waves 0-3.
-      if (s + 2 >= S) {
+      if (NA == 1 && t == 0 && c > 0) {
+        // single halo stage, several chunks (C = 128): the stage is re-filled at the chunk boundary, in the open -- the CU's other
+        // workgroup has the matrix pipe meanwhile
+        wg_barrier();                        // everybody is done with the previous chunk's tile
+#pragma unroll
+        for (int k = 0; k < NAI; ++k) issue_a(k, c);
+        wait_dma_all();
+      } else if (s + 2 >= S) {
         wait_dma_all();
       } else {
         int en = t == 0 ? 0 : (t == 1 ? 1 : (t <= 5 ? 2 : 0));
@@ -258,7 +265,12 @@ int launch_conv3x3_halo(const void* X, const void* W, const void* bias, void* Y,
   // where it wins (tools/experiments/conv3x3_check.py time, profiles/r06_conv3x3_halo.txt): few input channels (the halo tile is most
   // of a step's traffic) or many pixels; at C >= 256 on <= 130 000 pixels the 256 x 256 implicit-GEMM tile is 2-5 % ahead
   if (C > 128 && (long)B * H * Wd < 400000) return 1;
-  const bool one_chunk = C == 64;                       // single halo stage, 64-channel tiles, two workgroups per CU
+  static int c1max = -1;                                // (experiment knob, read once: largest C that takes the single-stage form)
+  if (c1max < 0) {
+    const char* e = getenv("RFN_CONV_HALO_C1");
+    c1max = e ? atoi(e) : 64;
+  }
+  const bool one_chunk = C <= c1max;                    // single halo stage, 64-channel tiles, two workgroups per CU
   const int BN = (N % 128 == 0 && !one_chunk) ? 128 : 64;
   const long blocks = (long)B * tiles_y * tiles_x * (N / BN);
   if (blocks >= (1L << 31)) return 1;
