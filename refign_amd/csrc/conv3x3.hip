@@ -63,8 +63,8 @@ template <int I, int N, typename F> __device__ __forceinline__ void c3_static_fo
   }
 }
 
-// NA = halo stages: 2, or 1 for C == 64 (a single chunk per tile: nothing to prefetch) -- with BN = 64 that is 76 KB of LDS and
-// <= 128 registers, so TWO workgroups share a CU and one's prologue / epilogue runs under the other's taps
+// NA = halo stages: 2, or 1 for C <= 128 (one or two chunks per tile) -- with BN = 64 and 4 waves that is 76 KB of LDS, so TWO
+// workgroups share a CU and one's prologue / chunk refill / epilogue runs under the other's taps
 template <int DT, int BN, int NA>
 __global__ __launch_bounds__(NA == 1 ? 256 : 512) void conv3x3_halo_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                            const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y, int H,
@@ -265,12 +265,9 @@ int launch_conv3x3_halo(const void* X, const void* W, const void* bias, void* Y,
   // where it wins (tools/experiments/conv3x3_check.py time, profiles/r06_conv3x3_halo.txt): few input channels (the halo tile is most
   // of a step's traffic) or many pixels; at C >= 256 on <= 130 000 pixels the 256 x 256 implicit-GEMM tile is 2-5 % ahead
   if (C > 128 && (long)B * H * Wd < 400000) return 1;
-  static int c1max = -1;                                // (experiment knob, read once: largest C that takes the single-stage form)
-  if (c1max < 0) {
-    const char* e = getenv("RFN_CONV_HALO_C1");
-    c1max = e ? atoi(e) : 64;
-  }
-  const bool one_chunk = C <= c1max;                    // single halo stage, 64-channel tiles, two workgroups per CU
+  // C <= 128: a single halo stage (re-filled in the open at the chunk boundary), 64-channel tiles, 4-wave workgroups, two per CU --
+  // 3-5 % ahead of the double-buffered 8-wave form at C = 128, level with it from C = 256 on (profiles/r06_conv3x3_halo.txt)
+  const bool one_chunk = C <= 128;
   const int BN = (N % 128 == 0 && !one_chunk) ? 128 : 64;
   const long blocks = (long)B * tiles_y * tiles_x * (N / BN);
   if (blocks >= (1L << 31)) return 1;
