@@ -65,9 +65,11 @@ template <int I, int N, typename F> __device__ __forceinline__ void c3_static_fo
 
 // NA = halo stages: 2, or 1 for C <= 128 (one or two chunks per tile) -- with BN = 64 and 4 waves that is 76 KB of LDS, so TWO
 // workgroups share a CU and one's prologue / chunk refill / epilogue runs under the other's taps
-template <int DT, int BN, int NA>
+// OUT32: fp32 result, fp32 bias (the split-bf16 convolutions of the matcher's head: C = 3 Cp channels per pixel, split32.py).
+// C % 32 == 0: a last half chunk reads zeros for its upper 32 channels; N % 8 == 0: filter rows past N are clamped, stores masked.
+template <int DT, int BN, int NA, bool OUT32>
 __global__ __launch_bounds__(NA == 1 ? 256 : 512) void conv3x3_halo_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
-                                                           const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y, int H,
+                                                           const void* __restrict__ bias_, void* __restrict__ Y_, int H,
                                                            int W, int C, int N, long ldw, long ldy, int tiles_y, int tiles_x,
                                                            int act, const void* __restrict__ zero) {
   using E = Elem<DT>;
@@ -85,20 +87,22 @@ __global__ __launch_bounds__(NA == 1 ? 256 : 512) void conv3x3_halo_kernel(const
   const int pw = wave & 3, cw = NWV == 8 ? wave >> 2 : 0;
 
   int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int NT = N / BN;
+  const int NT = (N + BN - 1) / BN;
   const int nt = bid % NT;
   bid /= NT;
   const int tx = bid % tiles_x;
   bid /= tiles_x;
   const int ty = bid % tiles_y, b = bid / tiles_y;
   const int y0 = ty * kC3TH, x0 = tx * kC3TW, n0 = nt * BN;
-  const int nchunks = C / 64, S = nchunks * 9;
+  const int nchunks = (C + 63) / 64, S = nchunks * 9;
+  const bool half_tail = (C & 63) != 0;        // the last chunk holds 32 channels: source pieces 4-7 of its rows are zeros
 
   // ---- DMA sources: lane = (row of the instruction's 8, 16-byte piece); source piece = piece ^ swizzle(row) ----------------------
   // halo instructions wave + 8 k: waves 0-3 carry six of the 44, waves 4-7 five
   const int drow = lane >> 3, piece = lane & 7;
   const int na = NWV == 8 ? (wave < 4 ? 6 : 5) : 11;            // (scalar)
   unsigned aoff[NAI];
+  unsigned ahigh = 0u, bhigh = 0u;
 #pragma unroll
   for (int k = 0; k < NAI; ++k) {
     const int row = 8 * (wave + NWV * k) + drow;
@@ -107,26 +111,33 @@ __global__ __launch_bounds__(NA == 1 ? 256 : 512) void conv3x3_halo_kernel(const
     const bool ok = row < kC3HP && y >= 0 && y < H && x >= 0 && x < W;
     const int sp = piece ^ ((row >> 1) & 7);
     aoff[k] = ok ? (unsigned)((((long)(b * H + y) * W + x) * C) * 2 + sp * 16) : 0xffffffffu;
+    if (sp >= 4) ahigh |= 1u << k;            // (per lane: this instruction's piece is in the upper half of the row)
   }
   unsigned boff[NBI];
 #pragma unroll
   for (int k = 0; k < NBI; ++k) {
     const int n = 8 * (wave + NWV * k) + drow;
     const int sp = piece ^ ((n >> 1) & 7);
-    boff[k] = (unsigned)(((long)(n0 + n) * ldw) * 2 + sp * 16);
+    boff[k] = (unsigned)(((long)min(n0 + n, N - 1) * ldw) * 2 + sp * 16);
+    if (sp >= 4) bhigh |= 1u << k;
   }
   const unsigned char* Xb = (const unsigned char*)X;
   const unsigned char* Wb = (const unsigned char*)Wt;
   auto issue_a = [&](int k, int chunk) {
-    const void* src = aoff[k] != 0xffffffffu ? (const void*)(Xb + aoff[k] + (long)chunk * 128) : zero;
+    const bool cut = half_tail && chunk == nchunks - 1 && ((ahigh >> k) & 1u);
+    const void* src = (aoff[k] != 0xffffffffu && !cut) ? (const void*)(Xb + aoff[k] + (long)chunk * 128) : zero;
     lds_dma16(src, smem + (chunk & (NA - 1)) * kC3AB + (wave + NWV * k) * 1024);
   };
   auto issue_b = [&](int s) {                // step s = 9 chunk + tap
     const int c = s / 9, t = s - 9 * c;
     const long koff = ((long)t * C + (long)c * 64) * 2;
     unsigned char* dst = smem + NA * kC3AB + (s & (kC3NB - 1)) * BSTAGE;
+    const bool tail = half_tail && c == nchunks - 1;
 #pragma unroll
-    for (int k = 0; k < NBI; ++k) lds_dma16(Wb + boff[k] + koff, dst + (wave + NWV * k) * 1024);
+    for (int k = 0; k < NBI; ++k) {
+      const bool cut = tail && ((bhigh >> k) & 1u);
+      lds_dma16(cut ? zero : (const void*)(Wb + boff[k] + koff), dst + (wave + NWV * k) * 1024);
+    }
   };
 
   f32x16 acc[CB][2];
@@ -210,78 +221,125 @@ __global__ __launch_bounds__(NA == 1 ? 256 : 512) void conv3x3_halo_kernel(const
   }
   wg_barrier();                              // everybody is done with the stages: the staging block lies over the halo stages
 
-  // ---- epilogue: + bias, activation, 16-bit rounding -> LDS [pixel][channel] -> 16-byte row-contiguous stores ----------------------
-  constexpr int PITCH = WC + 8;              // halfs
-  static_assert(NWV * 64 * PITCH * 2 <= NA * kC3AB + kC3NB * BSTAGE, "staging block fits the stages");
-  uint16_t* stg = (uint16_t*)smem + wave * 64 * PITCH;
+  // ---- epilogue: + bias, activation, rounding -> LDS [pixel][channel] -> 16-byte row-contiguous stores (channels past N masked) ----
+  if constexpr (!OUT32) {
+    const uint16_t* bias = (const uint16_t*)bias_;
+    uint16_t* Y = (uint16_t*)Y_;
+    constexpr int PITCH = WC + 8;              // halfs
+    static_assert(NWV * 64 * PITCH * 2 <= NA * kC3AB + kC3NB * BSTAGE, "staging block fits the stages");
+    uint16_t* stg = (uint16_t*)smem + wave * 64 * PITCH;
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int a = 0; a < CB; ++a)
+      for (int a = 0; a < CB; ++a)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ch = 32 * a + 8 * q + 4 * g;                // four consecutive output channels of the wave's half
-        float bf[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr) unpack4<DT>(*(const u32x2*)(bias + n0 + cw * WC + ch), bf);
-        float v[4];
+        for (int q = 0; q < 4; ++q) {
+          const int ch = 32 * a + 8 * q + 4 * g;                // four consecutive output channels of the wave's share
+          float bf[4] = {0.f, 0.f, 0.f, 0.f};
+          if (bias != nullptr && n0 + cw * WC + ch < N) unpack4<DT>(*(const u32x2*)(bias + n0 + cw * WC + ch), bf);
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float z = acc[a][p][4 * q + e] + bf[e];
-          if (act == 1) z = fmaxf(z, 0.f);
-          else if (act == 3) z = z > 0.f ? z : 0.1f * z;
-          v[e] = z;
+          for (int e = 0; e < 4; ++e) {
+            float z = acc[a][p][4 * q + e] + bf[e];
+            if (act == 1) z = fmaxf(z, 0.f);
+            else if (act == 3) z = z > 0.f ? z : 0.1f * z;
+            v[e] = z;
+          }
+          *(u32x2*)(stg + (p * 32 + j) * PITCH + ch) = pack4<DT>(v[0], v[1], v[2], v[3]);
         }
-        *(u32x2*)(stg + (p * 32 + j) * PITCH + ch) = pack4<DT>(v[0], v[1], v[2], v[3]);
-      }
-  __syncthreads();
-  constexpr int OPR = WC / 8;                // 16-byte pieces per pixel (of this wave's channels)
-  constexpr int RPI = 64 / OPR;              // pixels per store instruction
-  const int opiece = lane % OPR, orow = lane / OPR;
+    __syncthreads();
+    constexpr int OPR = WC / 8;                // 16-byte pieces per pixel (of this wave's channels)
+    constexpr int RPI = 64 / OPR;              // pixels per store instruction
+    const int opiece = lane % OPR, orow = lane / OPR;
 #pragma unroll
-  for (int it = 0; it < 64 / RPI; ++it) {
-    const int prow = it * RPI + orow;
-    const int y = y0 + 2 * pw + (prow >> 5), x = x0 + (prow & 31);
-    const u32x4 val = *(const u32x4*)(stg + prow * PITCH + opiece * 8);
-    if (y < H && x < W) *(u32x4*)(Y + ((long)(b * H + y) * W + x) * ldy + n0 + cw * WC + opiece * 8) = val;
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int prow = it * RPI + orow;
+      const int y = y0 + 2 * pw + (prow >> 5), x = x0 + (prow & 31);
+      const u32x4 val = *(const u32x4*)(stg + prow * PITCH + opiece * 8);
+      const int ch0 = n0 + cw * WC + opiece * 8;
+      if (y < H && x < W && ch0 < N) *(u32x4*)(Y + ((long)(b * H + y) * W + x) * ldy + ch0) = val;
+    }
+  } else {
+    const float* bias = (const float*)bias_;
+    float* Y = (float*)Y_;
+    constexpr int PITCH = WC + 4;              // floats
+    static_assert(NWV * 64 * PITCH * 4 <= NA * kC3AB + kC3NB * BSTAGE, "staging block fits the stages");
+    float* stg = (float*)smem + wave * 64 * PITCH;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ch = 32 * a + 8 * q + 4 * g;
+          f32x4 bf = {0.f, 0.f, 0.f, 0.f};
+          if (bias != nullptr && n0 + cw * WC + ch < N) bf = *(const f32x4*)(bias + n0 + cw * WC + ch);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float z = acc[a][p][4 * q + e] + bf[e];
+            if (act == 1) z = fmaxf(z, 0.f);
+            else if (act == 3) z = z > 0.f ? z : 0.1f * z;
+            v[e] = z;
+          }
+          *(f32x4*)(stg + (p * 32 + j) * PITCH + ch) = v;
+        }
+    __syncthreads();
+    constexpr int OPR = WC / 4;                // 16-byte pieces per pixel (of this wave's channels)
+    constexpr int RPI = 64 / OPR;
+    const int opiece = lane % OPR, orow = lane / OPR;
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int prow = it * RPI + orow;
+      const int y = y0 + 2 * pw + (prow >> 5), x = x0 + (prow & 31);
+      const f32x4 val = *(const f32x4*)(stg + prow * PITCH + opiece * 4);
+      const int ch0 = n0 + cw * WC + opiece * 4;
+      if (y < H && x < W && ch0 < N) *(f32x4*)(Y + ((long)(b * H + y) * W + x) * ldy + ch0) = val;
+    }
   }
 }
 
-// Launch; the caller (rfn_conv2d_nhwc) has checked the geometry (3 x 3, stride 1, padding 1, no dilation, no residual).  Returns
-// RFN_OK, an error, or 1 when the problem is outside this kernel's domain (the caller then takes the implicit-GEMM kernel).
+// Launch; the caller (rfn_conv2d_nhwc / rfn_conv2d_nhwc_o32) has checked the geometry (3 x 3, stride 1, padding 1, no dilation, no
+// residual).  out32: fp32 result and bias.  Returns RFN_OK, an error, or 1 when the problem is outside this kernel's domain (the caller
+// then takes the implicit-GEMM kernel).
 int launch_conv3x3_halo(const void* X, const void* W, const void* bias, void* Y, int B, int H, int Wd, int C, int N, long ldw,
-                        long ldy, int act, int dtype, hipStream_t s) {
+                        long ldy, int act, int dtype, int out32, hipStream_t s) {
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("RFN_CONV_HALO");
     enabled = (e == nullptr || e[0] != '0') ? 1 : 0;
   }
   if (!enabled) return 1;
-  if (C % 64 != 0 || N % 64 != 0 || ldy % 8 != 0 || ldw % 8 != 0) return 1;
+  if (C % 32 != 0 || N % 8 != 0 || ldy % (out32 ? 4 : 8) != 0 || ldw % 8 != 0 || ldw < 9L * C) return 1;
   if ((long)B * H * Wd * C * 2 >= (1L << 32) || (long)N * ldw * 2 >= (1L << 32)) return 1;     // 32-bit byte offsets
-  if ((((size_t)X | (size_t)W | (size_t)Y) & 15) != 0 || (bias != nullptr && ((size_t)bias & 7) != 0)) return 1;
+  if ((((size_t)X | (size_t)W | (size_t)Y) & 15) != 0 || (bias != nullptr && ((size_t)bias & (out32 ? 15 : 7)) != 0)) return 1;
+  if ((out32 && dtype != 1) || N < 32) return 1;           // (a 64-channel tile for fewer than 32 output channels is mostly padding)
   const int tiles_y = cdiv(H, kC3TH), tiles_x = cdiv(Wd, kC3TW);
   // small or narrow maps waste the 8 x 32 tile (the matcher's 16 x 16 and 32 x 32 levels): the implicit-GEMM kernel keeps those
   if ((long)B * H * Wd < 4096 || (double)H * Wd < 0.7 * (double)tiles_y * kC3TH * tiles_x * kC3TW) return 1;
   // where it wins (tools/experiments/conv3x3_check.py time, profiles/r06_conv3x3_halo.txt): few input channels (the halo tile is most
-  // of a step's traffic) or many pixels; at C >= 256 on <= 130 000 pixels the 256 x 256 implicit-GEMM tile is 2-5 % ahead
-  if (C > 128 && (long)B * H * Wd < 400000) return 1;
+  // of a step's traffic), many pixels, or few output channels (the implicit-GEMM kernel is then on its small tiles); with N >= 256 and
+  // C >= 256 on <= 130 000 pixels its 256 x 256 tile is 2-5 % ahead
+  if (N >= 256 && C > 128 && (long)B * H * Wd < 400000) return 1;
   // C <= 128: a single halo stage (re-filled in the open at the chunk boundary), 64-channel tiles, 4-wave workgroups, two per CU --
   // 3-5 % ahead of the double-buffered 8-wave form at C = 128, level with it from C = 256 on (profiles/r06_conv3x3_halo.txt)
   const bool one_chunk = C <= 128;
   const int BN = (N % 128 == 0 && !one_chunk) ? 128 : 64;
-  const long blocks = (long)B * tiles_y * tiles_x * (N / BN);
+  const long blocks = (long)B * tiles_y * tiles_x * cdiv(N, BN);
   if (blocks >= (1L << 31)) return 1;
   static void* zero_page = nullptr;          // looked up once (first call is an eager warm-up, never inside a capture)
   if (zero_page == nullptr && hipGetSymbolAddress(&zero_page, HIP_SYMBOL(g_zero_page_c3)) != hipSuccess)
     return fail(RFN_ELAUNCH, "conv3x3_halo: zero page symbol");
-#define RFN_C3(DT_, BN_, NA_)                                                                                                    \
-  hipLaunchKernelGGL((conv3x3_halo_kernel<DT_, BN_, NA_>), dim3((unsigned)blocks), dim3(NA_ == 1 ? 256 : 512), 0, s, (const uint16_t*)X,           \
-                     (const uint16_t*)W, (const uint16_t*)bias, (uint16_t*)Y, H, Wd, C, N, ldw, ldy, tiles_y, tiles_x, act,       \
+#define RFN_C3(DT_, BN_, NA_, O32_)                                                                                               \
+  hipLaunchKernelGGL((conv3x3_halo_kernel<DT_, BN_, NA_, O32_>), dim3((unsigned)blocks), dim3(NA_ == 1 ? 256 : 512), 0, s,          \
+                     (const uint16_t*)X, (const uint16_t*)W, bias, Y, H, Wd, C, N, ldw, ldy, tiles_y, tiles_x, act,                \
                      (const void*)zero_page)
-  if (dtype == 1) {
-    if (one_chunk) RFN_C3(1, 64, 1); else if (BN == 128) RFN_C3(1, 128, 2); else RFN_C3(1, 64, 2);
+  if (out32) {
+    if (one_chunk) RFN_C3(1, 64, 1, true); else if (BN == 128) RFN_C3(1, 128, 2, true); else RFN_C3(1, 64, 2, true);
+  } else if (dtype == 1) {
+    if (one_chunk) RFN_C3(1, 64, 1, false); else if (BN == 128) RFN_C3(1, 128, 2, false); else RFN_C3(1, 64, 2, false);
   } else {
-    if (one_chunk) RFN_C3(2, 64, 1); else if (BN == 128) RFN_C3(2, 128, 2); else RFN_C3(2, 64, 2);
+    if (one_chunk) RFN_C3(2, 64, 1, false); else if (BN == 128) RFN_C3(2, 128, 2, false); else RFN_C3(2, 64, 2, false);
   }
 #undef RFN_C3
   return check_launch("conv3x3_halo_kernel");

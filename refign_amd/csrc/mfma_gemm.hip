@@ -72,7 +72,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // == 0 and the weight rows are [tap][c] zero-padded to a multiple of 64 (pieces past the last tap read the zero page).
 // conv3x3.hip: RFN_OK / an error, or 1 = outside its domain
 int launch_conv3x3_halo(const void* X, const void* W, const void* bias, void* Y, int B, int H, int Wd, int C, int N, long ldw,
-                        long ldy, int act, int dtype, hipStream_t s);
+                        long ldy, int act, int dtype, int out32, hipStream_t s);
 
 struct ConvGeom {
   int H, W, C, OH, OW, KH, KW, stride, pad, dil;
@@ -1416,7 +1416,7 @@ int rfn_conv2d_nhwc(const void* X, const void* W, const void* bias, const void* 
   hipStream_t s = (hipStream_t)stream;
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1 && res == nullptr) {
     // halo-tiled form (conv3x3.hip): the input tile staged once per 64 channels instead of once per tap
-    const int rc = launch_conv3x3_halo(X, W, bias, Y, B, H, Wd, C, N, ldw, ldy, act, dtype, s);
+    const int rc = launch_conv3x3_halo(X, W, bias, Y, B, H, Wd, C, N, ldw, ldy, act, dtype, 0, s);
     if (rc != 1) return rc;
   }
   return dtype == 1 ? launch_nt<1, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s)
@@ -1456,6 +1456,10 @@ int rfn_conv2d_nhwc_o32(const void* X, const void* W, const float* bias, int act
     RFN_REQUIRE(ldw % 8 == 0 && ldw >= K && ldy % 4 == 0 && ldy >= N && M < (1L << 31) && K / 8 < 65536, "conv2d_nhwc_o32: ld");
     ConvGeom cg{H, Wd, C, OH, OW, KH, KW, stride, pad, dil, C / 8, (unsigned)((0x100000000ULL + C / 8 - 1) / (C / 8)),
                 (unsigned)((0x100000000ULL + KW - 1) / KW), nullptr, 0, 0};
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1) {       // halo-tiled form (conv3x3.hip)
+      const int rc = launch_conv3x3_halo(X, W, bias, Y, B, H, Wd, C, N, ldw, ldy, act, 1, 1, s);
+      if (rc != 1) return rc;
+    }
     return launch_nt<1, true>(X, W, Y, M, N, K, 0, ldw, ldy, epi, cg, s, true);
   }
   // data gradient: X = grad_y (B, OH, OW, N), Y = dx (B, H, W, C), W = Wt[c][(tap, n)]

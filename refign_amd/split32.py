@@ -181,11 +181,18 @@ def attention(q, kv, heads, scale):
 # ---------------------------------------------------------------------------------------------------------------------
 # convolution (groups == 1, square geometry)
 # ---------------------------------------------------------------------------------------------------------------------
+def _cp(C):
+    """Channels per split term: C to a multiple of 8 -- of 32 above 64 channels, so that the 3 Cp channels of a pixel are a multiple
+    of 32 and the 3 x 3 layers take the halo-tiled kernel (csrc/conv3x3.hip: 64-channel chunks, a last half chunk allowed); the
+    decoders' first layers see 84-87 channels (uawarpc.py:136-160): 96, i.e. 9-14 % more products on those layers."""
+    return -(-C // 32) * 32 if C > 64 else -(-C // 8) * 8
+
+
 def _nhwc3(x, order):
-    """NCHW-shaped fp32 -> (B, H, W, 3 Cp) bf16: the split terms `order` concatenated along the channels (Cp = C to 8)."""
+    """NCHW-shaped fp32 -> (B, H, W, 3 Cp) bf16: the split terms `order` concatenated along the channels (Cp = _cp(C))."""
     xh = x.permute(0, 2, 3, 1)
     B, H, W, C = xh.shape
-    Cp = -(-C // 8) * 8
+    Cp = _cp(C)
     # rows = pixels; a channels-last tensor (also a channel slice of one) has uniformly strided rows: no copy
     if not (xh.stride(3) == 1 and xh.stride(2) >= C and xh.stride(1) == W * xh.stride(2) and xh.stride(0) == H * xh.stride(1)):
         xh = xh.contiguous()
@@ -196,7 +203,7 @@ def _nhwc3(x, order):
 def _w3(w, order):
     """(N, C, KH, KW) fp32 -> packed bf16 rows [n][(tap, 3 Cp)] with the split terms `order` per tap; N padded to 8."""
     N, C, KH, KW = w.shape
-    Cp = -(-C // 8) * 8
+    Cp = _cp(C)
     hi, lo = split2(w)
     w3 = torch.zeros((N, 3 * Cp, KH, KW), dtype=BF, device=w.device)
     for i, which in enumerate(order):
@@ -250,7 +257,7 @@ def cat_split(parts):
     import ctypes
     B, _, H, W = parts[0].shape
     C = sum(p.shape[1] for p in parts)
-    Cp = -(-C // 8) * 8
+    Cp = _cp(C)
     if not (1 <= len(parts) <= 4 and Cp <= 96 and all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 4
                                                       and p.shape[0] == B and tuple(p.shape[2:]) == (H, W) for p in parts)):
         return None
@@ -274,7 +281,7 @@ def conv2d_parts(parts, weight, bias=None, stride=1, padding=0, dilation=1, act=
     if torch.is_grad_enabled() or not isinstance(stride, int) or not isinstance(padding, int) or not isinstance(dilation, int):
         return None
     N, C, KH, KW = weight.shape
-    if sum(p.shape[1] for p in parts) != C or 3 * (-(-C // 8) * 8) * KH * KW // 8 >= 65536:
+    if sum(p.shape[1] for p in parts) != C or 3 * _cp(C) * KH * KW // 8 >= 65536:
         return None
     got = cat_split(parts)
     if got is None:
@@ -366,6 +373,6 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, act=0):
     N, C, KH, KW = weight.shape
     if x.shape[1] != C or (x.requires_grad and torch.is_grad_enabled() and s & (s - 1)):
         return None
-    if 3 * (-(-C // 8) * 8) * KH * KW // 8 >= 65536 or 3 * (-(-N // 8) * 8) * KH * KW // 8 >= 65536:
+    if 3 * _cp(C) * KH * KW // 8 >= 65536 or 3 * _cp(N) * KH * KW // 8 >= 65536:
         return None
     return _Conv2dFn.apply(x, weight, bias, s, p, d, act)

@@ -89,3 +89,25 @@ def test_halo_tiled_conv3x3_is_repeatable_under_memory_load(dev):
             y = conv.conv2d_mfma(x, w, None, 1, 1, 1, act='relu', dtype=torch.float16)
             assert torch.equal(y, first)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,H,W,C,N,act", [(2, 50, 70, 128, 128, 3), (1, 67, 90, 96, 64, 3), (2, 40, 64, 64, 32, 0), (1, 48, 100, 128, 96, 1),
+                                           (2, 135, 240, 32, 128, 3)])
+def test_halo_tiled_conv3x3_fp32_result_of_split_products(dev, B, H, W, C, N, act):
+    """The split-bf16 convolutions of the matcher's head (split32.conv2d_parts: 3 C channels per pixel, fp32 result and bias) on the
+    halo-tiled kernel: a last half chunk (3 C % 64 == 32), output channels that do not fill the last 64-channel tile, every
+    activation -- against torch fp32 (three bf16 products leave ~2^-16 relative)."""
+    from refign_amd import split32
+    torch.manual_seed(C + N)
+    x = torch.randn(B, C, H, W, device=dev)
+    w = torch.randn(N, C, 3, 3, device=dev) * (9 * C) ** -0.5
+    bias = torch.randn(N, device=dev) * 0.1
+    with torch.no_grad():
+        # (up to 96 channels the decoders' first layers hand over the PARTS of a concatenation: split32.conv2d_parts)
+        y = split32.conv2d_parts([x[:, :C // 2], x[:, C // 2:]], w, bias, 1, 1, 1, act) if C <= 96 else \
+            split32.conv2d(x, w, bias, 1, 1, 1, act)
+        ref = F.conv2d(x, w, bias, padding=1)
+    assert y is not None and tuple(y.shape) == (B, N, H, W)
+    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.1) if act == 3 else ref)
+    err = float((y - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-4, err
