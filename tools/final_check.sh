@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/${1:-final}; mkdir -p $O
-RFN_TEST_REPORT_DIR=$O timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
+RFN_TEST_REPORT_DIR=$O timeout 1800 python -m pytest tests -x -q -m gpu --tb=short 2>&1 | tail -40 > $O/pytest_gpu.txt
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_n1.json
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --no-cpu --no-roofline 2>/dev/null | grep '^{"metric"' > $O/bench_torchrun_n1.json
 timeout 900 python bench.py --precision fp32 --no-cpu --steps 10 2>/dev/null | tail -1 > $O/bench_fp32_n1.json
