@@ -634,6 +634,13 @@ def _failed_backward_capture_case(dev, monkeypatch):
     (a replayed pass next to an eagerly run one is a combination nothing else exercises).  In the step's own precision map (bf16
     autocast: BatchNorm on csrc/bn.hip)."""
     from refign_amd.trainer import Trainer
+    import gc
+    # (a likely cause of the rare full-suite failure: after ~600 tests -- the 1080 x 1920 MiT-B5 goldens among them -- the caching
+    # allocator may have to RELEASE cached blocks to serve a request made inside a capture, which is itself illegal while
+    # capturing: the FORWARD capture then fails, with another warning than the one this test waits for.  Start from an empty cache.)
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     out = {}
     for mode in ("fail", "eager"):
         monkeypatch.setenv("RFN_GRAPH_STUDENT", "1" if mode == "fail" else "0")
